@@ -1,0 +1,97 @@
+"""ctypes binding of libd3d_hip.so -- the C ABI declared in include/d3d.h.
+
+There is no CPU fallback: if the library is missing or a call fails the caller
+gets an exception.  PyTorch is only used by callers for device memory and
+streams; every argument crossing this boundary is a raw pointer or an int.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libd3d_hip.so")
+
+_lib = None
+
+vp = ctypes.c_void_p
+i32 = ctypes.c_int
+i64 = ctypes.c_int64
+f32 = ctypes.c_float
+sz = ctypes.c_size_t
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+
+# name -> (restype, argtypes); mirrors include/d3d.h one to one
+SIGNATURES = {
+    "d3d_abi_version": (i32, []),
+    "d3d_last_error": (ctypes.c_char_p, []),
+    "d3d_voxelize_workspace_bytes": (sz, [i64, i32, i32, i32]),
+    "d3d_voxelize": (i32, [vp, i64, i32, vp, i32, _f32p, _f32p, _i32p, i32, i32, vp, vp, vp, vp,
+                           i32, vp, vp, sz, vp]),
+    "d3d_subm_rulebook_workspace_bytes": (sz, [i32]),
+    "d3d_subm_rulebook": (i32, [vp, vp, i32, i32, _i32p, _i32p, vp, vp, vp, sz, vp]),
+    "d3d_conv_rulebook_workspace_bytes": (sz, [i32, _i32p]),
+    "d3d_conv_rulebook": (i32, [vp, vp, i32, i32, _i32p, _i32p, _i32p, _i32p, _i32p, vp, vp, i32,
+                                vp, vp, vp, vp, sz, vp]),
+    "d3d_sparse_conv_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "d3d_sparse_conv_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "d3d_dense_scatter": (i32, [vp, vp, i32, i32, i32, _i32p, i32, vp, vp]),
+    "d3d_dense_gather": (i32, [vp, vp, i32, i32, i32, _i32p, i32, vp, vp]),
+    "d3d_rotate_nms_workspace_bytes": (sz, [i32]),
+    "d3d_rotate_nms": (i32, [vp, i32, f32, i32, vp, vp, vp, sz, vp]),
+    "d3d_rotate_iou": (i32, [vp, i32, vp, i32, vp, vp]),
+    "d3d_nms": (i32, [vp, i32, f32, i32, vp, vp, vp, sz, vp]),
+}
+
+D3D_F32 = 0
+D3D_BF16 = 1
+
+
+class D3dError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libd3d_hip.so (once).  Raises if it was not built -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise D3dError(
+                "%s not found: build it with `python -m det3d_amd.csrc.build` "
+                "(__graft_entry__.build()); det3d_amd has no CPU fallback" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if L.d3d_abi_version() != 1:
+            raise D3dError("libd3d_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().d3d_last_error()
+        raise D3dError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def f32_array(vals):
+    return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def i32_array(vals):
+    return (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+def ptr(t):
+    """data pointer of a (contiguous) torch tensor, or None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "C ABI needs contiguous buffers"
+    return t.data_ptr()
+
+
+def stream_ptr(device=None):
+    import torch
+
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,90 @@
+// Shared host/device helpers for libd3d_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/d3d.h"
+
+int d3d_set_error(int code, const char *fmt, ...);
+
+#define D3D_HIP_TRY(expr)                                                                  \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return d3d_set_error(D3D_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                           __FILE__, __LINE__);                                            \
+  } while (0)
+
+#define D3D_LAUNCH_TRY(name)                                                             \
+  do {                                                                                   \
+    hipError_t _e = hipGetLastError();                                                   \
+    if (_e != hipSuccess)                                                                \
+      return d3d_set_error(D3D_EHIP, "launch of %s failed: %s (%s:%d)", name,             \
+                           hipGetErrorString(_e), __FILE__, __LINE__);                   \
+  } while (0)
+
+#define D3D_REQUIRE(cond, ...)                                   \
+  do {                                                           \
+    if (!(cond)) return d3d_set_error(D3D_EINVAL, __VA_ARGS__);  \
+  } while (0)
+
+static inline size_t d3d_align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// bump allocator over the caller's workspace
+struct D3dArena {
+  char *base;
+  size_t size;
+  size_t off;
+  D3dArena(void *p, size_t n) : base((char *)p), size(n), off(0) {}
+  template <class T> T *take(size_t count) {
+    size_t bytes = d3d_align_up(count * sizeof(T));
+    if (off + bytes > size) return nullptr;
+    T *r = (T *)(base + off);
+    off += bytes;
+    return r;
+  }
+};
+
+static inline int d3d_next_pow2(int64_t x) {
+  int64_t p = 1;
+  while (p < x) p <<= 1;
+  return (int)p;
+}
+
+// ---------------------------------------------------------------- device side
+#define D3D_WAVE 64
+#define D3D_EMPTY_KEY 0xFFFFFFFFu
+
+__device__ __forceinline__ uint32_t d3d_hash_u32(uint32_t k, uint32_t mask) {
+  // Fibonacci hashing + xor-fold: cheap, spreads the regular (z,y,x) lattice
+  k *= 2654435761u;
+  k ^= k >> 15;
+  return k & mask;
+}
+
+// insert `key` into an open-addressing table of (mask+1) slots; returns slot.
+__device__ __forceinline__ uint32_t d3d_hash_insert(uint32_t *keys, uint32_t mask, uint32_t key) {
+  uint32_t s = d3d_hash_u32(key, mask);
+  while (true) {
+    uint32_t cur = keys[s];
+    if (cur == key) return s;
+    if (cur == D3D_EMPTY_KEY) {
+      uint32_t old = atomicCAS(&keys[s], D3D_EMPTY_KEY, key);
+      if (old == D3D_EMPTY_KEY || old == key) return s;
+    }
+    s = (s + 1) & mask;
+  }
+}
+
+// returns slot of `key` or 0xFFFFFFFF
+__device__ __forceinline__ uint32_t d3d_hash_find(const uint32_t *keys, uint32_t mask,
+                                                  uint32_t key) {
+  uint32_t s = d3d_hash_u32(key, mask);
+  while (true) {
+    uint32_t cur = keys[s];
+    if (cur == key) return s;
+    if (cur == D3D_EMPTY_KEY) return D3D_EMPTY_KEY;
+    s = (s + 1) & mask;
+  }
+}

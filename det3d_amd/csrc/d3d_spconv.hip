@@ -1,0 +1,448 @@
+// Sparse 3D convolution arithmetic for gfx950 (wave64, MFMA), output-stationary:
+//
+//   out[o, :] = bias + sum_k  feat[nbr[k][o], :] @ W[k]          (fwd and dgrad)
+//   dW[k]     = sum_o  feat[nbr[k][o], :]^T (x) dout[o, :]       (wgrad)
+//
+// spconv (the reference's un-vendored dependency) runs 27 x {gather kernel, cuBLAS
+// GEMM, scatter-add kernel} per layer through HBM.  Here one launch per layer
+// gathers rows straight into MFMA operand registers and keeps the [sites x Cout]
+// tile in accumulators across all kernel offsets, so the only HBM/L2 traffic is
+// the algorithmic one: P gathered rows + the index table + each output row once.
+// The path is memory-bound (<= 60 FLOP/B, ridge ~300): MFMA is used only on the
+// dense [16 sites x Cin] . [Cin x Cout] tile so that arithmetic never shows up.
+//
+// MFMA operand mapping (16x16 tiles; C/D: col = lane&15, row = (lane>>4)*4 + reg):
+//   D^T form:  A = W[k]^T tile (rows = cout), B = gathered features (cols = sites)
+//   => each lane ends up with 4 CONSECUTIVE couts of ONE site: 8/16-byte row stores,
+//   and the B operand for lane (site = lane&15, kgroup = lane>>4) is one contiguous
+//   16-byte piece of the gathered row -- no LDS, no transposes on the hot path.
+#include "d3d_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round to nearest even
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// ===================================================================== forward
+// One wave = MT tiles of 16 output sites x all COUT columns.  256 threads = 4 waves.
+template <int CIN, int COUT, int MT, bool BF16>
+__global__ void __launch_bounds__(256)
+    spconv_fwd_mfma_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
+                           const float *__restrict__ bias, const int32_t *__restrict__ nbr,
+                           int cap, int n_out, int kvol, void *__restrict__ out_) {
+  constexpr int NT = COUT / 16;
+  // k-steps per kernel offset and elements each lane holds per step
+  constexpr int KW = BF16 ? ((CIN % 32 == 0) ? 32 : 16) : 16;  // channels per k-step
+  constexpr int KS = CIN / KW;
+  constexpr int EPL = KW / 4;  // elements per lane per step (8 | 4 bf16, 4 f32)
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int row0 = (blockIdx.x * 4 + wave) * (MT * 16);
+  if (row0 >= n_out) return;
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  int site[MT];
+  bool live[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    site[m] = row0 + m * 16 + lr;
+    live[m] = site[m] < n_out;
+  }
+  int idx[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) idx[m] = live[m] ? nbr[site[m]] : -1;
+
+  for (int k = 0; k < kvol; ++k) {
+    int nxt[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      nxt[m] = (k + 1 < kvol && live[m]) ? nbr[(int64_t)(k + 1) * cap + site[m]] : -1;
+    bool any = false;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) any |= idx[m] >= 0;
+    if (__ballot(any) != 0ull) {
+      if constexpr (BF16) {
+        const uint16_t *feat = (const uint16_t *)feat_;
+        const uint16_t *wk = (const uint16_t *)wpack_ + (int64_t)k * COUT * CIN;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int ch = ks * KW + lg * EPL;
+          if constexpr (KW == 32) {
+            uint4 fb[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              fb[m] = idx[m] >= 0 ? *(const uint4 *)(feat + (int64_t)idx[m] * CIN + ch)
+                                  : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              uint4 wa = *(const uint4 *)(wk + (n * 16 + lr) * CIN + ch);
+#pragma unroll
+              for (int m = 0; m < MT; ++m)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, fb[m]),
+                    acc[m][n], 0, 0, 0);
+            }
+          } else {
+            uint2 fb[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              fb[m] = idx[m] >= 0 ? *(const uint2 *)(feat + (int64_t)idx[m] * CIN + ch)
+                                  : make_uint2(0, 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              uint2 wa = *(const uint2 *)(wk + (n * 16 + lr) * CIN + ch);
+#pragma unroll
+              for (int m = 0; m < MT; ++m)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
+                    __builtin_bit_cast(s16x4_t, wa), __builtin_bit_cast(s16x4_t, fb[m]),
+                    acc[m][n], 0, 0, 0);
+            }
+          }
+        }
+      } else {
+        const float *feat = (const float *)feat_;
+        const float *wk = (const float *)wpack_ + (int64_t)k * COUT * CIN;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int ch = ks * 16 + lg * 4;
+          float4 fb[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            fb[m] = idx[m] >= 0 ? *(const float4 *)(feat + (int64_t)idx[m] * CIN + ch)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            float4 wa = *(const float4 *)(wk + (n * 16 + lr) * CIN + ch);
+            // 16x16x4 f32 MFMA: lane group lg supplies k = lg; four of them walk the
+            // lane's 4 consecutive channels (any consistent k labelling is a valid sum)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, fb[m].x, acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, fb[m].y, acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, fb[m].z, acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, fb[m].w, acc[m][n], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) idx[m] = nxt[m];
+  }
+
+  // epilogue: lane holds couts [n*16 + lg*4, +4) of site[m]
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    if (!live[m]) continue;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int co = n * 16 + lg * 4;
+      f32x4_t v = acc[m][n];
+      if (bias) {
+        v[0] += bias[co + 0];
+        v[1] += bias[co + 1];
+        v[2] += bias[co + 2];
+        v[3] += bias[co + 3];
+      }
+      if constexpr (BF16) {
+        uint16_t *o = (uint16_t *)out_ + (int64_t)site[m] * COUT + co;
+        uint2 pk;
+        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        *(uint2 *)o = pk;
+      } else {
+        float *o = (float *)out_ + (int64_t)site[m] * COUT + co;
+        *(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+// generic fallback (any cin/cout, e.g. the 4->16 / 5->16 stem): one thread per
+// (site, cout), f32 accumulate.  Also the on-device second opinion in tests.
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+    spconv_fwd_generic_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
+                              const float *__restrict__ bias, const int32_t *__restrict__ nbr,
+                              int cap, int n_out, int kvol, int cin, int cout,
+                              void *__restrict__ out_) {
+  const int64_t total = (int64_t)n_out * cout;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    int o = (int)(t / cout);
+    int co = (int)(t - (int64_t)o * cout);
+    float acc = bias ? bias[co] : 0.f;
+    for (int k = 0; k < kvol; ++k) {
+      int i = nbr[(int64_t)k * cap + o];
+      if (i < 0) continue;
+      if constexpr (BF16) {
+        const uint16_t *f = (const uint16_t *)feat_ + (int64_t)i * cin;
+        const uint16_t *w = (const uint16_t *)wpack_ + ((int64_t)k * cout + co) * cin;
+        for (int c = 0; c < cin; ++c) acc = fmaf(bf16_to_f32(f[c]), bf16_to_f32(w[c]), acc);
+      } else {
+        const float *f = (const float *)feat_ + (int64_t)i * cin;
+        const float *w = (const float *)wpack_ + ((int64_t)k * cout + co) * cin;
+        for (int c = 0; c < cin; ++c) acc = fmaf(f[c], w[c], acc);
+      }
+    }
+    if constexpr (BF16)
+      ((uint16_t *)out_)[t] = f32_to_bf16(acc);
+    else
+      ((float *)out_)[t] = acc;
+  }
+}
+
+template <int CIN, int COUT, int MT, bool BF16>
+static int launch_fwd(const void *feat, const void *wpack, const float *bias, const int32_t *nbr,
+                      int cap, int n_out, int kvol, void *out, hipStream_t stream) {
+  const int rows_per_block = 4 * MT * 16;
+  const int nb = (n_out + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL((spconv_fwd_mfma_kernel<CIN, COUT, MT, BF16>), dim3(nb), dim3(256), 0, stream,
+                     feat, wpack, bias, nbr, cap, n_out, kvol, out);
+  D3D_LAUNCH_TRY("spconv_fwd_mfma_kernel");
+  return D3D_OK;
+}
+
+#define FWD_CASE(CI, CO, MT)                                                                   \
+  if (cin == CI && cout == CO) {                                                               \
+    return dtype == D3D_BF16                                                                   \
+               ? launch_fwd<CI, CO, MT, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, stream) \
+               : launch_fwd<CI, CO, MT, false>(feat, wpack, bias, nbr, cap, n_out, kvol, out, stream); \
+  }
+
+extern "C" int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const float *bias,
+                                   const int32_t *nbr, int cap, int n_out, int kvol, int cin,
+                                   int cout, int dtype, void *out, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  D3D_REQUIRE(dtype == D3D_F32 || dtype == D3D_BF16, "d3d_sparse_conv_fwd: dtype %d", dtype);
+  D3D_REQUIRE(n_out >= 0 && n_out <= cap && kvol >= 1 && cin >= 1 && cout >= 1,
+              "d3d_sparse_conv_fwd: n_out=%d cap=%d kvol=%d cin=%d cout=%d", n_out, cap, kvol, cin,
+              cout);
+  if (n_out == 0) return D3D_OK;
+  D3D_REQUIRE(feat && wpack && nbr && out, "d3d_sparse_conv_fwd: null pointer");
+  FWD_CASE(16, 16, 2)
+  FWD_CASE(16, 32, 2)
+  FWD_CASE(32, 16, 2)
+  FWD_CASE(32, 32, 2)
+  FWD_CASE(32, 64, 2)
+  FWD_CASE(64, 32, 2)
+  FWD_CASE(64, 64, 2)
+  FWD_CASE(64, 128, 1)
+  FWD_CASE(128, 64, 2)
+  FWD_CASE(128, 128, 1)
+  int64_t items = (int64_t)n_out * cout;
+  int nb = (int)((items + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  if (dtype == D3D_BF16)
+    hipLaunchKernelGGL(spconv_fwd_generic_kernel<true>, dim3(nb), dim3(256), 0, stream, feat, wpack,
+                       bias, nbr, cap, n_out, kvol, cin, cout, out);
+  else
+    hipLaunchKernelGGL(spconv_fwd_generic_kernel<false>, dim3(nb), dim3(256), 0, stream, feat,
+                       wpack, bias, nbr, cap, n_out, kvol, cin, cout, out);
+  D3D_LAUNCH_TRY("spconv_fwd_generic_kernel");
+  return D3D_OK;
+}
+
+// ======================================================================= wgrad
+// bf16 MFMA wgrad.  grid = (kvol, splits): a block owns one kernel offset and a
+// contiguous range of output sites; it stages 64 gathered feature rows and the 64
+// matching dout rows in LDS as [16 sites][16 ch] bf16 tiles, then every wave pulls
+// transposed fragments with ds_read_b64_tr_b16 (sites become the MFMA k dimension)
+// and accumulates its share of the [CIN x COUT] tile; partial sums are added to
+// dW with f32 atomics (splits-way contention only).
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256)
+    spconv_wgrad_mfma_kernel(const uint16_t *__restrict__ feat, const uint16_t *__restrict__ dout,
+                             const int32_t *__restrict__ nbr, int cap, int n_out,
+                             int rows_per_split, float *__restrict__ dw) {
+  constexpr int CIT = CIN / 16, COT = COUT / 16;
+  constexpr int TILES = CIT * COT;
+  constexpr int TPW = (TILES + 3) / 4;  // tiles per wave
+  constexpr int STEP = 64;              // sites staged per iteration
+  // [chunk(4)][ch tile][16 sites][16 ch] bf16
+  __shared__ __attribute__((aligned(16))) uint16_t lds_f[4 * CIT * 256];
+  __shared__ __attribute__((aligned(16))) uint16_t lds_d[4 * COT * 256];
+  const int k = blockIdx.x;
+  const int s0 = blockIdx.y * rows_per_split;
+  int s1 = s0 + rows_per_split;
+  if (s1 > n_out) s1 = n_out;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+
+  f32x4_t acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int FSEG = CIN / 8;   // 16-byte segments per feature row
+  constexpr int DSEG = COUT / 8;
+  for (int base = s0; base < s1; base += STEP) {
+    // ---- stage gathered feature rows
+    for (int e = threadIdx.x; e < STEP * FSEG; e += 256) {
+      int r = e / FSEG, seg = e - r * FSEG;
+      int site = base + r;
+      int i = site < s1 ? nbr[(int64_t)k * cap + site] : -1;
+      uint4 v = i >= 0 ? *(const uint4 *)(feat + (int64_t)i * CIN + seg * 8) : make_uint4(0, 0, 0, 0);
+      int off = ((r >> 4) * CIT + (seg >> 1)) * 256 + (r & 15) * 16 + (seg & 1) * 8;
+      *(uint4 *)(lds_f + off) = v;
+    }
+    for (int e = threadIdx.x; e < STEP * DSEG; e += 256) {
+      int r = e / DSEG, seg = e - r * DSEG;
+      int site = base + r;
+      uint4 v = site < s1 ? *(const uint4 *)(dout + (int64_t)site * COUT + seg * 8)
+                          : make_uint4(0, 0, 0, 0);
+      int off = ((r >> 4) * COT + (seg >> 1)) * 256 + (r & 15) * 16 + (seg & 1) * 8;
+      *(uint4 *)(lds_d + off) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int chunk = 0; chunk < 4; ++chunk) {
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        int tile = wave + t * 4;
+        if (tile < TILES) {
+          int cit = tile / COT, cot = tile - cit * COT;
+          // lane reads column lr of the 4x16 sub-matrix of sites [lg*4, lg*4+4)
+          const uint16_t *pa = lds_f + (chunk * CIT + cit) * 256 + lg * 64 + lr * 4;
+          const uint16_t *pb = lds_d + (chunk * COT + cot) * 256 + lg * 64 + lr * 4;
+          // ds_read_b64_tr_b16 addressing: each lane passes the address of ITS 8 bytes in
+          // the row-major 4x16 block; hardware returns the transposed column.
+          s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t *)(pa));
+          s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t *)(pb));
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    int tile = wave + t * 4;
+    if (tile < TILES) {
+      int cit = tile / COT, cot = tile - cit * COT;
+      float *o = dw + ((int64_t)k * CIN + cit * 16 + lg * 4) * COUT + cot * 16 + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(o + r * COUT, acc[t][r]);
+    }
+  }
+}
+
+// generic wgrad (any dtype / channel count): block = (offset k, site split); each
+// thread owns dW elements e = tid + j*256 and walks the split's sites.
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+    spconv_wgrad_generic_kernel(const void *__restrict__ feat_, const void *__restrict__ dout_,
+                                const int32_t *__restrict__ nbr, int cap, int n_out,
+                                int rows_per_split, int cin, int cout, float *__restrict__ dw) {
+  extern __shared__ float smem[];  // [R][cin] + [R][cout]
+  constexpr int R = 32;
+  float *sf = smem, *sd = smem + R * cin;
+  const int k = blockIdx.x;
+  const int s0 = blockIdx.y * rows_per_split;
+  int s1 = s0 + rows_per_split;
+  if (s1 > n_out) s1 = n_out;
+  const int nel = cin * cout;
+  constexpr int MAXE = 64;  // supports cin*cout <= 16384
+  float acc[MAXE];
+#pragma unroll
+  for (int j = 0; j < MAXE; ++j) acc[j] = 0.f;
+  for (int base = s0; base < s1; base += R) {
+    for (int e = threadIdx.x; e < R * cin; e += 256) {
+      int r = e / cin, c = e - r * cin;
+      int site = base + r;
+      int i = site < s1 ? nbr[(int64_t)k * cap + site] : -1;
+      float v = 0.f;
+      if (i >= 0)
+        v = BF16 ? bf16_to_f32(((const uint16_t *)feat_)[(int64_t)i * cin + c])
+                 : ((const float *)feat_)[(int64_t)i * cin + c];
+      sf[e] = v;
+    }
+    for (int e = threadIdx.x; e < R * cout; e += 256) {
+      int r = e / cout, c = e - r * cout;
+      int site = base + r;
+      float v = 0.f;
+      if (site < s1)
+        v = BF16 ? bf16_to_f32(((const uint16_t *)dout_)[(int64_t)site * cout + c])
+                 : ((const float *)dout_)[(int64_t)site * cout + c];
+      sd[e] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MAXE; ++j) {
+      int e = threadIdx.x + j * 256;
+      if (e < nel) {
+        int ci = e / cout, co = e - ci * cout;
+        float a = acc[j];
+        for (int r = 0; r < R; ++r) a = fmaf(sf[r * cin + ci], sd[r * cout + co], a);
+        acc[j] = a;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < MAXE; ++j) {
+    int e = threadIdx.x + j * 256;
+    if (e < nel) atomicAdd(&dw[(int64_t)k * nel + e], acc[j]);
+  }
+}
+
+#define WGRAD_CASE(CI, CO)                                                                      \
+  if (dtype == D3D_BF16 && cin == CI && cout == CO) {                                           \
+    hipLaunchKernelGGL((spconv_wgrad_mfma_kernel<CI, CO>), dim3(kvol, splits), dim3(256), 0,    \
+                       stream, (const uint16_t *)feat, (const uint16_t *)dout, nbr, cap, n_out, \
+                       rows_per_split, dw);                                                     \
+    D3D_LAUNCH_TRY("spconv_wgrad_mfma_kernel");                                                 \
+    return D3D_OK;                                                                              \
+  }
+
+extern "C" int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const int32_t *nbr,
+                                     int cap, int n_out, int kvol, int cin, int cout, int dtype,
+                                     float *dw, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  D3D_REQUIRE(dtype == D3D_F32 || dtype == D3D_BF16, "d3d_sparse_conv_wgrad: dtype %d", dtype);
+  D3D_REQUIRE(n_out >= 0 && n_out <= cap && kvol >= 1 && cin >= 1 && cout >= 1,
+              "d3d_sparse_conv_wgrad: bad sizes");
+  D3D_REQUIRE(cin * cout <= 16384, "d3d_sparse_conv_wgrad: cin*cout=%d > 16384", cin * cout);
+  D3D_REQUIRE(dw, "d3d_sparse_conv_wgrad: null dw");
+  D3D_HIP_TRY(hipMemsetAsync(dw, 0, (size_t)kvol * cin * cout * sizeof(float), stream));
+  if (n_out == 0) return D3D_OK;
+  D3D_REQUIRE(feat && dout && nbr, "d3d_sparse_conv_wgrad: null pointer");
+  // enough blocks to fill 256 CUs a few times over, but >= 1024 sites per split
+  int splits = (256 * 4 + kvol - 1) / kvol;
+  int max_splits = (n_out + 1023) / 1024;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int rows_per_split = (n_out + splits - 1) / splits;
+  rows_per_split = (rows_per_split + 63) / 64 * 64;
+  splits = (n_out + rows_per_split - 1) / rows_per_split;
+  WGRAD_CASE(16, 16)
+  WGRAD_CASE(16, 32)
+  WGRAD_CASE(32, 32)
+  WGRAD_CASE(32, 64)
+  WGRAD_CASE(64, 64)
+  WGRAD_CASE(64, 128)
+  WGRAD_CASE(128, 128)
+  size_t smem = (size_t)32 * (cin + cout) * sizeof(float);
+  if (dtype == D3D_BF16)
+    hipLaunchKernelGGL(spconv_wgrad_generic_kernel<true>, dim3(kvol, splits), dim3(256), smem,
+                       stream, feat, dout, nbr, cap, n_out, rows_per_split, cin, cout, dw);
+  else
+    hipLaunchKernelGGL(spconv_wgrad_generic_kernel<false>, dim3(kvol, splits), dim3(256), smem,
+                       stream, feat, dout, nbr, cap, n_out, rows_per_split, cin, cout, dw);
+  D3D_LAUNCH_TRY("spconv_wgrad_generic_kernel");
+  return D3D_OK;
+}

@@ -1,0 +1,466 @@
+"""spconv-shaped API over the HIP sparse-conv kernels (C ABI in include/d3d.h).
+
+Mirrors what det3d/models/backbones/scn.py uses from the (un-vendored) `spconv`
+package: SparseConvTensor (with mutable .features and .dense()), SparseSequential,
+SparseModule, SubMConv3d, SparseConv3d -- same constructor arguments, weight
+layout [kD, kH, kW, Cin, Cout] and state-dict names, so reference checkpoints and
+the unmodified scn.py-style module stacks work (seam B3).
+
+MI355X-native differences under the hood:
+  * rulebooks are output-stationary neighbour tables built on device
+    (d3d_subm_rulebook / d3d_conv_rulebook); strided outputs come out sorted by
+    linear cell index (canonical order);
+  * `SparseSequential.plan()` enqueues every rulebook of a backbone as one chain
+    (device-side counts) and pays ONE host sync for all output sizes instead of one
+    per strided layer;
+  * conv fwd / dgrad / wgrad are single launches per layer (d3d_sparse_conv_*).
+There is no CPU implementation here: tensors must live on the GPU.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+
+_DT = {torch.float32: _lib.D3D_F32, torch.bfloat16: _lib.D3D_BF16}
+
+
+def _triple(v):
+    if isinstance(v, (list, tuple)):
+        assert len(v) == 3
+        return [int(x) for x in v]
+    return [int(v)] * 3
+
+
+def _need_cuda(t, what):
+    if not t.is_cuda:
+        raise _lib.D3dError("%s: tensor is on %s; det3d_amd sparse ops run on the GPU only "
+                            "(no CPU fallback)" % (what, t.device))
+
+
+class Rulebook:
+    """Neighbour tables of one conv geometry (shared through `indice_key`)."""
+
+    def __init__(self, kvol, cap_in, cap_out, nbr_out, nbr_in, pair_count, n_in, n_out,
+                 out_indices, out_shape, subm):
+        self.kvol = kvol
+        self.cap_in = cap_in
+        self.cap_out = cap_out
+        self.nbr_out = nbr_out      # int32 [kvol*cap_out]
+        self.nbr_in = nbr_in        # int32 [kvol*cap_in] (strided only)
+        self.pair_count = pair_count  # int32 [kvol] device
+        self.n_in = n_in
+        self.n_out = n_out
+        self.out_indices = out_indices
+        self.out_shape = out_shape
+        self.subm = subm
+
+    def pairs(self):
+        """number of rulebook pairs P (host int; one small D2H)."""
+        return int(self.pair_count.sum().item())
+
+    def canonical_pairs(self):
+        """(k, in_row, out_row) triples as a sorted numpy array -- test helper."""
+        t = self.nbr_out.view(self.kvol, self.cap_out)[:, : self.n_out].cpu().numpy()
+        k, o = np.nonzero(t >= 0)
+        trip = np.stack([k, t[k, o], o], axis=1).astype(np.int64)
+        order = np.lexsort((trip[:, 2], trip[:, 1], trip[:, 0]))
+        return trip[order]
+
+
+def conv_out_shape(in_shape, ksize, stride, padding):
+    return [(in_shape[j] + 2 * padding[j] - ksize[j]) // stride[j] + 1 for j in range(3)]
+
+
+def _count_tensor(n, device):
+    return torch.tensor([int(n)], dtype=torch.int32, device=device)
+
+
+def build_subm_rulebook(indices, n_dev, n, cap, batch, spatial_shape, ksize):
+    """Enqueue d3d_subm_rulebook.  `n` may be None while the count is still only on
+    the device (planning); `cap` bounds it."""
+    L = _lib.lib()
+    dev = indices.device
+    kvol = ksize[0] * ksize[1] * ksize[2]
+    nbr = torch.empty((kvol * cap,), dtype=torch.int32, device=dev)
+    pc = torch.empty((kvol,), dtype=torch.int32, device=dev)
+    wsb = L.d3d_subm_rulebook_workspace_bytes(cap)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    rc = L.d3d_subm_rulebook(indices.data_ptr(), n_dev.data_ptr(), cap, batch,
+                             _lib.i32_array(spatial_shape), _lib.i32_array(ksize), nbr.data_ptr(),
+                             pc.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
+    _lib.check(rc, "d3d_subm_rulebook")
+    return Rulebook(kvol, cap, cap, nbr, None, pc, n, n, indices, list(spatial_shape), True)
+
+
+def build_conv_rulebook(indices, n_dev, n, cap_in, batch, in_shape, ksize, stride, padding):
+    """Enqueue d3d_conv_rulebook; returns (rulebook, n_out_dev).  rulebook.n_out and
+    .out_indices are provisional (capacity views) until `finalize_conv_rulebook`."""
+    L = _lib.lib()
+    dev = indices.device
+    out_shape = conv_out_shape(in_shape, ksize, stride, padding)
+    kvol = ksize[0] * ksize[1] * ksize[2]
+    fan = 1
+    for j in range(3):
+        fan *= -(-ksize[j] // stride[j])  # ceil(k/s): outputs one input can reach per axis
+    cells = batch * out_shape[0] * out_shape[1] * out_shape[2]
+    cap_out = int(max(1, min(cap_in * fan, cells)))
+    coords_out = torch.empty((cap_out, 4), dtype=torch.int32, device=dev)
+    n_out_dev = torch.empty((1,), dtype=torch.int32, device=dev)
+    nbr_out = torch.empty((kvol * cap_out,), dtype=torch.int32, device=dev)
+    nbr_in = torch.empty((kvol * cap_in,), dtype=torch.int32, device=dev)
+    pc = torch.empty((kvol,), dtype=torch.int32, device=dev)
+    oshape = _lib.i32_array(out_shape)
+    wsb = L.d3d_conv_rulebook_workspace_bytes(batch, oshape)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    rc = L.d3d_conv_rulebook(indices.data_ptr(), n_dev.data_ptr(), cap_in, batch,
+                             _lib.i32_array(in_shape), _lib.i32_array(ksize),
+                             _lib.i32_array(stride), _lib.i32_array(padding), oshape,
+                             coords_out.data_ptr(), n_out_dev.data_ptr(), cap_out,
+                             nbr_out.data_ptr(), nbr_in.data_ptr(), pc.data_ptr(), ws.data_ptr(),
+                             wsb, _lib.stream_ptr(dev))
+    _lib.check(rc, "d3d_conv_rulebook")
+    rb = Rulebook(kvol, cap_in, cap_out, nbr_out, nbr_in, pc, n, None, coords_out, out_shape, False)
+    return rb, n_out_dev
+
+
+def finalize_conv_rulebook(rb, n_in, n_out):
+    if n_out > rb.cap_out:
+        raise _lib.D3dError("conv rulebook overflow: %d outputs > capacity %d" % (n_out, rb.cap_out))
+    rb.n_in = n_in
+    rb.n_out = n_out
+    rb.out_indices = rb.out_indices[:n_out]
+    return rb
+
+
+# --------------------------------------------------------------------- autograd
+class _SparseConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, weight, bias, rb):
+        _need_cuda(feats, "sparse conv")
+        L = _lib.lib()
+        if feats.dtype not in _DT:
+            raise _lib.D3dError("sparse conv supports float32 / bfloat16 features, got %s" % feats.dtype)
+        feats = feats.contiguous()
+        kvol, cin, cout = rb.kvol, weight.shape[-2], weight.shape[-1]
+        assert feats.shape[0] == rb.n_in and feats.shape[1] == cin, (feats.shape, rb.n_in, cin)
+        wpack = weight.detach().reshape(kvol, cin, cout).transpose(1, 2).contiguous().to(feats.dtype)
+        out = torch.empty((rb.n_out, cout), dtype=feats.dtype, device=feats.device)
+        b = bias.detach().float().contiguous() if bias is not None else None
+        rc = L.d3d_sparse_conv_fwd(feats.data_ptr(), wpack.data_ptr(), _lib.ptr(b),
+                                   rb.nbr_out.data_ptr(), rb.cap_out, rb.n_out, kvol, cin, cout,
+                                   _DT[feats.dtype], out.data_ptr(), _lib.stream_ptr(feats.device))
+        _lib.check(rc, "d3d_sparse_conv_fwd")
+        ctx.save_for_backward(feats, weight)
+        ctx.rb = rb
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        L = _lib.lib()
+        feats, weight = ctx.saved_tensors
+        rb = ctx.rb
+        kvol, cin, cout = rb.kvol, weight.shape[-2], weight.shape[-1]
+        gout = gout.contiguous().to(feats.dtype)
+        dt = _DT[feats.dtype]
+        stream = _lib.stream_ptr(feats.device)
+        gin = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            w3 = weight.detach().reshape(kvol, cin, cout)
+            if rb.subm:
+                # (j -> i at offset k)  <=>  (i -> j at offset kvol-1-k): same table, W flipped
+                wd = w3.flip(0).contiguous().to(feats.dtype)
+                nbr, cap = rb.nbr_out, rb.cap_out
+            else:
+                wd = w3.contiguous().to(feats.dtype)
+                nbr, cap = rb.nbr_in, rb.cap_in
+            gin = torch.empty((rb.n_in, cin), dtype=feats.dtype, device=feats.device)
+            rc = L.d3d_sparse_conv_fwd(gout.data_ptr(), wd.data_ptr(), None, nbr.data_ptr(), cap,
+                                       rb.n_in, kvol, cout, cin, dt, gin.data_ptr(), stream)
+            _lib.check(rc, "d3d_sparse_conv_fwd(dgrad)")
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=feats.device)
+            rc = L.d3d_sparse_conv_wgrad(feats.data_ptr(), gout.data_ptr(), rb.nbr_out.data_ptr(),
+                                         rb.cap_out, rb.n_out, kvol, cin, cout, dt, gw.data_ptr(),
+                                         stream)
+            _lib.check(rc, "d3d_sparse_conv_wgrad")
+            gw = gw.reshape(weight.shape).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gout.float().sum(0)
+        return gin, gw, gb, None
+
+
+class _DenseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, indices, batch, shape):
+        _need_cuda(feats, "SparseConvTensor.dense")
+        L = _lib.lib()
+        feats = feats.contiguous()
+        n, c = feats.shape
+        out = torch.empty((batch, c, shape[0], shape[1], shape[2]), dtype=feats.dtype,
+                          device=feats.device)
+        rc = L.d3d_dense_scatter(feats.data_ptr(), indices.data_ptr(), n, c, batch,
+                                 _lib.i32_array(shape), _DT[feats.dtype], out.data_ptr(),
+                                 _lib.stream_ptr(feats.device))
+        _lib.check(rc, "d3d_dense_scatter")
+        ctx.save_for_backward(indices)
+        ctx.meta = (n, c, batch, list(shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        (indices,) = ctx.saved_tensors
+        n, c, batch, shape = ctx.meta
+        g = g.contiguous()
+        gf = torch.empty((n, c), dtype=g.dtype, device=g.device)
+        rc = L.d3d_dense_gather(g.data_ptr(), indices.data_ptr(), n, c, batch,
+                                _lib.i32_array(shape), _DT[g.dtype], gf.data_ptr(),
+                                _lib.stream_ptr(g.device))
+        _lib.check(rc, "d3d_dense_gather")
+        return gf, None, None, None
+
+
+# ------------------------------------------------------------------- public API
+class SparseConvTensor:
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
+        """features [N, C]; indices [N, 4] int32 (batch, z, y, x)."""
+        self.features = features
+        self.indices = indices.int().contiguous() if indices.dtype != torch.int32 else indices.contiguous()
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)
+        self.indice_dict = {}
+        self.grid = grid
+
+    @property
+    def spatial_size(self):
+        return int(np.prod(self.spatial_shape))
+
+    def find_indice_pair(self, key):
+        if key is None:
+            return None
+        return self.indice_dict.get(key)
+
+    def dense(self, channels_first=True):
+        out = _DenseFn.apply(self.features, self.indices, self.batch_size, self.spatial_shape)
+        if not channels_first:
+            return out.permute(0, 2, 3, 4, 1).contiguous()
+        return out
+
+
+class SparseModule(nn.Module):
+    """marker base class, like spconv.SparseModule"""
+    pass
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0,
+                 dilation=1, groups=1, bias=True, subm=False, output_padding=0, transposed=False,
+                 inverse=False, indice_key=None, **kwargs):
+        super().__init__()
+        assert ndim == 3 and groups == 1 and not transposed and not inverse
+        assert _triple(dilation) == [1, 1, 1], "dilation is not used on the Det3D hot path"
+        self.ndim = ndim
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _triple(kernel_size)
+        self.stride = _triple(stride)
+        self.padding = _triple(padding)
+        self.subm = subm
+        self.indice_key = indice_key
+        self.weight = nn.Parameter(torch.empty(*self.kernel_size, in_channels, out_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # spconv v1.x: kaiming_uniform_(a=sqrt(5)) on the [kD,kH,kW,Cin,Cout] tensor
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self):
+        return "%d, %d, kernel_size=%s, stride=%s, padding=%s, subm=%s, indice_key=%s" % (
+            self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding,
+            self.subm, self.indice_key)
+
+    # -- geometry ---------------------------------------------------------------
+    def out_spatial_shape(self, in_shape):
+        if self.subm:
+            return list(in_shape)
+        return conv_out_shape(in_shape, self.kernel_size, self.stride, self.padding)
+
+    def _rulebook_key(self):
+        return self.indice_key if self.indice_key is not None else ("_anon", id(self))
+
+    def _get_rulebook(self, x):
+        """Planned (SparseSequential.plan) or cached-by-indice_key rulebook, else build it
+        now -- a strided build on this unplanned path costs one host sync."""
+        key = self._rulebook_key()
+        rb = x.indice_dict.get(key)
+        if rb is not None:
+            return rb
+        n = x.indices.shape[0]
+        n_dev = _count_tensor(n, x.indices.device)
+        if self.subm:
+            rb = build_subm_rulebook(x.indices, n_dev, n, max(n, 1), x.batch_size, x.spatial_shape,
+                                     self.kernel_size)
+        else:
+            rb, n_out_dev = build_conv_rulebook(x.indices, n_dev, n, max(n, 1), x.batch_size,
+                                                x.spatial_shape, self.kernel_size, self.stride,
+                                                self.padding)
+            finalize_conv_rulebook(rb, n, int(n_out_dev.item()))
+        x.indice_dict[key] = rb
+        return rb
+
+    def forward(self, x):
+        assert isinstance(x, SparseConvTensor)
+        rb = self._get_rulebook(x)
+        out_feats = _SparseConvFn.apply(x.features, self.weight, self.bias, rb)
+        out = SparseConvTensor(out_feats, rb.out_indices if not self.subm else x.indices,
+                               self.out_spatial_shape(x.spatial_shape), x.batch_size, x.grid)
+        out.indice_dict = x.indice_dict
+        return out
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None, **kwargs):
+        # like spconv, stride/padding are accepted and ignored for submanifold convs
+        super().__init__(3, in_channels, out_channels, kernel_size, 1, 0, dilation, groups, bias,
+                         subm=True, indice_key=indice_key)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None, **kwargs):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                         groups, bias, subm=False, indice_key=indice_key)
+
+
+def is_spconv_module(m):
+    return isinstance(m, SparseModule)
+
+
+class SparseSequential(SparseModule):
+    """spconv.SparseSequential: sparse modules get the SparseConvTensor, plain
+    nn.Modules (BatchNorm1d, ReLU) are applied to `.features`."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        from collections import OrderedDict
+
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError("name exists.")
+            self.add_module(name, module)
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError("index {} is out of range".format(idx))
+        if idx < 0:
+            idx += len(self)
+        it = iter(self._modules.values())
+        for _ in range(idx):
+            next(it)
+        return next(it)
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError("name exists")
+        self.add_module(name, module)
+
+    def forward(self, input):
+        for k, module in self._modules.items():
+            if is_spconv_module(module):
+                input = module(input)
+            else:
+                if isinstance(input, SparseConvTensor):
+                    if input.indices.shape[0] != 0:
+                        input.features = module(input.features)
+                else:
+                    input = module(input)
+        return input
+
+    # -- one-sync geometry planning ----------------------------------------------
+    def conv_layers(self):
+        """SparseConvolution modules in execution order (descends into children that
+        define `conv_layers`, e.g. residual blocks, and nested SparseSequentials)."""
+        out = []
+        for m in self._modules.values():
+            if isinstance(m, SparseConvolution):
+                out.append(m)
+            elif hasattr(m, "conv_layers"):
+                out.extend(m.conv_layers())
+        return out
+
+    def plan(self, x):
+        """Build every rulebook this stack needs for input `x` with a single host
+        sync: the strided chain is enqueued against capacity-sized buffers with
+        device-side counts, the counts are read once, then the submanifold tables
+        are enqueued with exact sizes.  Fills x.indice_dict."""
+        layers = self.conv_layers()
+        dev = x.indices.device
+        n0 = x.indices.shape[0]
+        # ---- phase A: strided chain
+        cur_idx, cur_n_dev, cur_cap, cur_shape = x.indices, _count_tensor(n0, dev), max(n0, 1), list(x.spatial_shape)
+        chain = []  # (layer, rb, n_out_dev, level_before)
+        levels = [dict(indices=cur_idx, n_dev=cur_n_dev, cap=cur_cap, shape=cur_shape)]
+        for m in layers:
+            if m.subm:
+                continue
+            rb, n_out_dev = build_conv_rulebook(cur_idx, cur_n_dev, None, cur_cap, x.batch_size,
+                                                cur_shape, m.kernel_size, m.stride, m.padding)
+            chain.append((m, rb, n_out_dev))
+            cur_idx, cur_n_dev, cur_cap, cur_shape = rb.out_indices, n_out_dev, rb.cap_out, rb.out_shape
+            levels.append(dict(indices=cur_idx, n_dev=cur_n_dev, cap=cur_cap, shape=cur_shape))
+        # ---- the one sync
+        if chain:
+            counts = torch.cat([c[2] for c in chain]).cpu().tolist()
+        else:
+            counts = []
+        ns = [n0] + [int(c) for c in counts]
+        for li, (m, rb, _) in enumerate(chain):
+            finalize_conv_rulebook(rb, ns[li], ns[li + 1])
+            key = m._rulebook_key()
+            x.indice_dict[key] = rb
+            levels[li + 1]["indices"] = rb.out_indices
+            levels[li + 1]["cap"] = max(ns[li + 1], 1)
+        # ---- phase B: submanifold tables with exact sizes
+        level = 0
+        for m in layers:
+            if not m.subm:
+                level += 1
+                continue
+            key = m._rulebook_key()
+            if key in x.indice_dict:
+                continue
+            lv = levels[level]
+            n = ns[level]
+            x.indice_dict[key] = build_subm_rulebook(lv["indices"], _count_tensor(n, dev), n,
+                                                     max(n, 1), x.batch_size, lv["shape"],
+                                                     m.kernel_size)
+        return x.indice_dict
+
+
+class ToDense(SparseModule):
+    def forward(self, x):
+        return x.dense()

@@ -1,0 +1,177 @@
+/*
+ * d3d.h -- C ABI of libd3d_hip.so: the MI355X (gfx950) hot path of Det3D,
+ *          voxelize -> VFE -> sparse 3D conv -> dense -> rotated NMS.
+ *
+ * Conventions (all entry points):
+ *   - plain C, no torch / pybind types; every pointer marked "dev" is a device
+ *     (HBM) pointer owned by the caller, the library never allocates or frees
+ *     caller-visible memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every
+ *     call only enqueues work on that stream and returns, no hidden syncs;
+ *   - returns 0 on success, a negative D3D_E* code otherwise; the message for
+ *     the calling thread's last failure is d3d_last_error();
+ *   - "count" outputs (number of voxels, number of active output sites) are
+ *     written to DEVICE memory so a whole geometry chain can be enqueued
+ *     without a host round trip; buffers are sized by the caller to the
+ *     capacities documented per call;
+ *   - workspace is caller-provided scratch; *_workspace_bytes() gives the size.
+ *
+ * Each entry point names the reference interface it replaces (path:line under
+ * the Det3D tree) -- the reference has no FFI of its own for most of them: the
+ * seams are Python functions and the un-vendored
+ * spconv extension.
+ */
+#ifndef D3D_H
+#define D3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D3D_ABI_VERSION 1
+
+#define D3D_OK 0
+#define D3D_EINVAL -1    /* bad argument / unsupported shape           */
+#define D3D_ECAPACITY -2 /* workspace or key space too small            */
+#define D3D_EHIP -3      /* HIP runtime error (see d3d_last_error())    */
+
+/* feature element types of the sparse-conv kernels */
+#define D3D_F32 0
+#define D3D_BF16 1
+
+typedef void *d3d_stream_t;
+
+int d3d_abi_version(void);
+const char *d3d_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Voxelizer.  Replaces det3d/ops/point_cloud/point_cloud_ops.py:112-184
+ * (points_to_voxel + _points_to_voxel_reverse_kernel :7-55), its C++ twin
+ * point_cloud_ops.h:12-71, VoxelGenerator.generate
+ * (det3d/core/input/voxel_generator.py:19-27) and, with `mean_feats`, the
+ * mean VFE det3d/models/readers/voxel_encoder.py:206-211.  One call handles a
+ * whole batch laid out like collate_kitti does
+ * (det3d/torchie/parallel/collate.py:100-137): frames concatenated along dim
+ * 0, frame b = rows [frame_offsets[b], frame_offsets[b+1]).
+ *
+ *  points        dev  [n_points, point_stride] f32 (x,y,z,extra...)
+ *  frame_offsets dev  [batch+1] i32
+ *  voxel_size[3], range[6] (xyzxyz), grid[3] (x,y,z) -- host; grid is
+ *                 round((hi-lo)/vs) computed in f32 exactly as the reference.
+ *  max_points T, max_voxels M (per frame, with the reference's early `break`)
+ * outputs (capacity rows = batch*M):
+ *  coors      dev [batch*M, 4] i32 (b, z, y, x), frames packed back to back
+ *  num_points dev [batch*M]    i32
+ *  voxels     dev [batch*M, T, point_stride] f32 zero padded, or NULL
+ *  mean_feats dev [batch*M, n_mean_ch] f32 = sum_t voxels[:, t, :n_mean_ch] /
+ *             num_points, or NULL
+ *  num_voxels dev [batch+1] i32: per-frame voxel count, then the total
+ */
+size_t d3d_voxelize_workspace_bytes(int64_t n_points, int batch, int max_points, int max_voxels);
+int d3d_voxelize(const float *points, int64_t n_points, int point_stride,
+                 const int32_t *frame_offsets, int batch, const float *voxel_size,
+                 const float *range, const int32_t *grid, int max_points, int max_voxels,
+                 int32_t *coors, int32_t *num_points, float *voxels, float *mean_feats,
+                 int n_mean_ch, int32_t *num_voxels, void *workspace, size_t workspace_bytes,
+                 d3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Rulebooks.  Replace spconv's get_indice_pairs (called from
+ * SubMConv3d/SparseConv3d.forward; call sites det3d/models/backbones/scn.py:
+ * 22-43,106-157,323-355; spconv itself is not vendored -- SURVEY.md App. A).
+ * Layout is output-stationary: nbr[k*cap + o] = input row that reaches output
+ * row o through kernel offset k (k = (kz*kH + ky)*kW + kx), or -1.
+ *
+ *  coords dev [n,4] i32 (b,z,y,x); n is read from DEVICE memory (*n_dev) so
+ *  the chain voxelize -> rulebooks needs no host sync; `cap` bounds n.
+ *  pair_count dev [kvol] i32: pairs per offset (centre included).
+ */
+size_t d3d_subm_rulebook_workspace_bytes(int cap);
+int d3d_subm_rulebook(const int32_t *coords, const int32_t *n_dev, int cap, int batch,
+                      const int32_t *spatial_shape /* host [3] z,y,x */,
+                      const int32_t *ksize /* host [3] */, int32_t *nbr /* dev [kvol*cap] */,
+                      int32_t *pair_count, void *workspace, size_t workspace_bytes,
+                      d3d_stream_t stream);
+
+/* strided (regular) sparse conv: out = floor((in + 2p - k)/s) + 1 per dim;
+ * output sites = cells with >= 1 active input in their receptive field,
+ * emitted sorted ascending by ((b*D + z)*H + y)*W + x (canonical order of
+ * SURVEY.md App. A.3).
+ *  coords_out dev [cap_out,4]; n_out_dev dev [1]
+ *  nbr_out dev [kvol*cap_out]: output row o, offset k -> input row / -1
+ *  nbr_in  dev [kvol*cap_in] : input row i, offset k -> output row / -1
+ */
+size_t d3d_conv_rulebook_workspace_bytes(int batch, const int32_t *out_shape);
+int d3d_conv_rulebook(const int32_t *coords_in, const int32_t *n_in_dev, int cap_in, int batch,
+                      const int32_t *in_shape, const int32_t *ksize, const int32_t *stride,
+                      const int32_t *padding, const int32_t *out_shape, int32_t *coords_out,
+                      int32_t *n_out_dev, int cap_out, int32_t *nbr_out, int32_t *nbr_in,
+                      int32_t *pair_count, void *workspace, size_t workspace_bytes,
+                      d3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Sparse convolution arithmetic.  Replaces spconv's indice_conv /
+ * indice_conv_backward (gather -> GEMM -> scatter-add per offset, SURVEY.md
+ * App. A.2).  Output-stationary: out[o,:] = bias + sum_k in[nbr[k][o],:] @ W[k].
+ *
+ *  feat   dev [n_in, cin]  dtype (D3D_F32 | D3D_BF16)
+ *  wpack  dev [kvol, cout, cin] dtype  (W[k] transposed: cin contiguous)
+ *  bias   dev [cout] f32 or NULL
+ *  nbr    dev [kvol*cap] (see above), n_out rows are produced
+ *  out    dev [n_out, cout] dtype
+ * The same entry point computes the data gradient: pass grad_out as `feat`,
+ * nbr_in (strided) or nbr with flipped k (submanifold) and W[k] untransposed.
+ */
+int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const float *bias,
+                        const int32_t *nbr, int cap, int n_out, int kvol, int cin, int cout,
+                        int dtype, void *out, d3d_stream_t stream);
+
+/* weight gradient: dw[k][ci][co] = sum_o feat[nbr[k][o]][ci] * dout[o][co]
+ *  dw dev [kvol, cin, cout] f32, overwritten. */
+int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const int32_t *nbr, int cap,
+                          int n_out, int kvol, int cin, int cout, int dtype, float *dw,
+                          d3d_stream_t stream);
+
+/* SparseConvTensor.dense() (spconv; call sites scn.py:192-195,363-367):
+ * scatter feat[n,c] to dense [batch, c, D, H, W] (zero elsewhere; the caller
+ * views it as [batch, c*D, H, W]).  `dense` is fully written.  The backward
+ * is d3d_dense_gather. */
+int d3d_dense_scatter(const void *feat, const int32_t *coords, int n, int c, int batch,
+                      const int32_t *spatial_shape, int dtype, void *dense, d3d_stream_t stream);
+int d3d_dense_gather(const void *dense, const int32_t *coords, int n, int c, int batch,
+                     const int32_t *spatial_shape, int dtype, void *feat, d3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Rotated NMS.  Replaces rotate_nms_cc (det3d/ops/nms/nms_cpu.py:34-45) +
+ * rotate_non_max_suppression_cpu (det3d/ops/nms/nms_cpu.h:73-169), as driven
+ * by box_torch_ops.rotate_nms (det3d/core/bbox/box_torch_ops.py:528-549).
+ *  boxes dev [n,5] f32 (x, y, w, l, r) ALREADY sorted by descending score
+ *  keep  dev [max_keep] i32 indices into boxes, ascending = score order
+ *  n_keep dev [1] i32
+ * Semantics: skip pair if standup-AABB IoU <= 0; suppress if polygon IoU >=
+ * thresh (the reference CPU rule, not the `>` of its unused GPU kernels).
+ */
+size_t d3d_rotate_nms_workspace_bytes(int n);
+int d3d_rotate_nms(const float *boxes, int n, float thresh, int max_keep, int32_t *keep,
+                   int32_t *n_keep, void *workspace, size_t workspace_bytes,
+                   d3d_stream_t stream);
+
+/* pairwise rotated BEV IoU, iou[m,n]; boxes as above.  Covers the north-star
+ * "rotated-IoU / iou3d" item (det3d/ops/iou3d/src/iou3d_kernel.cu:214-221,
+ * dead code in the reference). */
+int d3d_rotate_iou(const float *boxes_a, int m, const float *boxes_b, int n, float *iou,
+                   d3d_stream_t stream);
+
+/* axis-aligned NMS with the reference's +1 pixel convention and `>` rule
+ * (det3d/ops/nms/nms_gpu.py:22-33,67-126; nms_kernel.cu:38-157).
+ *  boxes dev [n,4] f32 (x1,y1,x2,y2) sorted by descending score. */
+int d3d_nms(const float *boxes, int n, float thresh, int max_keep, int32_t *keep,
+            int32_t *n_keep, void *workspace, size_t workspace_bytes, d3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D3D_H */

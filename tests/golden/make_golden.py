@@ -1,0 +1,290 @@
+"""Regenerate tests/golden/*.npz|*.pt by RUNNING THE REFERENCE'S OWN PYTHON CODE
+(/root/reference/det3d, loaded through ref_loader's stubs) on small seeded inputs.
+
+    python tests/golden/make_golden.py
+
+Only works in the build container (needs /root/reference).  The produced files are
+committed; tests never import the reference.  What each file pins:
+
+  voxel_cases.npz   det3d/ops/point_cloud/point_cloud_ops.py:7-55,112-184 run as plain
+                    Python (numba.jit stubbed to identity) -> voxels/coors/num_points
+  rotate_iou.npz    det3d/ops/nms/nms_gpu.py:180-416 (devRotateIoU, the numba-CUDA
+                    rotated IoU) run as plain Python -> IoU of box pairs
+  vfe_pfn.pt        VoxelFeatureExtractorV3 (voxel_encoder.py:197-211), PillarFeatureNet +
+                    PointPillarsScatter (pillar_encoder.py:17-211)
+  rpn.pt            RPN (necks/rpn.py:22-159) in three stride configurations
+  head.pt           MultiGroupHead forward / loss / predict (mg_head.py:385-1085), losses
+                    (losses.py), second_box_decode (box_torch_ops.py:80-148).  predict()'s
+                    rotate_nms_cc needs the boost extension, which cannot be built here:
+                    it is replaced by this repo's oracle NMS, so head.pt pins everything
+                    in predict() EXCEPT the polygon step.
+  anchors_targets.npz  AnchorGeneratorRange + create_target_np (core/anchor/*)
+"""
+import collections
+import collections.abc
+import logging
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import ref_loader  # noqa: E402
+
+for _n in ("Iterable", "Mapping", "Sequence"):
+    if not hasattr(collections, _n):
+        setattr(collections, _n, getattr(collections.abc, _n))
+
+KITTI_RANGE = [0, -40.0, -3.0, 70.4, 40.0, 1.0]
+KITTI_VS = [0.05, 0.05, 0.1]
+PP_RANGE = [0, -39.68, -3, 69.12, 39.68, 1]
+PP_VS = [0.16, 0.16, 4]
+
+
+def voxel_cases():
+    pc = ref_loader.ref("det3d.ops.point_cloud.point_cloud_ops")
+    rng = np.random.default_rng(1234)
+    out = {}
+
+    def run(name, pts, vs, rg, T, M):
+        v, c, n = pc.points_to_voxel(pts, vs, rg, T, True, M)
+        out[name + "_points"] = pts
+        out[name + "_cfg"] = np.array(list(vs) + list(rg) + [T, M], dtype=np.float64)
+        out[name + "_voxels"] = v
+        out[name + "_coors"] = c
+        out[name + "_num"] = n
+
+    # (i) sparse random cloud, no cap, incl. out-of-range points
+    pts = rng.uniform([-2, -42, -3.5, 0], [72, 42, 1.5, 1], size=(1200, 4)).astype(np.float32)
+    run("sparse", pts, KITTI_VS, KITTI_RANGE, 5, 20000)
+    # (ii) max_voxels cap + early break
+    run("capped", pts, KITTI_VS, KITTI_RANGE, 5, 150)
+    # (iii) clustered: many points per voxel (> T), points exactly on cell/range boundaries
+    centers = rng.uniform([5, -10, -2, 0], [30, 10, 0, 1], size=(40, 4))
+    cl = (centers[rng.integers(0, 40, 1500)] + rng.normal(0, 0.03, (1500, 4))).astype(np.float32)
+    edge = np.array([[0, -40, -3, .5], [70.4, 40, 1, .5], [70.39999, 39.99999, 0.99999, .5],
+                     [0.05, -39.95, -2.9, .1], [0.1, 0.0, 0.0, .2], [35.2, 0.05, -1.0, .3],
+                     [-0.0, -0.0, -0.0, .4]], dtype=np.float32)
+    run("clustered", np.concatenate([cl, edge]).astype(np.float32), KITTI_VS, KITTI_RANGE, 3, 20000)
+    # (iv) pillars (z collapses to one cell), T large, 5-channel points
+    p5 = rng.uniform([0, -39.68, -3, 0, 0], [69.12, 39.68, 1, 1, 0.5], size=(900, 5)).astype(np.float32)
+    p5[:300, :2] = p5[0, :2] + rng.normal(0, 0.05, (300, 2)).astype(np.float32)
+    run("pillars", p5, PP_VS, PP_RANGE, 100, 12000)
+    np.savez_compressed(os.path.join(HERE, "voxel_cases.npz"), **out)
+    print("voxel_cases:", {k: v.shape for k, v in out.items() if k.endswith("_voxels")})
+
+
+def rotate_iou_cases():
+    ng = ref_loader.ref("det3d.ops.nms.nms_gpu")
+    rng = np.random.default_rng(7)
+    n = 160
+    a = np.stack([rng.uniform(0, 6, n), rng.uniform(0, 6, n), rng.uniform(1, 3, n),
+                  rng.uniform(2, 5, n), rng.uniform(-3.2, 3.2, n)], 1).astype(np.float32)
+    b = a.copy()
+    b[:, :2] += rng.normal(0, 1.0, (n, 2)).astype(np.float32)
+    b[:, 2:4] *= rng.uniform(0.7, 1.3, (n, 2)).astype(np.float32)
+    b[:, 4] += rng.normal(0, 0.6, n).astype(np.float32)
+    # special cases: identical, nested, 90 degrees, disjoint
+    a[:4] = [[1, 1, 2, 4, 0.3], [1, 1, 4, 4, 0], [1, 1, 2, 4, 0], [0, 0, 1, 1, 0]]
+    b[:4] = [[1, 1, 2, 4, 0.3], [1, 1, 1, 1, 0.5], [1, 1, 2, 4, np.pi / 2], [5, 5, 1, 1, 0.2]]
+    iou = np.array([ng.devRotateIoU(a[i].copy(), b[i].copy()) for i in range(n)], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "rotate_iou.npz"), a=a, b=b, iou=iou)
+    print("rotate_iou:", iou[:6])
+
+
+def vfe_pfn():
+    ve = ref_loader.ref("det3d.models.readers.voxel_encoder")
+    pe = ref_loader.ref("det3d.models.readers.pillar_encoder")
+    torch.manual_seed(0)
+    out = {}
+    M, T, C = 50, 5, 4
+    num = torch.randint(1, T + 1, (M,), dtype=torch.int32)
+    feats = torch.randn(M, T, C)
+    feats = feats * (torch.arange(T)[None, :] < num[:, None]).float()[:, :, None]
+    vfe = ve.VoxelFeatureExtractorV3(num_input_features=4)
+    out["vfe"] = dict(features=feats, num_voxels=num, out=vfe(feats, num))
+    vfe3 = ve.VoxelFeatureExtractorV3(num_input_features=3)
+    out["vfe3"] = dict(out=vfe3(feats, num))
+
+    M, T, C = 60, 12, 4
+    num = torch.randint(1, T + 1, (M,), dtype=torch.int32)
+    feats = torch.rand(M, T, C) * torch.tensor([69.0, 79.0, 4.0, 1.0]) + torch.tensor([0, -39.6, -3.0, 0])
+    feats = feats * (torch.arange(T)[None, :] < num[:, None]).float()[:, :, None]
+    coors = torch.stack([torch.randint(0, 2, (M,)), torch.zeros(M, dtype=torch.long),
+                         torch.randint(0, 496, (M,)), torch.randint(0, 432, (M,))], 1).int()
+    pfn = pe.PillarFeatureNet(num_input_features=4, num_filters=(16,), with_distance=False,
+                              voxel_size=PP_VS, pc_range=PP_RANGE)
+    pfn.train()
+    y_train = pfn(feats, num, coors)
+    pfn.eval()
+    y_eval = pfn(feats, num, coors)
+    # unique coords per batch for the scatter
+    lin = coors[:, 0].long() * 10 ** 7 + coors[:, 2].long() * 432 + coors[:, 3].long()
+    _, first = np.unique(lin.numpy(), return_index=True)
+    keep = torch.from_numpy(np.sort(first))
+    sc = pe.PointPillarsScatter(num_input_features=16)
+    canvas = sc(y_eval[keep].detach(), coors[keep], 2, [432, 496, 1])
+    out["pfn"] = dict(state=pfn.state_dict(), features=feats, num_voxels=num, coors=coors,
+                      out_train=y_train.detach(), out_eval=y_eval.detach(), keep=keep,
+                      canvas_nonzero=canvas.nonzero(), canvas_vals=canvas[canvas != 0],
+                      canvas_shape=torch.tensor(canvas.shape))
+    torch.save(out, os.path.join(HERE, "vfe_pfn.pt"))
+    print("vfe_pfn:", y_train.shape, canvas.shape)
+
+
+RPN_CFGS = {
+    "second": dict(layer_nums=[2], ds_layer_strides=[1], ds_num_filters=[16],
+                   us_layer_strides=[1], us_num_filters=[16], num_input_features=16),
+    "pillars": dict(layer_nums=[1, 2, 2], ds_layer_strides=[2, 2, 2], ds_num_filters=[8, 16, 32],
+                    us_layer_strides=[1, 2, 4], us_num_filters=[8, 8, 8], num_input_features=8),
+    "nusc_pp": dict(layer_nums=[1, 1, 1], ds_layer_strides=[2, 2, 2], ds_num_filters=[8, 16, 32],
+                    us_layer_strides=[0.5, 1, 2], us_num_filters=[8, 8, 8], num_input_features=8),
+    "cbgs": dict(layer_nums=[2, 2], ds_layer_strides=[1, 2], ds_num_filters=[8, 16],
+                 us_layer_strides=[1, 2], us_num_filters=[16, 16], num_input_features=16),
+}
+
+
+def rpn_cases():
+    rpn = ref_loader.ref("det3d.models.necks.rpn")
+    out = {}
+    for name, cfg in RPN_CFGS.items():
+        torch.manual_seed(hash(name) % 1000)
+        m = rpn.RPN(logger=logging.getLogger("RPN"), **cfg)
+        x = torch.randn(2, cfg["num_input_features"], 16, 24)
+        m.train()
+        y_train = m(x)
+        state_after_train = {k: v.clone() for k, v in m.state_dict().items()}
+        m.eval()
+        y_eval = m(x)
+        out[name] = dict(cfg=cfg, state=state_after_train, x=x, out_train=y_train.detach(),
+                         out_eval=y_eval.detach(), downsample_factor=float(m.downsample_factor))
+        print("rpn", name, tuple(y_train.shape))
+    torch.save(out, os.path.join(HERE, "rpn.pt"))
+
+
+def _patch_nms():
+    """predict() -> box_torch_ops.rotate_nms -> rotate_nms_cc needs the boost extension;
+    substitute this repo's oracle for that single function (documented above)."""
+    from oracle import clib
+
+    bto = ref_loader.ref("det3d.core.bbox.box_torch_ops")
+    bto.rotate_nms_cc = lambda dets, thresh: clib.rotate_nms_cc(dets, thresh)
+    return bto
+
+
+def head_cases():
+    bto = _patch_nms()
+    mg = ref_loader.ref("det3d.models.bbox_heads.mg_head")
+    coders = ref_loader.ref("det3d.core.bbox.box_coders")
+    ref_loader.ref("det3d.models.losses.losses")
+    out = {}
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+
+    def make(name, tasks, coder, loss_aux, in_ch, H, W, direction_offset, test_cfg):
+        torch.manual_seed(3)
+        head = mg.MultiGroupHead(
+            mode="3d", in_channels=in_ch, norm_cfg=None, tasks=tasks, weights=[1] * len(tasks),
+            box_coder=coder, encode_background_as_zeros=True,
+            loss_norm=dict(type="NormByNumPositives", pos_cls_weight=1.0, neg_cls_weight=2.0),
+            loss_cls=dict(type="SigmoidFocalLoss", alpha=0.25, gamma=2.0, loss_weight=1.0),
+            use_sigmoid_score=True,
+            loss_bbox=dict(type="WeightedSmoothL1Loss", sigma=3.0,
+                           code_weights=[1.0] * coder.code_size, codewise=True, loss_weight=2.0),
+            encode_rad_error_by_sin=not coder.vec_encode, loss_aux=loss_aux,
+            direction_offset=direction_offset, logger=logging.getLogger("head"))
+        B = 2
+        x = torch.randn(B, in_ch, H, W)
+        # make some logits large so predict() has detections
+        for t in head.tasks:
+            torch.nn.init.normal_(t.conv_cls.bias, 0.0, 1.5)
+        preds = head(x)
+        anchors, labels, reg_targets = [], [], []
+        for ti, t in enumerate(tasks):
+            nc = len(t["class_names"])
+            A = H * W * 2 * nc
+            an = torch.zeros(B, A, coder.n_dim)
+            ys, xs = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+            base = torch.stack([xs * 2.0 + 1.0, ys * 2.0 - 10.0], -1).reshape(H * W, 1, 2)
+            an[:, :, :2] = base.expand(H * W, 2 * nc, 2).reshape(1, A, 2)
+            an[:, :, 2] = -1.0
+            an[:, :, 3:6] = torch.tensor([1.6, 3.9, 1.56])
+            rot = torch.tensor([0.0, 1.57]).repeat(H * W * nc)
+            an[:, :, -1] = rot
+            anchors.append(an)
+            lab = torch.randint(-1, nc + 1, (B, A), dtype=torch.int32)
+            lab[torch.rand(B, A) < 0.8] = 0
+            labels.append(lab)
+            reg_targets.append(torch.randn(B, A, coder.code_size) * 0.3)
+        example = dict(voxels=None, num_points=None, coordinates=None, anchors=anchors, labels=labels,
+                       reg_targets=reg_targets, metadata=[dict(token=i) for i in range(B)])
+        head.train()
+        losses = head.loss(example, preds)
+        total = sum(losses["loss"])
+        grads = torch.autograd.grad(total, [x.requires_grad_(False)] if False else list(head.parameters()),
+                                    allow_unused=True)
+        head.eval()
+        with torch.no_grad():
+            dets = head.predict(example, head(x), test_cfg)
+        rec = dict(
+            tasks=tasks, coder=dict(n_dim=coder.n_dim, vec=coder.vec_encode, linear_dim=coder.linear_dim),
+            loss_aux=loss_aux, in_ch=in_ch, direction_offset=direction_offset, test_cfg=dict(test_cfg, nms=dict(test_cfg["nms"])),
+            state=head.state_dict(), x=x, preds=[{k: v.detach() for k, v in p.items()} for p in preds],
+            anchors=anchors, labels=labels, reg_targets=reg_targets,
+            loss=[l.detach() for l in losses["loss"]],
+            loss_parts={k: [torch.as_tensor(v).detach().float() for v in losses[k]]
+                        for k in ("cls_pos_loss", "cls_neg_loss", "dir_loss_reduced",
+                                  "cls_loss_reduced", "loc_loss_reduced")},
+            grad_norms=[float(g.norm()) if g is not None else 0.0 for g in grads],
+            dets=[{k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()} for d in dets])
+        out[name] = rec
+        print("head", name, "loss", [float(l) for l in losses["loss"]], "dets", [d["scores"].shape[0] for d in dets])
+
+    kitti_test = Cfg(nms=Cfg(use_rotate_nms=True, use_multi_class_nms=False, nms_pre_max_size=1000,
+                             nms_post_max_size=100, nms_iou_threshold=0.01),
+                     score_threshold=0.3, post_center_limit_range=[0, -40.0, -5.0, 70.4, 40.0, 5.0],
+                     max_per_img=100)
+    make("kitti", [dict(num_class=1, class_names=["Car"])],
+         coders.GroundBox3dCoderTorch(False, False, n_dim=7),
+         dict(type="WeightedSoftmaxClassificationLoss", name="direction_classifier", loss_weight=0.2),
+         16, 8, 10, 0.0, kitti_test)
+    nusc_test = Cfg(nms=Cfg(use_rotate_nms=True, use_multi_class_nms=False, nms_pre_max_size=1000,
+                            nms_post_max_size=83, nms_iou_threshold=0.2),
+                    score_threshold=0.1, post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
+                    max_per_img=500)
+    make("nusc", [dict(num_class=1, class_names=["car"]),
+                  dict(num_class=2, class_names=["truck", "construction_vehicle"])],
+         coders.GroundBox3dCoderTorch(False, True, n_dim=9), None, 16, 6, 8, 0.0, nusc_test)
+    lyft_test = Cfg(nms=Cfg(use_rotate_nms=True, use_multi_class_nms=False, nms_pre_max_size=1000,
+                            nms_post_max_size=80, nms_iou_threshold=0.2),
+                    score_threshold=0.1, post_center_limit_range=[-100, -100, -10.0, 100, 100, 10.0],
+                    max_per_img=500)
+    make("lyft", [dict(num_class=2, class_names=["car", "bus"])],
+         coders.GroundBox3dCoderTorch(False, False, n_dim=7),
+         dict(type="WeightedSoftmaxClassificationLoss", name="direction_classifier", loss_weight=0.2),
+         16, 6, 8, 0.785, lyft_test)
+    torch.save(out, os.path.join(HERE, "head.pt"))
+
+
+def main():
+    ref_loader.install()
+    which = sys.argv[1:] or ["voxel", "iou", "vfe", "rpn", "head"]
+    if "voxel" in which:
+        voxel_cases()
+    if "iou" in which:
+        rotate_iou_cases()
+    if "vfe" in which:
+        vfe_pfn()
+    if "rpn" in which:
+        rpn_cases()
+    if "head" in which:
+        head_cases()
+
+
+if __name__ == "__main__":
+    main()

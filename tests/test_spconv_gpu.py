@@ -1,0 +1,207 @@
+"""HIP rulebooks + sparse conv (fwd / dgrad / wgrad) vs oracle/spconv_ref.py.
+Rulebooks: bit-exact as canonical sorted sets.  Features: f32
+path within 1e-4 (fp32 reassociation), bf16 path within the bf16 budget stated inline."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import spconv_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_sparse(rng, batch, shape, n_per, c, clustered=True):
+    idx = []
+    for b in range(batch):
+        if clustered:
+            ctr = rng.integers(0, [shape[0], shape[1], shape[2]], size=(max(n_per // 12, 1), 3))
+            pts = ctr[rng.integers(0, len(ctr), n_per * 2)] + rng.integers(-2, 3, size=(n_per * 2, 3))
+            pts = np.clip(pts, 0, np.array(shape) - 1)
+            pts = np.unique(pts, axis=0)
+            rng.shuffle(pts)
+            pts = pts[:n_per]
+        else:
+            lin = rng.choice(shape[0] * shape[1] * shape[2], size=n_per, replace=False)
+            pts = np.stack([lin // (shape[1] * shape[2]), (lin // shape[2]) % shape[1], lin % shape[2]], 1)
+        idx.append(np.concatenate([np.full((len(pts), 1), b), pts], 1))
+    idx = np.concatenate(idx).astype(np.int32)
+    feats = rng.standard_normal((len(idx), c)).astype(np.float32)
+    return idx, feats
+
+
+GEOMS = [
+    ([3, 3, 3], [1, 1, 1], [0, 0, 0], True),
+    ([3, 3, 3], [2, 2, 2], [1, 1, 1], False),
+    ([3, 3, 3], [2, 2, 2], [0, 1, 1], False),
+    ([3, 1, 1], [2, 1, 1], [0, 0, 0], False),
+    ([1, 1, 1], [1, 1, 1], [0, 0, 0], True),
+]
+
+
+def _build(idx, batch, shape, ksize, stride, padding, subm):
+    from det3d_amd import spconv
+
+    ind = torch.from_numpy(idx).cuda()
+    n = len(idx)
+    n_dev = torch.tensor([n], dtype=torch.int32, device="cuda")
+    if subm:
+        return spconv.build_subm_rulebook(ind, n_dev, n, max(n, 1), batch, shape, ksize)
+    rb, n_out = spconv.build_conv_rulebook(ind, n_dev, n, max(n, 1), batch, shape, ksize, stride, padding)
+    return spconv.finalize_conv_rulebook(rb, n, int(n_out.item()))
+
+
+@pytest.mark.parametrize("ksize,stride,padding,subm", GEOMS)
+def test_rulebook_bit_exact(ksize, stride, padding, subm):
+    rng = np.random.default_rng(1)
+    shape = [11, 40, 36]
+    idx, _ = _random_sparse(rng, 3, shape, 900, 1)
+    rb = _build(idx, 3, shape, ksize, stride, padding, subm)
+    out_idx, out_shape, pairs = R.get_indice_pairs(idx, 3, shape, ksize, stride, padding, subm)
+    assert rb.n_out == len(out_idx)
+    assert np.array_equal(rb.out_indices.cpu().numpy(), out_idx)  # sorted order for strided
+    assert list(rb.out_shape) == list(out_shape)
+    ref = R.canonical_pairs(pairs)
+    assert np.array_equal(rb.canonical_pairs(), ref)
+    assert rb.pairs() == len(ref)
+    pc = rb.pair_count.cpu().numpy()
+    assert pc.tolist() == [len(p[0]) for p in pairs]
+    if not subm:  # input-stationary twin table describes the same pair set
+        t = rb.nbr_in.view(rb.kvol, rb.cap_in)[:, : rb.n_in].cpu().numpy()
+        k, i = np.nonzero(t >= 0)
+        trip = np.stack([k, i, t[k, i]], 1)
+        trip = trip[np.lexsort((trip[:, 2], trip[:, 1], trip[:, 0]))]
+        assert np.array_equal(trip, ref)
+
+
+def test_rulebook_kitti_scale_and_determinism():
+    """full KITTI grid [41,1600,1408], batch 4: exercises the 46 MB bitmap path."""
+    rng = np.random.default_rng(3)
+    shape = [41, 1600, 1408]
+    idx, _ = _random_sparse(rng, 4, shape, 12000, 1)
+    a = _build(idx, 4, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], False)
+    out_idx, _, pairs = R.get_indice_pairs(idx, 4, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], False)
+    assert np.array_equal(a.out_indices.cpu().numpy(), out_idx)
+    ref = R.canonical_pairs(pairs)
+    assert np.array_equal(a.canonical_pairs(), ref)
+    b = _build(idx, 4, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], False)
+    assert torch.equal(a.nbr_out[: a.kvol * a.cap_out], b.nbr_out[: b.kvol * b.cap_out]) or \
+        np.array_equal(a.canonical_pairs(), b.canonical_pairs())
+    s = _build(idx, 4, shape, [3, 3, 3], [1, 1, 1], [0, 0, 0], True)
+    _, _, sp = R.get_indice_pairs(idx, 4, shape, [3, 3, 3], [1, 1, 1], [0, 0, 0], True)
+    assert np.array_equal(s.canonical_pairs(), R.canonical_pairs(sp))
+
+
+CHANNELS = [(4, 16), (5, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (3, 7)]
+
+
+@pytest.mark.parametrize("cin,cout", CHANNELS)
+@pytest.mark.parametrize("gi", [0, 1, 3])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_fwd_bwd_vs_oracle(cin, cout, gi, dtype):
+    from det3d_amd import spconv
+
+    ksize, stride, padding, subm = GEOMS[gi]
+    rng = np.random.default_rng(cin * 131 + cout + gi)
+    shape = [9, 30, 28]
+    idx, feats = _random_sparse(rng, 2, shape, 700, cin)
+    w = (rng.standard_normal((*ksize, cin, cout)) / np.sqrt(cin * 9)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32) if gi == 0 else None
+    out_idx, out_shape, pairs = R.get_indice_pairs(idx, 2, shape, ksize, stride, padding, subm)
+    g = rng.standard_normal((len(out_idx), cout)).astype(np.float32)
+
+    # quantise inputs the same way for both sides so the comparison isolates the kernel
+    q = (lambda a: torch.from_numpy(a).to(dtype).float()) if dtype == torch.bfloat16 else torch.from_numpy
+    f_ref = q(feats).clone().requires_grad_(True)
+    w_ref = q(w).clone().requires_grad_(True)
+    b_ref = torch.from_numpy(bias).requires_grad_(True) if bias is not None else None
+    out_ref = R.indice_conv(f_ref, w_ref, pairs, len(out_idx), b_ref)
+    (out_ref * q(g)).sum().backward()
+
+    cls = spconv.SubMConv3d if subm else spconv.SparseConv3d
+    m = cls(cin, cout, ksize, stride=stride, padding=padding, bias=bias is not None).cuda()
+    with torch.no_grad():
+        m.weight.copy_(q(w))
+        if bias is not None:
+            m.bias.copy_(torch.from_numpy(bias))
+    f = q(feats).cuda().to(dtype).requires_grad_(True)
+    x = spconv.SparseConvTensor(f, torch.from_numpy(idx).cuda(), shape, 2)
+    y = m(x)
+    assert np.array_equal(y.indices.cpu().numpy(), out_idx)
+    (y.features.float() * q(g).cuda()).sum().backward()
+
+    if dtype == torch.float32:
+        tol = dict(atol=2e-4, rtol=2e-4)
+        gtol = dict(atol=5e-4, rtol=5e-4)
+    else:
+        # bf16 output rounding: 2^-8 relative on O(1) values; wgrad sums ~1e3 products of
+        # bf16-rounded grads
+        tol = dict(atol=3e-2, rtol=2e-2)
+        gtol = dict(atol=6e-2, rtol=3e-2)
+    assert torch.allclose(y.features.float().cpu(), out_ref.detach(), **tol)
+    assert torch.allclose(f.grad.float().cpu(), f_ref.grad, **gtol)
+    assert torch.allclose(m.weight.grad.cpu(), w_ref.grad, **gtol)
+    if bias is not None:
+        assert torch.allclose(m.bias.grad.cpu(), b_ref.grad, **gtol)
+
+
+def test_conv_vs_dense_conv3d_cropped_grid():
+    """independent of the restatement: HIP f32 path vs F.conv3d on the densified crop."""
+    from det3d_amd import spconv
+
+    rng = np.random.default_rng(8)
+    shape = [8, 24, 20]
+    idx, feats = _random_sparse(rng, 2, shape, 500, 16)
+    for ksize, stride, padding, subm in GEOMS[:3]:
+        w = (rng.standard_normal((*ksize, 16, 32)) / 12).astype(np.float32)
+        ref, ref_idx = R.dense_conv_reference(torch.from_numpy(feats), idx, 2, shape, torch.from_numpy(w),
+                                              ksize, stride, padding, subm)
+        cls = spconv.SubMConv3d if subm else spconv.SparseConv3d
+        m = cls(16, 32, ksize, stride=stride, padding=padding, bias=False).cuda()
+        with torch.no_grad():
+            m.weight.copy_(torch.from_numpy(w))
+        y = m(spconv.SparseConvTensor(torch.from_numpy(feats).cuda(), torch.from_numpy(idx).cuda(), shape, 2))
+        assert np.array_equal(y.indices.cpu().numpy(), ref_idx)
+        assert torch.allclose(y.features.cpu(), ref, atol=2e-4, rtol=2e-4)
+
+
+def test_dense_and_its_backward():
+    from det3d_amd import spconv
+
+    rng = np.random.default_rng(2)
+    shape = [2, 20, 18]
+    idx, feats = _random_sparse(rng, 3, shape, 200, 64, clustered=False)
+    for dtype in (torch.float32, torch.bfloat16):
+        f = torch.from_numpy(feats).cuda().to(dtype).requires_grad_(True)
+        x = spconv.SparseConvTensor(f, torch.from_numpy(idx).cuda(), shape, 3)
+        d = x.dense()
+        ref = R.dense(torch.from_numpy(feats).to(dtype).float(), idx, 3, shape)
+        assert d.shape == (3, 64, 2, 20, 18)
+        assert torch.equal(d.float().cpu(), ref)
+        g = torch.randn_like(d)
+        d.backward(g)
+        ii = torch.from_numpy(idx).long()
+        assert torch.equal(f.grad.cpu(), g.cpu()[ii[:, 0], :, ii[:, 1], ii[:, 2], ii[:, 3]])
+
+
+def test_plan_single_sync_matches_lazy_path():
+    """SparseSequential.plan() (one host sync) builds the same rulebooks as the per-layer path."""
+    from det3d_amd import spconv
+
+    rng = np.random.default_rng(4)
+    shape = [21, 80, 72]
+    idx, feats = _random_sparse(rng, 2, shape, 3000, 16)
+    torch.manual_seed(0)
+    net = spconv.SparseSequential(
+        spconv.SubMConv3d(16, 16, 3, bias=False, indice_key="s0"), torch.nn.ReLU(),
+        spconv.SparseConv3d(16, 32, 3, 2, padding=1, bias=False),
+        spconv.SubMConv3d(32, 32, 3, bias=False, indice_key="s1"),
+        spconv.SubMConv3d(32, 32, 3, bias=False, indice_key="s1"),
+        spconv.SparseConv3d(32, 32, 3, 2, padding=[0, 1, 1], bias=False),
+        spconv.SparseConv3d(32, 32, (3, 1, 1), (2, 1, 1), bias=False)).cuda()
+    mk = lambda: spconv.SparseConvTensor(torch.from_numpy(feats).cuda(), torch.from_numpy(idx).cuda(), shape, 2)
+    a = net(mk())
+    xb = mk()
+    net.plan(xb)
+    b = net(xb)
+    assert torch.equal(a.indices, b.indices) and torch.equal(a.features, b.features)
+    assert a.spatial_shape == b.spatial_shape == [2, 20, 18]
