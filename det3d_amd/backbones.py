@@ -1,0 +1,157 @@
+"""Backbones of the hot path, registry names / kwargs / forward signatures as in the
+reference:
+  SpMiddleFHD        det3d/models/backbones/scn.py:92-197   (KITTI SECOND)
+  SpMiddleResNetFHD  det3d/models/backbones/scn.py:308-370  (nuScenes / Lyft CBGS)
+  SparseBasicBlock   det3d/models/backbones/scn.py:46-89
+  PointPillarsScatter det3d/models/readers/pillar_encoder.py:158-211
+Module nesting (and therefore state-dict keys `backbone.middle_conv.<i>.*`) is identical.
+The sparse stacks run on the HIP kernels behind det3d_amd.spconv; `forward` plans all
+rulebooks of the stack with one host sync before running the layers.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import spconv
+from .nn_utils import build_norm_layer
+from .registry import BACKBONES
+from .spconv import SparseConv3d, SubMConv3d
+
+
+def conv3x3(in_planes, out_planes, stride=1, indice_key=None, bias=True):
+    return spconv.SubMConv3d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1,
+                             bias=bias, indice_key=indice_key)
+
+
+def conv1x1(in_planes, out_planes, stride=1, indice_key=None, bias=True):
+    return spconv.SubMConv3d(in_planes, out_planes, kernel_size=1, stride=stride, padding=1,
+                             bias=bias, indice_key=indice_key)
+
+
+class SparseBasicBlock(spconv.SparseModule):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, norm_cfg=None, downsample=None, indice_key=None):
+        super().__init__()
+        if norm_cfg is None:
+            norm_cfg = dict(type="BN1d", eps=1e-3, momentum=0.01)
+        bias = norm_cfg is not None  # always True after defaulting, as in the reference (:60-63)
+        self.conv1 = conv3x3(inplanes, planes, stride, indice_key=indice_key, bias=bias)
+        self.bn1 = build_norm_layer(norm_cfg, planes)[1]
+        self.relu = nn.ReLU()
+        self.conv2 = conv3x3(planes, planes, indice_key=indice_key, bias=bias)
+        self.bn2 = build_norm_layer(norm_cfg, planes)[1]
+        self.downsample = downsample
+        self.stride = stride
+
+    def conv_layers(self):
+        return [self.conv1, self.conv2]
+
+    def forward(self, x):
+        identity = x
+        out = self.conv1(x)
+        out.features = self.bn1(out.features)
+        out.features = self.relu(out.features)
+        out = self.conv2(out)
+        out.features = self.bn2(out.features)
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out.features = out.features + identity.features
+        out.features = self.relu(out.features)
+        return out
+
+
+class _SparseMiddle(nn.Module):
+    """shared forward of the two sparse backbones (scn.py:184-197 / :357-370)."""
+
+    def _run(self, voxel_features, coors, batch_size, input_shape):
+        sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]
+        coors = coors.int()
+        if torch.is_autocast_enabled():
+            voxel_features = voxel_features.to(torch.get_autocast_gpu_dtype())
+        ret = spconv.SparseConvTensor(voxel_features, coors, sparse_shape.tolist(), batch_size)
+        self.middle_conv.plan(ret)  # every rulebook of the stack, one host sync
+        ret = self.middle_conv(ret)
+        self.last_indice_dict = ret.indice_dict
+        ret = ret.dense()
+        N, C, D, H, W = ret.shape
+        return ret.view(N, C * D, H, W)
+
+    def init_weights(self, pretrained=None):
+        pass
+
+    def forward(self, voxel_features, coors, batch_size, input_shape):
+        return self._run(voxel_features, coors, batch_size, input_shape)
+
+
+@BACKBONES.register_module
+class SpMiddleFHD(_SparseMiddle):
+    def __init__(self, num_input_features=128, norm_cfg=None, name="SpMiddleFHD", **kwargs):
+        super().__init__()
+        self.name = name
+        self.dcn = None
+        self.zero_init_residual = False
+        if norm_cfg is None:
+            norm_cfg = dict(type="BN1d", eps=1e-3, momentum=0.01)
+
+        def bn(c):
+            return build_norm_layer(norm_cfg, c)[1]
+
+        layers = [SubMConv3d(num_input_features, 16, 3, bias=False, indice_key="subm0"), bn(16), nn.ReLU(),
+                  SubMConv3d(16, 16, 3, bias=False, indice_key="subm0"), bn(16), nn.ReLU(),
+                  SparseConv3d(16, 32, 3, 2, padding=1, bias=False), bn(32), nn.ReLU()]
+        for _ in range(2):
+            layers += [SubMConv3d(32, 32, 3, indice_key="subm1", bias=False), bn(32), nn.ReLU()]
+        layers += [SparseConv3d(32, 64, 3, 2, padding=1, bias=False), bn(64), nn.ReLU()]
+        for _ in range(3):
+            layers += [SubMConv3d(64, 64, 3, indice_key="subm2", bias=False), bn(64), nn.ReLU()]
+        layers += [SparseConv3d(64, 64, 3, 2, padding=[0, 1, 1], bias=False), bn(64), nn.ReLU()]
+        for _ in range(3):
+            layers += [SubMConv3d(64, 64, 3, indice_key="subm3", bias=False), bn(64), nn.ReLU()]
+        layers += [SparseConv3d(64, 64, (3, 1, 1), (2, 1, 1), bias=False), bn(64), nn.ReLU()]
+        self.middle_conv = spconv.SparseSequential(*layers)
+
+
+@BACKBONES.register_module
+class SpMiddleResNetFHD(_SparseMiddle):
+    def __init__(self, num_input_features=128, norm_cfg=None, name="SpMiddleResNetFHD", **kwargs):
+        super().__init__()
+        self.name = name
+        self.dcn = None
+        self.zero_init_residual = False
+        if norm_cfg is None:
+            norm_cfg = dict(type="BN1d", eps=1e-3, momentum=0.01)
+
+        def bn(c):
+            return build_norm_layer(norm_cfg, c)[1]
+
+        def block(c, key):
+            return SparseBasicBlock(c, c, norm_cfg=norm_cfg, indice_key=key)
+
+        self.middle_conv = spconv.SparseSequential(
+            SubMConv3d(num_input_features, 16, 3, bias=False, indice_key="res0"), bn(16), nn.ReLU(),
+            block(16, "res0"), block(16, "res0"),
+            SparseConv3d(16, 32, 3, 2, padding=1, bias=False), bn(32), nn.ReLU(),
+            block(32, "res1"), block(32, "res1"),
+            SparseConv3d(32, 64, 3, 2, padding=1, bias=False), bn(64), nn.ReLU(),
+            block(64, "res2"), block(64, "res2"),
+            SparseConv3d(64, 128, 3, 2, padding=[0, 1, 1], bias=False), bn(128), nn.ReLU(),
+            block(128, "res3"), block(128, "res3"),
+            SparseConv3d(128, 128, (3, 1, 1), (2, 1, 1), bias=False), bn(128), nn.ReLU())
+
+
+@BACKBONES.register_module
+class PointPillarsScatter(nn.Module):
+    def __init__(self, num_input_features=64, norm_cfg=None, name="PointPillarsScatter", **kwargs):
+        super().__init__()
+        self.name = "PointPillarsScatter"
+        self.nchannels = num_input_features
+
+    def forward(self, voxel_features, coords, batch_size, input_shape):
+        self.nx = int(input_shape[0])
+        self.ny = int(input_shape[1])
+        canvas = torch.zeros(batch_size, self.nchannels, self.nx * self.ny, dtype=voxel_features.dtype,
+                             device=voxel_features.device)
+        cell = (coords[:, 2] * self.nx + coords[:, 3]).long()
+        canvas[coords[:, 0].long(), :, cell] = voxel_features
+        return canvas.view(batch_size, self.nchannels, self.ny, self.nx)

@@ -1,0 +1,376 @@
+"""MultiGroupHead, det3d/models/bbox_heads/mg_head.py:
+  Head.forward            :221-230   1x1 convs, NHWC permute
+  MultiGroupHead.__init__ :385-500   per-task heads, 2 anchors (rotations) per class
+  prepare_loss_weights    :535-578
+  loss                    :580-695   focal + smooth-L1(sin-difference) + direction softmax
+  predict                 :697-803   decode, per-task detections, merge with label offsets
+  get_task_detections     :805-1085  sigmoid, score threshold, NMS, direction flip, range mask
+Same constructor kwargs, attribute names (`tasks.<t>.conv_{box,cls,dir}`) and output dict
+keys.  NMS goes to the HIP kernel (box_ops.rotate_nms); the multi-class NMS branch of the
+reference references undefined attributes (:911-913) and is not reachable from any shipped
+config, so it raises here.
+"""
+import logging
+from collections import defaultdict
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import box_ops
+from . import losses  # noqa: F401  (registers the loss classes)
+from .builder import build_loss
+from .registry import HEADS
+
+
+def one_hot_f(tensor, depth, dim=-1, on_value=1.0, dtype=torch.float32):
+    out = torch.zeros(*list(tensor.shape), depth, dtype=dtype, device=tensor.device)
+    out.scatter_(dim, tensor.unsqueeze(dim).long(), on_value)
+    return out
+
+
+def add_sin_difference(boxes1, boxes2):
+    """sin(a - b) = sin a cos b - cos a sin b, split over prediction / target (:29-34)"""
+    r1 = torch.sin(boxes1[..., -1:]) * torch.cos(boxes2[..., -1:])
+    r2 = torch.cos(boxes1[..., -1:]) * torch.sin(boxes2[..., -1:])
+    return torch.cat([boxes1[..., :-1], r1], dim=-1), torch.cat([boxes2[..., :-1], r2], dim=-1)
+
+
+def limit_period(val, offset=0.5, period=np.pi):
+    return val - torch.floor(val / period + offset) * period
+
+
+def get_direction_target(anchors, reg_targets, one_hot=True, dir_offset=0.0):
+    batch_size = reg_targets.shape[0]
+    anchors = anchors.view(batch_size, -1, anchors.shape[-1])
+    rot_gt = reg_targets[..., -1] + anchors[..., -1]
+    tgt = (limit_period(rot_gt - dir_offset, 0.5, np.pi * 2) > 0).long()
+    if one_hot:
+        tgt = one_hot_f(tgt, 2, dtype=anchors.dtype)
+    return tgt
+
+
+def _get_pos_neg_loss(cls_loss, labels):
+    batch_size = cls_loss.shape[0]
+    if cls_loss.shape[-1] == 1 or len(cls_loss.shape) == 2:
+        pos = ((labels > 0).type_as(cls_loss) * cls_loss.view(batch_size, -1)).sum() / batch_size
+        neg = ((labels == 0).type_as(cls_loss) * cls_loss.view(batch_size, -1)).sum() / batch_size
+    else:
+        pos = cls_loss[..., 1:].sum() / batch_size
+        neg = cls_loss[..., 0].sum() / batch_size
+    return pos, neg
+
+
+def create_loss(loc_loss_ftor, cls_loss_ftor, box_preds, cls_preds, cls_targets, cls_weights,
+                reg_targets, reg_weights, num_class, encode_background_as_zeros=True,
+                encode_rad_error_by_sin=True, bev_only=False, box_code_size=9):
+    batch_size = int(box_preds.shape[0])
+    box_preds = box_preds.view(batch_size, -1, box_code_size - 2 if bev_only else box_code_size)
+    cls_preds = cls_preds.view(batch_size, -1, num_class if encode_background_as_zeros else num_class + 1)
+    cls_targets = cls_targets.squeeze(-1)
+    one_hot_targets = one_hot_f(cls_targets, depth=num_class + 1, dtype=box_preds.dtype)
+    if encode_background_as_zeros:
+        one_hot_targets = one_hot_targets[..., 1:]
+    if encode_rad_error_by_sin:
+        box_preds, reg_targets = add_sin_difference(box_preds, reg_targets)
+    loc_losses = loc_loss_ftor(box_preds, reg_targets, weights=reg_weights)
+    cls_losses = cls_loss_ftor(cls_preds, one_hot_targets, weights=cls_weights)
+    return loc_losses, cls_losses
+
+
+@HEADS.register_module
+class Head(nn.Module):
+    def __init__(self, num_input, num_pred, num_cls, use_dir=False, num_dir=0, header=True, name="",
+                 focal_loss_init=False, **kwargs):
+        super().__init__(**kwargs)
+        self.use_dir = use_dir
+        self.conv_box = nn.Conv2d(num_input, num_pred, 1)
+        self.conv_cls = nn.Conv2d(num_input, num_cls, 1)
+        if self.use_dir:
+            self.conv_dir = nn.Conv2d(num_input, num_dir, 1)
+
+    def forward(self, x):
+        ret = {"box_preds": self.conv_box(x).permute(0, 2, 3, 1).contiguous(),
+               "cls_preds": self.conv_cls(x).permute(0, 2, 3, 1).contiguous()}
+        if self.use_dir:
+            ret["dir_cls_preds"] = self.conv_dir(x).permute(0, 2, 3, 1).contiguous()
+        return ret
+
+
+@HEADS.register_module
+class MultiGroupHead(nn.Module):
+    def __init__(self, mode="3d", in_channels=[128], norm_cfg=None, tasks=[], weights=[],
+                 num_classes=[1], box_coder=None, with_cls=True, with_reg=True,
+                 reg_class_agnostic=False, encode_background_as_zeros=True,
+                 loss_norm=dict(type="NormByNumPositives", pos_class_weight=1.0, neg_class_weight=1.0),
+                 loss_cls=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=1.0),
+                 use_sigmoid_score=True, loss_bbox=dict(type="SmoothL1Loss", beta=1.0, loss_weight=1.0),
+                 encode_rad_error_by_sin=True, loss_aux=None, direction_offset=0.0, name="rpn",
+                 logger=None):
+        super().__init__()
+        assert with_cls or with_reg
+        num_classes = [len(t["class_names"]) for t in tasks]
+        self.class_names = [t["class_names"] for t in tasks]
+        self.num_anchor_per_locs = [2 * n for n in num_classes]
+        self.box_coder = box_coder
+        box_code_sizes = [box_coder.code_size] * len(num_classes)
+        self.with_cls = with_cls
+        self.with_reg = with_reg
+        self.in_channels = in_channels
+        self.num_classes = num_classes
+        self.reg_class_agnostic = reg_class_agnostic
+        self.encode_rad_error_by_sin = encode_rad_error_by_sin
+        self.encode_background_as_zeros = encode_background_as_zeros
+        self.use_sigmoid_score = use_sigmoid_score
+        self.box_n_dim = self.box_coder.code_size
+        self.anchor_dim = self.box_coder.n_dim
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_reg = build_loss(loss_bbox)
+        if loss_aux is not None:
+            self.loss_aux = build_loss(loss_aux)
+        self.loss_norm = loss_norm
+        self.logger = logger or logging.getLogger("MultiGroupHead")
+        self.use_direction_classifier = loss_aux is not None
+        if loss_aux:
+            self.direction_offset = direction_offset
+        self.bev_only = mode == "bev"
+
+        self.tasks = nn.ModuleList()
+        for num_c, num_a, box_cs in zip(num_classes, self.num_anchor_per_locs, box_code_sizes):
+            num_cls = num_a * num_c if self.encode_background_as_zeros else num_a * (num_c + 1)
+            num_pred = num_a * (box_cs - 2) if self.bev_only else num_a * box_cs
+            num_dir = num_a * 2 if self.use_direction_classifier else None
+            self.tasks.append(Head(in_channels, num_pred, num_cls, use_dir=self.use_direction_classifier,
+                                   num_dir=num_dir, header=False))
+        self.logger.info("Finish MultiGroupHead Initialization")
+
+    def init_weights(self, pretrained=None):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        return [task(x) for task in self.tasks]
+
+    # ------------------------------------------------------------------- loss
+    def prepare_loss_weights(self, labels, loss_norm=dict(type="NormByNumPositives", pos_cls_weight=1.0,
+                                                         neg_cls_weight=1.0), dtype=torch.float32):
+        kind = loss_norm["type"]
+        pos_w, neg_w = loss_norm["pos_cls_weight"], loss_norm["neg_cls_weight"]
+        cared = labels >= 0
+        positives = labels > 0
+        negatives = labels == 0
+        cls_weights = negatives.type(dtype) * neg_w + pos_w * positives.type(dtype)
+        reg_weights = positives.type(dtype)
+        if kind == "NormByNumExamples":
+            num_examples = torch.clamp(cared.type(dtype).sum(1, keepdim=True), min=1.0)
+            cls_weights = cls_weights / num_examples
+            reg_weights = reg_weights / torch.clamp(positives.sum(1, keepdim=True).type(dtype), min=1.0)
+        elif kind == "NormByNumPositives":
+            pos_normalizer = torch.clamp(positives.sum(1, keepdim=True).type(dtype), min=1.0)
+            reg_weights = reg_weights / pos_normalizer
+            cls_weights = cls_weights / pos_normalizer
+        elif kind == "NormByNumPosNeg":
+            pos_neg = torch.stack([positives, negatives], dim=-1).type(dtype)
+            normalizer = pos_neg.sum(1, keepdim=True)
+            cls_normalizer = torch.clamp((pos_neg * normalizer).sum(-1), min=1.0)
+            normalizer = torch.clamp(normalizer, min=1.0)
+            reg_weights = reg_weights / normalizer[:, 0:1, 0]
+            cls_weights = cls_weights / cls_normalizer
+        elif kind == "DontNorm":
+            reg_weights = reg_weights / torch.clamp(positives.sum(1, keepdim=True).type(dtype), min=1.0)
+        else:
+            raise ValueError("unknown loss norm type %s" % kind)
+        return cls_weights, reg_weights, cared
+
+    def loss(self, example, preds_dicts, **kwargs):
+        batch_anchors = example["anchors"]
+        batch_size_device = batch_anchors[0].shape[0]
+        rets = []
+        for task_id, preds_dict in enumerate(preds_dicts):
+            num_class = self.num_classes[task_id]
+            box_preds = preds_dict["box_preds"].float()
+            cls_preds = preds_dict["cls_preds"].float()
+            labels = example["labels"][task_id]
+            reg_targets = example["reg_targets"][task_id]
+            cls_weights, reg_weights, cared = self.prepare_loss_weights(labels, loss_norm=self.loss_norm,
+                                                                        dtype=torch.float32)
+            cls_targets = (labels * cared.type_as(labels)).unsqueeze(-1)
+            loc_loss, cls_loss = create_loss(self.loss_reg, self.loss_cls, box_preds, cls_preds, cls_targets,
+                                             cls_weights, reg_targets, reg_weights, num_class,
+                                             self.encode_background_as_zeros, self.encode_rad_error_by_sin,
+                                             bev_only=self.bev_only, box_code_size=self.box_n_dim)
+            loc_loss_reduced = loc_loss.sum() / batch_size_device * self.loss_reg._loss_weight
+            cls_pos_loss, cls_neg_loss = _get_pos_neg_loss(cls_loss, labels)
+            cls_pos_loss = cls_pos_loss / self.loss_norm["pos_cls_weight"]
+            cls_neg_loss = cls_neg_loss / self.loss_norm["neg_cls_weight"]
+            cls_loss_reduced = cls_loss.sum() / batch_size_device * self.loss_cls._loss_weight
+            loss = loc_loss_reduced + cls_loss_reduced
+            dir_loss = None
+            if self.use_direction_classifier:
+                dir_targets = get_direction_target(example["anchors"][task_id], reg_targets,
+                                                   dir_offset=self.direction_offset)
+                dir_logits = preds_dict["dir_cls_preds"].float().view(batch_size_device, -1, 2)
+                weights = (labels > 0).type_as(dir_logits)
+                weights = weights / torch.clamp(weights.sum(-1, keepdim=True), min=1.0)
+                dir_loss = self.loss_aux(dir_logits, dir_targets, weights=weights).sum() / batch_size_device
+                loss = loss + dir_loss * self.loss_aux._loss_weight
+            # logged scalars stay on the device (the reference does ~10 .cpu() syncs here,
+            # mg_head.py:657-666); the trainer reads them once per log interval
+            rets.append({
+                "loss": loss,
+                "cls_pos_loss": cls_pos_loss.detach(),
+                "cls_neg_loss": cls_neg_loss.detach(),
+                "dir_loss_reduced": dir_loss.detach() if dir_loss is not None else torch.tensor(0),
+                "cls_loss_reduced": cls_loss_reduced.detach().mean(),
+                "loc_loss_reduced": loc_loss_reduced.detach().mean(),
+                "loc_loss_elem": [(loc_loss[:, :, i].sum() / batch_size_device).detach()
+                                  for i in range(loc_loss.shape[-1])],
+                "num_pos": (labels > 0)[0].sum(),
+                "num_neg": (labels == 0)[0].sum(),
+            })
+        merged = defaultdict(list)
+        for ret in rets:
+            for k, v in ret.items():
+                merged[k].append(v)
+        return merged
+
+    # ---------------------------------------------------------------- predict
+    def predict(self, example, preds_dicts, test_cfg, **kwargs):
+        batch_anchors = example["anchors"]
+        rets = []
+        for task_id, preds_dict in enumerate(preds_dicts):
+            batch_size = batch_anchors[task_id].shape[0]
+            if "metadata" not in example or len(example["metadata"]) == 0:
+                meta_list = [None] * batch_size
+            else:
+                meta_list = example["metadata"]
+            batch_task_anchors = example["anchors"][task_id].view(batch_size, -1, self.anchor_dim)
+            if "anchors_mask" not in example:
+                batch_anchors_mask = [None] * batch_size
+            else:
+                batch_anchors_mask = example["anchors_mask"][task_id].view(batch_size, -1)
+            box_ndim = self.box_n_dim - 2 if self.bev_only else self.box_n_dim
+            batch_box_preds = preds_dict["box_preds"].float().view(batch_size, -1, box_ndim)
+            ncls = self.num_classes[task_id] + (0 if self.encode_background_as_zeros else 1)
+            batch_cls_preds = preds_dict["cls_preds"].float().view(batch_size, -1, ncls)
+            batch_reg_preds = self.box_coder.decode_torch(batch_box_preds[:, :, : self.box_coder.code_size],
+                                                          batch_task_anchors)
+            if self.use_direction_classifier:
+                batch_dir_preds = preds_dict["dir_cls_preds"].float().view(batch_size, -1, 2)
+            else:
+                batch_dir_preds = [None] * batch_size
+            rets.append(self.get_task_detections(task_id, ncls, test_cfg, batch_cls_preds, batch_reg_preds,
+                                                 batch_dir_preds, batch_anchors_mask, meta_list))
+        num_samples = len(rets[0])
+        ret_list = []
+        for i in range(num_samples):
+            ret = {}
+            for k in rets[0][i].keys():
+                if k in ("box3d_lidar", "scores"):
+                    ret[k] = torch.cat([r[i][k] for r in rets])
+                elif k == "label_preds":
+                    flag = 0
+                    for j, num_class in enumerate(self.num_classes):
+                        rets[j][i][k] += flag
+                        flag += num_class
+                    ret[k] = torch.cat([r[i][k] for r in rets])
+                elif k == "metadata":
+                    ret[k] = rets[0][i][k]
+            ret_list.append(ret)
+        return ret_list
+
+    def get_task_detections(self, task_id, num_class_with_bg, test_cfg, batch_cls_preds, batch_reg_preds,
+                            batch_dir_preds=None, batch_anchors_mask=None, meta_list=None):
+        nms_cfg = test_cfg["nms"] if isinstance(test_cfg, dict) else test_cfg.nms
+        tget = (lambda k: test_cfg[k]) if isinstance(test_cfg, dict) else (lambda k: getattr(test_cfg, k))
+        nget = (lambda k: nms_cfg[k]) if isinstance(nms_cfg, dict) else (lambda k: getattr(nms_cfg, k))
+        if nget("use_multi_class_nms"):
+            raise NotImplementedError("use_multi_class_nms: unreachable in the reference too "
+                                      "(mg_head.py:911-913 reads undefined attributes)")
+        post_center_range = tget("post_center_limit_range")
+        if len(post_center_range) > 0:
+            post_center_range = torch.tensor(post_center_range, dtype=batch_reg_preds.dtype,
+                                             device=batch_reg_preds.device)
+        else:
+            post_center_range = None
+        nms_func = box_ops.rotate_nms if nget("use_rotate_nms") else box_ops.nms
+        score_thr = tget("score_threshold")
+        out = []
+        for box_preds, cls_preds, dir_preds, a_mask, meta in zip(batch_reg_preds, batch_cls_preds,
+                                                                 batch_dir_preds, batch_anchors_mask,
+                                                                 meta_list):
+            if a_mask is not None:
+                box_preds = box_preds[a_mask]
+                cls_preds = cls_preds[a_mask]
+            box_preds = box_preds.float()
+            cls_preds = cls_preds.float()
+            dir_labels = None
+            if self.use_direction_classifier:
+                if a_mask is not None:
+                    dir_preds = dir_preds[a_mask]
+                dir_labels = torch.max(dir_preds, dim=-1)[1]
+            if self.encode_background_as_zeros:
+                assert self.use_sigmoid_score is True
+                total_scores = torch.sigmoid(cls_preds)
+            elif self.use_sigmoid_score:
+                total_scores = torch.sigmoid(cls_preds)[..., 1:]
+            else:
+                total_scores = torch.softmax(cls_preds, dim=-1)[..., 1:]
+
+            if num_class_with_bg == 1:
+                top_scores = total_scores.squeeze(-1)
+                top_labels = torch.zeros(total_scores.shape[0], device=total_scores.device, dtype=torch.long)
+            else:
+                top_scores, top_labels = torch.max(total_scores, dim=-1)
+            if score_thr > 0.0:
+                keep_mask = top_scores >= torch.tensor([score_thr], device=total_scores.device).type_as(total_scores)
+                top_scores = top_scores.masked_select(keep_mask)
+            if top_scores.shape[0] != 0:
+                if score_thr > 0.0:
+                    box_preds = box_preds[keep_mask]
+                    if self.use_direction_classifier:
+                        dir_labels = dir_labels[keep_mask]
+                    top_labels = top_labels[keep_mask]
+                boxes_for_nms = box_preds[:, [0, 1, 3, 4, -1]]
+                if not nget("use_rotate_nms"):
+                    corners = box_ops.center_to_corner_box2d(boxes_for_nms[:, :2], boxes_for_nms[:, 2:4],
+                                                             boxes_for_nms[:, 4])
+                    boxes_for_nms = box_ops.corner_to_standup_nd(corners)
+                selected = nms_func(boxes_for_nms, top_scores, pre_max_size=nget("nms_pre_max_size"),
+                                    post_max_size=nget("nms_post_max_size"),
+                                    iou_threshold=nget("nms_iou_threshold"))
+            else:
+                selected = torch.zeros([0], dtype=torch.long, device=box_preds.device)
+                box_preds = box_preds[:0]
+                top_labels = top_labels[:0]
+                if self.use_direction_classifier:
+                    dir_labels = dir_labels[:0]
+            selected_boxes = box_preds[selected]
+            selected_labels = top_labels[selected]
+            selected_scores = top_scores[selected]
+            if selected_boxes.shape[0] != 0:
+                box_preds = selected_boxes
+                if self.use_direction_classifier:
+                    sel_dir = dir_labels[selected]
+                    opp = ((box_preds[..., -1] - self.direction_offset) > 0) ^ sel_dir.bool()
+                    box_preds[..., -1] += torch.where(opp, torch.tensor(np.pi).type_as(box_preds),
+                                                      torch.tensor(0.0).type_as(box_preds))
+                if post_center_range is not None:
+                    mask = (box_preds[:, :3] >= post_center_range[:3]).all(1)
+                    mask &= (box_preds[:, :3] <= post_center_range[3:]).all(1)
+                    pred = {"box3d_lidar": box_preds[mask], "scores": selected_scores[mask],
+                            "label_preds": selected_labels[mask], "metadata": meta}
+                else:
+                    pred = {"box3d_lidar": box_preds, "scores": selected_scores,
+                            "label_preds": selected_labels, "metadata": meta}
+            else:
+                dtype, device = batch_reg_preds.dtype, batch_reg_preds.device
+                pred = {"box3d_lidar": torch.zeros([0, self.anchor_dim], dtype=dtype, device=device),
+                        "scores": torch.zeros([0], dtype=dtype, device=device),
+                        "label_preds": torch.zeros([0], dtype=top_labels.dtype, device=device),
+                        "metadata": meta}
+            out.append(pred)
+        return out

@@ -1,0 +1,97 @@
+"""Readers (voxel feature encoders).  Same registry names, constructor kwargs and forward
+signatures as the reference:
+  VoxelFeatureExtractorV3   det3d/models/readers/voxel_encoder.py:197-211
+  PFNLayer, PillarFeatureNet det3d/models/readers/pillar_encoder.py:17-155
+On the fused MI355X path the mean VFE is already produced by d3d_voxelize
+(`mean_feats`); VoxelFeatureExtractorV3 accepts those [M, C] rows and passes them on.
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .nn_utils import build_norm_layer, get_paddings_indicator
+from .registry import READERS
+
+
+@READERS.register_module
+class VoxelFeatureExtractorV3(nn.Module):
+    def __init__(self, num_input_features=4, norm_cfg=None, name="VoxelFeatureExtractorV3"):
+        super().__init__()
+        self.name = name
+        self.num_input_features = num_input_features
+
+    def forward(self, features, num_voxels, coors=None):
+        if features.dim() == 2:
+            # already-averaged rows from the fused voxelizer (d3d_voxelize mean_feats)
+            return features[:, : self.num_input_features].contiguous()
+        points_mean = features[:, :, : self.num_input_features].sum(dim=1, keepdim=False) / \
+            num_voxels.type_as(features).view(-1, 1)
+        return points_mean.contiguous()
+
+
+class PFNLayer(nn.Module):
+    def __init__(self, in_channels, out_channels, norm_cfg=None, last_layer=False):
+        super().__init__()
+        self.name = "PFNLayer"
+        self.last_vfe = last_layer
+        if not self.last_vfe:
+            out_channels = out_channels // 2
+        self.units = out_channels
+        if norm_cfg is None:
+            norm_cfg = dict(type="BN1d", eps=1e-3, momentum=0.01)
+        self.norm_cfg = norm_cfg
+        self.linear = nn.Linear(in_channels, self.units, bias=False)
+        self.norm = build_norm_layer(self.norm_cfg, self.units)[1]
+
+    def forward(self, inputs):
+        x = self.linear(inputs)
+        # BN over the channel axis of [M, T, C]: statistics over all M*T rows
+        x = self.norm(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+        x = F.relu(x)
+        x_max = torch.max(x, dim=1, keepdim=True)[0]
+        if self.last_vfe:
+            return x_max
+        x_repeat = x_max.repeat(1, inputs.shape[1], 1)
+        return torch.cat([x, x_repeat], dim=2)
+
+
+@READERS.register_module
+class PillarFeatureNet(nn.Module):
+    def __init__(self, num_input_features=4, num_filters=(64,), with_distance=False,
+                 voxel_size=(0.2, 0.2, 4), pc_range=(0, -40, -3, 70.4, 40, 1), norm_cfg=None):
+        super().__init__()
+        self.name = "PillarFeatureNet"
+        assert len(num_filters) > 0
+        self.num_input = num_input_features
+        num_input_features += 5
+        if with_distance:
+            num_input_features += 1
+        self._with_distance = with_distance
+        num_filters = [num_input_features] + list(num_filters)
+        layers = []
+        for i in range(len(num_filters) - 1):
+            layers.append(PFNLayer(num_filters[i], num_filters[i + 1], norm_cfg=norm_cfg,
+                                   last_layer=i >= len(num_filters) - 2))
+        self.pfn_layers = nn.ModuleList(layers)
+        self.vx = voxel_size[0]
+        self.vy = voxel_size[1]
+        self.x_offset = self.vx / 2 + pc_range[0]
+        self.y_offset = self.vy / 2 + pc_range[1]
+
+    def forward(self, features, num_voxels, coors):
+        dtype = features.dtype
+        points_mean = features[:, :, :3].sum(dim=1, keepdim=True) / \
+            num_voxels.type_as(features).view(-1, 1, 1)
+        f_cluster = features[:, :, :3] - points_mean
+        f_center = torch.zeros_like(features[:, :, :2])
+        f_center[:, :, 0] = features[:, :, 0] - (coors[:, 3].to(dtype).unsqueeze(1) * self.vx + self.x_offset)
+        f_center[:, :, 1] = features[:, :, 1] - (coors[:, 2].to(dtype).unsqueeze(1) * self.vy + self.y_offset)
+        parts = [features, f_cluster, f_center]
+        if self._with_distance:
+            parts.append(torch.norm(features[:, :, :3], 2, 2, keepdim=True))
+        features = torch.cat(parts, dim=-1)
+        mask = get_paddings_indicator(num_voxels, features.shape[1], axis=0)
+        features = features * torch.unsqueeze(mask, -1).type_as(features)
+        for pfn in self.pfn_layers:
+            features = pfn(features)
+        return features.squeeze()
