@@ -1,0 +1,207 @@
+"""Seeded synthetic inputs for parity tests and the benchmark (no datasets offline).
+
+  kitti_like_cloud     SURVEY.md 8d: 64-beam spinning lidar restricted to the camera FOV,
+                       ground plane at sensor height 1.73 m, exponential obstacles, planted
+                       car-sized boxes with surface points
+  create_anchors_3d_range   restates det3d/core/bbox/box_np_ops.py:733-805
+  assign_targets       restates the single-class path of create_target_np
+                       (det3d/core/anchor/target_ops.py:28-222) with the nearest-IoU
+                       similarity (region_similarity.py:73-93, box_np_ops.py:343-355,955-994)
+  make_example         the `example` dict collate_kitti would hand to the detector
+                       (det3d/torchie/parallel/collate.py:90-150), built from raw points by
+                       the device voxelizer
+Targets are "next" rows in SURVEY.md 8f: computed once per seed on the host (numpy) and
+cached, so timed loops measure the hot path, not label assignment.
+"""
+import numpy as np
+import torch
+
+CAR_SIZE = (1.6, 3.9, 1.56)  # w, l, h
+
+KITTI_CAR = dict(
+    voxel_size=[0.05, 0.05, 0.1], pc_range=[0, -40.0, -3.0, 70.4, 40.0, 1.0], max_points=5,
+    max_voxels=20000, anchor_ranges=[0, -40.0, -1.0, 70.4, 40.0, -1.0], sizes=list(CAR_SIZE),
+    rotations=[0, 1.57], matched_threshold=0.6, unmatched_threshold=0.45, out_size_factor=8)
+
+
+def kitti_like_cloud(seed, n_points=20000, n_cars=8):
+    """float32 [n_points, 4] (x, y, z, intensity) + gt boxes [n_cars, 7] (x,y,z,w,l,h,r)."""
+    rng = np.random.default_rng(seed)
+    # planted cars on the ground, z = box centre
+    gt = np.zeros((n_cars, 7), dtype=np.float32)
+    gt[:, 0] = rng.uniform(6, 60, n_cars)
+    gt[:, 1] = rng.uniform(-25, 25, n_cars)
+    gt[:, 2] = -1.73 + CAR_SIZE[2] / 2
+    gt[:, 3:6] = np.array(CAR_SIZE) * rng.uniform(0.9, 1.1, (n_cars, 3))
+    gt[:, 6] = rng.uniform(-np.pi, np.pi, n_cars)
+    n_car_pts = int(n_points * 0.15)
+    n_bg = n_points - n_car_pts
+    az = rng.uniform(-np.pi / 4, np.pi / 4, n_bg)
+    beams = np.deg2rad(np.linspace(-24.8, 2.0, 64))
+    el = beams[rng.integers(0, 64, n_bg)]
+    with np.errstate(divide="ignore"):
+        r_ground = np.where(el < 0, 1.73 / np.maximum(np.tan(-el), 1e-6), np.inf)
+    r_obst = 3.0 + rng.exponential(25.0, n_bg)
+    r = np.minimum(np.minimum(r_ground, r_obst), 80.0)
+    x = r * np.cos(el) * np.cos(az)
+    y = r * np.cos(el) * np.sin(az)
+    z = r * np.sin(el) + rng.normal(0, 0.02, n_bg)
+    bg = np.stack([x, y, z, rng.uniform(0, 1, n_bg)], 1)
+    # car surface points: sample faces of each box, rotate (clockwise for +r like the reference)
+    per = max(n_car_pts // max(n_cars, 1), 1)
+    cars = []
+    for b in gt:
+        u = rng.uniform(-0.5, 0.5, (per, 3))
+        face = rng.integers(0, 3, per)
+        sign = rng.choice([-0.5, 0.5], per)
+        u[np.arange(per), face] = sign
+        loc = u * b[3:6]
+        c, s = np.cos(b[6]), np.sin(b[6])
+        px = loc[:, 0] * c + loc[:, 1] * s + b[0]
+        py = -loc[:, 0] * s + loc[:, 1] * c + b[1]
+        cars.append(np.stack([px, py, loc[:, 2] + b[2], rng.uniform(0, 1, per)], 1))
+    pts = np.concatenate([bg] + cars)[:n_points]
+    if len(pts) < n_points:
+        pts = np.concatenate([pts, bg[: n_points - len(pts)]])
+    rng.shuffle(pts)  # Preprocess shuffles points in train mode (preprocess.py:215-217)
+    return pts.astype(np.float32), gt
+
+
+def create_anchors_3d_range(feature_size, anchor_range, sizes=CAR_SIZE, rotations=(0, np.pi / 2),
+                            dtype=np.float32):
+    """feature_size [D, H, W] (zyx) -> anchors [D, H, W, n_sizes, n_rots, 7]."""
+    anchor_range = np.array(anchor_range, dtype)
+    stride = (anchor_range[3] - anchor_range[0]) / feature_size[2]
+    zc = np.linspace(anchor_range[2], anchor_range[5], feature_size[0], dtype=dtype)
+    yc = np.linspace(anchor_range[1], anchor_range[4], feature_size[1], endpoint=False, dtype=dtype) + stride / 2
+    xc = np.linspace(anchor_range[0], anchor_range[3], feature_size[2], endpoint=False, dtype=dtype) + stride / 2
+    rotations = np.array(rotations, dtype=dtype)
+    sizes = np.reshape(np.array(sizes, dtype=dtype), [-1, 3])
+    X, Y, Z, R = np.meshgrid(xc, yc, zc, rotations, indexing="ij")  # [W, H, D, nrot]
+    ns = sizes.shape[0]
+    parts = [np.repeat(a[:, :, :, None, :], ns, axis=3)[..., None] for a in (X, Y, Z)]
+    sz = np.broadcast_to(sizes.reshape(1, 1, 1, ns, 1, 3), parts[0].shape[:-1] + (3,))
+    rot = np.repeat(R[:, :, :, None, :], ns, axis=3)[..., None]
+    ret = np.concatenate(parts + [sz, rot], axis=-1).astype(dtype)
+    return np.transpose(ret, [2, 1, 0, 3, 4, 5])
+
+
+def _limit_period(val, offset=0.5, period=np.pi):
+    return val - np.floor(val / period + offset) * period
+
+
+def _near_bbox(rb):
+    """rbbox2d_to_near_bbox: [N,5] (x,y,w,l,r) -> axis-aligned [N,4]"""
+    rots = np.abs(_limit_period(rb[:, -1], 0.5, np.pi))
+    cond = (rots > np.pi / 4)[:, None]
+    ctr = np.where(cond, rb[:, [0, 1, 3, 2]], rb[:, :4])
+    return np.concatenate([ctr[:, :2] - ctr[:, 2:] / 2, ctr[:, :2] + ctr[:, 2:] / 2], axis=-1)
+
+
+def _iou_aligned(a, b):
+    """iou_jit(eps=0): [N,4] x [K,4] -> [N,K]"""
+    iw = np.minimum(a[:, None, 2], b[None, :, 2]) - np.maximum(a[:, None, 0], b[None, :, 0])
+    ih = np.minimum(a[:, None, 3], b[None, :, 3]) - np.maximum(a[:, None, 1], b[None, :, 1])
+    inter = np.clip(iw, 0, None) * np.clip(ih, 0, None)
+    ua = ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]))[:, None] + \
+        ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))[None, :] - inter
+    return np.where((iw > 0) & (ih > 0), inter / ua, 0.0).astype(np.float32)
+
+
+def _encode(boxes, anchors):
+    """second_box_encode, 7-dim (box_np_ops.py second_box_encode)."""
+    xa, ya, za, wa, la, ha, ra = np.split(anchors, 7, axis=-1)
+    xg, yg, zg, wg, lg, hg, rg = np.split(boxes, 7, axis=-1)
+    diag = np.sqrt(la ** 2 + wa ** 2)
+    return np.concatenate([(xg - xa) / diag, (yg - ya) / diag, (zg - za) / ha, np.log(wg / wa),
+                           np.log(lg / la), np.log(hg / ha), rg - ra], axis=-1)
+
+
+def assign_targets(anchors, gt_boxes, matched_threshold=0.6, unmatched_threshold=0.45):
+    """anchors [A,7], gt [G,7] -> labels [A] i32 (1 pos / 0 neg / -1 ignore),
+    reg_targets [A,7] f32, reg_weights [A] f32."""
+    A = anchors.shape[0]
+    labels = np.full((A,), -1, dtype=np.int32)
+    targets = np.zeros((A, 7), dtype=np.float32)
+    if len(gt_boxes) == 0:
+        labels[:] = 0
+        return labels, targets, np.zeros((A,), np.float32)
+    ov = _iou_aligned(_near_bbox(anchors[:, [0, 1, 3, 4, 6]]), _near_bbox(gt_boxes[:, [0, 1, 3, 4, 6]]))
+    a2g = ov.argmax(axis=1)
+    a2g_max = ov[np.arange(A), a2g]
+    g2a_max = ov.max(axis=0)
+    g2a_max[g2a_max == 0] = -1
+    force = np.where(ov == g2a_max[None, :])[0]
+    labels[force] = 1
+    pos = a2g_max >= matched_threshold
+    labels[pos] = 1
+    bg = a2g_max < unmatched_threshold
+    labels[bg] = 0
+    labels[force] = 1
+    fg = np.where(labels > 0)[0]
+    targets[fg] = _encode(gt_boxes[a2g[fg]], anchors[fg])
+    weights = np.zeros((A,), np.float32)
+    weights[fg] = 1.0
+    return labels, targets, weights
+
+
+class KittiCarSynthetic:
+    """Cycles seeded frames of the KITTI-car SECOND geometry (BASELINE.json configs[1])."""
+
+    def __init__(self, n_points=20000, n_seeds=16, cfg=None, n_cars=8):
+        self.cfg = dict(KITTI_CAR if cfg is None else cfg)
+        from .point_cloud_ops import grid_size_of
+
+        self.grid = grid_size_of(self.cfg["voxel_size"], self.cfg["pc_range"])  # x, y, z
+        f = self.cfg["out_size_factor"]
+        self.feature_size = [1, int(self.grid[1]) // f, int(self.grid[0]) // f]
+        anc = create_anchors_3d_range(self.feature_size, self.cfg["anchor_ranges"], self.cfg["sizes"],
+                                      self.cfg["rotations"])
+        self.anchors = anc.reshape(-1, 7)
+        self.frames = []
+        for s in range(n_seeds):
+            pts, gt = kitti_like_cloud(s, n_points, n_cars)
+            lab, tgt, w = assign_targets(self.anchors, gt, self.cfg["matched_threshold"],
+                                         self.cfg["unmatched_threshold"])
+            self.frames.append(dict(points=pts, gt=gt, labels=lab, reg_targets=tgt, reg_weights=w))
+
+    def host_batch(self, step, batch_size, rank=0, world=1):
+        idx = [(step * batch_size * world + rank * batch_size + i) % len(self.frames) for i in range(batch_size)]
+        fr = [self.frames[i] for i in idx]
+        off = np.cumsum([0] + [len(f["points"]) for f in fr]).astype(np.int32)
+        return dict(points=np.concatenate([f["points"] for f in fr]), frame_offsets=off,
+                    anchors=np.stack([self.anchors] * batch_size),
+                    labels=np.stack([f["labels"] for f in fr]),
+                    reg_targets=np.stack([f["reg_targets"] for f in fr]),
+                    reg_weights=np.stack([f["reg_weights"] for f in fr]),
+                    gt=[f["gt"] for f in fr], metadata=[dict(token=int(i)) for i in idx])
+
+    def device_batch(self, step, batch_size, device, rank=0, world=1):
+        hb = self.host_batch(step, batch_size, rank, world)
+        t = lambda a: torch.from_numpy(a).to(device, non_blocking=True)
+        return dict(points=t(hb["points"]), frame_offsets=t(hb["frame_offsets"]),
+                    anchors=[t(hb["anchors"])], labels=[t(hb["labels"])],
+                    reg_targets=[t(hb["reg_targets"])], reg_weights=[t(hb["reg_weights"])],
+                    metadata=hb["metadata"], gt=hb["gt"])
+
+
+def make_example(batch, cfg, fused_mean=True, want_voxels=False):
+    """raw device points -> the collate_kitti-style `example` (device voxelizer, 1 sync)."""
+    from .point_cloud_ops import grid_size_of, voxelize_batch
+
+    vb = voxelize_batch(batch["points"], batch["frame_offsets"], cfg["voxel_size"], cfg["pc_range"],
+                        cfg["max_points"], cfg["max_voxels"], want_voxels=want_voxels or not fused_mean,
+                        mean_channels=batch["points"].shape[1] if fused_mean else 0)
+    out = vb.sync()
+    grid = grid_size_of(cfg["voxel_size"], cfg["pc_range"])
+    bsz = batch["frame_offsets"].numel() - 1
+    ex = dict(coordinates=out["coordinates"], num_points=out["num_points"], num_voxels=out["num_voxels"],
+              shape=np.stack([grid] * bsz), anchors=batch["anchors"], metadata=batch.get("metadata", []))
+    for k in ("labels", "reg_targets", "reg_weights"):
+        if k in batch:
+            ex[k] = batch[k]
+    if "voxels" in out:
+        ex["voxels"] = out["voxels"]
+    if fused_mean:
+        ex["voxel_mean"] = out["mean"]
+    return ex

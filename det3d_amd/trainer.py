@@ -1,0 +1,81 @@
+"""One optimizer step of the reference training loop, without its generic hook machinery:
+   forward -> sum(losses["loss"]) -> backward -> gradient mean over ranks -> clip(35) ->
+   true weight decay + Adam(0.9, 0.99) -> one-cycle lr / momentum
+References: det3d/torchie/trainer/trainer.py:347-415 (batch_processor_inline, train loop),
+det3d/core/utils/dist_utils.py:45-57 (DistOptimizerHook), hooks/optimizer.py:10-13 (clip),
+det3d/solver/fastai_optim.py:155-171 (p *= 1 - wd*lr, then Adam with weight_decay 0),
+det3d/solver/learning_schedules_fastai.py:68-95 (OneCycle, cosine annealing).
+"""
+import contextlib
+import math
+
+import numpy as np
+import torch
+
+from . import dist as d3d_dist
+
+
+def annealing_cos(start, end, pct):
+    return end + (start - end) / 2 * (math.cos(math.pi * pct) + 1)
+
+
+class OneCycle:
+    def __init__(self, total_step, lr_max=3e-3, moms=(0.95, 0.85), div_factor=10.0, pct_start=0.4):
+        self.total_step = max(int(total_step), 1)
+        self.lr_max, self.moms, self.div_factor, self.pct_start = lr_max, tuple(moms), div_factor, pct_start
+        self.low_lr = lr_max / div_factor
+
+    def at(self, step):
+        """(lr, beta1) for global step `step` -- LRSchedulerStep.step semantics: phase starts
+        are int(total * pct); the last phase whose start <= step wins."""
+        a1 = int(self.total_step * self.pct_start)
+        step = min(step, self.total_step)
+        if step >= a1 and self.total_step > a1:
+            pct = (step - a1) / (self.total_step - a1)
+            return (annealing_cos(self.lr_max, self.low_lr / 1e4, pct),
+                    annealing_cos(self.moms[1], self.moms[0], pct))
+        pct = step / max(a1, 1)
+        return annealing_cos(self.low_lr, self.lr_max, pct), annealing_cos(self.moms[0], self.moms[1], pct)
+
+
+class TrainStep:
+    def __init__(self, model, total_steps, lr_max=3e-3, wd=0.01, moms=(0.95, 0.85), div_factor=10.0,
+                 pct_start=0.4, grad_clip=35.0, autocast_dtype=None):
+        self.model = model
+        self.sched = OneCycle(total_steps, lr_max, moms, div_factor, pct_start)
+        self.wd = wd
+        self.grad_clip = grad_clip
+        self.autocast_dtype = autocast_dtype
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.bucket = d3d_dist.FlatGradBucket(self.params)
+        kw = dict(lr=self.sched.low_lr, betas=(moms[0], 0.99), weight_decay=0.0)
+        dev = self.params[0].device
+        try:
+            self.opt = torch.optim.Adam(self.params, fused=dev.type == "cuda", **kw)
+        except (RuntimeError, TypeError):
+            self.opt = torch.optim.Adam(self.params, foreach=True, **kw)
+        self.global_step = 0
+        self.last = {}
+
+    def _ctx(self):
+        if self.autocast_dtype is None:
+            return contextlib.nullcontext()
+        return torch.autocast(device_type="cuda", dtype=self.autocast_dtype)
+
+    def __call__(self, example):
+        lr, mom = self.sched.at(self.global_step)
+        for g in self.opt.param_groups:
+            g["lr"] = lr
+            g["betas"] = (mom, g["betas"][1])
+        self.bucket.zero()
+        with self._ctx():
+            losses = self.model(example, return_loss=True)
+        loss = sum(losses["loss"])
+        loss.backward()  # grads accumulate straight into the flat bucket views
+        self.bucket.allreduce_mean()
+        gnorm = self.bucket.clip_norm_(self.grad_clip)
+        torch._foreach_mul_(self.params, 1.0 - self.wd * lr)  # true weight decay, bn_wd=True
+        self.opt.step()
+        self.global_step += 1
+        self.last = dict(loss=loss.detach(), grad_norm=gnorm, lr=lr, losses=losses)
+        return loss.detach()

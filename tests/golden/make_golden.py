@@ -271,9 +271,48 @@ def head_cases():
     torch.save(out, os.path.join(HERE, "head.pt"))
 
 
+def anchors_targets():
+    bnp = ref_loader.ref("det3d.core.bbox.box_np_ops")
+    tops = ref_loader.ref("det3d.core.anchor.target_ops")
+    rng = np.random.default_rng(21)
+    fs = [1, 25, 22]
+    rg = [0, -40.0, -1.0, 70.4, 40.0, -1.0]
+    # numpy >= 2 returns a tuple from meshgrid; the reference (written for numpy 1.x) assigns
+    # into it (box_np_ops.py:791) -- shim the return type only
+    _mg = np.meshgrid
+    np.meshgrid = lambda *a, **k: list(_mg(*a, **k))
+    try:
+        anc = bnp.create_anchors_3d_range(fs, rg, [1.6, 3.9, 1.56], [0, 1.57])
+    finally:
+        np.meshgrid = _mg
+    anchors = anc.reshape(-1, 7)
+    gt = np.zeros((9, 7), np.float32)
+    gt[:, 0] = rng.uniform(5, 65, 9)
+    gt[:, 1] = rng.uniform(-35, 35, 9)
+    gt[:, 2] = -1.0
+    gt[:, 3:6] = np.array([1.6, 3.9, 1.56]) * rng.uniform(0.85, 1.15, (9, 3))
+    gt[:, 6] = rng.uniform(-3.1, 3.1, 9)
+    gt[0, :2] = anchors[200, :2]  # one exactly on an anchor centre
+    gt[0, 6] = 0.0
+
+    def sim(a, g):
+        return bnp.iou_jit(bnp.rbbox2d_to_near_bbox(a[:, [0, 1, 3, 4, 6]]),
+                           bnp.rbbox2d_to_near_bbox(g[:, [0, 1, 3, 4, 6]]), eps=0.0)
+
+    ret = tops.create_target_np(anchors, gt, sim, bnp.second_box_encode, matched_threshold=0.6,
+                                unmatched_threshold=0.45, positive_fraction=None, box_code_size=7)
+    np.savez_compressed(os.path.join(HERE, "anchors_targets.npz"), feature_size=np.array(fs),
+                        anchor_range=np.array(rg), anchors6d=anc, gt=gt, labels=ret["labels"],
+                        bbox_targets=ret["bbox_targets"], weights=ret["bbox_outside_weights"])
+    print("anchors_targets:", anc.shape, int((ret["labels"] > 0).sum()), "pos",
+          int((ret["labels"] == 0).sum()), "neg")
+
+
 def main():
     ref_loader.install()
-    which = sys.argv[1:] or ["voxel", "iou", "vfe", "rpn", "head"]
+    which = sys.argv[1:] or ["voxel", "iou", "vfe", "rpn", "head", "anchors"]
+    if "anchors" in which:
+        anchors_targets()
     if "voxel" in which:
         voxel_cases()
     if "iou" in which:

@@ -138,3 +138,37 @@ def test_reference_configs_build_unmodified():
         assert any(k.startswith("neck.blocks.0.1.") for k in keys)
         assert any(k.startswith("bbox_head.tasks.0.conv_box.") for k in keys)
         assert cfg.assigner.out_size_factor in (2, 4, 8)
+
+
+def test_anchor_generation_and_target_assignment_vs_reference_golden():
+    """synthetic.create_anchors_3d_range / assign_targets vs goldens made by the reference's
+    create_anchors_3d_range (box_np_ops.py:733-805) and create_target_np (target_ops.py:28-222)."""
+    import numpy as np
+
+    from det3d_amd import synthetic
+
+    z = np.load(os.path.join(GOLDEN, "anchors_targets.npz"))
+    anc = synthetic.create_anchors_3d_range(z["feature_size"].tolist(), z["anchor_range"].tolist(),
+                                            [1.6, 3.9, 1.56], [0, 1.57])
+    assert anc.shape == z["anchors6d"].shape and np.array_equal(anc, z["anchors6d"])
+    lab, tgt, w = synthetic.assign_targets(anc.reshape(-1, 7), z["gt"], 0.6, 0.45)
+    assert np.array_equal(lab, z["labels"])
+    assert np.allclose(tgt, z["bbox_targets"], atol=1e-6)
+    assert np.array_equal(w, z["weights"])
+    assert (lab > 0).sum() >= len(z["gt"]) - 1
+
+
+def test_synthetic_cloud_is_seeded_and_in_spec():
+    import numpy as np
+
+    from det3d_amd import synthetic
+
+    a, ga = synthetic.kitti_like_cloud(3, 5000)
+    b, gb = synthetic.kitti_like_cloud(3, 5000)
+    assert a.dtype == np.float32 and a.shape == (5000, 4) and np.array_equal(a, b) and np.array_equal(ga, gb)
+    assert np.abs(np.arctan2(a[:, 1], a[:, 0])).max() < np.pi / 2
+    ds = synthetic.KittiCarSynthetic(n_points=2000, n_seeds=2)
+    assert ds.anchors.shape == (200 * 176 * 2, 7)
+    hb = ds.host_batch(0, 3)
+    assert hb["points"].shape == (6000, 4) and hb["frame_offsets"].tolist() == [0, 2000, 4000, 6000]
+    assert hb["labels"].shape == (3, 70400) and (hb["labels"] > 0).sum() > 0
