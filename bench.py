@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""Benchmark of the Det3D hot path on MI355X: training frames/sec of KITTI-car SECOND
+(BASELINE.json configs[1]: kitti_car_vfev3_spmiddlefhd_rpn1_mghead, batch 4 per GPU, bf16).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the whole hot path over one batch of synthetic KITTI-range clouds that
+are already resident in HBM: device voxelizer + fused mean VFE -> SpMiddleFHD (HIP rulebooks,
+sparse conv fwd) -> RPN / head (MIOpen via PyTorch-ROCm, bf16 autocast) -> losses -> backward
+(HIP dgrad / wgrad) -> gradient mean over ranks (RCCL) -> clip -> true-WD Adam.  Rank 0 prints
+ONE JSON line; `roofline` describes the hand-written sparse-conv gather kernel
+(spconv_fwd_mfma_kernel, timed with HIP events on its launch stream inside the timed region),
+`cpu_baseline` is the CPU oracle port (reference CPU voxelizer + PyTorch-CPU model) timed on
+this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="frames per GPU (config samples_per_gpu)")
+    ap.add_argument("--points", type=int, default=20000, help="points per synthetic frame")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-launch-log", action="store_true")
+    return ap.parse_args()
+
+
+def b_alg(kind, cin, cout, n_out, pairs, kvol, esz):
+    """algorithmic bytes of one sparse-conv launch, SURVEY.md 8(d):
+    P*Cin*e (gathered rows) + P*8 (pair indices) + Nout*Cout*e (rows written once) + weights."""
+    return pairs * cin * esz + pairs * 8 + n_out * cout * esz + kvol * cin * cout * esz
+
+
+def cpu_baseline(cfg, ds, state_dict, batch):
+    """reference CPU path (oracle port) on the host cores: 1 small warm-up + 1 timed step."""
+    from oracle import model_ref as M
+    from det3d_amd import synthetic
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = M.SecondRef(cfg)
+    m.load_state_dict(state_dict)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=3e-4, betas=(0.9, 0.99))
+
+    def one(step, bsz):
+        hb = ds.host_batch(step, bsz)
+        ex = M.cpu_example(hb, synthetic.KITTI_CAR)
+        loss = sum(m(ex)["loss"])
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 35)
+        opt.step()
+
+    one(0, 1)  # primitive creation / page faults, untimed
+    t0 = time.perf_counter()
+    one(1, batch)
+    dt = time.perf_counter() - t0
+    return dict(value=batch / dt, unit="frames/s", cores=cores, kind="port",
+                sample="1 training step of %d frames (oracle CPU voxelizer + PyTorch-CPU fp32 "
+                       "SECOND fwd/bwd/Adam), after a 1-frame warm-up; %.1f s" % (batch, dt))
+
+
+def main():
+    args = parse()
+    from det3d_amd import Config, build_detector, synthetic
+    from det3d_amd import dist as D
+    from det3d_amd import spconv
+    from det3d_amd.trainer import TrainStep
+
+    rank, local_rank, world = D.init_dist()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the det3d_amd hot path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    torch.backends.cudnn.benchmark = True  # MIOpen find mode for the dense RPN convs
+
+    cfg = Config.fromfile(os.path.join(ROOT, "det3d_amd", "configs", "kitti_car_second.py"))
+    torch.manual_seed(0)
+    model = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg)
+    cpu_state = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).train()
+    if args.dtype == "bf16":
+        model.neck.to(memory_format=torch.channels_last)
+    D.broadcast_params(model)
+
+    n_seeds = 16
+    ds = synthetic.KittiCarSynthetic(n_points=args.points, n_seeds=n_seeds)
+    n_batches = max(n_seeds // args.batch, 1)
+    # inputs resident in HBM before the timed region: distinct batches per rank, cycled
+    batches = [ds.device_batch(i, args.batch, dev, rank, world) for i in range(n_batches)]
+    vox_cfg = synthetic.KITTI_CAR
+
+    total_steps = args.steps + args.warmup
+    step_fn = TrainStep(model, total_steps=max(total_steps, 100), lr_max=cfg.lr_config.lr_max,
+                        wd=cfg.optimizer.VALUE.wd, moms=cfg.lr_config.moms,
+                        div_factor=cfg.lr_config.div_factor, pct_start=cfg.lr_config.pct_start,
+                        grad_clip=cfg.optimizer_config.grad_clip.max_norm,
+                        autocast_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
+
+    def one_step(i):
+        ex = synthetic.make_example(batches[i % n_batches], vox_cfg, fused_mean=True)
+        return step_fn(ex)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    D.barrier()
+
+    if not args.no_launch_log:
+        spconv.LAUNCH_LOG = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = time.perf_counter() - t0
+    log, spconv.LAUNCH_LOG = spconv.LAUNCH_LOG, None
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+    frames = args.steps * args.batch * world
+    value = frames / elapsed
+
+    out = {
+        "metric": "training frames/sec (KITTI-car SECOND, voxelize->sparse conv->RPN->head->loss->bwd->step)",
+        "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "kitti_car_vfev3_spmiddlefhd_rpn1_mghead: %d frames/GPU x %d pts "
+                               "(synthetic KITTI-car-range clouds, ~16k voxels/frame), fwd+bwd+Adam"
+                               % (args.batch, args.points),
+                   "frames_per_gpu": args.batch, "points_per_frame": args.points,
+                   "parallelism": "dp%d" % world, "final_loss": round(float(loss), 4)},
+    }
+
+    if rank == 0 and log:
+        esz = 2 if args.dtype == "bf16" else 4
+        pair_cache = {}
+        groups = {}
+        for kind, cin, cout, n_out, rb, e0, e1 in log:
+            ms = e0.elapsed_time(e1)
+            if id(rb) not in pair_cache:
+                pair_cache[id(rb)] = rb.pairs()
+            P = pair_cache[id(rb)]
+            if kind == "wgrad":
+                key, byts = "spconv_wgrad %dx%d" % (cin, cout), None
+            else:
+                mfma = cin % 16 == 0 and cout % 16 == 0
+                key = ("spconv_fwd_mfma_kernel<%d,%d>" if mfma else "spconv_fwd_generic<%d,%d>") % (cin, cout)
+                byts = b_alg(kind, cin, cout, n_out, P, rb.kvol, esz)
+            g = groups.setdefault(key, dict(ms=0.0, bytes=0.0, launches=0, pairs=0))
+            g["ms"] += ms
+            g["launches"] += 1
+            g["pairs"] += P
+            if byts is not None:
+                g["bytes"] += byts
+        table = {}
+        for k, g in groups.items():
+            row = dict(launches_per_step=g["launches"] / args.steps,
+                       avg_us=round(1e3 * g["ms"] / g["launches"], 2),
+                       ms_per_step=round(g["ms"] / args.steps, 4))
+            if g["bytes"]:
+                row["achieved_GBs"] = round(g["bytes"] / (g["ms"] * 1e-3) / 1e9, 1)
+                row["B_alg_MB_per_launch"] = round(g["bytes"] / g["launches"] / 1e6, 2)
+            table[k] = row
+        fwd = {k: g for k, g in groups.items() if k.startswith("spconv_fwd_mfma")}
+        if fwd:
+            dom = max(fwd, key=lambda k: fwd[k]["ms"])
+            g = fwd[dom]
+            ach = g["bytes"] / (g["ms"] * 1e-3) / 1e9
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                               "traffic": None,
+                               "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
+                               "alg_bytes_per_launch": int(g["bytes"] / g["launches"]),
+                               "launches_timed": g["launches"]}
+            all_b = sum(v["bytes"] for v in fwd.values())
+            all_ms = sum(v["ms"] for v in fwd.values())
+            out["roofline"]["all_mfma_layers_GBs"] = round(all_b / (all_ms * 1e-3) / 1e9, 1)
+        out["kernels"] = table
+        out["sparse_conv_ms_per_step"] = round(sum(g["ms"] for g in groups.values()) / args.steps, 3)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(cfg, ds, cpu_state, args.batch)
+            out["config"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        except Exception as e:  # the baseline is a reported side figure, never the product path
+            out["cpu_baseline"] = {"error": repr(e)}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -26,6 +26,23 @@ from . import _lib
 
 _DT = {torch.float32: _lib.D3D_F32, torch.bfloat16: _lib.D3D_BF16}
 
+# bench.py sets this to a list to time every d3d_sparse_conv_fwd launch with HIP events
+# recorded on the launch stream: entries are (kind, cin, cout, n_out, rulebook, ev0, ev1)
+LAUNCH_LOG = None
+
+
+def _timed(kind, cin, cout, n_out, rb, dev, fn):
+    if LAUNCH_LOG is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    st = torch.cuda.current_stream(dev)
+    e0.record(st)
+    rc = fn()
+    e1.record(st)
+    LAUNCH_LOG.append((kind, cin, cout, n_out, rb, e0, e1))
+    return rc
+
 
 def _triple(v):
     if isinstance(v, (list, tuple)):
@@ -149,9 +166,9 @@ class _SparseConvFn(torch.autograd.Function):
         wpack = weight.detach().reshape(kvol, cin, cout).transpose(1, 2).contiguous().to(feats.dtype)
         out = torch.empty((rb.n_out, cout), dtype=feats.dtype, device=feats.device)
         b = bias.detach().float().contiguous() if bias is not None else None
-        rc = L.d3d_sparse_conv_fwd(feats.data_ptr(), wpack.data_ptr(), _lib.ptr(b),
-                                   rb.nbr_out.data_ptr(), rb.cap_out, rb.n_out, kvol, cin, cout,
-                                   _DT[feats.dtype], out.data_ptr(), _lib.stream_ptr(feats.device))
+        rc = _timed("fwd", cin, cout, rb.n_out, rb, feats.device, lambda: L.d3d_sparse_conv_fwd(
+            feats.data_ptr(), wpack.data_ptr(), _lib.ptr(b), rb.nbr_out.data_ptr(), rb.cap_out,
+            rb.n_out, kvol, cin, cout, _DT[feats.dtype], out.data_ptr(), _lib.stream_ptr(feats.device)))
         _lib.check(rc, "d3d_sparse_conv_fwd")
         ctx.save_for_backward(feats, weight)
         ctx.rb = rb
@@ -178,14 +195,15 @@ class _SparseConvFn(torch.autograd.Function):
                 wd = w3.contiguous().to(feats.dtype)
                 nbr, cap = rb.nbr_in, rb.cap_in
             gin = torch.empty((rb.n_in, cin), dtype=feats.dtype, device=feats.device)
-            rc = L.d3d_sparse_conv_fwd(gout.data_ptr(), wd.data_ptr(), None, nbr.data_ptr(), cap,
-                                       rb.n_in, kvol, cout, cin, dt, gin.data_ptr(), stream)
+            rc = _timed("dgrad", cout, cin, rb.n_in, rb, feats.device, lambda: L.d3d_sparse_conv_fwd(
+                gout.data_ptr(), wd.data_ptr(), None, nbr.data_ptr(), cap, rb.n_in, kvol, cout, cin,
+                dt, gin.data_ptr(), stream))
             _lib.check(rc, "d3d_sparse_conv_fwd(dgrad)")
         if ctx.needs_input_grad[1]:
             gw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=feats.device)
-            rc = L.d3d_sparse_conv_wgrad(feats.data_ptr(), gout.data_ptr(), rb.nbr_out.data_ptr(),
-                                         rb.cap_out, rb.n_out, kvol, cin, cout, dt, gw.data_ptr(),
-                                         stream)
+            rc = _timed("wgrad", cin, cout, rb.n_out, rb, feats.device, lambda: L.d3d_sparse_conv_wgrad(
+                feats.data_ptr(), gout.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, rb.n_out, kvol,
+                cin, cout, dt, gw.data_ptr(), stream))
             _lib.check(rc, "d3d_sparse_conv_wgrad")
             gw = gw.reshape(weight.shape).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
