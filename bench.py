@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-log", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -49,16 +50,29 @@ def b_alg(kind, cin, cout, n_out, pairs, kvol, esz):
     return pairs * cin * esz + pairs * 8 + n_out * cout * esz + kvol * cin * cout * esz
 
 
-def cpu_baseline(cfg, ds, state_dict, batch):
-    """reference CPU path (oracle port) on the host cores: 1 small warm-up + 1 timed step."""
-    from oracle import model_ref as M
-    from det3d_amd import synthetic
+def _cpu_threads():
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    # the reference's CPU path is DataLoader workers + a PyTorch-CPU model; past ~16 threads the
+    # small per-offset mm / index_add_ ops of the sparse layers only lose to OpenMP barriers
+    return max(1, min(avail, int(os.environ.get("D3D_CPU_THREADS", "16"))))
 
-    cores = os.cpu_count() or 1
+
+def cpu_baseline_worker(batch, points):
+    """runs in a child process (bench.py --cpu-baseline-only): reference CPU path (oracle port)
+    on the host cores, 1 one-frame warm-up + 1 timed step of `batch` frames."""
+    from det3d_amd import Config, synthetic
+    from oracle import model_ref as M
+
+    cores = _cpu_threads()
     torch.set_num_threads(cores)
+    cfg = Config.fromfile(os.path.join(ROOT, "det3d_amd", "configs", "kitti_car_second.py"))
+    torch.manual_seed(0)
     m = M.SecondRef(cfg)
-    m.load_state_dict(state_dict)
     m.train()
+    ds = synthetic.KittiCarSynthetic(n_points=points, n_seeds=batch + 1)
     opt = torch.optim.Adam(m.parameters(), lr=3e-4, betas=(0.9, 0.99))
 
     def one(step, bsz):
@@ -74,32 +88,50 @@ def cpu_baseline(cfg, ds, state_dict, batch):
     t0 = time.perf_counter()
     one(1, batch)
     dt = time.perf_counter() - t0
-    return dict(value=batch / dt, unit="frames/s", cores=cores, kind="port",
-                sample="1 training step of %d frames (oracle CPU voxelizer + PyTorch-CPU fp32 "
-                       "SECOND fwd/bwd/Adam), after a 1-frame warm-up; %.1f s" % (batch, dt))
+    print(json.dumps(dict(value=round(batch / dt, 4), unit="frames/s", cores=cores, kind="port",
+                          sample="1 training step of %d frames x %d pts (oracle CPU voxelizer + "
+                                 "PyTorch-CPU fp32 SECOND fwd/bwd/clip/Adam) after a 1-frame warm-up: "
+                                 "%.1f s on %d threads" % (batch, points, dt, cores))))
+
+
+def cpu_baseline(batch, points, budget_s=240):
+    import subprocess
+
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only",
+                            "--batch", str(batch), "--points", str(points)],
+                           capture_output=True, text=True, timeout=budget_s)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        return {"error": "rc=%d %s" % (r.returncode, r.stderr[-300:])}
+    except subprocess.TimeoutExpired:
+        return {"error": "cpu baseline exceeded its %d s budget" % budget_s}
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        return cpu_baseline_worker(args.batch, args.points)
     from det3d_amd import Config, build_detector, synthetic
     from det3d_amd import dist as D
     from det3d_amd import spconv
     from det3d_amd.trainer import TrainStep
 
+    t_start = time.perf_counter()
     rank, local_rank, world = D.init_dist()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the det3d_amd hot path has no CPU fallback")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    torch.backends.cudnn.benchmark = True  # MIOpen find mode for the dense RPN convs
+    # MIOpen immediate mode by default: exhaustive find on a cold perf-db cache takes tens of
+    # minutes for the RPN's bf16 fwd/dgrad/wgrad configs (measured: > 20 min on a fresh box)
+    torch.backends.cudnn.benchmark = bool(int(os.environ.get("D3D_MIOPEN_FIND", "0")))
 
     cfg = Config.fromfile(os.path.join(ROOT, "det3d_amd", "configs", "kitti_car_second.py"))
     torch.manual_seed(0)
     model = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg)
-    cpu_state = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev).train()
-    if args.dtype == "bf16":
-        model.neck.to(memory_format=torch.channels_last)
     D.broadcast_params(model)
 
     n_seeds = 16
@@ -120,8 +152,14 @@ def main():
         ex = synthetic.make_example(batches[i % n_batches], vox_cfg, fused_mean=True)
         return step_fn(ex)
 
+    def note(msg):
+        if rank == 0:
+            print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
     for i in range(args.warmup):
         one_step(i)
+        torch.cuda.synchronize()
+        note("warmup step %d done" % i)
     torch.cuda.synchronize()
     D.barrier()
 
@@ -134,6 +172,7 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
+    note("timed region done: %.3f s" % elapsed)
     log, spconv.LAUNCH_LOG = spconv.LAUNCH_LOG, None
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -156,6 +195,7 @@ def main():
     }
 
     if rank == 0 and log:
+        note("post-processing %d launch records" % len(log))
         esz = 2 if args.dtype == "bf16" else 4
         pair_cache = {}
         groups = {}
@@ -203,11 +243,11 @@ def main():
         out["sparse_conv_ms_per_step"] = round(sum(g["ms"] for g in groups.values()) / args.steps, 3)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            out["cpu_baseline"] = cpu_baseline(cfg, ds, cpu_state, args.batch)
+        note("cpu baseline (child process) ...")
+        out["cpu_baseline"] = cpu_baseline(args.batch, args.points)
+        if "value" in out["cpu_baseline"]:
             out["config"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
-        except Exception as e:  # the baseline is a reported side figure, never the product path
-            out["cpu_baseline"] = {"error": repr(e)}
+        note("cpu baseline done")
 
     if rank == 0:
         print(json.dumps(out))

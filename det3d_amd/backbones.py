@@ -68,7 +68,7 @@ class _SparseMiddle(nn.Module):
         sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]
         coors = coors.int()
         if torch.is_autocast_enabled():
-            voxel_features = voxel_features.to(torch.get_autocast_gpu_dtype())
+            voxel_features = voxel_features.to(torch.get_autocast_dtype("cuda"))
         ret = spconv.SparseConvTensor(voxel_features, coors, sparse_shape.tolist(), batch_size)
         self.middle_conv.plan(ret)  # every rulebook of the stack, one host sync
         ret = self.middle_conv(ret)

@@ -74,7 +74,8 @@ class TrainStep:
         loss.backward()  # grads accumulate straight into the flat bucket views
         self.bucket.allreduce_mean()
         gnorm = self.bucket.clip_norm_(self.grad_clip)
-        torch._foreach_mul_(self.params, 1.0 - self.wd * lr)  # true weight decay, bn_wd=True
+        with torch.no_grad():
+            torch._foreach_mul_(self.params, 1.0 - self.wd * lr)  # true weight decay, bn_wd=True
         self.opt.step()
         self.global_step += 1
         self.last = dict(loss=loss.detach(), grad_norm=gnorm, lr=lr, losses=losses)
