@@ -29,10 +29,14 @@ _DT = {torch.float32: _lib.D3D_F32, torch.bfloat16: _lib.D3D_BF16}
 # bench.py sets this to a list to time every d3d_sparse_conv_fwd launch with HIP events
 # recorded on the launch stream: entries are (kind, cin, cout, n_out, rulebook, ev0, ev1)
 LAUNCH_LOG = None
+LAUNCH_LOG_LIMIT = 256
+LAUNCH_FILTER = None  # optional predicate (kind, cin, cout) -> bool: a timing event pair costs
+#                       ~0.4 ms of stream time on ROCm, so bench.py times only a sample
 
 
 def _timed(kind, cin, cout, n_out, rb, dev, fn):
-    if LAUNCH_LOG is None:
+    if LAUNCH_LOG is None or len(LAUNCH_LOG) >= LAUNCH_LOG_LIMIT or \
+            (LAUNCH_FILTER is not None and not LAUNCH_FILTER(kind, cin, cout)):
         return fn()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
