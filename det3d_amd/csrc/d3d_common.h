@@ -77,6 +77,36 @@ __device__ __forceinline__ uint32_t d3d_hash_insert(uint32_t *keys, uint32_t mas
   }
 }
 
+// ---- packed (key, value) table: one 8-byte entry per slot = one load per probe
+#define D3D_EMPTY_KV 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ void d3d_kv_insert(unsigned long long *tab, uint32_t mask, uint32_t key,
+                                              uint32_t val) {
+  const unsigned long long entry = (unsigned long long)key | ((unsigned long long)val << 32);
+  uint32_t s = d3d_hash_u32(key, mask);
+  while (true) {
+    unsigned long long cur = tab[s];
+    if ((uint32_t)cur == key && cur != D3D_EMPTY_KV) return;  // duplicate coordinate: first wins
+    if (cur == D3D_EMPTY_KV) {
+      unsigned long long old = atomicCAS(&tab[s], D3D_EMPTY_KV, entry);
+      if (old == D3D_EMPTY_KV || (uint32_t)old == key) return;
+    }
+    s = (s + 1) & mask;
+  }
+}
+
+// value stored for `key`, or -1
+__device__ __forceinline__ int d3d_kv_find(const unsigned long long *tab, uint32_t mask,
+                                           uint32_t key) {
+  uint32_t s = d3d_hash_u32(key, mask);
+  while (true) {
+    unsigned long long cur = tab[s];
+    if (cur == D3D_EMPTY_KV) return -1;
+    if ((uint32_t)cur == key) return (int)(cur >> 32);
+    s = (s + 1) & mask;
+  }
+}
+
 // returns slot of `key` or 0xFFFFFFFF
 __device__ __forceinline__ uint32_t d3d_hash_find(const uint32_t *keys, uint32_t mask,
                                                   uint32_t key) {

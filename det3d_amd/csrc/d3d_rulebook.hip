@@ -46,30 +46,37 @@ __device__ __forceinline__ void rb_count_pairs(int32_t *pair_count, int k, bool 
 }
 
 // ------------------------------------------------------------- submanifold
+// key -> row table with packed 8-byte (key,row) entries (one load per probe) and the
+// mirror symmetry of odd kernels: input j feeds output i through offset k  <=>  i feeds j
+// through kvol-1-k, so only offsets k < kvol/2 are probed and both table entries are written.
 __global__ void __launch_bounds__(256)
     rb_hash_build_kernel(const int4 *coords, const int32_t *n_dev, int cap, RbGeom G,
-                         uint32_t *hkeys, int32_t *hvals, uint32_t hmask) {
+                         unsigned long long *tab, uint32_t hmask) {
   int n = *n_dev;
   n = n < cap ? n : cap;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     int4 c = coords[i];
-    uint32_t key = rb_lin(c.x, c.y, c.z, c.w, G.in_shape);
-    uint32_t s = d3d_hash_insert(hkeys, hmask, key);
-    hvals[s] = i;
+    d3d_kv_insert(tab, hmask, rb_lin(c.x, c.y, c.z, c.w, G.in_shape), (uint32_t)i);
   }
 }
 
 __global__ void __launch_bounds__(256)
     rb_subm_lookup_kernel(const int4 *coords, const int32_t *n_dev, int cap, RbGeom G,
-                          const uint32_t *hkeys, const int32_t *hvals, uint32_t hmask,
-                          int32_t *nbr, int32_t *pair_count) {
+                          const unsigned long long *tab, uint32_t hmask, int32_t *nbr,
+                          int32_t *pair_count) {
   int n = *n_dev;
   n = n < cap ? n : cap;
-  const int64_t total = (int64_t)n * G.kvol;
+  const int half = G.kvol / 2;  // centre offset
+  const int64_t total = (int64_t)n * (half + 1);
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
     int k = (int)(t / n);
     int i = (int)(t - (int64_t)k * n);
+    if (k == half) {  // centre: every site maps to itself
+      nbr[(int64_t)k * cap + i] = i;
+      rb_count_pairs(pair_count, k, true);
+      continue;
+    }
     int4 c = coords[i];
     int kz = k / (G.k[1] * G.k[2]);
     int ky = (k / G.k[2]) % G.k[1];
@@ -80,18 +87,22 @@ __global__ void __launch_bounds__(256)
     int x = c.w + kx - G.k[2] / 2;
     int r = -1;
     if (z >= 0 && z < G.in_shape[0] && y >= 0 && y < G.in_shape[1] && x >= 0 &&
-        x < G.in_shape[2]) {
-      uint32_t s = d3d_hash_find(hkeys, hmask, rb_lin(c.x, z, y, x, G.in_shape));
-      if (s != D3D_EMPTY_KEY) r = hvals[s];
-    }
+        x < G.in_shape[2])
+      r = d3d_kv_find(tab, hmask, rb_lin(c.x, z, y, x, G.in_shape));
     nbr[(int64_t)k * cap + i] = r;
+    if (r >= 0) nbr[(int64_t)(G.kvol - 1 - k) * cap + r] = i;  // mirror pair
     rb_count_pairs(pair_count, k, r >= 0);
   }
 }
 
+__global__ void rb_mirror_counts_kernel(int32_t *pair_count, int kvol) {
+  int k = threadIdx.x;
+  if (k < kvol / 2) pair_count[kvol - 1 - k] = pair_count[k];
+}
+
 extern "C" size_t d3d_subm_rulebook_workspace_bytes(int cap) {
   size_t h = (size_t)d3d_next_pow2((int64_t)cap * 2 < 1024 ? 1024 : (int64_t)cap * 2);
-  return d3d_align_up(h * 4) * 2 + 256;
+  return d3d_align_up(h * 8) + 256;
 }
 
 extern "C" int d3d_subm_rulebook(const int32_t *coords, const int32_t *n_dev, int cap, int batch,
@@ -112,6 +123,7 @@ extern "C" int d3d_subm_rulebook(const int32_t *coords, const int32_t *n_dev, in
     G.p[j] = ksize[j] / 2;
   }
   G.kvol = ksize[0] * ksize[1] * ksize[2];
+  D3D_REQUIRE(G.kvol <= 1024, "d3d_subm_rulebook: kernel volume %d too large", G.kvol);
   double cells = (double)batch * spatial_shape[0] * spatial_shape[1] * spatial_shape[2];
   if (cells >= 4294967295.0)
     return d3d_set_error(D3D_ECAPACITY, "d3d_subm_rulebook: %.0f cells exceed u32 keys", cells);
@@ -119,21 +131,28 @@ extern "C" int d3d_subm_rulebook(const int32_t *coords, const int32_t *n_dev, in
     return d3d_set_error(D3D_ECAPACITY, "d3d_subm_rulebook: workspace too small");
   const int hsize = d3d_next_pow2((int64_t)cap * 2 < 1024 ? 1024 : (int64_t)cap * 2);
   D3dArena A(workspace, workspace_bytes);
-  uint32_t *hkeys = A.take<uint32_t>(hsize);
-  int32_t *hvals = A.take<int32_t>(hsize);
-  D3D_HIP_TRY(hipMemsetAsync(hkeys, 0xFF, (size_t)hsize * 4, stream));
+  unsigned long long *tab = A.take<unsigned long long>(hsize);
+  const int half = G.kvol / 2;
+  D3D_HIP_TRY(hipMemsetAsync(tab, 0xFF, (size_t)hsize * 8, stream));
   D3D_HIP_TRY(hipMemsetAsync(pair_count, 0, (size_t)G.kvol * 4, stream));
+  // offsets above the centre are only written through the mirror rule: default them to -1
+  if (G.kvol > 1)
+    D3D_HIP_TRY(hipMemsetAsync(nbr + (size_t)(half + 1) * cap, 0xFF, (size_t)half * cap * 4, stream));
   int nb = (cap + 255) / 256;
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(rb_hash_build_kernel, dim3(nb), dim3(256), 0, stream, (const int4 *)coords,
-                     n_dev, cap, G, hkeys, hvals, (uint32_t)(hsize - 1));
+                     n_dev, cap, G, tab, (uint32_t)(hsize - 1));
   D3D_LAUNCH_TRY("rb_hash_build_kernel");
-  int64_t items = (int64_t)cap * G.kvol;
+  int64_t items = (int64_t)cap * (half + 1);
   int lb = (int)((items + 255) / 256);
   if (lb > 2048) lb = 2048;
   hipLaunchKernelGGL(rb_subm_lookup_kernel, dim3(lb), dim3(256), 0, stream, (const int4 *)coords,
-                     n_dev, cap, G, hkeys, hvals, (uint32_t)(hsize - 1), nbr, pair_count);
+                     n_dev, cap, G, tab, (uint32_t)(hsize - 1), nbr, pair_count);
   D3D_LAUNCH_TRY("rb_subm_lookup_kernel");
+  if (G.kvol > 1) {
+    hipLaunchKernelGGL(rb_mirror_counts_kernel, dim3(1), dim3(512), 0, stream, pair_count, G.kvol);
+    D3D_LAUNCH_TRY("rb_mirror_counts_kernel");
+  }
   return D3D_OK;
 }
 

@@ -31,22 +31,34 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round to nearest 
 }
 
 // ===================================================================== forward
-// One wave = MT tiles of 16 output sites x all COUT columns.  256 threads = 4 waves.
-template <int CIN, int COUT, int MT, bool BF16>
-__global__ void __launch_bounds__(256)
+// One wave = MT tiles of 16 output sites x all COUT columns; a block is WAVES waves that
+// share W[k]: the block stages W[k] (COUT x CIN) in LDS once per kernel offset (double
+// buffered, +16 B row padding so ds_read_b128 of 16 rows is conflict-free) -- with per-wave
+// global loads the weight fragments were 4x the gather traffic through L1/TA
+// (profiles/round1_kernel_stats_v0.txt).  The gathered rows go straight from global memory
+// into MFMA B-operand registers, the next offset's indices are prefetched.
+template <int CIN, int COUT, int MT, int WAVES, bool BF16>
+__global__ void __launch_bounds__(WAVES * 64)
     spconv_fwd_mfma_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
                            const float *__restrict__ bias, const int32_t *__restrict__ nbr,
                            int cap, int n_out, int kvol, void *__restrict__ out_) {
   constexpr int NT = COUT / 16;
-  // k-steps per kernel offset and elements each lane holds per step
+  constexpr int ESZ = BF16 ? 2 : 4;
   constexpr int KW = BF16 ? ((CIN % 32 == 0) ? 32 : 16) : 16;  // channels per k-step
   constexpr int KS = CIN / KW;
-  constexpr int EPL = KW / 4;  // elements per lane per step (8 | 4 bf16, 4 f32)
+  constexpr int EPL = KW / 4;             // elements per lane per step (8 | 4 bf16, 4 f32)
+  constexpr int ROWB = CIN * ESZ + 16;    // padded LDS row (bytes)
+  constexpr int WBYTES = COUT * ROWB;
+  constexpr int NTHREADS = WAVES * 64;
+  constexpr int SEGS = CIN * ESZ / 16;    // 16-byte segments per weight row
+  constexpr int WVEC = COUT * SEGS;       // 16-byte vectors in W[k]
+  constexpr int WPT = (WVEC + NTHREADS - 1) / NTHREADS;
+  __shared__ __attribute__((aligned(16))) unsigned char wlds[2 * WBYTES];
+
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int row0 = (blockIdx.x * 4 + wave) * (MT * 16);
-  if (row0 >= n_out) return;
+  const int row0 = (blockIdx.x * WAVES + wave) * (MT * 16);
 
   f32x4_t acc[MT][NT];
 #pragma unroll
@@ -65,18 +77,41 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
   for (int m = 0; m < MT; ++m) idx[m] = live[m] ? nbr[site[m]] : -1;
 
+  // stage W[0]
+  const unsigned char *wg = (const unsigned char *)wpack_;
+  uint4 wreg[WPT];
+#pragma unroll
+  for (int j = 0; j < WPT; ++j) {
+    int e = threadIdx.x + j * NTHREADS;
+    if (e < WVEC) wreg[j] = *(const uint4 *)(wg + (size_t)e * 16);
+  }
+#pragma unroll
+  for (int j = 0; j < WPT; ++j) {
+    int e = threadIdx.x + j * NTHREADS;
+    if (e < WVEC) *(uint4 *)(wlds + (e / SEGS) * ROWB + (e % SEGS) * 16) = wreg[j];
+  }
+  __syncthreads();
+
   for (int k = 0; k < kvol; ++k) {
+    const unsigned char *wcur = wlds + (k & 1) * WBYTES;
+    // prefetch next offset: indices + weights (global -> registers)
     int nxt[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
       nxt[m] = (k + 1 < kvol && live[m]) ? nbr[(int64_t)(k + 1) * cap + site[m]] : -1;
+    if (k + 1 < kvol) {
+#pragma unroll
+      for (int j = 0; j < WPT; ++j) {
+        int e = threadIdx.x + j * NTHREADS;
+        if (e < WVEC) wreg[j] = *(const uint4 *)(wg + ((size_t)(k + 1) * WVEC + e) * 16);
+      }
+    }
     bool any = false;
 #pragma unroll
     for (int m = 0; m < MT; ++m) any |= idx[m] >= 0;
     if (__ballot(any) != 0ull) {
       if constexpr (BF16) {
         const uint16_t *feat = (const uint16_t *)feat_;
-        const uint16_t *wk = (const uint16_t *)wpack_ + (int64_t)k * COUT * CIN;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int ch = ks * KW + lg * EPL;
@@ -88,7 +123,7 @@ __global__ void __launch_bounds__(256)
                                   : make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-              uint4 wa = *(const uint4 *)(wk + (n * 16 + lr) * CIN + ch);
+              uint4 wa = *(const uint4 *)(wcur + (n * 16 + lr) * ROWB + ch * 2);
 #pragma unroll
               for (int m = 0; m < MT; ++m)
                 acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
@@ -103,7 +138,7 @@ __global__ void __launch_bounds__(256)
                                   : make_uint2(0, 0);
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-              uint2 wa = *(const uint2 *)(wk + (n * 16 + lr) * CIN + ch);
+              uint2 wa = *(const uint2 *)(wcur + (n * 16 + lr) * ROWB + ch * 2);
 #pragma unroll
               for (int m = 0; m < MT; ++m)
                 acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
@@ -114,7 +149,6 @@ __global__ void __launch_bounds__(256)
         }
       } else {
         const float *feat = (const float *)feat_;
-        const float *wk = (const float *)wpack_ + (int64_t)k * COUT * CIN;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int ch = ks * 16 + lg * 4;
@@ -125,7 +159,7 @@ __global__ void __launch_bounds__(256)
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
-            float4 wa = *(const float4 *)(wk + (n * 16 + lr) * CIN + ch);
+            float4 wa = *(const float4 *)(wcur + (n * 16 + lr) * ROWB + ch * 4);
             // 16x16x4 f32 MFMA: lane group lg supplies k = lg; four of them walk the
             // lane's 4 consecutive channels (any consistent k labelling is a valid sum)
 #pragma unroll
@@ -139,6 +173,17 @@ __global__ void __launch_bounds__(256)
         }
       }
     }
+    // publish W[k+1] into the other LDS buffer (its last readers finished at the previous
+    // barrier), then one barrier per offset
+    if (k + 1 < kvol) {
+      unsigned char *wnext = wlds + ((k + 1) & 1) * WBYTES;
+#pragma unroll
+      for (int j = 0; j < WPT; ++j) {
+        int e = threadIdx.x + j * NTHREADS;
+        if (e < WVEC) *(uint4 *)(wnext + (e / SEGS) * ROWB + (e % SEGS) * 16) = wreg[j];
+      }
+    }
+    __syncthreads();
 #pragma unroll
     for (int m = 0; m < MT; ++m) idx[m] = nxt[m];
   }
@@ -205,22 +250,23 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-template <int CIN, int COUT, int MT, bool BF16>
+template <int CIN, int COUT, int MT, int WAVES, bool BF16>
 static int launch_fwd(const void *feat, const void *wpack, const float *bias, const int32_t *nbr,
                       int cap, int n_out, int kvol, void *out, hipStream_t stream) {
-  const int rows_per_block = 4 * MT * 16;
+  const int rows_per_block = WAVES * MT * 16;
   const int nb = (n_out + rows_per_block - 1) / rows_per_block;
-  hipLaunchKernelGGL((spconv_fwd_mfma_kernel<CIN, COUT, MT, BF16>), dim3(nb), dim3(256), 0, stream,
-                     feat, wpack, bias, nbr, cap, n_out, kvol, out);
+  hipLaunchKernelGGL((spconv_fwd_mfma_kernel<CIN, COUT, MT, WAVES, BF16>), dim3(nb),
+                     dim3(WAVES * 64), 0, stream, feat, wpack, bias, nbr, cap, n_out, kvol, out);
   D3D_LAUNCH_TRY("spconv_fwd_mfma_kernel");
   return D3D_OK;
 }
 
-#define FWD_CASE(CI, CO, MT)                                                                   \
-  if (cin == CI && cout == CO) {                                                               \
-    return dtype == D3D_BF16                                                                   \
-               ? launch_fwd<CI, CO, MT, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, stream) \
-               : launch_fwd<CI, CO, MT, false>(feat, wpack, bias, nbr, cap, n_out, kvol, out, stream); \
+#define FWD_CASE(CI, CO, MT, WV)                                                                \
+  if (cin == CI && cout == CO) {                                                                \
+    return dtype == D3D_BF16 ? launch_fwd<CI, CO, MT, WV, true>(feat, wpack, bias, nbr, cap,    \
+                                                                n_out, kvol, out, stream)       \
+                             : launch_fwd<CI, CO, MT, WV, false>(feat, wpack, bias, nbr, cap,   \
+                                                                 n_out, kvol, out, stream);     \
   }
 
 extern "C" int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const float *bias,
@@ -233,16 +279,16 @@ extern "C" int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const fl
               cout);
   if (n_out == 0) return D3D_OK;
   D3D_REQUIRE(feat && wpack && nbr && out, "d3d_sparse_conv_fwd: null pointer");
-  FWD_CASE(16, 16, 2)
-  FWD_CASE(16, 32, 2)
-  FWD_CASE(32, 16, 2)
-  FWD_CASE(32, 32, 2)
-  FWD_CASE(32, 64, 2)
-  FWD_CASE(64, 32, 2)
-  FWD_CASE(64, 64, 2)
-  FWD_CASE(64, 128, 1)
-  FWD_CASE(128, 64, 2)
-  FWD_CASE(128, 128, 1)
+  FWD_CASE(16, 16, 2, 4)
+  FWD_CASE(16, 32, 2, 4)
+  FWD_CASE(32, 16, 2, 4)
+  FWD_CASE(32, 32, 2, 8)
+  FWD_CASE(32, 64, 2, 8)
+  FWD_CASE(64, 32, 2, 8)
+  FWD_CASE(64, 64, 2, 8)
+  FWD_CASE(64, 128, 1, 8)
+  FWD_CASE(128, 64, 2, 8)
+  FWD_CASE(128, 128, 1, 8)
   int64_t items = (int64_t)n_out * cout;
   int nb = (int)((items + 255) / 256);
   if (nb > 4096) nb = 4096;
@@ -400,6 +446,64 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// stem layers (Cin = 3..5 -> 16): every thread walks its share of the split's sites with
+// the whole [CIN x COUT] tile in registers, then a wave shuffle reduction and one atomic
+// per wave and element.  (the generic kernel below needs ~0.9 ms for this layer)
+template <int CIN, int COUT, bool BF16>
+__global__ void __launch_bounds__(256)
+    spconv_wgrad_small_kernel(const void *__restrict__ feat_, const void *__restrict__ dout_,
+                              const int32_t *__restrict__ nbr, int cap, int n_out,
+                              int rows_per_split, float *__restrict__ dw) {
+  const int k = blockIdx.x;
+  const int s0 = blockIdx.y * rows_per_split;
+  int s1 = s0 + rows_per_split;
+  if (s1 > n_out) s1 = n_out;
+  float acc[CIN][COUT];
+#pragma unroll
+  for (int a = 0; a < CIN; ++a)
+#pragma unroll
+    for (int b = 0; b < COUT; ++b) acc[a][b] = 0.f;
+  for (int site = s0 + threadIdx.x; site < s1; site += 256) {
+    int i = nbr[(int64_t)k * cap + site];
+    if (i < 0) continue;
+    float f[CIN], d[COUT];
+#pragma unroll
+    for (int a = 0; a < CIN; ++a)
+      f[a] = BF16 ? bf16_to_f32(((const uint16_t *)feat_)[(int64_t)i * CIN + a])
+                  : ((const float *)feat_)[(int64_t)i * CIN + a];
+#pragma unroll
+    for (int b = 0; b < COUT; ++b)
+      d[b] = BF16 ? bf16_to_f32(((const uint16_t *)dout_)[(int64_t)site * COUT + b])
+                  : ((const float *)dout_)[(int64_t)site * COUT + b];
+#pragma unroll
+    for (int a = 0; a < CIN; ++a)
+#pragma unroll
+      for (int b = 0; b < COUT; ++b) acc[a][b] = fmaf(f[a], d[b], acc[a][b]);
+  }
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int a = 0; a < CIN; ++a)
+#pragma unroll
+    for (int b = 0; b < COUT; ++b) {
+      float v = acc[a][b];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0 && v != 0.f) atomicAdd(&dw[((int64_t)k * CIN + a) * COUT + b], v);
+    }
+}
+
+#define WGRAD_SMALL_CASE(CI, CO)                                                                 \
+  if (cin == CI && cout == CO) {                                                                 \
+    if (dtype == D3D_BF16)                                                                       \
+      hipLaunchKernelGGL((spconv_wgrad_small_kernel<CI, CO, true>), dim3(kvol, splits),          \
+                         dim3(256), 0, stream, feat, dout, nbr, cap, n_out, rows_per_split, dw); \
+    else                                                                                         \
+      hipLaunchKernelGGL((spconv_wgrad_small_kernel<CI, CO, false>), dim3(kvol, splits),         \
+                         dim3(256), 0, stream, feat, dout, nbr, cap, n_out, rows_per_split, dw); \
+    D3D_LAUNCH_TRY("spconv_wgrad_small_kernel");                                                 \
+    return D3D_OK;                                                                               \
+  }
+
 #define WGRAD_CASE(CI, CO)                                                                      \
   if (dtype == D3D_BF16 && cin == CI && cout == CO) {                                           \
     hipLaunchKernelGGL((spconv_wgrad_mfma_kernel<CI, CO>), dim3(kvol, splits), dim3(256), 0,    \
@@ -429,6 +533,9 @@ extern "C" int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const i
   int rows_per_split = (n_out + splits - 1) / splits;
   rows_per_split = (rows_per_split + 63) / 64 * 64;
   splits = (n_out + rows_per_split - 1) / rows_per_split;
+  WGRAD_SMALL_CASE(3, 16)
+  WGRAD_SMALL_CASE(4, 16)
+  WGRAD_SMALL_CASE(5, 16)
   WGRAD_CASE(16, 16)
   WGRAD_CASE(16, 32)
   WGRAD_CASE(32, 32)

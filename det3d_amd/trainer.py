@@ -71,7 +71,8 @@ class TrainStep:
         with self._ctx():
             losses = self.model(example, return_loss=True)
         loss = sum(losses["loss"])
-        loss.backward()  # grads accumulate straight into the flat bucket views
+        loss.backward()
+        self.bucket.gather()  # one cat; p.grad become slices of the flat buffer
         self.bucket.allreduce_mean()
         gnorm = self.bucket.clip_norm_(self.grad_clip)
         with torch.no_grad():

@@ -1,0 +1,111 @@
+"""Data-parallel step on CPU: world_size-2 gloo processes.  The flat-bucket gradient mean must
+equal the single-process gradient of the concatenated batch (no BN in the test net: exact)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _net():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(),
+                               torch.nn.Conv2d(8, 4, 1))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from det3d_amd import dist as D
+
+    r, lr, w = D.init_dist(backend="gloo")
+    assert (r, w) == (rank, world) and D.world_size() == world and D.get_rank() == rank
+    net = _net()
+    if rank == 1:  # diverge on purpose: broadcast_params must bring rank 1 back
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(1.0)
+    D.broadcast_params(net)
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(2, 3, 6, 6, generator=g)
+    bucket = D.FlatGradBucket(net.parameters())
+    bucket.zero()
+    # per-rank loss is a mean over the local batch; the DP gradient is the mean over ranks
+    net(x).pow(2).mean().backward()
+    bucket.gather()
+    bucket.allreduce_mean()
+    total = bucket.clip_norm_(1e9)
+    objs = D.all_gather_objects(dict(rank=rank, n=int(x.shape[0])))
+    D.barrier()
+    q.put((rank, [p.grad.clone() for p in net.parameters()], float(total), objs,
+           [p.detach().clone() for p in net.parameters()]))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_mean_equals_single_process():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # reference: one process, both shards
+    net = _net()
+    xs = [torch.randn(2, 3, 6, 6, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    loss = sum(net(x).pow(2).mean() for x in xs) / world
+    loss.backward()
+    ref = [p.grad for p in net.parameters()]
+    for rank, grads, total, objs, params in res:
+        for g, r in zip(grads, ref):
+            assert torch.allclose(g, r, atol=1e-6)
+        assert total == pytest.approx(float(torch.sqrt(sum((r ** 2).sum() for r in ref))), rel=1e-5)
+        assert [o["rank"] for o in objs] == [0, 1]
+        for p, q0 in zip(params, _net().parameters()):
+            assert torch.equal(p, q0)  # rank 1 was reset to rank 0's weights
+    # both ranks ended with identical gradients
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+
+
+def test_flat_bucket_clip_and_views_single_process():
+    from det3d_amd import dist as D
+
+    net = _net()
+    b = D.FlatGradBucket(net.parameters())
+    b.zero()
+    net(torch.randn(2, 3, 5, 5)).sum().backward()
+    flat = b.gather()
+    assert flat.numel() == sum(p.numel() for p in net.parameters())
+    for p in net.parameters():
+        assert p.grad.data_ptr() >= flat.data_ptr() and p.grad.shape == p.shape
+    n0 = float(b.clip_norm_(0.5))
+    assert float(torch.linalg.vector_norm(flat)) == pytest.approx(min(n0, 0.5), rel=1e-4)
+
+
+def test_one_cycle_schedule_matches_reference_formula():
+    from det3d_amd.trainer import OneCycle
+
+    s = OneCycle(1000, lr_max=3e-3, moms=(0.95, 0.85), div_factor=10.0, pct_start=0.4)
+    assert s.at(0) == pytest.approx((3e-4, 0.95))
+    assert s.at(400)[0] == pytest.approx(3e-3) and s.at(400)[1] == pytest.approx(0.85)
+    lr_end, mom_end = s.at(1000)
+    assert lr_end == pytest.approx(3e-4 / 1e4, rel=1e-3) and mom_end == pytest.approx(0.95)
+    assert s.at(200)[0] == pytest.approx(3e-4 + (3e-3 - 3e-4) / 2)
