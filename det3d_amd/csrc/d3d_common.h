@@ -57,9 +57,13 @@ static inline int d3d_next_pow2(int64_t x) {
 #define D3D_EMPTY_KEY 0xFFFFFFFFu
 
 __device__ __forceinline__ uint32_t d3d_hash_u32(uint32_t k, uint32_t mask) {
-  // Fibonacci hashing + xor-fold: cheap, spreads the regular (z,y,x) lattice
-  k *= 2654435761u;
-  k ^= k >> 15;
+  // murmur3 finalizer: keys are linear indices of a regular (z,y,x) lattice, and half of all
+  // probes are for ABSENT neighbours that walk to the next empty slot -- a weak mix clusters
+  k ^= k >> 16;
+  k *= 0x85ebca6bu;
+  k ^= k >> 13;
+  k *= 0xc2b2ae35u;
+  k ^= k >> 16;
   return k & mask;
 }
 

@@ -32,8 +32,11 @@ __device__ __forceinline__ uint32_t rb_lin(int b, int z, int y, int x, const int
   return (uint32_t)((((int64_t)b * shape[0] + z) * shape[1] + y) * shape[2] + x);
 }
 
-// wave-aggregated pair counting: one atomic per wave when the wave shares one k
+// wave-aggregated pair counting: one atomic per wave when the wave shares one k.  Optional
+// (pair_count == NULL skips it): kvol hot addresses serialise ~30k same-address atomics per
+// launch at L2, which was >50 % of the rulebook kernels' time (profiles/round1_kernel_stats_v1).
 __device__ __forceinline__ void rb_count_pairs(int32_t *pair_count, int k, bool found) {
+  if (pair_count == nullptr) return;
   unsigned long long m = __ballot(found);
   int k0 = __builtin_amdgcn_readfirstlane(k);
   bool uniform = __ballot(k != k0) == 0ull;
@@ -111,7 +114,7 @@ extern "C" int d3d_subm_rulebook(const int32_t *coords, const int32_t *n_dev, in
                                  d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   D3D_REQUIRE(cap >= 1 && batch >= 1, "d3d_subm_rulebook: cap/batch");
-  D3D_REQUIRE(coords && n_dev && nbr && pair_count, "d3d_subm_rulebook: null pointer");
+  D3D_REQUIRE(coords && n_dev && nbr, "d3d_subm_rulebook: null pointer");
   RbGeom G;
   G.batch = batch;
   for (int j = 0; j < 3; ++j) {
@@ -134,7 +137,7 @@ extern "C" int d3d_subm_rulebook(const int32_t *coords, const int32_t *n_dev, in
   unsigned long long *tab = A.take<unsigned long long>(hsize);
   const int half = G.kvol / 2;
   D3D_HIP_TRY(hipMemsetAsync(tab, 0xFF, (size_t)hsize * 8, stream));
-  D3D_HIP_TRY(hipMemsetAsync(pair_count, 0, (size_t)G.kvol * 4, stream));
+  if (pair_count) D3D_HIP_TRY(hipMemsetAsync(pair_count, 0, (size_t)G.kvol * 4, stream));
   // offsets above the centre are only written through the mirror rule: default them to -1
   if (G.kvol > 1)
     D3D_HIP_TRY(hipMemsetAsync(nbr + (size_t)(half + 1) * cap, 0xFF, (size_t)half * cap * 4, stream));
@@ -149,7 +152,7 @@ extern "C" int d3d_subm_rulebook(const int32_t *coords, const int32_t *n_dev, in
   hipLaunchKernelGGL(rb_subm_lookup_kernel, dim3(lb), dim3(256), 0, stream, (const int4 *)coords,
                      n_dev, cap, G, tab, (uint32_t)(hsize - 1), nbr, pair_count);
   D3D_LAUNCH_TRY("rb_subm_lookup_kernel");
-  if (G.kvol > 1) {
+  if (G.kvol > 1 && pair_count) {
     hipLaunchKernelGGL(rb_mirror_counts_kernel, dim3(1), dim3(512), 0, stream, pair_count, G.kvol);
     D3D_LAUNCH_TRY("rb_mirror_counts_kernel");
   }
@@ -283,7 +286,7 @@ extern "C" int d3d_conv_rulebook(const int32_t *coords_in, const int32_t *n_in_d
                                  size_t workspace_bytes, d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   D3D_REQUIRE(cap_in >= 1 && cap_out >= 1 && batch >= 1, "d3d_conv_rulebook: capacities");
-  D3D_REQUIRE(coords_in && n_in_dev && coords_out && n_out_dev && nbr_out && nbr_in && pair_count,
+  D3D_REQUIRE(coords_in && n_in_dev && coords_out && n_out_dev && nbr_out && nbr_in,
               "d3d_conv_rulebook: null pointer");
   RbGeom G;
   G.batch = batch;
@@ -313,7 +316,7 @@ extern "C" int d3d_conv_rulebook(const int32_t *coords_in, const int32_t *n_in_d
   if (!tiles) return d3d_set_error(D3D_ECAPACITY, "d3d_conv_rulebook: workspace carve failed");
 
   D3D_HIP_TRY(hipMemsetAsync(bitmap, 0, words * 4, stream));
-  D3D_HIP_TRY(hipMemsetAsync(pair_count, 0, (size_t)G.kvol * 4, stream));
+  if (pair_count) D3D_HIP_TRY(hipMemsetAsync(pair_count, 0, (size_t)G.kvol * 4, stream));
   int64_t items = (int64_t)cap_in * G.kvol;
   int nb = (int)((items + 255) / 256);
   if (nb > 2048) nb = 2048;

@@ -78,9 +78,17 @@ class Rulebook:
         self.out_shape = out_shape
         self.subm = subm
 
+    def pair_counts(self):
+        """pairs per kernel offset, int64 [kvol] on the device.  Counted on demand from the
+        table (the kernels skip their atomic counters on the hot path)."""
+        if self.pair_count is None:
+            t = self.nbr_out.view(self.kvol, self.cap_out)[:, : self.n_out]
+            self.pair_count = (t >= 0).sum(1)
+        return self.pair_count
+
     def pairs(self):
         """number of rulebook pairs P (host int; one small D2H)."""
-        return int(self.pair_count.sum().item())
+        return int(self.pair_counts().sum().item())
 
     def canonical_pairs(self):
         """(k, in_row, out_row) triples as a sorted numpy array -- test helper."""
@@ -99,24 +107,25 @@ def _count_tensor(n, device):
     return torch.tensor([int(n)], dtype=torch.int32, device=device)
 
 
-def build_subm_rulebook(indices, n_dev, n, cap, batch, spatial_shape, ksize):
+def build_subm_rulebook(indices, n_dev, n, cap, batch, spatial_shape, ksize, count_pairs=False):
     """Enqueue d3d_subm_rulebook.  `n` may be None while the count is still only on
     the device (planning); `cap` bounds it."""
     L = _lib.lib()
     dev = indices.device
     kvol = ksize[0] * ksize[1] * ksize[2]
     nbr = torch.empty((kvol * cap,), dtype=torch.int32, device=dev)
-    pc = torch.empty((kvol,), dtype=torch.int32, device=dev)
+    pc = torch.empty((kvol,), dtype=torch.int32, device=dev) if count_pairs else None
     wsb = L.d3d_subm_rulebook_workspace_bytes(cap)
     ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
     rc = L.d3d_subm_rulebook(indices.data_ptr(), n_dev.data_ptr(), cap, batch,
                              _lib.i32_array(spatial_shape), _lib.i32_array(ksize), nbr.data_ptr(),
-                             pc.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
+                             _lib.ptr(pc), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
     _lib.check(rc, "d3d_subm_rulebook")
     return Rulebook(kvol, cap, cap, nbr, None, pc, n, n, indices, list(spatial_shape), True)
 
 
-def build_conv_rulebook(indices, n_dev, n, cap_in, batch, in_shape, ksize, stride, padding):
+def build_conv_rulebook(indices, n_dev, n, cap_in, batch, in_shape, ksize, stride, padding,
+                        count_pairs=False):
     """Enqueue d3d_conv_rulebook; returns (rulebook, n_out_dev).  rulebook.n_out and
     .out_indices are provisional (capacity views) until `finalize_conv_rulebook`."""
     L = _lib.lib()
@@ -132,7 +141,7 @@ def build_conv_rulebook(indices, n_dev, n, cap_in, batch, in_shape, ksize, strid
     n_out_dev = torch.empty((1,), dtype=torch.int32, device=dev)
     nbr_out = torch.empty((kvol * cap_out,), dtype=torch.int32, device=dev)
     nbr_in = torch.empty((kvol * cap_in,), dtype=torch.int32, device=dev)
-    pc = torch.empty((kvol,), dtype=torch.int32, device=dev)
+    pc = torch.empty((kvol,), dtype=torch.int32, device=dev) if count_pairs else None
     oshape = _lib.i32_array(out_shape)
     wsb = L.d3d_conv_rulebook_workspace_bytes(batch, oshape)
     ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
@@ -140,7 +149,7 @@ def build_conv_rulebook(indices, n_dev, n, cap_in, batch, in_shape, ksize, strid
                              _lib.i32_array(in_shape), _lib.i32_array(ksize),
                              _lib.i32_array(stride), _lib.i32_array(padding), oshape,
                              coords_out.data_ptr(), n_out_dev.data_ptr(), cap_out,
-                             nbr_out.data_ptr(), nbr_in.data_ptr(), pc.data_ptr(), ws.data_ptr(),
+                             nbr_out.data_ptr(), nbr_in.data_ptr(), _lib.ptr(pc), ws.data_ptr(),
                              wsb, _lib.stream_ptr(dev))
     _lib.check(rc, "d3d_conv_rulebook")
     rb = Rulebook(kvol, cap_in, cap_out, nbr_out, nbr_in, pc, n, None, coords_out, out_shape, False)

@@ -87,7 +87,8 @@ int d3d_voxelize(const float *points, int64_t n_points, int point_stride,
  *
  *  coords dev [n,4] i32 (b,z,y,x); n is read from DEVICE memory (*n_dev) so
  *  the chain voxelize -> rulebooks needs no host sync; `cap` bounds n.
- *  pair_count dev [kvol] i32: pairs per offset (centre included).
+ *  pair_count dev [kvol] i32: pairs per offset (centre included), or NULL to skip the
+ *  counting (it costs same-address atomics; only reporting needs it).
  */
 size_t d3d_subm_rulebook_workspace_bytes(int cap);
 int d3d_subm_rulebook(const int32_t *coords, const int32_t *n_dev, int cap, int batch,

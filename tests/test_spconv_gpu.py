@@ -38,15 +38,16 @@ GEOMS = [
 ]
 
 
-def _build(idx, batch, shape, ksize, stride, padding, subm):
+def _build(idx, batch, shape, ksize, stride, padding, subm, count_pairs=True):
     from det3d_amd import spconv
 
     ind = torch.from_numpy(idx).cuda()
     n = len(idx)
     n_dev = torch.tensor([n], dtype=torch.int32, device="cuda")
     if subm:
-        return spconv.build_subm_rulebook(ind, n_dev, n, max(n, 1), batch, shape, ksize)
-    rb, n_out = spconv.build_conv_rulebook(ind, n_dev, n, max(n, 1), batch, shape, ksize, stride, padding)
+        return spconv.build_subm_rulebook(ind, n_dev, n, max(n, 1), batch, shape, ksize, count_pairs=count_pairs)
+    rb, n_out = spconv.build_conv_rulebook(ind, n_dev, n, max(n, 1), batch, shape, ksize, stride, padding,
+                                           count_pairs=count_pairs)
     return spconv.finalize_conv_rulebook(rb, n, int(n_out.item()))
 
 
@@ -64,7 +65,10 @@ def test_rulebook_bit_exact(ksize, stride, padding, subm):
     assert np.array_equal(rb.canonical_pairs(), ref)
     assert rb.pairs() == len(ref)
     pc = rb.pair_count.cpu().numpy()
-    assert pc.tolist() == [len(p[0]) for p in pairs]
+    assert pc.tolist() == [len(p[0]) for p in pairs]           # in-kernel counters
+    lazy = _build(idx, 3, shape, ksize, stride, padding, subm, count_pairs=False)
+    assert lazy.pair_count is None
+    assert lazy.pair_counts().cpu().tolist() == pc.tolist()     # counted on demand from the table
     if not subm:  # input-stationary twin table describes the same pair set
         t = rb.nbr_in.view(rb.kvol, rb.cap_in)[:, : rb.n_in].cpu().numpy()
         k, i = np.nonzero(t >= 0)
