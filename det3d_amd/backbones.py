@@ -50,10 +50,15 @@ class SparseBasicBlock(spconv.SparseModule):
     def forward(self, x):
         identity = x
         out = self.conv1(x)
-        out.features = self.bn1(out.features)
-        out.features = self.relu(out.features)
+        if spconv.FUSE_BN_RELU and spconv._fusable_bn(self.bn1, out.features):
+            out.features = spconv.bn_relu(self.bn1, out.features, relu=True)
+        else:
+            out.features = self.relu(self.bn1(out.features))
         out = self.conv2(out)
-        out.features = self.bn2(out.features)
+        if spconv.FUSE_BN_RELU and spconv._fusable_bn(self.bn2, out.features):
+            out.features = spconv.bn_relu(self.bn2, out.features, relu=False)
+        else:
+            out.features = self.bn2(out.features)
         if self.downsample is not None:
             identity = self.downsample(x)
         out.features = out.features + identity.features

@@ -20,6 +20,7 @@ SOURCES = [
     "d3d_voxelize.hip",
     "d3d_rulebook.hip",
     "d3d_spconv.hip",
+    "d3d_bn.hip",
     "d3d_dense.hip",
     "d3d_nms.hip",
 ]

@@ -1,0 +1,299 @@
+// BatchNorm1d (+ReLU) over the active sites of a sparse tensor, gfx950.
+//
+// The reference applies nn.BatchNorm1d and nn.ReLU as separate modules to `.features`
+// ([N, C], N ~ 10^5) after every sparse conv (det3d/models/backbones/scn.py:106-157,76-87).
+// In PyTorch-ROCm that is 3 + 3 kernels per layer at ~60 us for the two reductions
+// (profiles/round1_kernel_stats_v1.txt: 2.3 ms of a 13.3 ms step).  Here:
+//   fwd  = stats pass (per-channel sum / sum of squares, f32) + apply pass that derives
+//          mean / invstd / scale / shift in its prologue, updates the running statistics
+//          (block 0) and writes relu(x * scale + shift)
+//   bwd  = reduce pass (dbeta, dgamma; the ReLU mask is recomputed from x) + dx pass
+// Every pass is one coalesced 16 B/lane sweep over [N, C]: pure HBM streaming.
+// Statistics are accumulated with f32 atomics (LDS then global), so the last bits of
+// mean/var depend on arrival order -- the conv outputs themselves stay deterministic.
+#include "d3d_common.h"
+
+__device__ __forceinline__ float bn_bf16_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ uint32_t bn_f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+template <bool BF16> struct BnVec {
+  static constexpr int EPV = BF16 ? 8 : 4;  // elements per 16-byte vector
+  __device__ static void load(const void *base, int64_t vec_index, float *v) {
+    uint4 r = ((const uint4 *)base)[vec_index];
+    if (BF16) {
+      v[0] = bn_bf16_to_f32(r.x & 0xffffu); v[1] = bn_bf16_to_f32(r.x >> 16);
+      v[2] = bn_bf16_to_f32(r.y & 0xffffu); v[3] = bn_bf16_to_f32(r.y >> 16);
+      v[4] = bn_bf16_to_f32(r.z & 0xffffu); v[5] = bn_bf16_to_f32(r.z >> 16);
+      v[6] = bn_bf16_to_f32(r.w & 0xffffu); v[7] = bn_bf16_to_f32(r.w >> 16);
+    } else {
+      v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y);
+      v[2] = __uint_as_float(r.z); v[3] = __uint_as_float(r.w);
+    }
+  }
+  __device__ static void store(void *base, int64_t vec_index, const float *v) {
+    uint4 r;
+    if (BF16) {
+      r.x = bn_f32_to_bf16(v[0]) | (bn_f32_to_bf16(v[1]) << 16);
+      r.y = bn_f32_to_bf16(v[2]) | (bn_f32_to_bf16(v[3]) << 16);
+      r.z = bn_f32_to_bf16(v[4]) | (bn_f32_to_bf16(v[5]) << 16);
+      r.w = bn_f32_to_bf16(v[6]) | (bn_f32_to_bf16(v[7]) << 16);
+    } else {
+      r.x = __float_as_uint(v[0]); r.y = __float_as_uint(v[1]);
+      r.z = __float_as_uint(v[2]); r.w = __float_as_uint(v[3]);
+    }
+    ((uint4 *)base)[vec_index] = r;
+  }
+};
+
+#define BN_MAXC 256
+
+// thread -> (row lane, 16-byte segment of the row); segs = c / EPV divides 256
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+    bn_stats_kernel(const void *__restrict__ x, int n, int c, float *__restrict__ stats) {
+  constexpr int EPV = BnVec<BF16>::EPV;
+  __shared__ float red[2 * BN_MAXC];
+  for (int i = threadIdx.x; i < 2 * c; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int segs = c / EPV;
+  const int seg = threadIdx.x % segs, rl = threadIdx.x / segs, rp = 256 / segs;
+  float s[EPV], q[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) s[j] = q[j] = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * rp + rl; r < n; r += (int64_t)gridDim.x * rp) {
+    float v[EPV];
+    BnVec<BF16>::load(x, r * segs + seg, v);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      s[j] += v[j];
+      q[j] = fmaf(v[j], v[j], q[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    atomicAdd(&red[seg * EPV + j], s[j]);
+    atomicAdd(&red[c + seg * EPV + j], q[j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * c; i += 256) atomicAdd(&stats[i], red[i]);
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+    bn_apply_kernel(const void *__restrict__ x, int n, int c, const float *__restrict__ gamma,
+                    const float *__restrict__ beta, float *running_mean, float *running_var,
+                    float momentum, float eps, int training, int relu,
+                    const float *__restrict__ stats, void *__restrict__ y, float *save_mean,
+                    float *save_invstd) {
+  constexpr int EPV = BnVec<BF16>::EPV;
+  __shared__ float scale[BN_MAXC], shift[BN_MAXC];
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    float mean, var;
+    if (training) {
+      mean = stats[ch] / (float)n;
+      var = fmaxf(stats[c + ch] / (float)n - mean * mean, 0.f);  // biased, as F.batch_norm
+    } else {
+      mean = running_mean[ch];
+      var = running_var[ch];
+    }
+    float invstd = rsqrtf(var + eps);
+    float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
+    scale[ch] = g * invstd;
+    shift[ch] = b - mean * g * invstd;
+    if (blockIdx.x == 0) {
+      if (save_mean) save_mean[ch] = mean;
+      if (save_invstd) save_invstd[ch] = invstd;
+      if (training && running_mean) {
+        float unbiased = n > 1 ? var * ((float)n / (float)(n - 1)) : var;
+        running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * mean;
+        running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
+      }
+    }
+  }
+  __syncthreads();
+  const int segs = c / EPV;
+  const int seg = threadIdx.x % segs, rl = threadIdx.x / segs, rp = 256 / segs;
+  float sc[EPV], sh[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    sc[j] = scale[seg * EPV + j];
+    sh[j] = shift[seg * EPV + j];
+  }
+  for (int64_t r = (int64_t)blockIdx.x * rp + rl; r < n; r += (int64_t)gridDim.x * rp) {
+    float v[EPV];
+    BnVec<BF16>::load(x, r * segs + seg, v);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      float z = fmaf(v[j], sc[j], sh[j]);
+      v[j] = relu ? fmaxf(z, 0.f) : z;
+    }
+    BnVec<BF16>::store(y, r * segs + seg, v);
+  }
+}
+
+// dz = dy * [z > 0] ; dbeta = sum dz ; dgamma = sum dz * xhat
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+    bn_bwd_reduce_kernel(const void *__restrict__ x, const void *__restrict__ dy, int n, int c,
+                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                         const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
+                         float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  constexpr int EPV = BnVec<BF16>::EPV;
+  __shared__ float red[2 * BN_MAXC];
+  for (int i = threadIdx.x; i < 2 * c; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int segs = c / EPV;
+  const int seg = threadIdx.x % segs, rl = threadIdx.x / segs, rp = 256 / segs;
+  float mu[EPV], is[EPV], g[EPV], b[EPV], sg[EPV], sb[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    int ch = seg * EPV + j;
+    mu[j] = mean[ch];
+    is[j] = invstd[ch];
+    g[j] = gamma ? gamma[ch] : 1.f;
+    b[j] = beta ? beta[ch] : 0.f;
+    sg[j] = sb[j] = 0.f;
+  }
+  for (int64_t r = (int64_t)blockIdx.x * rp + rl; r < n; r += (int64_t)gridDim.x * rp) {
+    float v[EPV], d[EPV];
+    BnVec<BF16>::load(x, r * segs + seg, v);
+    BnVec<BF16>::load(dy, r * segs + seg, d);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      float xh = (v[j] - mu[j]) * is[j];
+      float dz = (relu && fmaf(xh, g[j], b[j]) <= 0.f) ? 0.f : d[j];
+      sb[j] += dz;
+      sg[j] = fmaf(dz, xh, sg[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    atomicAdd(&red[seg * EPV + j], sg[j]);
+    atomicAdd(&red[c + seg * EPV + j], sb[j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < c; i += 256) {
+    atomicAdd(&dgamma[i], red[i]);
+    atomicAdd(&dbeta[i], red[c + i]);
+  }
+}
+
+// dx = gamma * invstd * (dz - dbeta/N - xhat * dgamma/N)
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+    bn_bwd_dx_kernel(const void *__restrict__ x, const void *__restrict__ dy, int n, int c,
+                     const float *__restrict__ gamma, const float *__restrict__ beta,
+                     const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
+                     const float *__restrict__ dgamma, const float *__restrict__ dbeta,
+                     void *__restrict__ dx) {
+  constexpr int EPV = BnVec<BF16>::EPV;
+  const int segs = c / EPV;
+  const int seg = threadIdx.x % segs, rl = threadIdx.x / segs, rp = 256 / segs;
+  float mu[EPV], is[EPV], g[EPV], b[EPV], c1[EPV], c2[EPV];
+  const float inv_n = 1.f / (float)n;
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    int ch = seg * EPV + j;
+    mu[j] = mean[ch];
+    is[j] = invstd[ch];
+    g[j] = gamma ? gamma[ch] : 1.f;
+    b[j] = beta ? beta[ch] : 0.f;
+    c1[j] = dbeta[ch] * inv_n;
+    c2[j] = dgamma[ch] * inv_n;
+  }
+  for (int64_t r = (int64_t)blockIdx.x * rp + rl; r < n; r += (int64_t)gridDim.x * rp) {
+    float v[EPV], d[EPV];
+    BnVec<BF16>::load(x, r * segs + seg, v);
+    BnVec<BF16>::load(dy, r * segs + seg, d);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      float xh = (v[j] - mu[j]) * is[j];
+      float dz = (relu && fmaf(xh, g[j], b[j]) <= 0.f) ? 0.f : d[j];
+      v[j] = g[j] * is[j] * (dz - c1[j] - xh * c2[j]);
+    }
+    BnVec<BF16>::store(dx, r * segs + seg, v);
+  }
+}
+
+static int bn_check(int n, int c, int dtype, const char *who) {
+  D3D_REQUIRE(dtype == D3D_F32 || dtype == D3D_BF16, "%s: dtype %d", who, dtype);
+  const int epv = dtype == D3D_BF16 ? 8 : 4;
+  D3D_REQUIRE(n >= 1, "%s: n=%d (empty batches are the caller's business)", who, n);
+  D3D_REQUIRE(c >= epv && c <= BN_MAXC && c % epv == 0 && 256 % (c / epv) == 0,
+              "%s: c=%d unsupported (need c %% %d == 0, c/%d | 256, c <= %d)", who, c, epv, epv,
+              BN_MAXC);
+  return D3D_OK;
+}
+
+static int bn_grid(int n, int c, int dtype) {
+  const int rp = 256 / (c / (dtype == D3D_BF16 ? 8 : 4));
+  int nb = (n + rp - 1) / rp;
+  // ~4 row-tiles per block keeps >= 1000 blocks on big layers and few atomics per channel
+  nb = (nb + 3) / 4;
+  if (nb > 2048) nb = 2048;
+  return nb < 1 ? 1 : nb;
+}
+
+extern "C" int d3d_bn_relu_fwd(const void *x, int n, int c, int dtype, const float *gamma,
+                               const float *beta, float *running_mean, float *running_var,
+                               float momentum, float eps, int training, int relu, void *y,
+                               float *save_mean, float *save_invstd, float *stats_ws,
+                               d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = bn_check(n, c, dtype, "d3d_bn_relu_fwd");
+  if (rc) return rc;
+  D3D_REQUIRE(x && y, "d3d_bn_relu_fwd: null pointer");
+  D3D_REQUIRE(training ? stats_ws != nullptr : (running_mean && running_var),
+              "d3d_bn_relu_fwd: training needs stats_ws, eval needs running stats");
+  const int nb = bn_grid(n, c, dtype);
+  if (training) {
+    D3D_HIP_TRY(hipMemsetAsync(stats_ws, 0, (size_t)2 * c * sizeof(float), stream));
+    if (dtype == D3D_BF16)
+      hipLaunchKernelGGL(bn_stats_kernel<true>, dim3(nb), dim3(256), 0, stream, x, n, c, stats_ws);
+    else
+      hipLaunchKernelGGL(bn_stats_kernel<false>, dim3(nb), dim3(256), 0, stream, x, n, c, stats_ws);
+    D3D_LAUNCH_TRY("bn_stats_kernel");
+  }
+  if (dtype == D3D_BF16)
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(nb), dim3(256), 0, stream, x, n, c, gamma, beta,
+                       running_mean, running_var, momentum, eps, training, relu, stats_ws, y,
+                       save_mean, save_invstd);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(nb), dim3(256), 0, stream, x, n, c, gamma, beta,
+                       running_mean, running_var, momentum, eps, training, relu, stats_ws, y,
+                       save_mean, save_invstd);
+  D3D_LAUNCH_TRY("bn_apply_kernel");
+  return D3D_OK;
+}
+
+extern "C" int d3d_bn_relu_bwd(const void *x, const void *dy, int n, int c, int dtype,
+                               const float *gamma, const float *beta, const float *save_mean,
+                               const float *save_invstd, int relu, void *dx, float *dgamma,
+                               float *dbeta, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = bn_check(n, c, dtype, "d3d_bn_relu_bwd");
+  if (rc) return rc;
+  D3D_REQUIRE(x && dy && dx && dgamma && dbeta && save_mean && save_invstd,
+              "d3d_bn_relu_bwd: null pointer");
+  const int nb = bn_grid(n, c, dtype);
+  D3D_HIP_TRY(hipMemsetAsync(dgamma, 0, (size_t)c * sizeof(float), stream));
+  D3D_HIP_TRY(hipMemsetAsync(dbeta, 0, (size_t)c * sizeof(float), stream));
+  if (dtype == D3D_BF16) {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nb), dim3(256), 0, stream, x, dy, n, c,
+                       gamma, beta, save_mean, save_invstd, relu, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma,
+                       beta, save_mean, save_invstd, relu, dgamma, dbeta, dx);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nb), dim3(256), 0, stream, x, dy, n, c,
+                       gamma, beta, save_mean, save_invstd, relu, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(nb), dim3(256), 0, stream, x, dy, n, c,
+                       gamma, beta, save_mean, save_invstd, relu, dgamma, dbeta, dx);
+  }
+  D3D_LAUNCH_TRY("bn_bwd kernels");
+  return D3D_OK;
+}

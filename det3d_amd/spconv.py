@@ -28,6 +28,7 @@ _DT = {torch.float32: _lib.D3D_F32, torch.bfloat16: _lib.D3D_BF16}
 
 # bench.py sets this to a list to time every d3d_sparse_conv_fwd launch with HIP events
 # recorded on the launch stream: entries are (kind, cin, cout, n_out, rulebook, ev0, ev1)
+FUSE_BN_RELU = True  # SparseSequential / SparseBasicBlock route BatchNorm1d(+ReLU) to d3d_bn_relu_*
 LAUNCH_LOG = None
 LAUNCH_LOG_LIMIT = 256
 LAUNCH_FILTER = None  # optional predicate (kind, cin, cout) -> bool: a timing event pair costs
@@ -222,6 +223,69 @@ class _SparseConvFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gout.float().sum(0)
         return gin, gw, gb, None
+
+
+class _BNReLUFn(torch.autograd.Function):
+    """BatchNorm1d (+ReLU) on [N, C] features through d3d_bn_relu_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, training, relu):
+        L = _lib.lib()
+        x = x.contiguous()
+        n, c = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        save = torch.empty((4, c), dtype=torch.float32, device=dev)  # mean, invstd, stats scratch
+        rc = L.d3d_bn_relu_fwd(x.data_ptr(), n, c, _DT[x.dtype], _lib.ptr(weight), _lib.ptr(bias),
+                               _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum),
+                               float(eps), int(training), int(relu), y.data_ptr(),
+                               save[0].data_ptr(), save[1].data_ptr(), save[2].data_ptr(),
+                               _lib.stream_ptr(dev))
+        _lib.check(rc, "d3d_bn_relu_fwd")
+        ctx.save_for_backward(x, weight, bias, save)
+        ctx.relu = relu
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise _lib.D3dError("fused sparse BN backward is implemented for training mode only")
+        L = _lib.lib()
+        x, weight, bias, save = ctx.saved_tensors
+        n, c = x.shape
+        dy = dy.contiguous().to(x.dtype)
+        dx = torch.empty_like(x)
+        g = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        rc = L.d3d_bn_relu_bwd(x.data_ptr(), dy.data_ptr(), n, c, _DT[x.dtype], _lib.ptr(weight),
+                               _lib.ptr(bias), save[0].data_ptr(), save[1].data_ptr(), int(ctx.relu),
+                               dx.data_ptr(), g[0].data_ptr(), g[1].data_ptr(),
+                               _lib.stream_ptr(x.device))
+        _lib.check(rc, "d3d_bn_relu_bwd")
+        gw = g[0].to(weight.dtype) if weight is not None else None
+        gb = g[1].to(bias.dtype) if bias is not None else None
+        return dx, gw, gb, None, None, None, None, None, None
+
+
+def _fusable_bn(bn, feats):
+    """plain affine nn.BatchNorm1d with running stats, on CUDA f32/bf16 features whose channel
+    count the kernel supports (c/8 | 256 for bf16, c/4 | 256 for f32)."""
+    if type(bn) is not nn.BatchNorm1d or not feats.is_cuda or feats.dtype not in _DT or feats.dim() != 2:
+        return False
+    if bn.momentum is None or not bn.track_running_stats or bn.weight is None:
+        return False
+    if feats.shape[0] < 2 or (not bn.training and torch.is_grad_enabled() and feats.requires_grad):
+        return False
+    c = feats.shape[1]
+    epv = 8 if feats.dtype == torch.bfloat16 else 4
+    return c % epv == 0 and c <= 256 and 256 % (c // epv) == 0
+
+
+def bn_relu(bn, feats, relu):
+    """apply `bn` (an nn.BatchNorm1d) and optionally ReLU to sparse features with the fused HIP
+    kernels; state (running stats) lives in the module exactly as with F.batch_norm."""
+    return _BNReLUFn.apply(feats, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                           bn.momentum, bn.eps, bn.training, relu)
 
 
 class _DenseFn(torch.autograd.Function):
@@ -420,15 +484,24 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for k, module in self._modules.items():
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            module = mods[i]
             if is_spconv_module(module):
                 input = module(input)
+            elif isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] != 0:
+                    # BatchNorm1d [+ ReLU] on the active sites -> one fused HIP op
+                    if FUSE_BN_RELU and _fusable_bn(module, input.features):
+                        relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+                        input.features = bn_relu(module, input.features, relu)
+                        i += 2 if relu else 1
+                        continue
+                    input.features = module(input.features)
             else:
-                if isinstance(input, SparseConvTensor):
-                    if input.indices.shape[0] != 0:
-                        input.features = module(input.features)
-                else:
-                    input = module(input)
+                input = module(input)
+            i += 1
         return input
 
     # -- one-sync geometry planning ----------------------------------------------

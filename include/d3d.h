@@ -136,6 +136,26 @@ int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const int32_t *nbr
                           int n_out, int kvol, int cin, int cout, int dtype, float *dw,
                           d3d_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * BatchNorm1d (+ReLU) over the active sites: replaces the nn.BatchNorm1d / nn.ReLU module
+ * pairs that spconv.SparseSequential applies to `.features` after every sparse conv
+ * (det3d/models/backbones/scn.py:106-157; residual blocks :76-87), F.batch_norm semantics
+ * (biased variance to normalise, unbiased into running_var, eps, momentum).
+ *  x, y, dy, dx dev [n,c] dtype; gamma/beta/running_* dev [c] f32 (gamma/beta may be NULL)
+ *  training=1: batch statistics (stats_ws dev [2c] f32 scratch), running stats updated in
+ *              place, save_mean/save_invstd dev [c] written for the backward
+ *  training=0: running statistics, stats_ws unused
+ *  relu=1 fuses max(0, .) into the apply pass (and its mask into the backward).
+ *  bwd overwrites dgamma/dbeta dev [c] f32 and dx.
+ */
+int d3d_bn_relu_fwd(const void *x, int n, int c, int dtype, const float *gamma, const float *beta,
+                    float *running_mean, float *running_var, float momentum, float eps,
+                    int training, int relu, void *y, float *save_mean, float *save_invstd,
+                    float *stats_ws, d3d_stream_t stream);
+int d3d_bn_relu_bwd(const void *x, const void *dy, int n, int c, int dtype, const float *gamma,
+                    const float *beta, const float *save_mean, const float *save_invstd, int relu,
+                    void *dx, float *dgamma, float *dbeta, d3d_stream_t stream);
+
 /* SparseConvTensor.dense() (spconv; call sites scn.py:192-195,363-367):
  * scatter feat[n,c] to dense [batch, c, D, H, W] (zero elsewhere; the caller
  * views it as [batch, c*D, H, W]).  `dense` is fully written.  The backward

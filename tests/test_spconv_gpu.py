@@ -209,3 +209,73 @@ def test_plan_single_sync_matches_lazy_path():
     b = net(xb)
     assert torch.equal(a.indices, b.indices) and torch.equal(a.features, b.features)
     assert a.spatial_shape == b.spatial_shape == [2, 20, 18]
+
+
+@pytest.mark.parametrize("c", [16, 32, 64, 128])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("relu", [True, False])
+def test_fused_bn_relu_vs_torch(c, dtype, relu):
+    """d3d_bn_relu_fwd/bwd vs nn.BatchNorm1d(+ReLU) in f32 on the same (dtype-rounded) input:
+    outputs, running statistics, input / weight / bias gradients."""
+    from det3d_amd import spconv
+
+    torch.manual_seed(c + relu)
+    n = 5003
+    x0 = (torch.randn(n, c) * torch.linspace(0.5, 2.0, c) + torch.linspace(-1, 1, c)).to(dtype)
+    g = torch.randn(n, c).to(dtype)
+    ref = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5)
+        ref.bias.uniform_(-0.5, 0.5)
+    mine = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).cuda()
+    mine.load_state_dict(ref.state_dict())
+    xr = x0.float().clone().requires_grad_(True)
+    yr = ref(xr)
+    yr = torch.relu(yr) if relu else yr
+    (yr * g.float()).sum().backward()
+    xm = x0.cuda().clone().requires_grad_(True)
+    assert spconv._fusable_bn(mine, xm)
+    ym = spconv.bn_relu(mine, xm, relu)
+    assert ym.dtype == dtype
+    (ym.float() * g.cuda().float()).sum().backward()
+    tol = dict(atol=1e-4, rtol=1e-4) if dtype == torch.float32 else dict(atol=3e-2, rtol=2e-2)
+    assert torch.allclose(ym.float().cpu(), yr.detach(), **tol)
+    assert torch.allclose(mine.running_mean.cpu(), ref.running_mean, atol=1e-5, rtol=1e-4)
+    assert torch.allclose(mine.running_var.cpu(), ref.running_var, atol=1e-5, rtol=1e-4)
+    gtol = dict(atol=2e-3, rtol=2e-3) if dtype == torch.float32 else dict(atol=6e-2, rtol=5e-2)
+    assert torch.allclose(xm.grad.float().cpu(), xr.grad, **gtol)
+    wscale = float(ref.weight.grad.abs().max())
+    assert torch.allclose(mine.weight.grad.cpu(), ref.weight.grad, atol=(2e-3 if dtype == torch.float32 else 2e-2) * wscale)
+    assert torch.allclose(mine.bias.grad.cpu(), ref.bias.grad, atol=(2e-3 if dtype == torch.float32 else 2e-2) * float(ref.bias.grad.abs().max()))
+    # eval mode uses the running statistics
+    mine.eval(); ref.eval()
+    with torch.no_grad():
+        ye = spconv.bn_relu(mine, x0.cuda(), relu)
+        yre = ref(x0.float())
+        yre = torch.relu(yre) if relu else yre
+    assert torch.allclose(ye.float().cpu(), yre, **tol)
+
+
+def test_sequential_fuses_bn_relu_transparently():
+    from det3d_amd import spconv
+
+    rng = np.random.default_rng(6)
+    shape = [9, 30, 28]
+    idx, feats = _random_sparse(rng, 2, shape, 600, 16)
+    torch.manual_seed(1)
+    net = spconv.SparseSequential(spconv.SubMConv3d(16, 32, 3, bias=False, indice_key="a"),
+                                  torch.nn.BatchNorm1d(32, eps=1e-3, momentum=0.01), torch.nn.ReLU(),
+                                  spconv.SubMConv3d(32, 32, 3, bias=False, indice_key="a"),
+                                  torch.nn.BatchNorm1d(32, eps=1e-3, momentum=0.01), torch.nn.ReLU()).cuda()
+    mk = lambda: spconv.SparseConvTensor(torch.from_numpy(feats).cuda(), torch.from_numpy(idx).cuda(), shape, 2)
+    import copy
+    net2 = copy.deepcopy(net)
+    spconv.FUSE_BN_RELU = True
+    a = net(mk()).features
+    spconv.FUSE_BN_RELU = False
+    try:
+        b = net2(mk()).features
+    finally:
+        spconv.FUSE_BN_RELU = True
+    assert torch.allclose(a, b, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(net[1].running_var, net2[1].running_var, atol=1e-6, rtol=1e-4)
