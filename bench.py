@@ -250,8 +250,21 @@ def main():
                            "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
                            "alg_bytes_per_launch": int(g["bytes"] / g["launches"]),
                            "launches_timed": g["launches"],
+                           "traffic_source": None,
                            "note": "HIP events on the launch stream, 64->64 fwd+dgrad launches of the "
                                    "last 2 timed steps; B_alg per SURVEY.md 8(d)"}
+    if rank == 0 and "roofline" in out:
+        # HBM traffic needs PMC passes (rocprofv3 --pmc cannot run inside this process): take the
+        # committed measurement of the same workload if there is one
+        pmc_path = os.path.join(ROOT, "profiles", "round1_pmc_spconv.json")
+        try:
+            pmc = json.load(open(pmc_path))
+            w = pmc["workload"]
+            if (w["frames_per_gpu"], w["points_per_frame"], w["dtype"]) == (args.batch, args.points, args.dtype):
+                out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/round1_pmc_spconv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, read side x2 per MI355X_MICROARCH.md)"
+        except (OSError, KeyError, ValueError):
+            pass
     if rank == 0 and table_log:
         table = {}
         groups = group(table_log)

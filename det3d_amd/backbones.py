@@ -155,6 +155,11 @@ class PointPillarsScatter(nn.Module):
     def forward(self, voxel_features, coords, batch_size, input_shape):
         self.nx = int(input_shape[0])
         self.ny = int(input_shape[1])
+        if voxel_features.is_cuda and voxel_features.dtype in (torch.float32, torch.bfloat16):
+            # pillars are a one-cell-deep sparse tensor: d3d_dense_scatter (HIP) with D = 1
+            idx = torch.stack([coords[:, 0], torch.zeros_like(coords[:, 0]), coords[:, 2], coords[:, 3]], 1)
+            st = spconv.SparseConvTensor(voxel_features, idx.int(), [1, self.ny, self.nx], batch_size)
+            return st.dense().view(batch_size, self.nchannels, self.ny, self.nx)
         canvas = torch.zeros(batch_size, self.nchannels, self.nx * self.ny, dtype=voxel_features.dtype,
                              device=voxel_features.device)
         cell = (coords[:, 2] * self.nx + coords[:, 3]).long()

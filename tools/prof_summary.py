@@ -1,0 +1,44 @@
+"""Summarise rocprofv3 rocpd sqlite output on the GPU box (the .db files exceed what gpurun
+copies back).  usage:
+    prof_summary.py kernels <db> <window_ms> <steps> <out.txt> [header...]
+    prof_summary.py pmc <db> <counter> <out.txt>
+"""
+import sqlite3
+import sys
+
+
+def kernels(db, window_ms, steps, out, header):
+    cur = sqlite3.connect(db).cursor()
+    t1 = cur.execute("select max(end) from kernels").fetchone()[0]
+    w0 = t1 - int(float(window_ms) * 1e6)
+    rows = cur.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3 from kernels "
+                       "where start > ? group by name order by 3 desc", (w0,)).fetchall()
+    tot = sum(r[2] for r in rows)
+    n = sum(r[1] for r in rows)
+    steps = float(steps)
+    with open(out, "w") as f:
+        for h in header:
+            f.write("# %s\n" % h)
+        f.write("# steady-state window = last %.1f ms of the trace (%g timed steps)\n" % (float(window_ms), steps))
+        f.write("# %d kernels, GPU busy %.2f ms/step, %d launches/step\n" % (n, tot / 1e3 / steps, n / steps))
+        f.write("%12s %12s %10s %7s  %s\n" % ("us/step", "calls/step", "avg_us", "pct", "kernel"))
+        for r in rows[:80]:
+            f.write("%12.1f %12.1f %10.2f %6.1f%%  %s\n" % (r[2] / steps, r[1] / steps, r[3], 100 * r[2] / tot, r[0][:130]))
+
+
+def pmc(db, counter, out):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, count(*), avg(counter_value), sum(counter_value), avg(duration)/1e3 from pmc_events "
+                       "where counter_name = ? group by name order by 4 desc", (counter,)).fetchall()
+    with open(out, "w") as f:
+        f.write("# rocprofv3 --kernel-trace --pmc %s ; per kernel: launches, avg counter value per launch, avg duration us\n" % counter)
+        f.write("# (counter summed over its instances; FETCH_SIZE/WRITE_SIZE are in KiB -- see MI355X_MICROARCH.md HBM notes)\n")
+        for r in rows[:60]:
+            f.write("%8d %16.1f %10.2f  %s\n" % (r[1], r[2], r[4], r[0][:130]))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "kernels":
+        kernels(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6:])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
