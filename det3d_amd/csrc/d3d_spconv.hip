@@ -303,88 +303,130 @@ extern "C" int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const fl
 }
 
 // ======================================================================= wgrad
-// bf16 MFMA wgrad.  grid = (kvol, splits): a block owns one kernel offset and a
-// contiguous range of output sites; it stages 64 gathered feature rows and the 64
-// matching dout rows in LDS as [16 sites][16 ch] bf16 tiles, then every wave pulls
-// transposed fragments with ds_read_b64_tr_b16 (sites become the MFMA k dimension)
-// and accumulates its share of the [CIN x COUT] tile; partial sums are added to
-// dW with f32 atomics (splits-way contention only).
-template <int CIN, int COUT>
+// bf16 MFMA wgrad.  grid = (kvol / KG, splits): a block owns KG consecutive kernel offsets and
+// a contiguous range of output sites.  Per tile of STEP sites the dout rows are staged in LDS
+// ONCE and reused for the KG offsets (v1 re-read dout 27x: 100 MB FETCH_SIZE per launch,
+// profiles/round1_pmc_fetch_size.txt); per (tile, offset) stage the gathered feature rows are
+// staged as [16 sites][16 ch] bf16 tiles and every wave pulls transposed fragments with
+// ds_read_b64_tr_b16 (sites become the MFMA k dimension).  Stages are software pipelined:
+// the next stage's global loads are issued before the current stage's MFMAs, LDS is double
+// buffered, one barrier per stage.  Partial sums go to dW with f32 atomics.
+template <int CIN, int COUT, int KG, int STEP>
 __global__ void __launch_bounds__(256)
     spconv_wgrad_mfma_kernel(const uint16_t *__restrict__ feat, const uint16_t *__restrict__ dout,
                              const int32_t *__restrict__ nbr, int cap, int n_out,
                              int rows_per_split, float *__restrict__ dw) {
   constexpr int CIT = CIN / 16, COT = COUT / 16;
   constexpr int TILES = CIT * COT;
-  constexpr int TPW = (TILES + 3) / 4;  // tiles per wave
-  constexpr int STEP = 64;              // sites staged per iteration
-  // [chunk(4)][ch tile][16 sites][16 ch] bf16
-  __shared__ __attribute__((aligned(16))) uint16_t lds_f[4 * CIT * 256];
-  __shared__ __attribute__((aligned(16))) uint16_t lds_d[4 * COT * 256];
-  const int k = blockIdx.x;
+  constexpr int TPW = (TILES + 3) / 4;  // MFMA tiles per wave
+  constexpr int CHUNKS = STEP / 16;
+  constexpr int FSEG = CIN / 8, DSEG = COUT / 8;  // 16-byte segments per row
+  constexpr int FV = STEP * FSEG / 256, DV = STEP * DSEG / 256;  // vectors per thread
+  static_assert(STEP * FSEG % 256 == 0 && STEP * DSEG % 256 == 0, "staging shape");
+  // [buffer][chunk][ch tile][16 sites][16 ch] bf16
+  __shared__ __attribute__((aligned(16))) uint16_t lds_f[2 * CHUNKS * CIT * 256];
+  __shared__ __attribute__((aligned(16))) uint16_t lds_d[2 * CHUNKS * COT * 256];
+  const int k0 = blockIdx.x * KG;
   const int s0 = blockIdx.y * rows_per_split;
   int s1 = s0 + rows_per_split;
   if (s1 > n_out) s1 = n_out;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, lg = lane >> 4;
 
-  f32x4_t acc[TPW];
+  f32x4_t acc[KG][TPW];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int kk = 0; kk < KG; ++kk)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[kk][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  constexpr int FSEG = CIN / 8;   // 16-byte segments per feature row
-  constexpr int DSEG = COUT / 8;
-  for (int base = s0; base < s1; base += STEP) {
-    // ---- stage gathered feature rows
-    for (int e = threadIdx.x; e < STEP * FSEG; e += 256) {
+  const int ntiles = (s1 - s0 + STEP - 1) / STEP;
+  const int nstages = ntiles * KG;
+  uint4 fr[FV], dr[DV];
+
+  auto load_stage = [&](int st) {
+    const int tile = st / KG, kk = st - tile * KG;
+    const int base = s0 + tile * STEP;
+#pragma unroll
+    for (int j = 0; j < FV; ++j) {
+      int e = threadIdx.x + j * 256;
       int r = e / FSEG, seg = e - r * FSEG;
       int site = base + r;
-      int i = site < s1 ? nbr[(int64_t)k * cap + site] : -1;
-      uint4 v = i >= 0 ? *(const uint4 *)(feat + (int64_t)i * CIN + seg * 8) : make_uint4(0, 0, 0, 0);
-      int off = ((r >> 4) * CIT + (seg >> 1)) * 256 + (r & 15) * 16 + (seg & 1) * 8;
-      *(uint4 *)(lds_f + off) = v;
+      int i = site < s1 ? nbr[(int64_t)(k0 + kk) * cap + site] : -1;
+      fr[j] = i >= 0 ? *(const uint4 *)(feat + (int64_t)i * CIN + seg * 8) : make_uint4(0, 0, 0, 0);
     }
-    for (int e = threadIdx.x; e < STEP * DSEG; e += 256) {
-      int r = e / DSEG, seg = e - r * DSEG;
-      int site = base + r;
-      uint4 v = site < s1 ? *(const uint4 *)(dout + (int64_t)site * COUT + seg * 8)
+    if (kk == 0) {
+#pragma unroll
+      for (int j = 0; j < DV; ++j) {
+        int e = threadIdx.x + j * 256;
+        int r = e / DSEG, seg = e - r * DSEG;
+        int site = base + r;
+        dr[j] = site < s1 ? *(const uint4 *)(dout + (int64_t)site * COUT + seg * 8)
                           : make_uint4(0, 0, 0, 0);
-      int off = ((r >> 4) * COT + (seg >> 1)) * 256 + (r & 15) * 16 + (seg & 1) * 8;
-      *(uint4 *)(lds_d + off) = v;
+      }
     }
+  };
+  auto store_stage = [&](int st) {
+    const int tile = st / KG, kk = st - tile * KG;
+    uint16_t *bf = lds_f + (st & 1) * (CHUNKS * CIT * 256);
+#pragma unroll
+    for (int j = 0; j < FV; ++j) {
+      int e = threadIdx.x + j * 256;
+      int r = e / FSEG, seg = e - r * FSEG;
+      *(uint4 *)(bf + ((r >> 4) * CIT + (seg >> 1)) * 256 + (r & 15) * 16 + (seg & 1) * 8) = fr[j];
+    }
+    if (kk == 0) {
+      uint16_t *bd = lds_d + (tile & 1) * (CHUNKS * COT * 256);
+#pragma unroll
+      for (int j = 0; j < DV; ++j) {
+        int e = threadIdx.x + j * 256;
+        int r = e / DSEG, seg = e - r * DSEG;
+        *(uint4 *)(bd + ((r >> 4) * COT + (seg >> 1)) * 256 + (r & 15) * 16 + (seg & 1) * 8) = dr[j];
+      }
+    }
+  };
+
+  if (nstages > 0) load_stage(0);
+  for (int st = 0; st < nstages; ++st) {
+    const int tile = st / KG, kk = st - tile * KG;
+    store_stage(st);
     __syncthreads();
+    if (st + 1 < nstages) load_stage(st + 1);  // in flight during the MFMAs below
+    const uint16_t *bf = lds_f + (st & 1) * (CHUNKS * CIT * 256);
+    const uint16_t *bd = lds_d + (tile & 1) * (CHUNKS * COT * 256);
 #pragma unroll
-    for (int chunk = 0; chunk < 4; ++chunk) {
+    for (int kq = 0; kq < KG; ++kq) {
+      if (kq != kk) continue;  // keeps acc[] statically indexed
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) {
-        int tile = wave + t * 4;
-        if (tile < TILES) {
-          int cit = tile / COT, cot = tile - cit * COT;
-          // lane reads column lr of the 4x16 sub-matrix of sites [lg*4, lg*4+4)
-          const uint16_t *pa = lds_f + (chunk * CIT + cit) * 256 + lg * 64 + lr * 4;
-          const uint16_t *pb = lds_d + (chunk * COT + cot) * 256 + lg * 64 + lr * 4;
-          // ds_read_b64_tr_b16 addressing: each lane passes the address of ITS 8 bytes in
-          // the row-major 4x16 block; hardware returns the transposed column.
-          s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4_t *)(pa));
-          s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4_t *)(pb));
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc[t], 0, 0, 0);
+      for (int chunk = 0; chunk < CHUNKS; ++chunk) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          int tl = wave + t * 4;
+          if (tl < TILES) {
+            int cit = tl / COT, cot = tl - cit * COT;
+            // each lane passes the address of ITS 8 bytes in the row-major 4x16 block of
+            // sites [lg*4, lg*4+4); the hardware returns the transposed column lr
+            s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4_t *)(bf + (chunk * CIT + cit) * 256 + lg * 64 + lr * 4));
+            s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4_t *)(bd + (chunk * COT + cot) * 256 + lg * 64 + lr * 4));
+            acc[kq][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc[kq][t], 0, 0, 0);
+          }
         }
       }
     }
-    __syncthreads();
   }
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    int tile = wave + t * 4;
-    if (tile < TILES) {
-      int cit = tile / COT, cot = tile - cit * COT;
-      float *o = dw + ((int64_t)k * CIN + cit * 16 + lg * 4) * COUT + cot * 16 + lr;
+  for (int kk = 0; kk < KG; ++kk)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(o + r * COUT, acc[t][r]);
+    for (int t = 0; t < TPW; ++t) {
+      int tl = wave + t * 4;
+      if (tl < TILES) {
+        int cit = tl / COT, cot = tl - cit * COT;
+        float *o = dw + ((int64_t)(k0 + kk) * CIN + cit * 16 + lg * 4) * COUT + cot * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(o + r * COUT, acc[kk][t][r]);
+      }
     }
-  }
 }
 
 // generic wgrad (any dtype / channel count): block = (offset k, site split); each
@@ -504,13 +546,25 @@ __global__ void __launch_bounds__(256)
     return D3D_OK;                                                                               \
   }
 
-#define WGRAD_CASE(CI, CO)                                                                      \
-  if (dtype == D3D_BF16 && cin == CI && cout == CO) {                                           \
-    hipLaunchKernelGGL((spconv_wgrad_mfma_kernel<CI, CO>), dim3(kvol, splits), dim3(256), 0,    \
-                       stream, (const uint16_t *)feat, (const uint16_t *)dout, nbr, cap, n_out, \
-                       rows_per_split, dw);                                                     \
-    D3D_LAUNCH_TRY("spconv_wgrad_mfma_kernel");                                                 \
-    return D3D_OK;                                                                              \
+template <int CI, int CO, int KG, int STEP>
+static int launch_wgrad(const void *feat, const void *dout, const int32_t *nbr, int cap, int n_out,
+                        int kvol, int splits, int rows_per_split, float *dw, hipStream_t stream) {
+  hipLaunchKernelGGL((spconv_wgrad_mfma_kernel<CI, CO, KG, STEP>), dim3(kvol / KG, splits), dim3(256),
+                     0, stream, (const uint16_t *)feat, (const uint16_t *)dout, nbr, cap, n_out,
+                     rows_per_split, dw);
+  D3D_LAUNCH_TRY("spconv_wgrad_mfma_kernel");
+  return D3D_OK;
+}
+
+// offsets are grouped by 3 (27 = 9 x 3, (3,1,1) = 1 x 3) when the [Cin x Cout] tile is small
+// enough to keep 3 accumulator sets in registers
+#define WGRAD_CASE(CI, CO, STEP)                                                                 \
+  if (dtype == D3D_BF16 && cin == CI && cout == CO) {                                            \
+    if (kvol % 3 == 0 && CI * CO <= 4096)                                                        \
+      return launch_wgrad<CI, CO, 3, STEP>(feat, dout, nbr, cap, n_out, kvol, splits,            \
+                                           rows_per_split, dw, stream);                          \
+    return launch_wgrad<CI, CO, 1, STEP>(feat, dout, nbr, cap, n_out, kvol, splits,              \
+                                         rows_per_split, dw, stream);                            \
   }
 
 extern "C" int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const int32_t *nbr,
@@ -526,23 +580,24 @@ extern "C" int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const i
   if (n_out == 0) return D3D_OK;
   D3D_REQUIRE(feat && dout && nbr, "d3d_sparse_conv_wgrad: null pointer");
   // enough blocks to fill 256 CUs a few times over, but >= 1024 sites per split
-  int splits = (256 * 4 + kvol - 1) / kvol;
+  const int kgroups = (kvol % 3 == 0 && cin * cout <= 4096 && cin >= 16) ? kvol / 3 : kvol;
+  int splits = (256 * 4 + kgroups - 1) / kgroups;
   int max_splits = (n_out + 1023) / 1024;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   int rows_per_split = (n_out + splits - 1) / splits;
-  rows_per_split = (rows_per_split + 63) / 64 * 64;
+  rows_per_split = (rows_per_split + 127) / 128 * 128;
   splits = (n_out + rows_per_split - 1) / rows_per_split;
   WGRAD_SMALL_CASE(3, 16)
   WGRAD_SMALL_CASE(4, 16)
   WGRAD_SMALL_CASE(5, 16)
-  WGRAD_CASE(16, 16)
-  WGRAD_CASE(16, 32)
-  WGRAD_CASE(32, 32)
-  WGRAD_CASE(32, 64)
-  WGRAD_CASE(64, 64)
-  WGRAD_CASE(64, 128)
-  WGRAD_CASE(128, 128)
+  WGRAD_CASE(16, 16, 128)
+  WGRAD_CASE(16, 32, 128)
+  WGRAD_CASE(32, 32, 128)
+  WGRAD_CASE(32, 64, 128)
+  WGRAD_CASE(64, 64, 128)
+  WGRAD_CASE(64, 128, 64)
+  WGRAD_CASE(128, 128, 64)
   size_t smem = (size_t)32 * (cin + cout) * sizeof(float);
   if (dtype == D3D_BF16)
     hipLaunchKernelGGL(spconv_wgrad_generic_kernel<true>, dim3(kvol, splits), dim3(256), smem,
