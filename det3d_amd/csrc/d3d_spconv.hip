@@ -16,6 +16,8 @@
 //   => each lane ends up with 4 CONSECUTIVE couts of ONE site: 8/16-byte row stores,
 //   and the B operand for lane (site = lane&15, kgroup = lane>>4) is one contiguous
 //   16-byte piece of the gathered row -- no LDS, no transposes on the hot path.
+#include <stdlib.h>
+
 #include "d3d_common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -311,7 +313,7 @@ extern "C" int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const fl
 // ds_read_b64_tr_b16 (sites become the MFMA k dimension).  Stages are software pipelined:
 // the next stage's global loads are issued before the current stage's MFMAs, LDS is double
 // buffered, one barrier per stage.  Partial sums go to dW with f32 atomics.
-template <int CIN, int COUT, int KG, int STEP>
+template <int CIN, int COUT, int KG, int STEP, bool PIPE>
 __global__ void __launch_bounds__(256)
     spconv_wgrad_mfma_kernel(const uint16_t *__restrict__ feat, const uint16_t *__restrict__ dout,
                              const int32_t *__restrict__ nbr, int cap, int n_out,
@@ -321,11 +323,12 @@ __global__ void __launch_bounds__(256)
   constexpr int TPW = (TILES + 3) / 4;  // MFMA tiles per wave
   constexpr int CHUNKS = STEP / 16;
   constexpr int FSEG = CIN / 8, DSEG = COUT / 8;  // 16-byte segments per row
-  constexpr int FV = STEP * FSEG / 256, DV = STEP * DSEG / 256;  // vectors per thread
-  static_assert(STEP * FSEG % 256 == 0 && STEP * DSEG % 256 == 0, "staging shape");
+  constexpr int FN = STEP * FSEG, DN = STEP * DSEG;             // 16-byte vectors per tile
+  constexpr int FV = (FN + 255) / 256, DV = (DN + 255) / 256;   // vectors per thread
   // [buffer][chunk][ch tile][16 sites][16 ch] bf16
-  __shared__ __attribute__((aligned(16))) uint16_t lds_f[2 * CHUNKS * CIT * 256];
-  __shared__ __attribute__((aligned(16))) uint16_t lds_d[2 * CHUNKS * COT * 256];
+  constexpr int NBUF = PIPE ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) uint16_t lds_f[NBUF * CHUNKS * CIT * 256];
+  __shared__ __attribute__((aligned(16))) uint16_t lds_d[NBUF * CHUNKS * COT * 256];
   const int k0 = blockIdx.x * KG;
   const int s0 = blockIdx.y * rows_per_split;
   int s1 = s0 + rows_per_split;
@@ -349,6 +352,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int j = 0; j < FV; ++j) {
       int e = threadIdx.x + j * 256;
+      if (FN % 256 != 0 && e >= FN) break;
       int r = e / FSEG, seg = e - r * FSEG;
       int site = base + r;
       int i = site < s1 ? nbr[(int64_t)(k0 + kk) * cap + site] : -1;
@@ -358,6 +362,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int j = 0; j < DV; ++j) {
         int e = threadIdx.x + j * 256;
+        if (DN % 256 != 0 && e >= DN) break;
         int r = e / DSEG, seg = e - r * DSEG;
         int site = base + r;
         dr[j] = site < s1 ? *(const uint4 *)(dout + (int64_t)site * COUT + seg * 8)
@@ -367,32 +372,38 @@ __global__ void __launch_bounds__(256)
   };
   auto store_stage = [&](int st) {
     const int tile = st / KG, kk = st - tile * KG;
-    uint16_t *bf = lds_f + (st & 1) * (CHUNKS * CIT * 256);
+    uint16_t *bf = lds_f + (PIPE ? (st & 1) : 0) * (CHUNKS * CIT * 256);
 #pragma unroll
     for (int j = 0; j < FV; ++j) {
       int e = threadIdx.x + j * 256;
+      if (FN % 256 != 0 && e >= FN) break;
       int r = e / FSEG, seg = e - r * FSEG;
       *(uint4 *)(bf + ((r >> 4) * CIT + (seg >> 1)) * 256 + (r & 15) * 16 + (seg & 1) * 8) = fr[j];
     }
     if (kk == 0) {
-      uint16_t *bd = lds_d + (tile & 1) * (CHUNKS * COT * 256);
+      uint16_t *bd = lds_d + (PIPE ? (tile & 1) : 0) * (CHUNKS * COT * 256);
 #pragma unroll
       for (int j = 0; j < DV; ++j) {
         int e = threadIdx.x + j * 256;
+        if (DN % 256 != 0 && e >= DN) break;
         int r = e / DSEG, seg = e - r * DSEG;
         *(uint4 *)(bd + ((r >> 4) * COT + (seg >> 1)) * 256 + (r & 15) * 16 + (seg & 1) * 8) = dr[j];
       }
     }
   };
 
-  if (nstages > 0) load_stage(0);
+  if (PIPE && nstages > 0) load_stage(0);
   for (int st = 0; st < nstages; ++st) {
     const int tile = st / KG, kk = st - tile * KG;
+    if (!PIPE) {
+      if (st > 0) __syncthreads();  // previous stage's fragment reads are done
+      load_stage(st);
+    }
     store_stage(st);
     __syncthreads();
-    if (st + 1 < nstages) load_stage(st + 1);  // in flight during the MFMAs below
-    const uint16_t *bf = lds_f + (st & 1) * (CHUNKS * CIT * 256);
-    const uint16_t *bd = lds_d + (tile & 1) * (CHUNKS * COT * 256);
+    if (PIPE && st + 1 < nstages) load_stage(st + 1);  // in flight during the MFMAs below
+    const uint16_t *bf = lds_f + (PIPE ? (st & 1) : 0) * (CHUNKS * CIT * 256);
+    const uint16_t *bd = lds_d + (PIPE ? (tile & 1) : 0) * (CHUNKS * COT * 256);
 #pragma unroll
     for (int kq = 0; kq < KG; ++kq) {
       if (kq != kk) continue;  // keeps acc[] statically indexed
@@ -546,25 +557,28 @@ __global__ void __launch_bounds__(256)
     return D3D_OK;                                                                               \
   }
 
-template <int CI, int CO, int KG, int STEP>
+template <int CI, int CO, int KG, int STEP, bool PIPE>
 static int launch_wgrad(const void *feat, const void *dout, const int32_t *nbr, int cap, int n_out,
                         int kvol, int splits, int rows_per_split, float *dw, hipStream_t stream) {
-  hipLaunchKernelGGL((spconv_wgrad_mfma_kernel<CI, CO, KG, STEP>), dim3(kvol / KG, splits), dim3(256),
-                     0, stream, (const uint16_t *)feat, (const uint16_t *)dout, nbr, cap, n_out,
-                     rows_per_split, dw);
+  hipLaunchKernelGGL((spconv_wgrad_mfma_kernel<CI, CO, KG, STEP, PIPE>), dim3(kvol / KG, splits),
+                     dim3(256), 0, stream, (const uint16_t *)feat, (const uint16_t *)dout, nbr, cap,
+                     n_out, rows_per_split, dw);
   D3D_LAUNCH_TRY("spconv_wgrad_mfma_kernel");
   return D3D_OK;
 }
 
+#define WGRAD_ARGS feat, dout, nbr, cap, n_out, kvol, splits, rows_per_split, dw, stream
 // offsets are grouped by 3 (27 = 9 x 3, (3,1,1) = 1 x 3) when the [Cin x Cout] tile is small
-// enough to keep 3 accumulator sets in registers
-#define WGRAD_CASE(CI, CO, STEP)                                                                 \
-  if (dtype == D3D_BF16 && cin == CI && cout == CO) {                                            \
-    if (kvol % 3 == 0 && CI * CO <= 4096)                                                        \
-      return launch_wgrad<CI, CO, 3, STEP>(feat, dout, nbr, cap, n_out, kvol, splits,            \
-                                           rows_per_split, dw, stream);                          \
-    return launch_wgrad<CI, CO, 1, STEP>(feat, dout, nbr, cap, n_out, kvol, splits,              \
-                                         rows_per_split, dw, stream);                            \
+// enough to keep 3 accumulator sets in registers; `variant` (tuning knob) picks tile / pipelining
+#define WGRAD_CASE(CI, CO)                                                                \
+  if (dtype == D3D_BF16 && cin == CI && cout == CO) {                                     \
+    if (kgroups != kvol) {                                                                \
+      if (variant == 0) return launch_wgrad<CI, CO, 3, 64, false>(WGRAD_ARGS);            \
+      if (variant == 1) return launch_wgrad<CI, CO, 3, 64, true>(WGRAD_ARGS);             \
+      return launch_wgrad<CI, CO, 3, 128, true>(WGRAD_ARGS);                              \
+    }                                                                                     \
+    if (variant == 0) return launch_wgrad<CI, CO, 1, 64, false>(WGRAD_ARGS);              \
+    return launch_wgrad<CI, CO, 1, 64, true>(WGRAD_ARGS);                                 \
   }
 
 extern "C" int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const int32_t *nbr,
@@ -580,8 +594,16 @@ extern "C" int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const i
   if (n_out == 0) return D3D_OK;
   D3D_REQUIRE(feat && dout && nbr, "d3d_sparse_conv_wgrad: null pointer");
   // enough blocks to fill 256 CUs a few times over, but >= 1024 sites per split
-  const int kgroups = (kvol % 3 == 0 && cin * cout <= 4096 && cin >= 16) ? kvol / 3 : kvol;
-  int splits = (256 * 4 + kgroups - 1) / kgroups;
+  // tuning knobs (tools/tune_wgrad.py): D3D_WGRAD_KG=1 disables offset grouping,
+  // D3D_WGRAD_BLOCKS = target number of blocks per launch
+  // defaults from the sweep on a KITTI batch (126k sites, 1.67M pairs, 64x64): KG=1 pipelined
+  // 64-site tiles 138 us, KG=3 pipelined 141 us, v1 (unpipelined) 149 us, 128-site tiles 199 us
+  static const int knob_kg = getenv("D3D_WGRAD_KG") ? atoi(getenv("D3D_WGRAD_KG")) : 1;
+  static const int knob_blocks = getenv("D3D_WGRAD_BLOCKS") ? atoi(getenv("D3D_WGRAD_BLOCKS")) : 1024;
+  static const int variant = getenv("D3D_WGRAD_VARIANT") ? atoi(getenv("D3D_WGRAD_VARIANT")) : 1;
+  const int kgroups =
+      (knob_kg == 3 && kvol % 3 == 0 && cin * cout <= 4096 && cin >= 16) ? kvol / 3 : kvol;
+  int splits = (knob_blocks + kgroups - 1) / kgroups;
   int max_splits = (n_out + 1023) / 1024;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -591,13 +613,13 @@ extern "C" int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const i
   WGRAD_SMALL_CASE(3, 16)
   WGRAD_SMALL_CASE(4, 16)
   WGRAD_SMALL_CASE(5, 16)
-  WGRAD_CASE(16, 16, 128)
-  WGRAD_CASE(16, 32, 128)
-  WGRAD_CASE(32, 32, 128)
-  WGRAD_CASE(32, 64, 128)
-  WGRAD_CASE(64, 64, 128)
-  WGRAD_CASE(64, 128, 64)
-  WGRAD_CASE(128, 128, 64)
+  WGRAD_CASE(16, 16)
+  WGRAD_CASE(16, 32)
+  WGRAD_CASE(32, 32)
+  WGRAD_CASE(32, 64)
+  WGRAD_CASE(64, 64)
+  WGRAD_CASE(64, 128)
+  WGRAD_CASE(128, 128)
   size_t smem = (size_t)32 * (cin + cout) * sizeof(float);
   if (dtype == D3D_BF16)
     hipLaunchKernelGGL(spconv_wgrad_generic_kernel<true>, dim3(kvol, splits), dim3(256), smem,
