@@ -21,6 +21,12 @@ import os
 import sys
 import time
 
+# PyTorch-ROCm only hands channels-last tensors to MIOpen as NHWC when this is set before the
+# first convolution; otherwise it converts to NCHW and MIOpen transposes again internally
+if "--no-channels-last" not in sys.argv:
+    os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
+    os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC_BATCHNORM", "1")
+
 import numpy as np
 import torch
 
@@ -40,6 +46,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-log", action="store_true")
+    ap.add_argument("--no-channels-last", action="store_true",
+                    help="NCHW dense()/RPN activations (default: channels-last, written directly by d3d_dense_scatter)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -132,6 +140,7 @@ def main():
     torch.manual_seed(0)
     model = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg)
     model = model.to(dev).train()
+    model.backbone.dense_channels_last = not args.no_channels_last
     D.broadcast_params(model)
 
     n_seeds = 16

@@ -78,9 +78,8 @@ class _SparseMiddle(nn.Module):
         self.middle_conv.plan(ret)  # every rulebook of the stack, one host sync
         ret = self.middle_conv(ret)
         self.last_indice_dict = ret.indice_dict
-        ret = ret.dense()
-        N, C, D, H, W = ret.shape
-        return ret.view(N, C * D, H, W)
+        # [B, C, D, H, W] -> [B, C*D, H, W]; optionally channels-last for MIOpen's NHWC kernels
+        return ret.dense_2d(channels_last=getattr(self, "dense_channels_last", False))
 
     def init_weights(self, pretrained=None):
         pass

@@ -3,10 +3,13 @@
 // zero fill of the dense tensor (the occupied fraction is ~19 % on KITTI).
 #include "d3d_common.h"
 
+// channels_last = 1 addresses the dense tensor as [B, H, W, C*D] (channel = c*D + z): the
+// memory layout of a channels-last [B, C*D, H, W] tensor, which MIOpen's NHWC conv kernels
+// consume without the NCHW<->NHWC transposes (0.63 ms/step in profiles/round1_kernel_stats_v2).
 template <typename T, bool GATHER>
 __global__ void __launch_bounds__(256)
     dense_move_kernel(T *__restrict__ feat, const int4 *__restrict__ coords, int n, int c, int D,
-                      int H, int W, T *__restrict__ dense) {
+                      int H, int W, int channels_last, T *__restrict__ dense) {
   // one thread per (site, channel); consecutive threads walk channels of one site so
   // the sparse side is coalesced, the dense side is a C-way strided access.
   const int64_t total = (int64_t)n * c;
@@ -16,7 +19,9 @@ __global__ void __launch_bounds__(256)
     int i = (int)(t / c);
     int ch = (int)(t - (int64_t)i * c);
     int4 q = coords[i];
-    int64_t off = ((int64_t)q.x * c + ch) * plane + ((int64_t)q.y * H + q.z) * W + q.w;
+    int64_t off = channels_last
+                      ? (((int64_t)q.x * H + q.z) * W + q.w) * ((int64_t)c * D) + (int64_t)ch * D + q.y
+                      : ((int64_t)q.x * c + ch) * plane + ((int64_t)q.y * H + q.z) * W + q.w;
     if (GATHER)
       feat[t] = dense[off];
     else
@@ -34,7 +39,7 @@ static int dense_args_ok(const void *feat, const int32_t *coords, int n, int c, 
 }
 
 extern "C" int d3d_dense_scatter(const void *feat, const int32_t *coords, int n, int c, int batch,
-                                 const int32_t *shape, int dtype, void *dense,
+                                 const int32_t *shape, int dtype, int channels_last, void *dense,
                                  d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = dense_args_ok(feat, coords, n, c, batch, shape, dtype, dense, "d3d_dense_scatter");
@@ -49,17 +54,18 @@ extern "C" int d3d_dense_scatter(const void *feat, const int32_t *coords, int n,
   if (dtype == D3D_BF16)
     hipLaunchKernelGGL((dense_move_kernel<uint16_t, false>), dim3(nb), dim3(256), 0, stream,
                        (uint16_t *)feat, (const int4 *)coords, n, c, shape[0], shape[1], shape[2],
-                       (uint16_t *)dense);
+                       channels_last, (uint16_t *)dense);
   else
     hipLaunchKernelGGL((dense_move_kernel<float, false>), dim3(nb), dim3(256), 0, stream,
                        (float *)feat, (const int4 *)coords, n, c, shape[0], shape[1], shape[2],
-                       (float *)dense);
+                       channels_last, (float *)dense);
   D3D_LAUNCH_TRY("dense_move_kernel<scatter>");
   return D3D_OK;
 }
 
 extern "C" int d3d_dense_gather(const void *dense, const int32_t *coords, int n, int c, int batch,
-                                const int32_t *shape, int dtype, void *feat, d3d_stream_t stream_) {
+                                const int32_t *shape, int dtype, int channels_last, void *feat,
+                                d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = dense_args_ok(feat, coords, n, c, batch, shape, dtype, dense, "d3d_dense_gather");
   if (rc) return rc;
@@ -70,11 +76,11 @@ extern "C" int d3d_dense_gather(const void *dense, const int32_t *coords, int n,
   if (dtype == D3D_BF16)
     hipLaunchKernelGGL((dense_move_kernel<uint16_t, true>), dim3(nb), dim3(256), 0, stream,
                        (uint16_t *)feat, (const int4 *)coords, n, c, shape[0], shape[1], shape[2],
-                       (uint16_t *)dense);
+                       channels_last, (uint16_t *)dense);
   else
     hipLaunchKernelGGL((dense_move_kernel<float, true>), dim3(nb), dim3(256), 0, stream,
                        (float *)feat, (const int4 *)coords, n, c, shape[0], shape[1], shape[2],
-                       (float *)dense);
+                       channels_last, (float *)dense);
   D3D_LAUNCH_TRY("dense_move_kernel<gather>");
   return D3D_OK;
 }

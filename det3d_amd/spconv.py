@@ -290,33 +290,37 @@ def bn_relu(bn, feats, relu):
 
 class _DenseFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, indices, batch, shape):
+    def forward(ctx, feats, indices, batch, shape, channels_last):
         _need_cuda(feats, "SparseConvTensor.dense")
         L = _lib.lib()
         feats = feats.contiguous()
         n, c = feats.shape
-        out = torch.empty((batch, c, shape[0], shape[1], shape[2]), dtype=feats.dtype,
-                          device=feats.device)
+        D, H, W = shape
+        if channels_last:  # memory [B, H, W, C*D], presented as a channels-last [B, C*D, H, W]
+            phys = torch.empty((batch, H, W, c * D), dtype=feats.dtype, device=feats.device)
+            out = phys.permute(0, 3, 1, 2)
+        else:
+            phys = out = torch.empty((batch, c, D, H, W), dtype=feats.dtype, device=feats.device)
         rc = L.d3d_dense_scatter(feats.data_ptr(), indices.data_ptr(), n, c, batch,
-                                 _lib.i32_array(shape), _DT[feats.dtype], out.data_ptr(),
-                                 _lib.stream_ptr(feats.device))
+                                 _lib.i32_array(shape), _DT[feats.dtype], int(channels_last),
+                                 phys.data_ptr(), _lib.stream_ptr(feats.device))
         _lib.check(rc, "d3d_dense_scatter")
         ctx.save_for_backward(indices)
-        ctx.meta = (n, c, batch, list(shape))
+        ctx.meta = (n, c, batch, list(shape), channels_last)
         return out
 
     @staticmethod
     def backward(ctx, g):
         L = _lib.lib()
         (indices,) = ctx.saved_tensors
-        n, c, batch, shape = ctx.meta
-        g = g.contiguous()
+        n, c, batch, shape, channels_last = ctx.meta
+        g = g.contiguous(memory_format=torch.channels_last) if channels_last else g.contiguous()
         gf = torch.empty((n, c), dtype=g.dtype, device=g.device)
         rc = L.d3d_dense_gather(g.data_ptr(), indices.data_ptr(), n, c, batch,
-                                _lib.i32_array(shape), _DT[g.dtype], gf.data_ptr(),
-                                _lib.stream_ptr(g.device))
+                                _lib.i32_array(shape), _DT[g.dtype], int(channels_last),
+                                gf.data_ptr(), _lib.stream_ptr(g.device))
         _lib.check(rc, "d3d_dense_gather")
-        return gf, None, None, None
+        return gf, None, None, None, None
 
 
 # ------------------------------------------------------------------- public API
@@ -340,10 +344,19 @@ class SparseConvTensor:
         return self.indice_dict.get(key)
 
     def dense(self, channels_first=True):
-        out = _DenseFn.apply(self.features, self.indices, self.batch_size, self.spatial_shape)
+        out = _DenseFn.apply(self.features, self.indices, self.batch_size, self.spatial_shape, False)
         if not channels_first:
             return out.permute(0, 2, 3, 4, 1).contiguous()
         return out
+
+    def dense_2d(self, channels_last=False):
+        """dense().view(B, C*D, H, W) in one step (what scn.py:192-195 does); with
+        channels_last=True the result is a channels-last tensor written directly by the kernel."""
+        if not channels_last:
+            d = self.dense()
+            n, c, dd, h, w = d.shape
+            return d.view(n, c * dd, h, w)
+        return _DenseFn.apply(self.features, self.indices, self.batch_size, self.spatial_shape, True)
 
 
 class SparseModule(nn.Module):

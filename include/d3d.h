@@ -159,11 +159,15 @@ int d3d_bn_relu_bwd(const void *x, const void *dy, int n, int c, int dtype, cons
 /* SparseConvTensor.dense() (spconv; call sites scn.py:192-195,363-367):
  * scatter feat[n,c] to dense [batch, c, D, H, W] (zero elsewhere; the caller
  * views it as [batch, c*D, H, W]).  `dense` is fully written.  The backward
- * is d3d_dense_gather. */
+ * is d3d_dense_gather.
+ * channels_last = 1 lays `dense` out as [batch, H, W, c*D] (channel = ch*D + z), i.e. the
+ * memory of a torch channels-last [batch, c*D, H, W] tensor. */
 int d3d_dense_scatter(const void *feat, const int32_t *coords, int n, int c, int batch,
-                      const int32_t *spatial_shape, int dtype, void *dense, d3d_stream_t stream);
+                      const int32_t *spatial_shape, int dtype, int channels_last, void *dense,
+                      d3d_stream_t stream);
 int d3d_dense_gather(const void *dense, const int32_t *coords, int n, int c, int batch,
-                     const int32_t *spatial_shape, int dtype, void *feat, d3d_stream_t stream);
+                     const int32_t *spatial_shape, int dtype, int channels_last, void *feat,
+                     d3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Rotated NMS.  Replaces rotate_nms_cc (det3d/ops/nms/nms_cpu.py:34-45) +

@@ -187,6 +187,27 @@ def test_dense_and_its_backward():
         assert torch.equal(f.grad.cpu(), g.cpu()[ii[:, 0], :, ii[:, 1], ii[:, 2], ii[:, 3]])
 
 
+def test_dense_2d_channels_last_equals_nchw():
+    from det3d_amd import spconv
+
+    rng = np.random.default_rng(12)
+    shape = [2, 24, 20]
+    idx, feats = _random_sparse(rng, 3, shape, 300, 64, clustered=False)
+    for dtype in (torch.float32, torch.bfloat16):
+        outs, grads = [], []
+        for cl in (False, True):
+            f = torch.from_numpy(feats).cuda().to(dtype).requires_grad_(True)
+            x = spconv.SparseConvTensor(f, torch.from_numpy(idx).cuda(), shape, 3)
+            d = x.dense_2d(channels_last=cl)
+            assert d.shape == (3, 128, 24, 20)
+            assert d.is_contiguous(memory_format=torch.channels_last) == cl or not cl
+            g = torch.arange(d.numel(), device="cuda", dtype=torch.float32).reshape(d.shape).to(dtype) / d.numel()
+            d.backward(g)
+            outs.append(d.detach().float().cpu().contiguous())
+            grads.append(f.grad.float().cpu())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(grads[0], grads[1])
+
+
 def test_plan_single_sync_matches_lazy_path():
     """SparseSequential.plan() (one host sync) builds the same rulebooks as the per-layer path."""
     from det3d_amd import spconv
