@@ -281,13 +281,23 @@ extern "C" int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const fl
               cout);
   if (n_out == 0) return D3D_OK;
   D3D_REQUIRE(feat && wpack && nbr && out, "d3d_sparse_conv_fwd: null pointer");
+  // tuning knob (tools/tune_fwd.py): alternative (MT, WAVES) tilings of the dominant 64->64 layer
+  static const int fwd_variant = getenv("D3D_FWD_VARIANT") ? atoi(getenv("D3D_FWD_VARIANT")) : 0;
+  if (fwd_variant && cin == 64 && cout == 64 && dtype == D3D_BF16) {
+    if (fwd_variant == 1) return launch_fwd<64, 64, 4, 4, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, stream);
+    if (fwd_variant == 2) return launch_fwd<64, 64, 4, 8, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, stream);
+    if (fwd_variant == 3) return launch_fwd<64, 64, 2, 4, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, stream);
+    if (fwd_variant == 4) return launch_fwd<64, 64, 1, 8, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, stream);
+    if (fwd_variant == 5) return launch_fwd<64, 64, 2, 16, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, stream);
+    if (fwd_variant == 6) return launch_fwd<64, 64, 2, 8, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, stream);
+  }
   FWD_CASE(16, 16, 2, 4)
   FWD_CASE(16, 32, 2, 4)
   FWD_CASE(32, 16, 2, 4)
   FWD_CASE(32, 32, 2, 8)
   FWD_CASE(32, 64, 2, 8)
   FWD_CASE(64, 32, 2, 8)
-  FWD_CASE(64, 64, 2, 8)
+  FWD_CASE(64, 64, 1, 16)  // sweep (tools/tune_fwd.py): MT1x16 53.5 us, MT2x8 56.9, MT4x8 66.8, MT2x4 97.3
   FWD_CASE(64, 128, 1, 8)
   FWD_CASE(128, 64, 2, 8)
   FWD_CASE(128, 128, 1, 8)
