@@ -209,7 +209,13 @@ def test_resnet_fhd_backbone_runs_and_is_self_consistent():
     # 27 train-mode BN + ReLU layers: compare gradient directions (see test_forward_loss_and_grads)
     cos = torch.nn.functional.cosine_similarity
     worst = [(float(cos(feats.grad.flatten(), feats2.grad.flatten(), dim=0)), "input")]
+    gmax = max(float(p.grad.abs().max()) for p in net2.parameters())
     for (n1, p1), (n2, p2) in zip(net.named_parameters(), net2.named_parameters()):
+        if float(p2.grad.abs().max()) < 1e-4 * gmax:
+            # a conv bias followed by train-mode BN has an exactly-zero true gradient (BN removes
+            # the mean): both sides hold rounding noise only
+            assert float(p1.grad.abs().max()) < 1e-3 * gmax, n1
+            continue
         worst.append((float(cos(p1.grad.flatten().float(), p2.grad.flatten().float(), dim=0)), n1))
     worst.sort()
     print("lowest gradient cosines:", [(round(c, 5), n) for c, n in worst[:5]])
