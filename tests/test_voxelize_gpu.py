@@ -111,3 +111,21 @@ def test_deterministic():
     for _ in range(3):
         b = points_to_voxel(pts, *KITTI, 5, True, 20000)
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_property_random_clouds_vs_oracle(oracle_lib):
+    """hypothesis-generated clouds (same generator as tests/test_voxel_property_cpu.py): HIP == oracle."""
+    from hypothesis import given, settings
+
+    from det3d_amd.point_cloud_ops import points_to_voxel
+    from test_voxel_property_cpu import RG, VS, clouds
+
+    @settings(max_examples=25, deadline=None)
+    @given(clouds())
+    def run(case):
+        pts, T, M = case
+        g = oracle_lib.points_to_voxel(pts, VS, RG, T, True, M)
+        h = points_to_voxel(pts, VS, RG, T, True, M)
+        assert all(np.array_equal(x, y) for x, y in zip(g, h))
+
+    run()
