@@ -36,6 +36,10 @@ SIGNATURES = {
     "d3d_sparse_conv_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "d3d_bn_relu_fwd": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp, vp, vp, vp]),
     "d3d_bn_relu_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "d3d_pfn_fwd": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp, vp, vp, vp, f32, f32,
+                          i32, vp, vp, vp, vp, vp, vp]),
+    "d3d_pfn_bwd": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp, vp, vp, vp, vp, vp,
+                          vp, vp, vp, vp]),
     "d3d_dense_scatter": (i32, [vp, vp, i32, i32, i32, _i32p, i32, i32, vp, vp]),
     "d3d_dense_gather": (i32, [vp, vp, i32, i32, i32, _i32p, i32, i32, vp, vp]),
     "d3d_rotate_nms_workspace_bytes": (sz, [i32]),

@@ -21,6 +21,7 @@ SOURCES = [
     "d3d_rulebook.hip",
     "d3d_spconv.hip",
     "d3d_bn.hip",
+    "d3d_pfn.hip",
     "d3d_dense.hip",
     "d3d_nms.hip",
 ]

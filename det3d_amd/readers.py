@@ -9,8 +9,60 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from . import _lib
 from .nn_utils import build_norm_layer, get_paddings_indicator
 from .registry import READERS
+
+FUSE_PFN = True  # single-layer PillarFeatureNet on CUDA goes through d3d_pfn_fwd / d3d_pfn_bwd
+
+
+class _PFNFn(torch.autograd.Function):
+    """decorate + Linear + BatchNorm1d + ReLU + max over T in two launches (d3d_pfn_fwd)."""
+
+    @staticmethod
+    def forward(ctx, voxels, num_points, coors, weight, gamma, beta, running_mean, running_var, momentum,
+                eps, training, geom):
+        L = _lib.lib()
+        voxels = voxels.contiguous()
+        num_points = num_points.int().contiguous()
+        coors = coors.int().contiguous()
+        m, t, c = voxels.shape
+        f = weight.shape[0]
+        dev = voxels.device
+        out = torch.empty((m, f), dtype=torch.float32, device=dev)
+        argmax = torch.empty((m, f), dtype=torch.int32, device=dev)
+        save = torch.empty((4, f), dtype=torch.float32, device=dev)
+        w = weight.detach().float().contiguous()
+        vx, vy, xo, yo = geom
+        rc = L.d3d_pfn_fwd(voxels.data_ptr(), num_points.data_ptr(), coors.data_ptr(), m, t, c, vx, vy, xo, yo,
+                           w.data_ptr(), f, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
+                           _lib.ptr(running_var), float(momentum), float(eps), int(training), out.data_ptr(),
+                           argmax.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), save[2].data_ptr(),
+                           _lib.stream_ptr(dev))
+        _lib.check(rc, "d3d_pfn_fwd")
+        ctx.save_for_backward(voxels, num_points, coors, w, gamma, save, out, argmax)
+        ctx.geom = geom
+        ctx.training = training
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.training:
+            raise _lib.D3dError("fused PFN backward is implemented for training mode only")
+        L = _lib.lib()
+        voxels, num_points, coors, w, gamma, save, out, argmax = ctx.saved_tensors
+        m, t, c = voxels.shape
+        f = w.shape[0]
+        vx, vy, xo, yo = ctx.geom
+        dout = dout.float().contiguous()
+        dw = torch.empty_like(w)
+        g = torch.empty((2, f), dtype=torch.float32, device=w.device)
+        rc = L.d3d_pfn_bwd(voxels.data_ptr(), num_points.data_ptr(), coors.data_ptr(), m, t, c, vx, vy, xo, yo,
+                           w.data_ptr(), f, _lib.ptr(gamma), save[0].data_ptr(), save[1].data_ptr(),
+                           out.data_ptr(), dout.data_ptr(), argmax.data_ptr(), dw.data_ptr(), g[0].data_ptr(),
+                           g[1].data_ptr(), _lib.stream_ptr(w.device))
+        _lib.check(rc, "d3d_pfn_bwd")
+        return None, None, None, dw, g[0], g[1], None, None, None, None, None, None
 
 
 @READERS.register_module
@@ -78,7 +130,27 @@ class PillarFeatureNet(nn.Module):
         self.x_offset = self.vx / 2 + pc_range[0]
         self.y_offset = self.vy / 2 + pc_range[1]
 
+    def _fusable(self, features):
+        if not (FUSE_PFN and features.is_cuda and features.dtype == torch.float32):
+            return False
+        if len(self.pfn_layers) != 1 or self._with_distance or features.shape[0] < 1:
+            return False
+        pfn = self.pfn_layers[0]
+        bn = pfn.norm
+        ok_bn = type(bn) is nn.BatchNorm1d and bn.track_running_stats and bn.momentum is not None \
+            and bn.weight is not None
+        if not bn.training and torch.is_grad_enabled() and pfn.linear.weight.requires_grad:
+            return False  # eval-mode backward: PyTorch path
+        return ok_bn and pfn.units <= 64 and 3 <= features.shape[2] <= 5
+
     def forward(self, features, num_voxels, coors):
+        if self._fusable(features):
+            pfn = self.pfn_layers[0]
+            bn = pfn.norm
+            out = _PFNFn.apply(features, num_voxels, coors, pfn.linear.weight, bn.weight, bn.bias,
+                               bn.running_mean, bn.running_var, bn.momentum, bn.eps, bn.training,
+                               (float(self.vx), float(self.vy), float(self.x_offset), float(self.y_offset)))
+            return out.squeeze()
         dtype = features.dtype
         points_mean = features[:, :, :3].sum(dim=1, keepdim=True) / \
             num_voxels.type_as(features).view(-1, 1, 1)

@@ -156,6 +156,27 @@ int d3d_bn_relu_bwd(const void *x, const void *dy, int n, int c, int dtype, cons
                     const float *beta, const float *save_mean, const float *save_invstd, int relu,
                     void *dx, float *dgamma, float *dbeta, d3d_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * PillarFeatureNet with one (last) PFNLayer: det3d/models/readers/pillar_encoder.py:115-155
+ * (decorate + mask) and :42-57 (Linear(c+5 -> f, no bias), BatchNorm1d over all m*t rows, ReLU,
+ * max over t), fused; nothing of size [m, t, *] is materialised.
+ *  voxels dev [m,t,c] f32 zero padded, num_points dev [m] i32, coors dev [m,4] i32 (b,z,y,x)
+ *  weight dev [f, c+5] f32 (nn.Linear layout), gamma/beta/running_* dev [f] f32, f <= 64, c in 3..5
+ *  out dev [m,f] f32; argmax dev [m,f] i32 (row index of the max, >= num_points for a padded row)
+ *  training=1: batch statistics via stats_ws dev [2f], running stats updated, save_* written
+ *  bwd overwrites dweight [f,c+5], dgamma [f], dbeta [f]  (points carry no gradient)
+ */
+int d3d_pfn_fwd(const float *voxels, const int32_t *num_points, const int32_t *coors, int m, int t,
+                int c, float vx, float vy, float x_offset, float y_offset, const float *weight, int f,
+                const float *gamma, const float *beta, float *running_mean, float *running_var,
+                float momentum, float eps, int training, float *out, int32_t *argmax,
+                float *save_mean, float *save_invstd, float *stats_ws, d3d_stream_t stream);
+int d3d_pfn_bwd(const float *voxels, const int32_t *num_points, const int32_t *coors, int m, int t,
+                int c, float vx, float vy, float x_offset, float y_offset, const float *weight, int f,
+                const float *gamma, const float *save_mean, const float *save_invstd,
+                const float *out, const float *dout, const int32_t *argmax, float *dweight,
+                float *dgamma, float *dbeta, d3d_stream_t stream);
+
 /* SparseConvTensor.dense() (spconv; call sites scn.py:192-195,363-367):
  * scatter feat[n,c] to dense [batch, c, D, H, W] (zero elsewhere; the caller
  * views it as [batch, c*D, H, W]).  `dense` is fully written.  The backward
