@@ -1,15 +1,28 @@
-"""RPN neck, det3d/models/necks/rpn.py:22-159: per block ZeroPad2d(1) + Conv3x3(stride) + BN
-+ ReLU then n x (Conv3x3 + BN + ReLU); deblocks are ConvTranspose2d (stride > 1) or a
-strided Conv2d (stride < 1); outputs concatenated on C.  Dense convs go to MIOpen/rocBLAS
-through PyTorch-ROCm (bf16 under autocast)."""
-import logging
+"""RPN neck (registry name `RPN`), behaviour of det3d/models/necks/rpn.py:22-159.
 
-import numpy as np
+Stage i:  ZeroPad2d(1) + Conv3x3(stride s_i) + BN + ReLU, then n_i x (Conv3x3(pad 1) + BN + ReLU),
+all bias-free.  The last len(us_layer_strides) stages each feed a "deblock": ConvTranspose2d
+(kernel = stride = u) when u > 1, otherwise a Conv2d with kernel = stride = round(1/u); + BN + ReLU.
+Deblock outputs are concatenated along C.  Child modules are numbered exactly like the reference
+(`blocks.<i>.<j>`, `deblocks.<i>.<j>`) so checkpoints load.  The dense convolutions run on
+MIOpen / rocBLAS through PyTorch-ROCm (bf16 under autocast, NHWC when the backbone hands over a
+channels-last tensor).
+"""
+import logging
+from functools import reduce
+from operator import mul
+
 import torch
 from torch import nn
 
 from .nn_utils import Sequential, build_norm_layer
 from .registry import NECKS
+
+_DEFAULT_NORM = dict(type="BN", eps=1e-3, momentum=0.01)
+
+
+def _prod(xs):
+    return reduce(mul, xs, 1)
 
 
 @NECKS.register_module
@@ -17,58 +30,57 @@ class RPN(nn.Module):
     def __init__(self, layer_nums, ds_layer_strides, ds_num_filters, us_layer_strides, us_num_filters,
                  num_input_features, norm_cfg=None, name="rpn", logger=None, **kwargs):
         super().__init__()
-        self._layer_strides = ds_layer_strides
-        self._num_filters = ds_num_filters
-        self._layer_nums = layer_nums
-        self._upsample_strides = us_layer_strides
-        self._num_upsample_filters = us_num_filters
+        n_stage, n_up = len(layer_nums), len(us_layer_strides)
+        if not (len(ds_layer_strides) == len(ds_num_filters) == n_stage):
+            raise AssertionError("layer_nums, ds_layer_strides and ds_num_filters must have equal length")
+        if len(us_num_filters) != n_up:
+            raise AssertionError("us_layer_strides and us_num_filters must have equal length")
+        self._norm_cfg = dict(norm_cfg) if norm_cfg is not None else dict(_DEFAULT_NORM)
+        self._layer_nums = list(layer_nums)
+        self._layer_strides = list(ds_layer_strides)
+        self._num_filters = list(ds_num_filters)
+        self._upsample_strides = list(us_layer_strides)
+        self._num_upsample_filters = list(us_num_filters)
         self._num_input_features = num_input_features
-        if norm_cfg is None:
-            norm_cfg = dict(type="BN", eps=1e-3, momentum=0.01)
-        self._norm_cfg = norm_cfg
-        assert len(self._layer_strides) == len(self._layer_nums)
-        assert len(self._num_filters) == len(self._layer_nums)
-        assert len(self._num_upsample_filters) == len(self._upsample_strides)
-        self._upsample_start_idx = len(self._layer_nums) - len(self._upsample_strides)
-        ratios = [self._upsample_strides[i] / np.prod(self._layer_strides[: i + self._upsample_start_idx + 1])
-                  for i in range(len(self._upsample_strides))]
-        assert all(r == ratios[0] for r in ratios)
+        self._upsample_start_idx = first_up = n_stage - n_up
 
-        in_filters = [self._num_input_features, *self._num_filters[:-1]]
-        blocks, deblocks = [], []
-        for i, layer_num in enumerate(self._layer_nums):
-            block, planes = self._make_layer(in_filters[i], self._num_filters[i], layer_num,
-                                             stride=self._layer_strides[i])
-            blocks.append(block)
-            j = i - self._upsample_start_idx
-            if j >= 0:
-                stride = self._upsample_strides[j]
-                out_c = self._num_upsample_filters[j]
-                if stride > 1:
-                    up = nn.ConvTranspose2d(planes, out_c, stride, stride=stride, bias=False)
-                else:
-                    s = int(np.round(1 / stride).astype(np.int64))
-                    up = nn.Conv2d(planes, out_c, s, stride=s, bias=False)
-                deblocks.append(Sequential(up, build_norm_layer(self._norm_cfg, out_c)[1], nn.ReLU()))
-        self.blocks = nn.ModuleList(blocks)
-        self.deblocks = nn.ModuleList(deblocks)
-        (logger or logging.getLogger("RPN")).info("Finish RPN Initialization")
+        # every deblock must bring its stage back to the same resolution
+        scale = [us_layer_strides[j] / _prod(ds_layer_strides[: j + first_up + 1]) for j in range(n_up)]
+        if any(v != scale[0] for v in scale):
+            raise AssertionError("inconsistent up/down-sampling strides: %s" % scale)
+
+        widths_in = [num_input_features] + list(ds_num_filters[:-1])
+        self.blocks = nn.ModuleList(
+            self._make_layer(widths_in[i], ds_num_filters[i], layer_nums[i], stride=ds_layer_strides[i])[0]
+            for i in range(n_stage))
+        self.deblocks = nn.ModuleList(
+            self._make_deblock(ds_num_filters[first_up + j], us_num_filters[j], us_layer_strides[j])
+            for j in range(n_up))
+        (logger if logger is not None else logging.getLogger("RPN")).info("Finish RPN Initialization")
+
+    def _norm(self, channels):
+        return build_norm_layer(self._norm_cfg, channels)[1]
+
+    def _make_layer(self, inplanes, planes, num_blocks, stride=1):
+        seq = Sequential(nn.ZeroPad2d(1), nn.Conv2d(inplanes, planes, 3, stride=stride, bias=False),
+                         self._norm(planes), nn.ReLU())
+        for _ in range(num_blocks):
+            for layer in (nn.Conv2d(planes, planes, 3, padding=1, bias=False), self._norm(planes), nn.ReLU()):
+                seq.add(layer)
+        return seq, planes
+
+    def _make_deblock(self, cin, cout, stride):
+        if stride > 1:
+            up = nn.ConvTranspose2d(cin, cout, stride, stride=stride, bias=False)
+        else:
+            k = int(round(1.0 / stride))
+            up = nn.Conv2d(cin, cout, k, stride=k, bias=False)
+        return Sequential(up, self._norm(cout), nn.ReLU())
 
     @property
     def downsample_factor(self):
-        factor = np.prod(self._layer_strides)
-        if len(self._upsample_strides) > 0:
-            factor /= self._upsample_strides[-1]
-        return factor
-
-    def _make_layer(self, inplanes, planes, num_blocks, stride=1):
-        block = Sequential(nn.ZeroPad2d(1), nn.Conv2d(inplanes, planes, 3, stride=stride, bias=False),
-                           build_norm_layer(self._norm_cfg, planes)[1], nn.ReLU())
-        for _ in range(num_blocks):
-            block.add(nn.Conv2d(planes, planes, 3, padding=1, bias=False))
-            block.add(build_norm_layer(self._norm_cfg, planes)[1])
-            block.add(nn.ReLU())
-        return block, planes
+        f = _prod(self._layer_strides)
+        return f / self._upsample_strides[-1] if self._upsample_strides else f
 
     def init_weights(self):
         for m in self.modules():
@@ -76,11 +88,10 @@ class RPN(nn.Module):
                 nn.init.xavier_uniform_(m.weight)
 
     def forward(self, x):
-        ups = []
-        for i, blk in enumerate(self.blocks):
-            x = blk(x)
-            if i - self._upsample_start_idx >= 0:
-                ups.append(self.deblocks[i - self._upsample_start_idx](x))
-        if len(ups) > 0:
-            x = torch.cat(ups, dim=1)
-        return x
+        outs = []
+        for i, stage in enumerate(self.blocks):
+            x = stage(x)
+            j = i - self._upsample_start_idx
+            if j >= 0:
+                outs.append(self.deblocks[j](x))
+        return torch.cat(outs, dim=1) if outs else x

@@ -1,60 +1,58 @@
-"""Type-keyed registries, same contract as det3d/utils/registry.py:6-78 and
-det3d/models/registry.py:3-10: `register_module` decorator, `build_from_cfg(cfg,
-registry, default_args)` pops "type" and passes the remaining keys as kwargs."""
+"""Type-keyed registries with the contract of det3d/utils/registry.py:6-78 and
+det3d/models/registry.py:3-10: classes register themselves under their __name__
+(`@REGISTRY.register_module`), and `build_from_cfg(cfg, registry, default_args)` takes a dict
+whose "type" names the class (or is the class) while the remaining keys become constructor kwargs."""
 import inspect
 
 
 class Registry:
+    """name -> class table."""
+
     def __init__(self, name):
         self._name = name
-        self._module_dict = {}
+        self._classes = {}
+
+    name = property(lambda self: self._name)
+    module_dict = property(lambda self: self._classes)
 
     def __repr__(self):
-        return "%s(name=%s, items=%s)" % (type(self).__name__, self._name, list(self._module_dict))
+        return "Registry(name=%s, items=%s)" % (self._name, sorted(self._classes))
 
-    @property
-    def name(self):
-        return self._name
-
-    @property
-    def module_dict(self):
-        return self._module_dict
+    def __contains__(self, key):
+        return key in self._classes
 
     def get(self, key):
-        return self._module_dict.get(key)
+        return self._classes.get(key)
 
     def register_module(self, cls):
         if not inspect.isclass(cls):
-            raise TypeError("module must be a class, but got %s" % type(cls))
-        if cls.__name__ in self._module_dict:
-            raise KeyError("%s is already registered in %s" % (cls.__name__, self._name))
-        self._module_dict[cls.__name__] = cls
+            raise TypeError("only classes can be registered, got %s" % type(cls))
+        key = cls.__name__
+        if key in self._classes:
+            raise KeyError("%s is already registered in %s" % (key, self._name))
+        self._classes[key] = cls
         return cls
 
 
 def build_from_cfg(cfg, registry, default_args=None):
-    if not (isinstance(cfg, dict) and "type" in cfg):
+    if not isinstance(cfg, dict) or "type" not in cfg:
         raise TypeError("cfg must be a dict with a 'type' key")
-    if not (default_args is None or isinstance(default_args, dict)):
+    if default_args is not None and not isinstance(default_args, dict):
         raise TypeError("default_args must be a dict or None")
-    args = dict(cfg)
-    kind = args.pop("type")
-    if isinstance(kind, str):
-        cls = registry.get(kind)
+    kwargs = {k: v for k, v in cfg.items() if k != "type"}
+    target = cfg["type"]
+    if inspect.isclass(target):
+        cls = target
+    elif isinstance(target, str):
+        cls = registry.get(target)
         if cls is None:
-            raise KeyError("%s is not in the %s registry" % (kind, registry.name))
-    elif inspect.isclass(kind):
-        cls = kind
+            raise KeyError("%s is not in the %s registry" % (target, registry.name))
     else:
-        raise TypeError("type must be a str or class, got %s" % type(kind))
-    for k, v in (default_args or {}).items():
-        args.setdefault(k, v)
-    return cls(**args)
+        raise TypeError("type must be a str or a class, got %s" % type(target))
+    for key, value in (default_args or {}).items():
+        kwargs.setdefault(key, value)
+    return cls(**kwargs)
 
 
-READERS = Registry("reader")
-BACKBONES = Registry("backbone")
-NECKS = Registry("neck")
-HEADS = Registry("head")
-LOSSES = Registry("loss")
-DETECTORS = Registry("detector")
+READERS, BACKBONES, NECKS = Registry("reader"), Registry("backbone"), Registry("neck")
+HEADS, LOSSES, DETECTORS = Registry("head"), Registry("loss"), Registry("detector")
