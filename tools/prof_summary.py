@@ -33,7 +33,9 @@ def pmc(db, counter, out):
     with open(out, "w") as f:
         f.write("# rocprofv3 --kernel-trace --pmc %s ; per kernel: launches, avg counter value per launch, avg duration us\n" % counter)
         f.write("# (counter summed over its instances; FETCH_SIZE/WRITE_SIZE are in KiB -- see MI355X_MICROARCH.md HBM notes)\n")
-        for r in rows[:60]:
+        ours = ("spconv", "rb_", "vox_", "bn_", "pfn_", "dense_move", "nms_", "rotate_iou", "d3d_scan")
+        keep = [r for i, r in enumerate(rows) if i < 40 or any(t in r[0] for t in ours)]
+        for r in keep:
             f.write("%8d %16.1f %10.2f  %s\n" % (r[1], r[2], r[4], r[0][:130]))
 
 
