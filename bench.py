@@ -7,7 +7,7 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One step = one pass of the whole hot path over one batch of synthetic KITTI-range clouds that
-are already resident in HBM: device voxelizer + fused mean VFE -> SpMiddleFHD (HIP rulebooks,
+are already resident in HBM: device voxelizer + fused mean VFE -> anchor target assignment (HIP) -> SpMiddleFHD (HIP rulebooks,
 sparse conv fwd) -> RPN / head (MIOpen via PyTorch-ROCm, bf16 autocast) -> losses -> backward
 (HIP dgrad / wgrad) -> gradient mean over ranks (RCCL) -> clip -> true-WD Adam.  Rank 0 prints
 ONE JSON line; `roofline` describes the hand-written sparse-conv gather kernel
@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-log", action="store_true")
+    ap.add_argument("--cached-targets", action="store_true",
+                    help="use the host-precomputed anchor targets instead of d3d_assign_targets in the step")
     ap.add_argument("--no-channels-last", action="store_true",
                     help="NCHW dense()/RPN activations (default: channels-last, written directly by d3d_dense_scatter)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -167,7 +169,8 @@ def main():
             spconv.LAUNCH_LOG.clear()
 
     def one_step(i):
-        ex = synthetic.make_example(batches[i % n_batches], vox_cfg, fused_mean=True)
+        ex = synthetic.make_example(batches[i % n_batches], vox_cfg, fused_mean=True,
+                                    device_targets=not args.cached_targets)
         drain_launch_log()
         return step_fn(ex)
 

@@ -23,6 +23,7 @@ SOURCES = [
     "d3d_bn.hip",
     "d3d_pfn.hip",
     "d3d_dense.hip",
+    "d3d_assign.hip",
     "d3d_nms.hip",
 ]
 

@@ -145,6 +145,34 @@ def assign_targets(anchors, gt_boxes, matched_threshold=0.6, unmatched_threshold
     return labels, targets, weights
 
 
+def assign_targets_device(anchors, gt, gt_count, matched_threshold=0.6, unmatched_threshold=0.45,
+                          gt_classes=None):
+    """d3d_assign_targets: anchors [A,7], gt [B,Gmax,7] (padded), gt_count [B] int32, all CUDA ->
+    labels [B,A] i32, reg_targets [B,A,7] f32, reg_weights [B,A] f32 (same rule as assign_targets)."""
+    from . import _lib
+
+    if not anchors.is_cuda:
+        raise _lib.D3dError("assign_targets_device needs device tensors (numpy path: assign_targets)")
+    L = _lib.lib()
+    anchors = anchors.float().contiguous()
+    gt = gt.float().contiguous()
+    gt_count = gt_count.int().contiguous()
+    B, gmax = gt.shape[0], gt.shape[1]
+    A = anchors.shape[0]
+    dev = anchors.device
+    labels = torch.empty((B, A), dtype=torch.int32, device=dev)
+    targets = torch.empty((B, A, 7), dtype=torch.float32, device=dev)
+    weights = torch.empty((B, A), dtype=torch.float32, device=dev)
+    wsb = L.d3d_assign_targets_workspace_bytes(A, B, gmax)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    cls = gt_classes.int().contiguous() if gt_classes is not None else None
+    rc = L.d3d_assign_targets(anchors.data_ptr(), A, gt.data_ptr(), _lib.ptr(cls), gt_count.data_ptr(), B,
+                              gmax, float(matched_threshold), float(unmatched_threshold), labels.data_ptr(),
+                              targets.data_ptr(), weights.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
+    _lib.check(rc, "d3d_assign_targets")
+    return labels, targets, weights
+
+
 class KittiCarSynthetic:
     """Cycles seeded frames of the KITTI-car SECOND geometry (BASELINE.json configs[1])."""
 
@@ -179,14 +207,22 @@ class KittiCarSynthetic:
     def device_batch(self, step, batch_size, device, rank=0, world=1):
         hb = self.host_batch(step, batch_size, rank, world)
         t = lambda a: torch.from_numpy(a).to(device, non_blocking=True)
+        gmax = max(max(len(g) for g in hb["gt"]), 1)
+        gt_pad = np.zeros((batch_size, gmax, 7), np.float32)
+        for i, g in enumerate(hb["gt"]):
+            gt_pad[i, : len(g)] = g
+        gt_count = np.array([len(g) for g in hb["gt"]], np.int32)
         return dict(points=t(hb["points"]), frame_offsets=t(hb["frame_offsets"]),
                     anchors=[t(hb["anchors"])], labels=[t(hb["labels"])],
                     reg_targets=[t(hb["reg_targets"])], reg_weights=[t(hb["reg_weights"])],
-                    metadata=hb["metadata"], gt=hb["gt"])
+                    metadata=hb["metadata"], gt=hb["gt"], gt_boxes=t(gt_pad), gt_count=t(gt_count),
+                    anchors_flat=t(self.anchors))
 
 
-def make_example(batch, cfg, fused_mean=True, want_voxels=False):
-    """raw device points -> the collate_kitti-style `example` (device voxelizer, 1 sync)."""
+def make_example(batch, cfg, fused_mean=True, want_voxels=False, device_targets=False):
+    """raw device points -> the collate_kitti-style `example` (device voxelizer, 1 sync).
+    device_targets=True recomputes labels / reg_targets from the frame's gt boxes with
+    d3d_assign_targets instead of using the cached host assignment."""
     from .point_cloud_ops import grid_size_of, voxelize_batch
 
     vb = voxelize_batch(batch["points"], batch["frame_offsets"], cfg["voxel_size"], cfg["pc_range"],
@@ -197,9 +233,14 @@ def make_example(batch, cfg, fused_mean=True, want_voxels=False):
     bsz = batch["frame_offsets"].numel() - 1
     ex = dict(coordinates=out["coordinates"], num_points=out["num_points"], num_voxels=out["num_voxels"],
               shape=np.stack([grid] * bsz), anchors=batch["anchors"], metadata=batch.get("metadata", []))
-    for k in ("labels", "reg_targets", "reg_weights"):
-        if k in batch:
-            ex[k] = batch[k]
+    if device_targets:
+        lab, tgt, w = assign_targets_device(batch["anchors_flat"], batch["gt_boxes"], batch["gt_count"],
+                                            cfg["matched_threshold"], cfg["unmatched_threshold"])
+        ex["labels"], ex["reg_targets"], ex["reg_weights"] = [lab], [tgt], [w]
+    else:
+        for k in ("labels", "reg_targets", "reg_weights"):
+            if k in batch:
+                ex[k] = batch[k]
     if "voxels" in out:
         ex["voxels"] = out["voxels"]
     if fused_mean:

@@ -191,6 +191,23 @@ int d3d_dense_gather(const void *dense, const int32_t *coords, int n, int c, int
                      d3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Anchor target assignment (the first "next" row): create_target_np
+ * (det3d/core/anchor/target_ops.py:28-222) with the nearest-IoU similarity
+ * (region_similarity.py:73-93, box_np_ops.py:343-355,955-994) and second_box_encode, for one
+ * task with 7-dim boxes, no positive/negative subsampling (sample_positive_fraction = -1).
+ *  anchors dev [A,7] f32; gt dev [batch,gmax,7] f32 padded; gt_count dev [batch] i32;
+ *  gt_classes dev [batch,gmax] i32 (1-based) or NULL (all class 1)
+ *  labels dev [batch,A] i32 (class / 0 background / -1 ignored), reg_targets dev [batch,A,7] f32,
+ *  reg_weights dev [batch,A] f32
+ */
+size_t d3d_assign_targets_workspace_bytes(int num_anchors, int batch, int gmax);
+int d3d_assign_targets(const float *anchors, int num_anchors, const float *gt,
+                       const int32_t *gt_classes, const int32_t *gt_count, int batch, int gmax,
+                       float matched_threshold, float unmatched_threshold, int32_t *labels,
+                       float *reg_targets, float *reg_weights, void *workspace,
+                       size_t workspace_bytes, d3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Rotated NMS.  Replaces rotate_nms_cc (det3d/ops/nms/nms_cpu.py:34-45) +
  * rotate_non_max_suppression_cpu (det3d/ops/nms/nms_cpu.h:73-169), as driven
  * by box_torch_ops.rotate_nms (det3d/core/bbox/box_torch_ops.py:528-549).
