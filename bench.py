@@ -132,7 +132,7 @@ def main():
     rank, local_rank, world = D.init_dist()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the det3d_amd hot path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     # MIOpen find mode for the dense RPN convs (+3 % over immediate mode, < 20 s on a cold
     # perf-db cache); D3D_MIOPEN_FIND=0 falls back to immediate mode
