@@ -42,7 +42,9 @@ def broadcast_params(module, src=0):
     if world_size() == 1:
         return
     tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
-    for dtype in {t.dtype for t in tensors}:
+    # every rank must issue the broadcasts in the SAME order: iterate dtypes sorted by name (a set
+    # of torch.dtype iterates in id() order, which differs between processes -> collective mismatch)
+    for dtype in sorted({t.dtype for t in tensors}, key=str):
         group = [t for t in tensors if t.dtype == dtype]
         flat = torch._utils._flatten_dense_tensors(group)
         dist.broadcast(flat, src)
