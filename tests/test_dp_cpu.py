@@ -21,9 +21,11 @@ def _free_port():
 
 
 def _net():
+    # BatchNorm in eval mode: an affine layer for the gradient check, but it brings int64
+    # (num_batches_tracked) and float32 buffers, so broadcast_params has several dtype groups
     torch.manual_seed(0)
-    return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(),
-                               torch.nn.Conv2d(8, 4, 1))
+    return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
+                               torch.nn.Conv2d(8, 4, 1)).eval()
 
 
 def _worker(rank, world, port, q):
@@ -39,6 +41,8 @@ def _worker(rank, world, port, q):
         with torch.no_grad():
             for p in net.parameters():
                 p.add_(1.0)
+            for b in net.buffers():
+                b.add_(3)
     D.broadcast_params(net)
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.randn(2, 3, 6, 6, generator=g)
@@ -52,7 +56,7 @@ def _worker(rank, world, port, q):
     objs = D.all_gather_objects(dict(rank=rank, n=int(x.shape[0])))
     D.barrier()
     q.put((rank, [p.grad.clone() for p in net.parameters()], float(total), objs,
-           [p.detach().clone() for p in net.parameters()]))
+           [p.detach().clone() for p in net.parameters()] + [b.clone() for b in net.buffers()]))
     torch.distributed.destroy_process_group()
 
 
@@ -78,8 +82,9 @@ def test_two_rank_gradient_mean_equals_single_process():
             assert torch.allclose(g, r, atol=1e-6)
         assert total == pytest.approx(float(torch.sqrt(sum((r ** 2).sum() for r in ref))), rel=1e-5)
         assert [o["rank"] for o in objs] == [0, 1]
-        for p, q0 in zip(params, _net().parameters()):
-            assert torch.equal(p, q0)  # rank 1 was reset to rank 0's weights
+        ref_net = _net()
+        for p, q0 in zip(params, list(ref_net.parameters()) + list(ref_net.buffers())):
+            assert torch.equal(p, q0)  # rank 1 was reset to rank 0's weights and buffers
     # both ranks ended with identical gradients
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b)
