@@ -55,8 +55,9 @@ def _worker(rank, world, port, q):
     total = bucket.clip_norm_(1e9)
     objs = D.all_gather_objects(dict(rank=rank, n=int(x.shape[0])))
     D.barrier()
-    q.put((rank, [p.grad.clone() for p in net.parameters()], float(total), objs,
-           [p.detach().clone() for p in net.parameters()] + [b.clone() for b in net.buffers()]))
+    # numpy through the queue: torch tensors are shared by fd and the worker may exit first
+    q.put((rank, [p.grad.numpy().copy() for p in net.parameters()], float(total), objs,
+           [p.detach().numpy().copy() for p in net.parameters()] + [b.numpy().copy() for b in net.buffers()]))
     torch.distributed.destroy_process_group()
 
 
@@ -68,6 +69,8 @@ def test_two_rank_gradient_mean_equals_single_process():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = [(r, [torch.from_numpy(g) for g in gs], tot, objs, [torch.from_numpy(np.asarray(p)) for p in ps])
+           for r, gs, tot, objs, ps in res]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
