@@ -18,6 +18,8 @@
 //   16-byte piece of the gathered row -- no LDS, no transposes on the hot path.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "d3d_common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -39,8 +41,10 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round to nearest 
 // global loads the weight fragments were 4x the gather traffic through L1/TA
 // (profiles/round1_kernel_stats_v0.txt).  The gathered rows go straight from global memory
 // into MFMA B-operand registers, the next offset's indices are prefetched.
+// launch bound: a 16-wave block puts 4 waves on every SIMD, so two resident blocks per CU need
+// <= 64 VGPRs (8 waves/SIMD); at 66 VGPRs only one block fits and the kernel is 45 % slower
 template <int CIN, int COUT, int MT, int WAVES, bool BF16>
-__global__ void __launch_bounds__(WAVES * 64)
+__global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 8 : 4))
     spconv_fwd_mfma_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
                            const float *__restrict__ bias, const int32_t *__restrict__ nbr,
                            int cap, int n_out, int kvol, void *__restrict__ out_) {
@@ -75,9 +79,31 @@ __global__ void __launch_bounds__(WAVES * 64)
     site[m] = row0 + m * 16 + lr;
     live[m] = site[m] < n_out;
   }
-  int idx[MT];
+  // gathered-row fragment of one (tile, k-step): 16 B (8 bf16 | 4 f32) or 8 B (4 bf16, Cin = 16)
+  using FragT = typename std::conditional<(BF16 && KW == 16), uint2, uint4>::type;
+  const unsigned char *fbase = (const unsigned char *)feat_;
+  auto gather = [&](const int(&ix)[MT], FragT(&f)[MT][KS]) {
 #pragma unroll
-  for (int m = 0; m < MT; ++m) idx[m] = live[m] ? nbr[site[m]] : -1;
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        FragT z = {};
+        f[m][ks] = ix[m] >= 0 ? *(const FragT *)(fbase + ((int64_t)ix[m] * CIN + ks * KW + lg * EPL) * ESZ)
+                              : z;
+      }
+  };
+
+  // software pipeline over kernel offsets: indices two offsets ahead, gathered rows one offset
+  // ahead (their L2 latency overlaps the previous offset's MFMAs, LDS traffic and barrier),
+  // weights one offset ahead through registers into the other LDS buffer
+  int idx0[MT], idx1[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    idx0[m] = live[m] ? nbr[site[m]] : -1;
+    idx1[m] = (kvol > 1 && live[m]) ? nbr[(int64_t)cap + site[m]] : -1;
+  }
+  FragT fcur[MT][KS];
+  gather(idx0, fcur);
 
   // stage W[0]
   const unsigned char *wg = (const unsigned char *)wpack_;
@@ -92,84 +118,63 @@ __global__ void __launch_bounds__(WAVES * 64)
     int e = threadIdx.x + j * NTHREADS;
     if (e < WVEC) *(uint4 *)(wlds + (e / SEGS) * ROWB + (e % SEGS) * 16) = wreg[j];
   }
+  // W[1] starts its trip now: a weight tile is loaded TWO offsets before it is used, because
+  // the per-offset MFMA work of a wave (~50 ns) cannot cover an L2 round trip (~1 us) -- with a
+  // one-offset distance every iteration waited for its own weight load before the barrier
+  if (kvol > 1) {
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+      int e = threadIdx.x + j * NTHREADS;
+      if (e < WVEC) wreg[j] = *(const uint4 *)(wg + ((size_t)WVEC + e) * 16);
+    }
+  }
   __syncthreads();
 
   for (int k = 0; k < kvol; ++k) {
     const unsigned char *wcur = wlds + (k & 1) * WBYTES;
-    // prefetch next offset: indices + weights (global -> registers)
-    int nxt[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-      nxt[m] = (k + 1 < kvol && live[m]) ? nbr[(int64_t)(k + 1) * cap + site[m]] : -1;
-    if (k + 1 < kvol) {
+    uint4 wfar[WPT];
+    if (k + 2 < kvol) {
 #pragma unroll
       for (int j = 0; j < WPT; ++j) {
         int e = threadIdx.x + j * NTHREADS;
-        if (e < WVEC) wreg[j] = *(const uint4 *)(wg + ((size_t)(k + 1) * WVEC + e) * 16);
+        if (e < WVEC) wfar[j] = *(const uint4 *)(wg + ((size_t)(k + 2) * WVEC + e) * 16);
       }
     }
+    int idx2[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      idx2[m] = (k + 2 < kvol && live[m]) ? nbr[(int64_t)(k + 2) * cap + site[m]] : -1;
+    FragT fnxt[MT][KS];
+    gather(idx1, fnxt);  // offset k+1 (all -1 past the end: no loads issued)
     bool any = false;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) any |= idx[m] >= 0;
+    for (int m = 0; m < MT; ++m) any |= idx0[m] >= 0;
     if (__ballot(any) != 0ull) {
-      if constexpr (BF16) {
-        const uint16_t *feat = (const uint16_t *)feat_;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const int ch = ks * KW + lg * EPL;
-          if constexpr (KW == 32) {
-            uint4 fb[MT];
+      for (int ks = 0; ks < KS; ++ks) {
+        const int ch = ks * KW + lg * EPL;
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-              fb[m] = idx[m] >= 0 ? *(const uint4 *)(feat + (int64_t)idx[m] * CIN + ch)
-                                  : make_uint4(0, 0, 0, 0);
+        for (int n = 0; n < NT; ++n) {
+          const FragT wa = *(const FragT *)(wcur + (n * 16 + lr) * ROWB + ch * ESZ);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-              uint4 wa = *(const uint4 *)(wcur + (n * 16 + lr) * ROWB + ch * 2);
-#pragma unroll
-              for (int m = 0; m < MT; ++m)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, fb[m]),
-                    acc[m][n], 0, 0, 0);
-            }
-          } else {
-            uint2 fb[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-              fb[m] = idx[m] >= 0 ? *(const uint2 *)(feat + (int64_t)idx[m] * CIN + ch)
-                                  : make_uint2(0, 0);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-              uint2 wa = *(const uint2 *)(wcur + (n * 16 + lr) * ROWB + ch * 2);
-#pragma unroll
-              for (int m = 0; m < MT; ++m)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
-                    __builtin_bit_cast(s16x4_t, wa), __builtin_bit_cast(s16x4_t, fb[m]),
-                    acc[m][n], 0, 0, 0);
-            }
-          }
-        }
-      } else {
-        const float *feat = (const float *)feat_;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const int ch = ks * 16 + lg * 4;
-          float4 fb[MT];
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-            fb[m] = idx[m] >= 0 ? *(const float4 *)(feat + (int64_t)idx[m] * CIN + ch)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            float4 wa = *(const float4 *)(wcur + (n * 16 + lr) * ROWB + ch * 4);
-            // 16x16x4 f32 MFMA: lane group lg supplies k = lg; four of them walk the
-            // lane's 4 consecutive channels (any consistent k labelling is a valid sum)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, fb[m].x, acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, fb[m].y, acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, fb[m].z, acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, fb[m].w, acc[m][n], 0, 0, 0);
+          for (int m = 0; m < MT; ++m) {
+            if constexpr (BF16 && KW == 32) {
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, fcur[m][ks]),
+                  acc[m][n], 0, 0, 0);
+            } else if constexpr (BF16) {
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
+                  __builtin_bit_cast(s16x4_t, wa), __builtin_bit_cast(s16x4_t, fcur[m][ks]),
+                  acc[m][n], 0, 0, 0);
+            } else {
+              // 16x16x4 f32 MFMA: lane group lg supplies k = lg; four of them walk the lane's 4
+              // consecutive channels (any consistent k labelling of A and B is a valid sum)
+              const float4 w4 = __builtin_bit_cast(float4, wa);
+              const float4 f4 = __builtin_bit_cast(float4, fcur[m][ks]);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, f4.x, acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, f4.y, acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, f4.z, acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, f4.w, acc[m][n], 0, 0, 0);
             }
           }
         }
@@ -187,7 +192,14 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < MT; ++m) idx[m] = nxt[m];
+    for (int j = 0; j < WPT; ++j) wreg[j] = wfar[j];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      idx0[m] = idx1[m];
+      idx1[m] = idx2[m];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) fcur[m][ks] = fnxt[m][ks];
+    }
   }
 
   // epilogue: lane holds couts [n*16 + lg*4, +4) of site[m]
