@@ -140,6 +140,49 @@ def test_reference_configs_build_unmodified():
         assert cfg.assigner.out_size_factor in (2, 4, 8)
 
 
+# parameter counts measured by building the reference's own config files with the reference's own
+# modules (kitti_car: examples/second/...; nusc_*: examples/{point_pillars,cbgs}/...; lyft: examples/cbgs/...)
+IN_REPO_CONFIGS = dict(nusc_cbgs=(7393148, 8, 6, 10), nusc_point_pillars=(4480236, 4, 6, 10),
+                       lyft_cbgs=(7347140, 8, 5, 7))
+
+
+@pytest.mark.parametrize("name", sorted(IN_REPO_CONFIGS))
+def test_in_repo_multi_group_configs_build(name):
+    """The in-repo restatements of BASELINE.json configs[2..4] build the same network (parameter count,
+    state-dict layout, head groups, box code size: n_dim + 1 with the angle-vector encoding) as the reference config they restate."""
+    from det3d_amd import Config, build_detector
+
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(here, "det3d_amd", "configs", name + ".py"))
+    m = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    n_param, factor, n_tasks, code = IN_REPO_CONFIGS[name]
+    assert sum(p.numel() for p in m.parameters()) == n_param
+    assert cfg.assigner.out_size_factor == factor
+    assert len(m.bbox_head.tasks) == n_tasks == len(cfg.tasks)
+    assert m.bbox_head.box_coder.code_size == code
+    gens = cfg.target_assigner.anchor_generators
+    assert [g.class_name for g in gens] == list(cfg.class_names)
+    assert all(g.anchor_ranges[2] == g.anchor_ranges[5] for g in gens)
+    ref = dict(nusc_cbgs="cbgs/configs/nusc_all_vfev3_spmiddleresnetfhd_rpn2_mghead_syncbn.py",
+               nusc_point_pillars="point_pillars/configs/nusc_all_point_pillars_mghead_syncbn.py",
+               lyft_cbgs="cbgs/configs/lyft_all_vfev3_spmiddleresnetfhd_rpn2_mghead_syncbn.py")[name]
+    ref = os.path.join("/root/reference/examples", ref)
+    if os.path.exists(ref):  # in the build container: field-by-field equality with the reference config
+
+        def norm(x):
+            if hasattr(x, "to_dict"):
+                x = x.to_dict()
+            if isinstance(x, dict):
+                return {k: norm(v) for k, v in x.items() if k not in ("logger", "box_coder")}
+            if isinstance(x, (list, tuple)):
+                return [norm(v) for v in x]
+            return x
+
+        rcfg = Config.fromfile(ref)
+        for key in ("tasks", "class_names", "test_cfg", "voxel_generator", "box_coder", "target_assigner", "model"):
+            assert norm(cfg[key]) == norm(rcfg[key]), key
+
+
 def test_anchor_generation_and_target_assignment_vs_reference_golden():
     """synthetic.create_anchors_3d_range / assign_targets vs goldens made by the reference's
     create_anchors_3d_range (box_np_ops.py:733-805) and create_target_np (target_ops.py:28-222)."""

@@ -89,3 +89,39 @@ def test_axis_aligned_nms(oracle_lib):
     ref = [int(order[i]) for i in oracle_lib.nms_sorted(boxes[order], 0.4)][:120]
     keep = nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), 1000, 120, 0.4)
     assert keep.cpu().tolist() == ref
+
+
+@pytest.mark.parametrize("name", ["kitti", "nusc", "lyft"])
+def test_head_predict_matches_reference_golden(name):
+    """MultiGroupHead.predict on the GPU (decode, score filter, top-k, HIP rotated NMS, direction
+    flip, range mask, multi-task merge) vs the detections the REFERENCE's predict() produced on the
+    same predictions (tests/golden/head.pt; its NMS step used this repo's oracle, see make_golden.py)."""
+    import logging
+
+    from det3d_amd import builder
+    from det3d_amd.bbox_heads import MultiGroupHead
+    from det3d_amd.config import ConfigDict
+
+    g = torch.load(os.path.join(GOLDEN, "head.pt"), weights_only=False)[name]
+    coder = builder.GroundBox3dCoderTorch(g["coder"]["linear_dim"], g["coder"]["vec"], n_dim=g["coder"]["n_dim"])
+    head = MultiGroupHead(
+        mode="3d", in_channels=g["in_ch"], norm_cfg=None, tasks=g["tasks"], weights=[1] * len(g["tasks"]),
+        box_coder=coder, encode_background_as_zeros=True,
+        loss_norm=dict(type="NormByNumPositives", pos_cls_weight=1.0, neg_cls_weight=2.0),
+        loss_cls=dict(type="SigmoidFocalLoss", alpha=0.25, gamma=2.0, loss_weight=1.0), use_sigmoid_score=True,
+        loss_bbox=dict(type="WeightedSmoothL1Loss", sigma=3.0, code_weights=[1.0] * coder.code_size,
+                       codewise=True, loss_weight=2.0),
+        encode_rad_error_by_sin=not coder.vec_encode, loss_aux=g["loss_aux"],
+        direction_offset=g["direction_offset"], logger=logging.getLogger("head"))
+    head.load_state_dict(g["state"])
+    head = head.cuda().eval()
+    example = dict(anchors=[a.cuda() for a in g["anchors"]], metadata=[dict(token=i) for i in range(2)])
+    with torch.no_grad():
+        dets = head.predict(example, head(g["x"].cuda()), ConfigDict(g["test_cfg"]))
+    assert len(dets) == len(g["dets"])
+    for d, r in zip(dets, g["dets"]):
+        assert d["box3d_lidar"].shape == r["box3d_lidar"].shape
+        assert torch.allclose(d["box3d_lidar"].cpu(), r["box3d_lidar"], atol=1e-4)
+        assert torch.allclose(d["scores"].cpu(), r["scores"], atol=1e-5)
+        assert torch.equal(d["label_preds"].cpu(), r["label_preds"])
+        assert d["metadata"] == r["metadata"]
