@@ -48,10 +48,15 @@ SIGNATURES = {
     "d3d_rotate_nms": (i32, [vp, i32, f32, i32, vp, vp, vp, sz, vp]),
     "d3d_rotate_iou": (i32, [vp, i32, vp, i32, vp, vp]),
     "d3d_nms": (i32, [vp, i32, f32, i32, vp, vp, vp, sz, vp]),
+    "d3d_iou3d_pairwise": (i32, [vp, i32, vp, i32, i32, vp, vp]),
+    "d3d_iou3d_nms_workspace_bytes": (sz, [i32]),
+    "d3d_iou3d_nms": (i32, [vp, i32, f32, i32, vp, vp, vp, sz, vp]),
+    "d3d_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
 }
 
 D3D_F32 = 0
 D3D_BF16 = 1
+D3D_IOU3D_OVERLAP, D3D_IOU3D_IOU_BEV, D3D_IOU3D_IOU_NORMAL = 0, 1, 2
 
 
 class D3dError(RuntimeError):

@@ -154,3 +154,24 @@ def rotate_iou(boxes_a, boxes_b):
                           _lib.stream_ptr(a.device))
     _lib.check(rc, "d3d_rotate_iou")
     return out
+
+
+def rotate_iou_gpu_eval(boxes, query_boxes, criterion=-1, device_id=0):
+    """Evaluation-side rotated IoU, signature of kitti_object_eval_python/rotate_iou.py:264-341:
+    boxes [N,5], query_boxes [K,5] as (cx, cy, dx, dy, r) -> [N,K]; criterion -1: IoU, 0: / area(query),
+    1: / area(box), 2: raw intersection area.  numpy in -> numpy out (same dtype) like the reference;
+    CUDA tensors in -> CUDA float32 tensor out (no host round trip)."""
+    import numpy as np
+
+    as_numpy = not torch.is_tensor(boxes)
+    dev = torch.device("cuda", device_id) if as_numpy else boxes.device
+    if dev.type != "cuda":
+        raise _lib.D3dError("rotate_iou_gpu_eval runs on the GPU only")
+    b = torch.as_tensor(np.asarray(boxes, dtype=np.float32) if as_numpy else boxes).to(dev).float().contiguous()
+    q = torch.as_tensor(np.asarray(query_boxes, dtype=np.float32) if as_numpy else query_boxes).to(dev).float().contiguous()
+    out = torch.zeros((b.shape[0], q.shape[0]), dtype=torch.float32, device=dev)
+    if out.numel():
+        rc = _lib.lib().d3d_rotate_iou_eval(b.data_ptr(), b.shape[0], q.data_ptr(), q.shape[0], int(criterion),
+                                            out.data_ptr(), _lib.stream_ptr(dev))
+        _lib.check(rc, "d3d_rotate_iou_eval")
+    return out.cpu().numpy().astype(np.asarray(boxes).dtype) if as_numpy else out

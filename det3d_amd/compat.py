@@ -40,7 +40,7 @@ def install(force=False):
     global _DONE
     if _DONE and not force:
         return
-    from . import box_ops, builder, config, point_cloud_ops, registry
+    from . import box_ops, builder, config, iou3d_utils, point_cloud_ops, registry
     from . import spconv as sp
 
     if force or not _real_module_available("det3d"):
@@ -69,6 +69,14 @@ def install(force=False):
         _alias("det3d.ops").__path__ = []
         _alias("det3d.ops.point_cloud").__path__ = []
         _alias("det3d.ops.point_cloud.point_cloud_ops", points_to_voxel=point_cloud_ops.points_to_voxel)
+        _alias("det3d.ops.iou3d").__path__ = []
+        _alias("det3d.ops.iou3d.iou3d_utils", **{k: getattr(iou3d_utils, k) for k in (
+            "boxes_iou_bev", "boxes_overlap_bev", "boxes_iou3d_gpu", "nms_gpu", "nms_normal_gpu")})
+        _alias("det3d.datasets").__path__ = []
+        _alias("det3d.datasets.utils").__path__ = []
+        _alias("det3d.datasets.utils.kitti_object_eval_python").__path__ = []
+        _alias("det3d.datasets.utils.kitti_object_eval_python.rotate_iou",
+               rotate_iou_gpu_eval=box_ops.rotate_iou_gpu_eval)
     if force or not _real_module_available("spconv"):
         _alias("spconv", SparseConvTensor=sp.SparseConvTensor, SparseSequential=sp.SparseSequential,
                SparseModule=sp.SparseModule, SubMConv3d=sp.SubMConv3d, SparseConv3d=sp.SparseConv3d,

@@ -25,6 +25,7 @@ SOURCES = [
     "d3d_dense.hip",
     "d3d_assign.hip",
     "d3d_nms.hip",
+    "d3d_iou3d.hip",
 ]
 
 FLAGS = [

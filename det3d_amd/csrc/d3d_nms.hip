@@ -12,6 +12,7 @@
 // Semantics follow the CPU rule the shipped configs execute: skip a pair when the
 // stand-up IoU <= 0 (nms_cpu.h:105), suppress when polygon IoU >= thresh (:157).
 #include "d3d_common.h"
+#include "d3d_nms_reduce.h"
 
 struct Quad {
   float x[4], y[4];
@@ -209,29 +210,6 @@ __global__ void __launch_bounds__(64)
     }
   }
   mask[(int64_t)i * nblk + cb] = bits;
-}
-
-#define NMS_MAX_BLK 256  // n <= 16384
-
-__global__ void __launch_bounds__(64)
-    nms_reduce_kernel(const unsigned long long *__restrict__ mask, int n, int nblk, int max_keep,
-                      int32_t *__restrict__ keep, int32_t *__restrict__ n_keep) {
-  __shared__ unsigned long long remv[NMS_MAX_BLK];
-  const int lane = threadIdx.x;
-  for (int w = lane; w < nblk; w += 64) remv[w] = 0ull;
-  __syncthreads();
-  int nk = 0;
-  for (int i = 0; i < n && nk < max_keep; ++i) {
-    const int blk = i >> 6;
-    const bool gone = (remv[blk] >> (i & 63)) & 1ull;
-    if (!gone) {
-      if (lane == 0) keep[nk] = i;
-      ++nk;
-      for (int w = blk + lane; w < nblk; w += 64) remv[w] |= mask[(int64_t)i * nblk + w];
-    }
-    __syncthreads();
-  }
-  if (lane == 0) *n_keep = nk;
 }
 
 extern "C" size_t d3d_rotate_nms_workspace_bytes(int n) {

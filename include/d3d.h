@@ -234,6 +234,32 @@ int d3d_rotate_iou(const float *boxes_a, int m, const float *boxes_b, int n, flo
 int d3d_nms(const float *boxes, int n, float thresh, int max_keep, int32_t *keep,
             int32_t *n_keep, void *workspace, size_t workspace_bytes, d3d_stream_t stream);
 
+/* ---- iou3d: BEV boxes dev [*,5] f32 (x1, y1, x2, y2, ry)  (det3d/ops/iou3d/iou3d_utils.py) ------------
+ * d3d_iou3d_pairwise replaces iou3d_cuda.boxes_overlap_bev_gpu / boxes_iou_bev_gpu
+ * (det3d/ops/iou3d/src/iou3d.cpp:30-70 -> iou3d_kernel.cu:108-248): out[m,n] = intersection area
+ * (D3D_IOU3D_OVERLAP), rotated IoU s/(sa+sb-s, floored at 1e-8) (D3D_IOU3D_IOU_BEV) or the axis-aligned
+ * IoU that ignores ry (D3D_IOU3D_IOU_NORMAL, iou3d_kernel.cu:295-304). */
+#define D3D_IOU3D_OVERLAP 0
+#define D3D_IOU3D_IOU_BEV 1
+#define D3D_IOU3D_IOU_NORMAL 2
+int d3d_iou3d_pairwise(const float *boxes_a, int m, const float *boxes_b, int n, int mode, float *out,
+                       d3d_stream_t stream);
+
+/* replaces iou3d_cuda.nms_gpu (normal = 0) / nms_normal_gpu (normal = 1)  (iou3d.cpp:73-160, kernels
+ * iou3d_kernel.cu:250-352).  boxes sorted by descending score; box j > i is suppressed when
+ * IoU(i, j) > thresh (strict).  thresh must be >= 0.  keep dev [n] int32 positions, *n_keep dev int32.
+ * The reference copies the bitmask to the host and loops there; here everything stays on the device. */
+size_t d3d_iou3d_nms_workspace_bytes(int n);
+int d3d_iou3d_nms(const float *boxes, int n, float thresh, int normal, int32_t *keep, int32_t *n_keep,
+                  void *workspace, size_t workspace_bytes, d3d_stream_t stream);
+
+/* replaces rotate_iou_gpu_eval (det3d/datasets/utils/kitti_object_eval_python/rotate_iou.py:305-341;
+ * numba-CUDA in the reference): boxes dev [n,5], query_boxes dev [k,5] as (cx, cy, dx, dy, r), r clockwise
+ * positive; out[n,k] = area(box ^ query) divided by: criterion -1 the union, 0 area(query),
+ * 1 area(box), 2 nothing (raw intersection area)  (devRotateIoUEval :246-258). */
+int d3d_rotate_iou_eval(const float *boxes, int n, const float *query_boxes, int k, int criterion,
+                        float *out, d3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

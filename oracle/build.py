@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libd3d_oracle.so")
 REF_DIR = os.path.join(HERE, "_ref")
 REFERENCE_ROOT = "/root/reference"
-C_SOURCES = ["voxel_oracle.c", "nms_oracle.c"]
+C_SOURCES = ["voxel_oracle.c", "nms_oracle.c", "iou3d_oracle.c"]
 
 
 def _stale(target, deps):
@@ -28,7 +28,7 @@ def _stale(target, deps):
 def build_oracle(force=False):
     srcs = [os.path.join(HERE, s) for s in C_SOURCES]
     if force or _stale(LIB, srcs):
-        cmd = ["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-o", LIB] + srcs + ["-lm"]
+        cmd = ["gcc", "-O2", "-std=c11", "-ffp-contract=off", "-fPIC", "-shared", "-o", LIB] + srcs + ["-lm"]
         subprocess.run(cmd, check=True)
     return LIB
 
@@ -58,8 +58,40 @@ def build_ref(force=False):
     return out
 
 
+def ref_iou3d_module_path():
+    suffix = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+    return os.path.join(REF_DIR, "d3d_ref_iou3d" + suffix)
+
+
+def build_ref_iou3d(force=False):
+    """Host build of the reference's iou3d DEVICE functions (iou3d_kernel.cu:13-304).  The part of the
+    file before its <<<>>> launchers is written to a temporary directory and #included by
+    ref_wrap_iou3d.cc; nothing of it enters the repo."""
+    out = ref_iou3d_module_path()
+    cu = os.path.join(REFERENCE_ROOT, "det3d/ops/iou3d/src/iou3d_kernel.cu")
+    if not os.path.exists(cu):
+        return out if os.path.exists(out) else None
+    import tempfile
+
+    import pybind11
+
+    os.makedirs(REF_DIR, exist_ok=True)
+    src = os.path.join(HERE, "ref_wrap_iou3d.cc")
+    if force or _stale(out, [src, cu]):
+        text = open(cu).read()
+        cut = text.index("void boxesoverlapLauncher")
+        with tempfile.TemporaryDirectory() as tmp:
+            with open(os.path.join(tmp, "iou3d_dev.inc"), "w") as f:
+                f.write(text[:cut])
+            cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-ffp-contract=off",
+                   "-DIOU3D_DEV_INC=\"iou3d_dev.inc\"", "-I", tmp, "-I", pybind11.get_include(),
+                   "-I", sysconfig.get_paths()["include"], src, "-o", out]
+            subprocess.run(cmd, check=True)
+    return out
+
+
 def build(force=False):
-    return build_oracle(force), build_ref(force)
+    return build_oracle(force), build_ref(force), build_ref_iou3d(force)
 
 
 if __name__ == "__main__":

@@ -34,6 +34,12 @@ def lib():
         L.d3d_oracle_rotate_nms.restype = ctypes.c_int
         L.d3d_oracle_nms.argtypes = [f32p, ctypes.c_int, ctypes.c_float, i32p]
         L.d3d_oracle_nms.restype = ctypes.c_int
+        L.d3d_oracle_iou3d_pairwise.argtypes = [f32p, ctypes.c_int, f32p, ctypes.c_int, ctypes.c_int, f32p]
+        L.d3d_oracle_iou3d_pairwise.restype = None
+        L.d3d_oracle_iou3d_nms.argtypes = [f32p, ctypes.c_int, ctypes.c_float, ctypes.c_int, i32p, f32p]
+        L.d3d_oracle_iou3d_nms.restype = ctypes.c_int
+        L.d3d_oracle_rotate_iou_eval.argtypes = [f32p, ctypes.c_int, f32p, ctypes.c_int, ctypes.c_int, f32p]
+        L.d3d_oracle_rotate_iou_eval.restype = None
         _LIB = L
     return _LIB
 
@@ -142,3 +148,49 @@ def nms_sorted(boxes, thresh):
     k = lib().d3d_oracle_nms(_p(boxes, ctypes.c_float), boxes.shape[0], float(thresh),
                              _p(keep, ctypes.c_int32))
     return keep[:k].tolist()
+
+
+# ---------------------------------------------------------------------- iou3d
+def ref_iou3d_module():
+    """The reference's iou3d device functions compiled for the host (oracle/_ref), or None."""
+    path = _build.ref_iou3d_module_path()
+    if not os.path.exists(path):
+        path = _build.build_ref_iou3d()
+    if not path or not os.path.exists(path):
+        return None
+    spec = importlib.util.spec_from_file_location("d3d_ref_iou3d", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def iou3d_pairwise(a, b, mode):
+    """mode: "overlap" | "iou_bev" | "iou_normal"; boxes (x1, y1, x2, y2, ry)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    out = np.empty((a.shape[0], b.shape[0]), dtype=np.float32)
+    lib().d3d_oracle_iou3d_pairwise(_p(a, ctypes.c_float), a.shape[0], _p(b, ctypes.c_float), b.shape[0],
+                                    {"overlap": 0, "iou_bev": 1, "iou_normal": 2}[mode], _p(out, ctypes.c_float))
+    return out
+
+
+def iou3d_nms(boxes_sorted, thresh, normal=False, return_margin=False):
+    boxes = np.ascontiguousarray(boxes_sorted, dtype=np.float32)
+    n = boxes.shape[0]
+    keep = np.empty((max(n, 1),), dtype=np.int32)
+    margin = ctypes.c_float(0.0)
+    k = lib().d3d_oracle_iou3d_nms(_p(boxes, ctypes.c_float), n, float(thresh), int(normal),
+                                   _p(keep, ctypes.c_int32), ctypes.byref(margin))
+    res = keep[:k].tolist()
+    return (res, margin.value) if return_margin else res
+
+
+def rotate_iou_eval(boxes, query_boxes, criterion=-1):
+    """rotate_iou_gpu_eval (kitti_object_eval_python/rotate_iou.py:305-341): [N, K]."""
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+    q = np.ascontiguousarray(query_boxes, dtype=np.float32)
+    out = np.zeros((boxes.shape[0], q.shape[0]), dtype=np.float32)
+    if out.size:
+        lib().d3d_oracle_rotate_iou_eval(_p(boxes, ctypes.c_float), boxes.shape[0], _p(q, ctypes.c_float),
+                                         q.shape[0], int(criterion), _p(out, ctypes.c_float))
+    return out

@@ -10,6 +10,8 @@ committed; tests never import the reference.  What each file pins:
                     Python (numba.jit stubbed to identity) -> voxels/coors/num_points
   rotate_iou.npz    det3d/ops/nms/nms_gpu.py:180-416 (devRotateIoU, the numba-CUDA
                     rotated IoU) run as plain Python -> IoU of box pairs
+  rotate_iou_eval.npz  datasets/utils/kitti_object_eval_python/rotate_iou.py:246-258
+                    (devRotateIoUEval) run as plain Python, criteria -1 / 0 / 1 / 2
   vfe_pfn.pt        VoxelFeatureExtractorV3 (voxel_encoder.py:197-211), PillarFeatureNet +
                     PointPillarsScatter (pillar_encoder.py:17-211)
   rpn.pt            RPN (necks/rpn.py:22-159) in three stride configurations
@@ -94,6 +96,35 @@ def rotate_iou_cases():
     iou = np.array([ng.devRotateIoU(a[i].copy(), b[i].copy()) for i in range(n)], dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, "rotate_iou.npz"), a=a, b=b, iou=iou)
     print("rotate_iou:", iou[:6])
+
+
+def rotate_iou_eval_cases():
+    """devRotateIoUEval (kitti_object_eval_python/rotate_iou.py:246-258) run as Python on float32 arrays,
+    all four criteria.  Pairs whose intersection polygon would overrun the reference's 8-point scratch
+    (IndexError here, undefined behaviour on the device) are dropped."""
+    ri = ref_loader.ref("det3d.datasets.utils.kitti_object_eval_python.rotate_iou")
+    rng = np.random.default_rng(11)
+    n = 120
+    a = np.stack([rng.uniform(0, 6, n), rng.uniform(0, 6, n), rng.uniform(1, 3, n),
+                  rng.uniform(2, 5, n), rng.uniform(-3.2, 3.2, n)], 1).astype(np.float32)
+    b = a.copy()
+    b[:, :2] += rng.normal(0, 1.0, (n, 2)).astype(np.float32)
+    b[:, 2:4] *= rng.uniform(0.7, 1.3, (n, 2)).astype(np.float32)
+    b[:, 4] += rng.normal(0, 0.6, n).astype(np.float32)
+    a[:5] = [[1, 1, 2, 4, 0.3], [1, 1, 4, 4, 0], [1, 1, 2, 4, 0], [0, 0, 1, 1, 0], [0, 0, 2, 2, 0]]
+    b[:5] = [[1, 1, 2, 4, 0.3], [1, 1, 1, 1, 0.5], [1, 1, 2, 4, np.pi / 2], [5, 5, 1, 1, 0.2], [2, 0, 2, 2, 0]]
+    keep, vals = [], []
+    for i in range(n):
+        try:
+            row = [ri.devRotateIoUEval(a[i].copy(), b[i].copy(), c) for c in (-1, 0, 1, 2)]
+        except IndexError:
+            continue
+        keep.append(i)
+        vals.append(row)
+    keep = np.array(keep)
+    np.savez_compressed(os.path.join(HERE, "rotate_iou_eval.npz"), rbox1=a[keep], rbox2=b[keep],
+                        criteria=np.array([-1, 0, 1, 2]), value=np.array(vals, dtype=np.float64))
+    print("rotate_iou_eval:", len(keep), "pairs", np.array(vals)[:6, 0])
 
 
 def vfe_pfn():
@@ -310,13 +341,15 @@ def anchors_targets():
 
 def main():
     ref_loader.install()
-    which = sys.argv[1:] or ["voxel", "iou", "vfe", "rpn", "head", "anchors"]
+    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors"]
     if "anchors" in which:
         anchors_targets()
     if "voxel" in which:
         voxel_cases()
     if "iou" in which:
         rotate_iou_cases()
+    if "ioueval" in which:
+        rotate_iou_eval_cases()
     if "vfe" in which:
         vfe_pfn()
     if "rpn" in which:
