@@ -44,6 +44,7 @@ SIGNATURES = {
     "d3d_dense_gather": (i32, [vp, vp, i32, i32, i32, _i32p, i32, i32, vp, vp]),
     "d3d_assign_targets_workspace_bytes": (sz, [i32, i32, i32]),
     "d3d_assign_targets": (i32, [vp, i32, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, sz, vp]),
+    "d3d_assign_targets_task": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp]),
     "d3d_rotate_nms_workspace_bytes": (sz, [i32]),
     "d3d_rotate_nms": (i32, [vp, i32, f32, i32, vp, vp, vp, sz, vp]),
     "d3d_rotate_iou": (i32, [vp, i32, vp, i32, vp, vp]),

@@ -2,39 +2,66 @@
 //
 // Reference (CPU, inside DataLoader workers): AssignTarget
 // det3d/datasets/pipelines/preprocess.py:346-483 -> TargetAssigner.assign_v2
-// det3d/core/anchor/target_assigner.py:68-142 -> create_target_np
-// det3d/core/anchor/target_ops.py:28-222 with NearestIouSimilarity
-// (det3d/core/bbox/region_similarity.py:73-93: rbbox2d_to_near_bbox box_np_ops.py:343-355 +
-// iou_jit(eps=0) :955-994) and second_box_encode (box_np_ops.py second_box_encode).
+// det3d/core/anchor/target_assigner.py:68-142 (one create_target_np call PER CLASS of the task: the
+// class's own anchors against the gt boxes of that class, per-class thresholds, results interleaved
+// along the anchors-per-location axis) -> create_target_np det3d/core/anchor/target_ops.py:28-222 with
+// NearestIouSimilarity (det3d/core/bbox/region_similarity.py:73-93: rbbox2d_to_near_bbox
+// box_np_ops.py:343-355 + iou_jit(eps=0) :955-994) and second_box_encode (box_np_ops.py:52-113; 7-dim
+// KITTI / Lyft boxes, 9-dim nuScenes boxes with velocities, optional angle-vector encoding).
 //
-// Two passes over (frame, anchor), the gt boxes of a frame (<= a few dozen) are looped in
-// registers; the per-gt maximum over all anchors (the "force match" rule, incl. ties) goes
-// through atomicMax on the float bits (IoU >= 0, so the int order is the float order).
-//   pass 1: best gt per anchor (max IoU, first argmax) + per-gt maxima
-//   pass 2: labels (positive: IoU >= matched or tied with a gt's maximum; negative: IoU <
-//           unmatched; else -1 = ignored), box encodings for positives, regression weights
-// Integer outputs are bit-exact w.r.t. the numpy restatement (same float32 op order, no FMA
-// contraction); encodings differ by libm-vs-device log (1 ulp).
+// Anchor a of a task with K classes and R rotations per class belongs to class (a / R) % K -- the
+// layout assign_v2 produces by concatenating the per-class anchor sets on axis -2.  Two passes over
+// (frame, anchor); the gt boxes of a frame (<= a few dozen) are looped in registers and only those of
+// the anchor's class take part.  The per-gt maximum over all anchors (the "force match" rule, ties
+// included) goes through atomicMax on the float bits (IoU >= 0, so the int order is the float order).
+//   pass 1: best gt per anchor (max IoU, first argmax among the class's gts) + per-gt maxima
+//   pass 2: labels (positive: IoU >= matched or tied with a gt's maximum; negative: IoU < unmatched;
+//           else -1 = ignored; a class without gt in the frame: all background), box encodings for
+//           positives, regression weights
+// Integer outputs are bit-exact w.r.t. the numpy original (same float32 op order, no FMA contraction);
+// encodings differ by libm-vs-device log / cos / sin (1-2 ulp).
 #include "d3d_common.h"
 
 #define ASG_PI 3.14159274101257324f  // float32(np.pi)
+#define ASG_MAX_CLASSES 8
 
 struct AsgBox {
   float x0, y0, x1, y1;
 };
 
+struct AsgTask {
+  int nd;          // box dimension: 7 (x,y,z,w,l,h,r) or 9 (x,y,z,w,l,h,vx,vy,r)
+  int code;        // encoding size
+  int vec;         // encode_angle_vector
+  int k;           // classes in this task
+  int r;           // anchors per location and class (rotations x sizes)
+  float matched[ASG_MAX_CLASSES], unmatched[ASG_MAX_CLASSES];
+};
+
+// np.nan_to_num on the gt boxes (target_assigner.py:96)
+__device__ __forceinline__ float asg_num(float v) {
+  if (v != v) return 0.f;
+  if (v > 3.402823466e38f) return 3.402823466e38f;
+  if (v < -3.402823466e38f) return -3.402823466e38f;
+  return v;
+}
+
 // rbbox2d_to_near_bbox on (x, y, w, l, r): standing or lying axis-aligned box
-__device__ __forceinline__ AsgBox asg_near(const float *b7) {
-  float r = b7[6];
+__device__ __forceinline__ AsgBox asg_near(float x, float y, float w, float l, float r) {
   float lp = r - floorf(r / ASG_PI + 0.5f) * ASG_PI;  // limit_period(r, 0.5, pi)
   bool swap = fabsf(lp) > (ASG_PI / 4.f);
-  float dx = swap ? b7[4] : b7[3], dy = swap ? b7[3] : b7[4];
+  float dx = swap ? l : w, dy = swap ? w : l;
   AsgBox o;
-  o.x0 = b7[0] - dx / 2.f;
-  o.y0 = b7[1] - dy / 2.f;
-  o.x1 = b7[0] + dx / 2.f;
-  o.y1 = b7[1] + dy / 2.f;
+  o.x0 = x - dx / 2.f;
+  o.y0 = y - dy / 2.f;
+  o.x1 = x + dx / 2.f;
+  o.y1 = y + dy / 2.f;
   return o;
+}
+
+__device__ __forceinline__ AsgBox asg_near_box(const float *b, int nd, bool clean) {
+  if (clean) return asg_near(asg_num(b[0]), asg_num(b[1]), asg_num(b[3]), asg_num(b[4]), asg_num(b[nd - 1]));
+  return asg_near(b[0], b[1], b[3], b[4], b[nd - 1]);
 }
 
 // iou_jit(eps = 0): query box q against box a
@@ -47,22 +74,28 @@ __device__ __forceinline__ float asg_iou(const AsgBox &a, const AsgBox &q) {
   return inter / ua;
 }
 
+__device__ __forceinline__ int asg_class_of(const int32_t *gt_classes, int idx) {
+  return gt_classes ? gt_classes[idx] : 1;
+}
+
 __global__ void __launch_bounds__(256)
     asg_pass1_kernel(const float *__restrict__ anchors, int A, const float *__restrict__ gt,
-                     const int32_t *__restrict__ gt_count, int batch, int gmax,
-                     float *__restrict__ a_max, int32_t *__restrict__ a_arg,
+                     const int32_t *__restrict__ gt_classes, const int32_t *__restrict__ gt_count, int batch,
+                     int gmax, AsgTask T, float *__restrict__ a_max, int32_t *__restrict__ a_arg,
                      int32_t *__restrict__ g_max_bits) {
   const int64_t total = (int64_t)batch * A;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
     int b = (int)(t / A), a = (int)(t - (int64_t)b * A);
-    AsgBox ab = asg_near(anchors + (int64_t)a * 7);
+    const int cls = T.k > 1 ? (a / T.r) % T.k + 1 : 0;  // 0: single-class task, every gt takes part
+    AsgBox ab = asg_near_box(anchors + (int64_t)a * T.nd, T.nd, false);
     int n = gt_count[b];
     n = n < gmax ? n : gmax;
     float best = -1.f;
-    int arg = 0;
+    int arg = -1;
     for (int g = 0; g < n; ++g) {
-      AsgBox gb = asg_near(gt + ((int64_t)b * gmax + g) * 7);
+      if (cls && asg_class_of(gt_classes, b * gmax + g) != cls) continue;
+      AsgBox gb = asg_near_box(gt + ((int64_t)b * gmax + g) * T.nd, T.nd, true);
       float iou = asg_iou(ab, gb);
       if (iou > best) {  // argmax = first maximum, like np.argmax
         best = iou;
@@ -70,45 +103,51 @@ __global__ void __launch_bounds__(256)
       }
       if (iou > 0.f) atomicMax(&g_max_bits[b * gmax + g], __float_as_int(iou));
     }
-    a_max[t] = n > 0 ? best : 0.f;
-    a_arg[t] = arg;
+    a_max[t] = arg >= 0 ? best : 0.f;
+    a_arg[t] = arg;  // -1: no gt of this anchor's class in the frame
   }
 }
 
 __global__ void __launch_bounds__(256)
     asg_pass2_kernel(const float *__restrict__ anchors, int A, const float *__restrict__ gt,
                      const int32_t *__restrict__ gt_classes, const int32_t *__restrict__ gt_count,
-                     int batch, int gmax, float matched, float unmatched,
-                     const float *__restrict__ a_max, const int32_t *__restrict__ a_arg,
-                     const int32_t *__restrict__ g_max_bits, int32_t *__restrict__ labels,
-                     float *__restrict__ reg_targets, float *__restrict__ reg_weights) {
+                     int batch, int gmax, AsgTask T, const float *__restrict__ a_max,
+                     const int32_t *__restrict__ a_arg, const int32_t *__restrict__ g_max_bits,
+                     int32_t *__restrict__ labels, float *__restrict__ reg_targets,
+                     float *__restrict__ reg_weights) {
   const int64_t total = (int64_t)batch * A;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
     int b = (int)(t / A), a = (int)(t - (int64_t)b * A);
-    const float *an = anchors + (int64_t)a * 7;
+    const float *an = anchors + (int64_t)a * T.nd;
+    const int ci = T.k > 1 ? (a / T.r) % T.k : 0;
+    const int cls = T.k > 1 ? ci + 1 : 0;
     int n = gt_count[b];
     n = n < gmax ? n : gmax;
-    int label = n > 0 ? -1 : 0;  // no gt in the frame: everything is background (:150-151)
-    float enc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (n > 0) {
+    const int arg = a_arg[t];
+    int label = 0;  // no gt of the class in the frame: everything is background (:150-151)
+    float enc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (arg >= 0) {
+      label = -1;
       const float best = a_max[t];
-      const int arg = a_arg[t];
-      const int cls = gt_classes ? gt_classes[b * gmax + arg] : 1;
+      const int gcls = asg_class_of(gt_classes, b * gmax + arg);
       // force match: this anchor attains some gt's maximum overlap (ties included, :118-124)
       bool force = false;
-      AsgBox ab = asg_near(an);
+      AsgBox ab = asg_near_box(an, T.nd, false);
       for (int g = 0; g < n && !force; ++g) {
+        if (cls && asg_class_of(gt_classes, b * gmax + g) != cls) continue;
         int mb = g_max_bits[b * gmax + g];
         if (mb <= 0) continue;  // a gt no anchor touches matches nothing (:109-110)
-        AsgBox gb = asg_near(gt + ((int64_t)b * gmax + g) * 7);
+        AsgBox gb = asg_near_box(gt + ((int64_t)b * gmax + g) * T.nd, T.nd, true);
         force = __float_as_int(asg_iou(ab, gb)) == mb;
       }
-      if (best >= matched) label = cls;
-      if (best < unmatched) label = 0;
-      if (force) label = cls;
-      if (label > 0) {  // second_box_encode(gt[arg], anchor), 7-dim, log sizes
-        const float *gb = gt + ((int64_t)b * gmax + arg) * 7;
+      if (best >= T.matched[ci]) label = gcls;
+      if (best < T.unmatched[ci]) label = 0;
+      if (force) label = gcls;
+      if (label > 0) {  // second_box_encode(gt[arg], anchor), log sizes
+        const float *gp = gt + ((int64_t)b * gmax + arg) * T.nd;
+        float gb[9];
+        for (int j = 0; j < T.nd; ++j) gb[j] = asg_num(gp[j]);
         float diag = sqrtf(an[4] * an[4] + an[3] * an[3]);
         enc[0] = (gb[0] - an[0]) / diag;
         enc[1] = (gb[1] - an[1]) / diag;
@@ -116,13 +155,24 @@ __global__ void __launch_bounds__(256)
         enc[3] = logf(gb[3] / an[3]);
         enc[4] = logf(gb[4] / an[4]);
         enc[5] = logf(gb[5] / an[5]);
-        enc[6] = gb[6] - an[6];
+        int o = 6;
+        if (T.nd == 9) {
+          enc[6] = gb[6] - an[6];
+          enc[7] = gb[7] - an[7];
+          o = 8;
+        }
+        const float rg = gb[T.nd - 1], ra = an[T.nd - 1];
+        if (T.vec) {
+          enc[o] = cosf(rg) - cosf(ra);
+          enc[o + 1] = sinf(rg) - sinf(ra);
+        } else {
+          enc[o] = rg - ra;
+        }
       }
     }
     labels[t] = label;
     reg_weights[t] = label > 0 ? 1.f : 0.f;
-#pragma unroll
-    for (int j = 0; j < 7; ++j) reg_targets[t * 7 + j] = enc[j];
+    for (int j = 0; j < T.code; ++j) reg_targets[t * T.code + j] = enc[j];
   }
 }
 
@@ -131,17 +181,15 @@ extern "C" size_t d3d_assign_targets_workspace_bytes(int num_anchors, int batch,
   return d3d_align_up(ba * 4) * 2 + d3d_align_up((size_t)batch * gmax * 4) + 256;
 }
 
-extern "C" int d3d_assign_targets(const float *anchors, int num_anchors, const float *gt,
-                                  const int32_t *gt_classes, const int32_t *gt_count, int batch,
-                                  int gmax, float matched_threshold, float unmatched_threshold,
-                                  int32_t *labels, float *reg_targets, float *reg_weights,
-                                  void *workspace, size_t workspace_bytes, d3d_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  D3D_REQUIRE(num_anchors >= 1 && batch >= 1 && gmax >= 1, "d3d_assign_targets: sizes");
+static int asg_run(const float *anchors, int num_anchors, const AsgTask &T, const float *gt,
+                   const int32_t *gt_classes, const int32_t *gt_count, int batch, int gmax, int32_t *labels,
+                   float *reg_targets, float *reg_weights, void *workspace, size_t workspace_bytes,
+                   hipStream_t stream, const char *who) {
+  D3D_REQUIRE(num_anchors >= 1 && batch >= 1 && gmax >= 1, "%s: sizes", who);
   D3D_REQUIRE(anchors && gt && gt_count && labels && reg_targets && reg_weights && workspace,
-              "d3d_assign_targets: null pointer");
+              "%s: null pointer", who);
   if (workspace_bytes < d3d_assign_targets_workspace_bytes(num_anchors, batch, gmax))
-    return d3d_set_error(D3D_ECAPACITY, "d3d_assign_targets: workspace too small");
+    return d3d_set_error(D3D_ECAPACITY, "%s: workspace too small", who);
   D3dArena A(workspace, workspace_bytes);
   const size_t ba = (size_t)batch * num_anchors;
   float *a_max = A.take<float>(ba);
@@ -150,12 +198,52 @@ extern "C" int d3d_assign_targets(const float *anchors, int num_anchors, const f
   D3D_HIP_TRY(hipMemsetAsync(g_max, 0, (size_t)batch * gmax * 4, stream));
   int nb = (int)((ba + 255) / 256);
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(asg_pass1_kernel, dim3(nb), dim3(256), 0, stream, anchors, num_anchors, gt,
-                     gt_count, batch, gmax, a_max, a_arg, g_max);
+  hipLaunchKernelGGL(asg_pass1_kernel, dim3(nb), dim3(256), 0, stream, anchors, num_anchors, gt, gt_classes,
+                     gt_count, batch, gmax, T, a_max, a_arg, g_max);
   D3D_LAUNCH_TRY("asg_pass1_kernel");
   hipLaunchKernelGGL(asg_pass2_kernel, dim3(nb), dim3(256), 0, stream, anchors, num_anchors, gt,
-                     gt_classes, gt_count, batch, gmax, matched_threshold, unmatched_threshold, a_max,
-                     a_arg, g_max, labels, reg_targets, reg_weights);
+                     gt_classes, gt_count, batch, gmax, T, a_max, a_arg, g_max, labels, reg_targets,
+                     reg_weights);
   D3D_LAUNCH_TRY("asg_pass2_kernel");
   return D3D_OK;
+}
+
+extern "C" int d3d_assign_targets(const float *anchors, int num_anchors, const float *gt,
+                                  const int32_t *gt_classes, const int32_t *gt_count, int batch,
+                                  int gmax, float matched_threshold, float unmatched_threshold,
+                                  int32_t *labels, float *reg_targets, float *reg_weights,
+                                  void *workspace, size_t workspace_bytes, d3d_stream_t stream_) {
+  AsgTask T;
+  T.nd = 7, T.code = 7, T.vec = 0, T.k = 1, T.r = 1;
+  T.matched[0] = matched_threshold;
+  T.unmatched[0] = unmatched_threshold;
+  return asg_run(anchors, num_anchors, T, gt, gt_classes, gt_count, batch, gmax, labels, reg_targets,
+                 reg_weights, workspace, workspace_bytes, (hipStream_t)stream_, "d3d_assign_targets");
+}
+
+extern "C" int d3d_assign_targets_task(const float *anchors, int num_anchors, int box_dim, int num_classes,
+                                       int anchors_per_class, const float *matched_thresholds,
+                                       const float *unmatched_thresholds, int encode_angle_vector,
+                                       const float *gt, const int32_t *gt_classes, const int32_t *gt_count,
+                                       int batch, int gmax, int32_t *labels, float *reg_targets,
+                                       float *reg_weights, void *workspace, size_t workspace_bytes,
+                                       d3d_stream_t stream_) {
+  D3D_REQUIRE(box_dim == 7 || box_dim == 9, "d3d_assign_targets_task: box_dim %d (7 or 9)", box_dim);
+  D3D_REQUIRE(num_classes >= 1 && num_classes <= ASG_MAX_CLASSES,
+              "d3d_assign_targets_task: num_classes %d (1..%d)", num_classes, ASG_MAX_CLASSES);
+  D3D_REQUIRE(anchors_per_class >= 1, "d3d_assign_targets_task: anchors_per_class");
+  D3D_REQUIRE(num_anchors % (num_classes * anchors_per_class) == 0,
+              "d3d_assign_targets_task: %d anchors is not a multiple of %d classes x %d", num_anchors,
+              num_classes, anchors_per_class);
+  D3D_REQUIRE(matched_thresholds && unmatched_thresholds, "d3d_assign_targets_task: null thresholds");
+  D3D_REQUIRE(num_classes == 1 || gt_classes, "d3d_assign_targets_task: gt_classes required for > 1 class");
+  AsgTask T;
+  T.nd = box_dim, T.vec = encode_angle_vector ? 1 : 0, T.k = num_classes, T.r = anchors_per_class;
+  T.code = box_dim - 1 + (T.vec ? 2 : 1);
+  for (int i = 0; i < ASG_MAX_CLASSES; ++i) {
+    T.matched[i] = matched_thresholds[i < num_classes ? i : 0];
+    T.unmatched[i] = unmatched_thresholds[i < num_classes ? i : 0];
+  }
+  return asg_run(anchors, num_anchors, T, gt, gt_classes, gt_count, batch, gmax, labels, reg_targets,
+                 reg_weights, workspace, workspace_bytes, (hipStream_t)stream_, "d3d_assign_targets_task");
 }

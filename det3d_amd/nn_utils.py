@@ -10,24 +10,7 @@ import torch
 from torch import nn
 
 
-class DistributedSyncBN(nn.SyncBatchNorm):
-    """`norm_cfg=dict(type="SyncBN", ...)` -> cross-rank batch statistics over RCCL.
-
-    Built on torch.nn.SyncBatchNorm (one fused [2C+1] all-gather per layer instead of the
-    reference's 2 + 4 small all-reduces, det3d/ops/syncbn/syncbn.py:49-50,99-103).  The
-    reference normalises with the UNBIASED variance (syncbn.py:57-66); torch uses the
-    biased one -- a (n-1)/n factor on the variance, < 1e-4 at the site counts of this path;
-    documented in DESIGN.md rather than reproduced.
-    """
-
-    def forward(self, input):
-        if input.dim() == 2:  # sparse features [N, C]: treat sites as the batch
-            return super().forward(input[:, :, None])[:, :, 0]
-        return super().forward(input)
-
-    def _check_input_dim(self, input):
-        if input.dim() < 2:
-            raise ValueError("expected at least 2D input (got %dD)" % input.dim())
+from .syncbn import DistributedSyncBN  # noqa: E402  (reference semantics, det3d/ops/syncbn/syncbn.py)
 
 
 norm_cfg = {

@@ -68,8 +68,9 @@ def kitti_like_cloud(seed, n_points=20000, n_cars=8):
 
 
 def create_anchors_3d_range(feature_size, anchor_range, sizes=CAR_SIZE, rotations=(0, np.pi / 2),
-                            dtype=np.float32):
-    """feature_size [D, H, W] (zyx) -> anchors [D, H, W, n_sizes, n_rots, 7]."""
+                            dtype=np.float32, velocities=None):
+    """feature_size [D, H, W] (zyx) -> anchors [D, H, W, n_sizes, n_rots, 7], or [..., 9] =
+    (x, y, z, w, l, h, vx, vy, r) when `velocities` is given (box_np_ops.py:733-805)."""
     anchor_range = np.array(anchor_range, dtype)
     stride = (anchor_range[3] - anchor_range[0]) / feature_size[2]
     zc = np.linspace(anchor_range[2], anchor_range[5], feature_size[0], dtype=dtype)
@@ -80,7 +81,9 @@ def create_anchors_3d_range(feature_size, anchor_range, sizes=CAR_SIZE, rotation
     X, Y, Z, R = np.meshgrid(xc, yc, zc, rotations, indexing="ij")  # [W, H, D, nrot]
     ns = sizes.shape[0]
     parts = [np.repeat(a[:, :, :, None, :], ns, axis=3)[..., None] for a in (X, Y, Z)]
-    sz = np.broadcast_to(sizes.reshape(1, 1, 1, ns, 1, 3), parts[0].shape[:-1] + (3,))
+    if velocities is not None:
+        sizes = np.hstack([sizes, np.array(velocities, dtype=dtype).reshape(-1, 2)])
+    sz = np.broadcast_to(sizes.reshape(1, 1, 1, ns, 1, -1), parts[0].shape[:-1] + (sizes.shape[1],))
     rot = np.repeat(R[:, :, :, None, :], ns, axis=3)[..., None]
     ret = np.concatenate(parts + [sz, rot], axis=-1).astype(dtype)
     return np.transpose(ret, [2, 1, 0, 3, 4, 5])
@@ -108,40 +111,89 @@ def _iou_aligned(a, b):
     return np.where((iw > 0) & (ih > 0), inter / ua, 0.0).astype(np.float32)
 
 
-def _encode(boxes, anchors):
-    """second_box_encode, 7-dim (box_np_ops.py second_box_encode)."""
-    xa, ya, za, wa, la, ha, ra = np.split(anchors, 7, axis=-1)
-    xg, yg, zg, wg, lg, hg, rg = np.split(boxes, 7, axis=-1)
+def _encode(boxes, anchors, encode_angle_vector=False):
+    """second_box_encode (box_np_ops.py:52-113): 7-dim boxes or 9-dim (+ vx, vy before the angle),
+    log sizes, plain velocity differences, angle difference or (cos, sin) differences."""
+    nd = anchors.shape[-1]
+    a = np.split(anchors, nd, axis=-1)
+    g = np.split(boxes, nd, axis=-1)
+    (xa, ya, za, wa, la, ha), ra = a[:6], a[-1]
+    (xg, yg, zg, wg, lg, hg), rg = g[:6], g[-1]
     diag = np.sqrt(la ** 2 + wa ** 2)
-    return np.concatenate([(xg - xa) / diag, (yg - ya) / diag, (zg - za) / ha, np.log(wg / wa),
-                           np.log(lg / la), np.log(hg / ha), rg - ra], axis=-1)
+    ret = [(xg - xa) / diag, (yg - ya) / diag, (zg - za) / ha, np.log(wg / wa), np.log(lg / la), np.log(hg / ha)]
+    if nd == 9:
+        ret += [g[6] - a[6], g[7] - a[7]]
+    ret += [np.cos(rg) - np.cos(ra), np.sin(rg) - np.sin(ra)] if encode_angle_vector else [rg - ra]
+    return np.concatenate(ret, axis=-1)
 
 
-def assign_targets(anchors, gt_boxes, matched_threshold=0.6, unmatched_threshold=0.45):
-    """anchors [A,7], gt [G,7] -> labels [A] i32 (1 pos / 0 neg / -1 ignore),
-    reg_targets [A,7] f32, reg_weights [A] f32."""
-    A = anchors.shape[0]
+def assign_targets(anchors, gt_boxes, matched_threshold=0.6, unmatched_threshold=0.45, gt_classes=None,
+                   encode_angle_vector=False):
+    """create_target_np (target_ops.py:28-222) without subsampling: anchors [A,nd], gt [G,nd] ->
+    labels [A] i32 (class / 0 neg / -1 ignore), reg_targets [A,code] f32, reg_weights [A] f32."""
+    A, nd = anchors.shape
+    code = nd - 1 + (2 if encode_angle_vector else 1)
     labels = np.full((A,), -1, dtype=np.int32)
-    targets = np.zeros((A, 7), dtype=np.float32)
+    targets = np.zeros((A, code), dtype=np.float32)
     if len(gt_boxes) == 0:
         labels[:] = 0
         return labels, targets, np.zeros((A,), np.float32)
-    ov = _iou_aligned(_near_bbox(anchors[:, [0, 1, 3, 4, 6]]), _near_bbox(gt_boxes[:, [0, 1, 3, 4, 6]]))
+    cls = np.ones((len(gt_boxes),), np.int32) if gt_classes is None else np.asarray(gt_classes, np.int32)
+    bev = [0, 1, 3, 4, nd - 1]
+    ov = _iou_aligned(_near_bbox(anchors[:, bev]), _near_bbox(gt_boxes[:, bev]))
     a2g = ov.argmax(axis=1)
     a2g_max = ov[np.arange(A), a2g]
     g2a_max = ov.max(axis=0)
     g2a_max[g2a_max == 0] = -1
     force = np.where(ov == g2a_max[None, :])[0]
-    labels[force] = 1
+    labels[force] = cls[a2g[force]]
     pos = a2g_max >= matched_threshold
-    labels[pos] = 1
+    labels[pos] = cls[a2g[pos]]
     bg = a2g_max < unmatched_threshold
     labels[bg] = 0
-    labels[force] = 1
+    labels[force] = cls[a2g[force]]
     fg = np.where(labels > 0)[0]
-    targets[fg] = _encode(gt_boxes[a2g[fg]], anchors[fg])
+    targets[fg] = _encode(gt_boxes[a2g[fg]], anchors[fg], encode_angle_vector)
     weights = np.zeros((A,), np.float32)
     weights[fg] = 1.0
+    return labels, targets, weights
+
+
+def task_anchors(feature_size, generators):
+    """TargetAssigner.generate_anchors (target_assigner.py:144-166) for one task group: `generators` =
+    the task's anchor_generator dicts (class order).  Returns anchors [A, nd] in the concatenated layout
+    (anchor a -> class (a // R) % K), K, R, matched [K], unmatched [K]."""
+    per_class = []
+    for g in generators:
+        anc = create_anchors_3d_range(feature_size, g["anchor_ranges"], g["sizes"], g["rotations"],
+                                      velocities=g.get("velocities"))
+        per_class.append(anc.reshape(*anc.shape[:3], -1, anc.shape[-1]))
+    r = per_class[0].shape[3]
+    assert all(p.shape[3] == r for p in per_class), "classes of a task must have equally many anchors per cell"
+    anchors = np.concatenate(per_class, axis=-2)
+    return (np.ascontiguousarray(anchors.reshape(-1, anchors.shape[-1])), len(generators), r,
+            np.array([g["matched_threshold"] for g in generators], np.float32),
+            np.array([g["unmatched_threshold"] for g in generators], np.float32))
+
+
+def assign_targets_task(anchors, num_classes, per_class, matched, unmatched, gt_boxes, gt_classes,
+                        encode_angle_vector=False):
+    """TargetAssigner.assign_v2 (target_assigner.py:68-142) on the concatenated anchor layout: class k's
+    anchors against the gt boxes of class k + 1 (ids within the task), NaN gt entries read as 0."""
+    A, nd = anchors.shape
+    code = nd - 1 + (2 if encode_angle_vector else 1)
+    cls_of = (np.arange(A) // per_class) % num_classes
+    labels = np.zeros((A,), np.int32)
+    targets = np.zeros((A, code), np.float32)
+    weights = np.zeros((A,), np.float32)
+    gt_boxes = np.nan_to_num(np.asarray(gt_boxes, np.float32).reshape(-1, nd))
+    gt_classes = np.asarray(gt_classes, np.int32).reshape(-1)
+    for k in range(num_classes):
+        sel = np.where(cls_of == k)[0]
+        m = gt_classes == k + 1
+        lab, tgt, w = assign_targets(anchors[sel], gt_boxes[m], matched[k], unmatched[k], gt_classes[m],
+                                     encode_angle_vector)
+        labels[sel], targets[sel], weights[sel] = lab, tgt, w
     return labels, targets, weights
 
 
@@ -170,6 +222,42 @@ def assign_targets_device(anchors, gt, gt_count, matched_threshold=0.6, unmatche
                               gmax, float(matched_threshold), float(unmatched_threshold), labels.data_ptr(),
                               targets.data_ptr(), weights.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
     _lib.check(rc, "d3d_assign_targets")
+    return labels, targets, weights
+
+
+def assign_targets_task_device(anchors, num_classes, per_class, matched, unmatched, gt, gt_classes, gt_count,
+                                encode_angle_vector=False, limit_gt_angle=False):
+    """d3d_assign_targets_task: anchors [A,nd] (layout of task_anchors), gt [B,Gmax,nd] padded, gt_classes
+    [B,Gmax] (1-based within the task), gt_count [B] -- all CUDA -> labels [B,A] i32, reg_targets
+    [B,A,code] f32, reg_weights [B,A] f32.  limit_gt_angle applies AssignTarget's limit_period(r, 0.5, 2 pi)
+    (preprocess.py:415-419) to the gt yaw first."""
+    from . import _lib
+
+    if not anchors.is_cuda:
+        raise _lib.D3dError("assign_targets_task_device needs device tensors (numpy path: assign_targets_task)")
+    L = _lib.lib()
+    anchors = anchors.float().contiguous()
+    gt = gt.float().contiguous()
+    if limit_gt_angle:
+        gt = gt.clone()
+        r = gt[..., -1]
+        gt[..., -1] = r - torch.floor(r / (2 * np.pi) + 0.5) * (2 * np.pi)
+    gt_count = gt_count.int().contiguous()
+    gt_classes = gt_classes.int().contiguous() if gt_classes is not None else None
+    (A, nd), (B, gmax) = anchors.shape, gt.shape[:2]
+    code = nd - 1 + (2 if encode_angle_vector else 1)
+    dev = anchors.device
+    labels = torch.empty((B, A), dtype=torch.int32, device=dev)
+    targets = torch.empty((B, A, code), dtype=torch.float32, device=dev)
+    weights = torch.empty((B, A), dtype=torch.float32, device=dev)
+    wsb = L.d3d_assign_targets_workspace_bytes(A, B, gmax)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    rc = L.d3d_assign_targets_task(anchors.data_ptr(), A, nd, int(num_classes), int(per_class),
+                                   _lib.f32_array(matched), _lib.f32_array(unmatched), int(encode_angle_vector),
+                                   gt.data_ptr(), _lib.ptr(gt_classes), gt_count.data_ptr(), B, gmax,
+                                   labels.data_ptr(), targets.data_ptr(), weights.data_ptr(), ws.data_ptr(), wsb,
+                                   _lib.stream_ptr(dev))
+    _lib.check(rc, "d3d_assign_targets_task")
     return labels, targets, weights
 
 

@@ -207,6 +207,24 @@ int d3d_assign_targets(const float *anchors, int num_anchors, const float *gt,
                        float *reg_targets, float *reg_weights, void *workspace,
                        size_t workspace_bytes, d3d_stream_t stream);
 
+/* One task group of a multi-group head, as TargetAssigner.assign_v2 does it
+ * (det3d/core/anchor/target_assigner.py:68-142): every class of the task has its own anchors and
+ * thresholds and is matched only against the gt boxes of that class.
+ *  anchors dev [A, box_dim] f32 in the concatenated layout of generate_anchors (:144-166): anchor a
+ *    belongs to class (a / anchors_per_class) % num_classes;  box_dim 7 or 9 (nuScenes: + vx, vy)
+ *  matched_thresholds / unmatched_thresholds HOST [num_classes] f32 (num_classes <= 8)
+ *  encode_angle_vector: box coder option (ground_box3d_coder); code = box_dim - 1 + (vector ? 2 : 1)
+ *  gt dev [batch,gmax,box_dim] f32 padded (NaN entries are read as 0 like np.nan_to_num, :96),
+ *  gt_classes dev [batch,gmax] i32, 1-based WITHIN the task; gt_count dev [batch] i32
+ *  labels dev [batch,A] i32, reg_targets dev [batch,A,code] f32, reg_weights dev [batch,A] f32
+ *  workspace: d3d_assign_targets_workspace_bytes(A, batch, gmax) */
+int d3d_assign_targets_task(const float *anchors, int num_anchors, int box_dim, int num_classes,
+                            int anchors_per_class, const float *matched_thresholds,
+                            const float *unmatched_thresholds, int encode_angle_vector, const float *gt,
+                            const int32_t *gt_classes, const int32_t *gt_count, int batch, int gmax,
+                            int32_t *labels, float *reg_targets, float *reg_weights, void *workspace,
+                            size_t workspace_bytes, d3d_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Rotated NMS.  Replaces rotate_nms_cc (det3d/ops/nms/nms_cpu.py:34-45) +
  * rotate_non_max_suppression_cpu (det3d/ops/nms/nms_cpu.h:73-169), as driven

@@ -12,6 +12,8 @@ committed; tests never import the reference.  What each file pins:
                     rotated IoU) run as plain Python -> IoU of box pairs
   rotate_iou_eval.npz  datasets/utils/kitti_object_eval_python/rotate_iou.py:246-258
                     (devRotateIoUEval) run as plain Python, criteria -1 / 0 / 1 / 2
+  task_targets.npz  TargetAssigner.assign_v2 (core/anchor/target_assigner.py:68-142) on two-class task
+                    groups: nuScenes 9-dim boxes + angle-vector coder, Lyft 7-dim boxes
   vfe_pfn.pt        VoxelFeatureExtractorV3 (voxel_encoder.py:197-211), PillarFeatureNet +
                     PointPillarsScatter (pillar_encoder.py:17-211)
   rpn.pt            RPN (necks/rpn.py:22-159) in three stride configurations
@@ -339,11 +341,76 @@ def anchors_targets():
           int((ret["labels"] == 0).sum()), "neg")
 
 
+def task_targets():
+    """TargetAssigner.generate_anchors / generate_anchors_dict / assign_v2 (target_assigner.py:68-200) for the
+    nuScenes [bus, trailer] task group: 9-dim boxes, angle-vector box coder, per-class anchors + thresholds, a
+    NaN velocity, a class-less frame; and the Lyft [motorcycle, bicycle] group with 7-dim boxes."""
+    bnp = ref_loader.ref("det3d.core.bbox.box_np_ops")
+    ta = ref_loader.ref("det3d.core.anchor.target_assigner")
+    ag = ref_loader.ref("det3d.core.anchor.anchor_generator")
+    bc = ref_loader.ref("det3d.core.bbox.box_coders")
+    rs = ref_loader.ref("det3d.core.bbox.region_similarity")
+    _mg = np.meshgrid
+    np.meshgrid = lambda *a, **k: list(_mg(*a, **k))
+    out = {}
+    try:
+        for tag, nd, vec, rng_xy, gens in (
+                ("nusc", 9, True, 51.2, [("bus", [2.94, 10.5, 3.47], -0.085, 0.55, 0.4),
+                                         ("trailer", [2.90, 12.29, 3.87], 0.115, 0.5, 0.35)]),
+                ("lyft", 7, False, 100.8, [("motorcycle", [0.97, 2.36, 1.60], -0.9, 0.55, 0.4),
+                                           ("bicycle", [0.64, 1.76, 1.46], -1.04, 0.55, 0.4)])):
+            generators = [ag.AnchorGeneratorRange(sizes=sz, anchor_ranges=[-rng_xy, -rng_xy, z, rng_xy, rng_xy, z],
+                                                  rotations=[0, 1.57], velocities=[0, 0] if nd == 9 else None,
+                                                  match_threshold=hi, unmatch_threshold=lo, class_name=name)
+                          for name, sz, z, hi, lo in gens]
+            assigner = ta.TargetAssigner(box_coder=bc.GroundBox3dCoder(vec_encode=vec, n_dim=nd),
+                                         anchor_generators=generators,
+                                         region_similarity_calculator=rs.NearestIouSimilarity(),
+                                         positive_fraction=None, sample_size=512)
+            fmap = [1, 32, 32]
+            anchors = assigner.generate_anchors(fmap)["anchors"]
+            adict = assigner.generate_anchors_dict(fmap)
+            out[tag + "_anchors"] = anchors.reshape(-1, nd)
+            rng = np.random.default_rng(5 if nd == 9 else 6)
+            for frame, (n0, n1) in enumerate([(4, 3), (0, 5), (0, 0)]):
+                n = n0 + n1
+                gt = np.zeros((n, nd), np.float32)
+                names = np.array([gens[0][0]] * n0 + [gens[1][0]] * n1)
+                cls = np.array([1] * n0 + [2] * n1, np.int32)
+                gt[:, 0] = rng.uniform(-0.8 * rng_xy, 0.8 * rng_xy, n)
+                gt[:, 1] = rng.uniform(-0.8 * rng_xy, 0.8 * rng_xy, n)
+                for i in range(n):
+                    gt[i, 2] = gens[cls[i] - 1][2]
+                    gt[i, 3:6] = np.array(gens[cls[i] - 1][1]) * rng.uniform(0.85, 1.15, 3)
+                gt[:, -1] = rng.uniform(-3.1, 3.1, n)
+                if nd == 9:
+                    gt[:, 6:8] = rng.normal(0, 2, (n, 2))
+                    if n:
+                        gt[0, 6:8] = np.nan                      # unlabeled velocity (nan_to_num in assign_v2)
+                if n:
+                    flat = anchors.reshape(-1, nd)
+                    gt[0, :2] = flat[(16 * 32 + 16) * 4 + 2 * (cls[0] - 1), :2]   # exactly on an anchor centre
+                    gt[0, -1] = 0.0
+                ret = assigner.assign_v2(adict, gt.copy(), None, gt_classes=cls, gt_names=names)
+                out["%s_f%d_gt" % (tag, frame)] = gt
+                out["%s_f%d_cls" % (tag, frame)] = cls
+                out["%s_f%d_labels" % (tag, frame)] = ret["labels"]
+                out["%s_f%d_targets" % (tag, frame)] = ret["bbox_targets"]
+                out["%s_f%d_weights" % (tag, frame)] = ret["bbox_outside_weights"]
+                print("task_targets", tag, frame, anchors.shape, "pos per class",
+                      [(ret["labels"] == c).sum() for c in (1, 2)], "ignored", (ret["labels"] < 0).sum())
+    finally:
+        np.meshgrid = _mg
+    np.savez_compressed(os.path.join(HERE, "task_targets.npz"), **out)
+
+
 def main():
     ref_loader.install()
-    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors"]
+    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks"]
     if "anchors" in which:
         anchors_targets()
+    if "tasks" in which:
+        task_targets()
     if "voxel" in which:
         voxel_cases()
     if "iou" in which:

@@ -215,3 +215,36 @@ def test_synthetic_cloud_is_seeded_and_in_spec():
     hb = ds.host_batch(0, 3)
     assert hb["points"].shape == (6000, 4) and hb["frame_offsets"].tolist() == [0, 2000, 4000, 6000]
     assert hb["labels"].shape == (3, 70400) and (hb["labels"] > 0).sum() > 0
+
+
+TASK_GENS = dict(
+    nusc=(9, True, [dict(sizes=[2.94, 10.5, 3.47], anchor_ranges=[-51.2, -51.2, -0.085, 51.2, 51.2, -0.085],
+                         rotations=[0, 1.57], velocities=[0, 0], matched_threshold=0.55, unmatched_threshold=0.4),
+                    dict(sizes=[2.90, 12.29, 3.87], anchor_ranges=[-51.2, -51.2, 0.115, 51.2, 51.2, 0.115],
+                         rotations=[0, 1.57], velocities=[0, 0], matched_threshold=0.5, unmatched_threshold=0.35)]),
+    lyft=(7, False, [dict(sizes=[0.97, 2.36, 1.60], anchor_ranges=[-100.8, -100.8, -0.9, 100.8, 100.8, -0.9],
+                          rotations=[0, 1.57], matched_threshold=0.55, unmatched_threshold=0.4),
+                     dict(sizes=[0.64, 1.76, 1.46], anchor_ranges=[-100.8, -100.8, -1.04, 100.8, 100.8, -1.04],
+                          rotations=[0, 1.57], matched_threshold=0.55, unmatched_threshold=0.4)]))
+
+
+@pytest.mark.parametrize("tag", ["nusc", "lyft"])
+def test_task_group_anchors_and_targets_vs_reference_assign_v2(tag):
+    """synthetic.task_anchors / assign_targets_task vs goldens made by the reference's TargetAssigner
+    (generate_anchors + assign_v2, target_assigner.py:68-166): two-class task groups, per-class anchors and
+    thresholds, 9-dim boxes with the angle-vector coder (nuScenes) and 7-dim boxes (Lyft)."""
+    import numpy as np
+
+    from det3d_amd import synthetic
+
+    z = np.load(os.path.join(GOLDEN, "task_targets.npz"))
+    nd, vec, gens = TASK_GENS[tag]
+    anchors, k, r, hi, lo = synthetic.task_anchors([1, 32, 32], gens)
+    assert (k, r) == (2, 2) and np.array_equal(anchors, z[tag + "_anchors"])
+    for f in range(3):
+        lab, tgt, w = synthetic.assign_targets_task(anchors, k, r, hi, lo, z["%s_f%d_gt" % (tag, f)],
+                                                    z["%s_f%d_cls" % (tag, f)], encode_angle_vector=vec)
+        assert np.array_equal(lab, z["%s_f%d_labels" % (tag, f)]), f
+        assert np.array_equal(w, z["%s_f%d_weights" % (tag, f)])
+        assert tgt.shape == z["%s_f%d_targets" % (tag, f)].shape
+        assert np.allclose(tgt, z["%s_f%d_targets" % (tag, f)], atol=1e-6)
