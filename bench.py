@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-launch-log", action="store_true")
     ap.add_argument("--cached-targets", action="store_true",
                     help="use the host-precomputed anchor targets instead of d3d_assign_targets in the step")
+    ap.add_argument("--no-gc-freeze", action="store_true",
+                    help="do not gc.freeze() after warm-up (shows the cost of full CPython collections)")
     ap.add_argument("--no-channels-last", action="store_true",
                     help="NCHW dense()/RPN activations (default: channels-last, written directly by d3d_dense_scatter)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -126,6 +128,7 @@ def main():
     from det3d_amd import Config, build_detector, synthetic
     from det3d_amd import dist as D
     from det3d_amd import spconv
+    from det3d_amd import trainer
     from det3d_amd.trainer import TrainStep
 
     t_start = time.perf_counter()
@@ -183,6 +186,12 @@ def main():
         torch.cuda.synchronize()
         note("warmup step %d done" % i)
     torch.cuda.synchronize()
+    # The step allocates a few thousand short-lived Python containers; CPython's generational collector
+    # then walks every tracked object of the process (torch + numpy: ~10^6) in a full collection every few
+    # steps, 40-80 ms each, which showed up as a bimodal 8.5 / 12.5 ms step.  Freezing what exists after
+    # warm-up (gc stays enabled) makes later collections scan only what the loop itself creates.
+    if not args.no_gc_freeze:
+        trainer.freeze_gc()
     D.barrier()
 
     # HIP-event timing of individual launches perturbs the stream (~0.4 ms per event pair on
@@ -191,6 +200,7 @@ def main():
     sample_from = max(args.steps - 2, 0)
     spconv.LAUNCH_FILTER = lambda kind, cin, cout: kind != "wgrad" and cin == 64 and cout == 64
     torch.cuda.synchronize()
+    ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == sample_from and not args.no_launch_log:
@@ -199,7 +209,11 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
-    note("timed region done: %.3f s" % elapsed)
+    ms1 = torch.cuda.memory_stats(dev)
+    # hipMalloc / hipFree inside the timed region would stall the stream: report them
+    alloc_delta = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
+    alloc_delta["reserved_MB"] = int(ms1.get("reserved_bytes.all.current", 0) >> 20)
+    note("timed region done: %.3f s; allocator during it: %s" % (elapsed, alloc_delta))
     drain_launch_log()
     log = list(records)
     table_log = []

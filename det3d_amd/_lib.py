@@ -32,10 +32,11 @@ SIGNATURES = {
     "d3d_conv_rulebook_workspace_bytes": (sz, [i32, _i32p]),
     "d3d_conv_rulebook": (i32, [vp, vp, i32, i32, _i32p, _i32p, _i32p, _i32p, _i32p, vp, vp, i32,
                                 vp, vp, vp, vp, sz, vp]),
+    "d3d_pack_conv_weights": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "d3d_sparse_conv_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "d3d_sparse_conv_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "d3d_bn_relu_fwd": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp, vp, vp, vp]),
-    "d3d_bn_relu_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "d3d_bn_relu_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "d3d_pfn_fwd": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp, vp, vp, vp, f32, f32,
                           i32, vp, vp, vp, vp, vp, vp]),
     "d3d_pfn_bwd": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp, vp, vp, vp, vp, vp,
@@ -57,6 +58,7 @@ SIGNATURES = {
 
 D3D_F32 = 0
 D3D_BF16 = 1
+D3D_BN_COPIES = 8
 D3D_IOU3D_OVERLAP, D3D_IOU3D_IOU_BEV, D3D_IOU3D_IOU_NORMAL = 0, 1, 2
 
 

@@ -21,6 +21,7 @@
 // Integer outputs are bit-exact w.r.t. the numpy original (same float32 op order, no FMA contraction);
 // encodings differ by libm-vs-device log / cos / sin (1-2 ulp).
 #include "d3d_common.h"
+#include "d3d_fill.h"
 
 #define ASG_PI 3.14159274101257324f  // float32(np.pi)
 #define ASG_MAX_CLASSES 8
@@ -195,7 +196,7 @@ static int asg_run(const float *anchors, int num_anchors, const AsgTask &T, cons
   float *a_max = A.take<float>(ba);
   int32_t *a_arg = A.take<int32_t>(ba);
   int32_t *g_max = A.take<int32_t>((size_t)batch * gmax);
-  D3D_HIP_TRY(hipMemsetAsync(g_max, 0, (size_t)batch * gmax * 4, stream));
+  D3D_HIP_TRY(d3d_fill_async(stream, g_max, 0, (size_t)batch * gmax * 4));
   int nb = (int)((ba + 255) / 256);
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(asg_pass1_kernel, dim3(nb), dim3(256), 0, stream, anchors, num_anchors, gt, gt_classes,

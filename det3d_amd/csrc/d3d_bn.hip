@@ -12,6 +12,8 @@
 // Statistics are accumulated with f32 atomics (LDS then global), so the last bits of
 // mean/var depend on arrival order -- the conv outputs themselves stay deterministic.
 #include "d3d_common.h"
+#include "d3d_fill.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ float bn_bf16_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
 __device__ __forceinline__ uint32_t bn_f32_to_bf16(float f) {
@@ -65,7 +67,21 @@ __global__ void __launch_bounds__(256)
   float s[EPV], q[EPV];
 #pragma unroll
   for (int j = 0; j < EPV; ++j) s[j] = q[j] = 0.f;
-  for (int64_t r = (int64_t)blockIdx.x * rp + rl; r < n; r += (int64_t)gridDim.x * rp) {
+  const int64_t step = (int64_t)gridDim.x * rp;
+  int64_t r = (int64_t)blockIdx.x * rp + rl;
+  for (; r + 3 * step < n; r += 4 * step) {  // four independent 16-byte loads in flight per lane
+    float v[4][EPV];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) BnVec<BF16>::load(x, (r + u * step) * segs + seg, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) {
+        s[j] += v[u][j];
+        q[j] = fmaf(v[u][j], v[u][j], q[j]);
+      }
+  }
+  for (; r < n; r += step) {
     float v[EPV];
     BnVec<BF16>::load(x, r * segs + seg, v);
 #pragma unroll
@@ -80,7 +96,8 @@ __global__ void __launch_bounds__(256)
     atomicAdd(&red[c + seg * EPV + j], q[j]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * c; i += 256) atomicAdd(&stats[i], red[i]);
+  float *dst = stats + (size_t)(blockIdx.x % D3D_BN_COPIES) * 2 * c;  // spread same-address atomics
+  for (int i = threadIdx.x; i < 2 * c; i += 256) atomicAdd(&dst[i], red[i]);
 }
 
 template <bool BF16>
@@ -95,8 +112,13 @@ __global__ void __launch_bounds__(256)
   for (int ch = threadIdx.x; ch < c; ch += 256) {
     float mean, var;
     if (training) {
-      mean = stats[ch] / (float)n;
-      var = fmaxf(stats[c + ch] / (float)n - mean * mean, 0.f);  // biased, as F.batch_norm
+      float s1 = 0.f, s2 = 0.f;
+      for (int k = 0; k < D3D_BN_COPIES; ++k) {
+        s1 += stats[(size_t)k * 2 * c + ch];
+        s2 += stats[(size_t)k * 2 * c + c + ch];
+      }
+      mean = s1 / (float)n;
+      var = fmaxf(s2 / (float)n - mean * mean, 0.f);  // biased, as F.batch_norm
     } else {
       mean = running_mean[ch];
       var = running_var[ch];
@@ -124,7 +146,23 @@ __global__ void __launch_bounds__(256)
     sc[j] = scale[seg * EPV + j];
     sh[j] = shift[seg * EPV + j];
   }
-  for (int64_t r = (int64_t)blockIdx.x * rp + rl; r < n; r += (int64_t)gridDim.x * rp) {
+  const int64_t step = (int64_t)gridDim.x * rp;
+  int64_t r = (int64_t)blockIdx.x * rp + rl;
+  for (; r + 3 * step < n; r += 4 * step) {
+    float v[4][EPV];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) BnVec<BF16>::load(x, (r + u * step) * segs + seg, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) {
+        float z = fmaf(v[u][j], sc[j], sh[j]);
+        v[u][j] = relu ? fmaxf(z, 0.f) : z;
+      }
+      BnVec<BF16>::store(y, (r + u * step) * segs + seg, v[u]);
+    }
+  }
+  for (; r < n; r += step) {
     float v[EPV];
     BnVec<BF16>::load(x, r * segs + seg, v);
 #pragma unroll
@@ -142,7 +180,7 @@ __global__ void __launch_bounds__(256)
     bn_bwd_reduce_kernel(const void *__restrict__ x, const void *__restrict__ dy, int n, int c,
                          const float *__restrict__ gamma, const float *__restrict__ beta,
                          const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
-                         float *__restrict__ dgamma, float *__restrict__ dbeta) {
+                         float *__restrict__ partial) {
   constexpr int EPV = BnVec<BF16>::EPV;
   __shared__ float red[2 * BN_MAXC];
   for (int i = threadIdx.x; i < 2 * c; i += 256) red[i] = 0.f;
@@ -159,7 +197,26 @@ __global__ void __launch_bounds__(256)
     b[j] = beta ? beta[ch] : 0.f;
     sg[j] = sb[j] = 0.f;
   }
-  for (int64_t r = (int64_t)blockIdx.x * rp + rl; r < n; r += (int64_t)gridDim.x * rp) {
+  const int64_t step = (int64_t)gridDim.x * rp;
+  int64_t r = (int64_t)blockIdx.x * rp + rl;
+  for (; r + step < n; r += 2 * step) {  // 2 rows x 2 tensors = four loads in flight per lane
+    float v[2][EPV], d[2][EPV];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      BnVec<BF16>::load(x, (r + u * step) * segs + seg, v[u]);
+      BnVec<BF16>::load(dy, (r + u * step) * segs + seg, d[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) {
+        float xh = (v[u][j] - mu[j]) * is[j];
+        float dz = (relu && fmaf(xh, g[j], b[j]) <= 0.f) ? 0.f : d[u][j];
+        sb[j] += dz;
+        sg[j] = fmaf(dz, xh, sg[j]);
+      }
+  }
+  for (; r < n; r += step) {
     float v[EPV], d[EPV];
     BnVec<BF16>::load(x, r * segs + seg, v);
     BnVec<BF16>::load(dy, r * segs + seg, d);
@@ -177,10 +234,8 @@ __global__ void __launch_bounds__(256)
     atomicAdd(&red[c + seg * EPV + j], sb[j]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < c; i += 256) {
-    atomicAdd(&dgamma[i], red[i]);
-    atomicAdd(&dbeta[i], red[c + i]);
-  }
+  float *dst = partial + (size_t)(blockIdx.x % D3D_BN_COPIES) * 2 * c;  // [copy][dgamma | dbeta]
+  for (int i = threadIdx.x; i < 2 * c; i += 256) atomicAdd(&dst[i], red[i]);
 }
 
 // dx = gamma * invstd * (dz - dbeta/N - xhat * dgamma/N)
@@ -189,9 +244,20 @@ __global__ void __launch_bounds__(256)
     bn_bwd_dx_kernel(const void *__restrict__ x, const void *__restrict__ dy, int n, int c,
                      const float *__restrict__ gamma, const float *__restrict__ beta,
                      const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
-                     const float *__restrict__ dgamma, const float *__restrict__ dbeta,
-                     void *__restrict__ dx) {
+                     const float *__restrict__ partial, float *__restrict__ dgamma,
+                     float *__restrict__ dbeta, void *__restrict__ dx) {
   constexpr int EPV = BnVec<BF16>::EPV;
+  __shared__ float tot[2 * BN_MAXC];
+  for (int i = threadIdx.x; i < 2 * c; i += 256) {  // fold the replicated partial sums
+    float t = 0.f;
+    for (int k = 0; k < D3D_BN_COPIES; ++k) t += partial[(size_t)k * 2 * c + i];
+    tot[i] = t;
+    if (blockIdx.x == 0) {
+      if (i < c) dgamma[i] = t;
+      else dbeta[i - c] = t;
+    }
+  }
+  __syncthreads();
   const int segs = c / EPV;
   const int seg = threadIdx.x % segs, rl = threadIdx.x / segs, rp = 256 / segs;
   float mu[EPV], is[EPV], g[EPV], b[EPV], c1[EPV], c2[EPV];
@@ -203,10 +269,30 @@ __global__ void __launch_bounds__(256)
     is[j] = invstd[ch];
     g[j] = gamma ? gamma[ch] : 1.f;
     b[j] = beta ? beta[ch] : 0.f;
-    c1[j] = dbeta[ch] * inv_n;
-    c2[j] = dgamma[ch] * inv_n;
+    c1[j] = tot[c + ch] * inv_n;
+    c2[j] = tot[ch] * inv_n;
   }
-  for (int64_t r = (int64_t)blockIdx.x * rp + rl; r < n; r += (int64_t)gridDim.x * rp) {
+  const int64_t step = (int64_t)gridDim.x * rp;
+  int64_t r = (int64_t)blockIdx.x * rp + rl;
+  for (; r + step < n; r += 2 * step) {
+    float v[2][EPV], d[2][EPV];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      BnVec<BF16>::load(x, (r + u * step) * segs + seg, v[u]);
+      BnVec<BF16>::load(dy, (r + u * step) * segs + seg, d[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) {
+        float xh = (v[u][j] - mu[j]) * is[j];
+        float dz = (relu && fmaf(xh, g[j], b[j]) <= 0.f) ? 0.f : d[u][j];
+        v[u][j] = g[j] * is[j] * (dz - c1[j] - xh * c2[j]);
+      }
+      BnVec<BF16>::store(dx, (r + u * step) * segs + seg, v[u]);
+    }
+  }
+  for (; r < n; r += step) {
     float v[EPV], d[EPV];
     BnVec<BF16>::load(x, r * segs + seg, v);
     BnVec<BF16>::load(dy, r * segs + seg, d);
@@ -233,11 +319,19 @@ static int bn_check(int n, int c, int dtype, const char *who) {
 static int bn_grid(int n, int c, int dtype) {
   const int rp = 256 / (c / (dtype == D3D_BF16 ? 8 : 4));
   int nb = (n + rp - 1) / rp;
-  // every block ends with one global atomic per channel on the same 2c addresses, and
-  // same-address atomics serialise at L2 (~20 ns each): 1125 blocks cost 23 us on an 18 MB
-  // tensor (profiles/round1_kernel_stats_v2.txt).  <= 2 blocks per CU, >= 8 row tiles each.
-  nb = (nb + 7) / 8;
-  if (nb > 512) nb = 512;
+  // A streaming pass wants many wavefronts with several loads in flight each (the sweeps are unrolled
+  // 4x), but every block ends with one global atomic per channel, and same-address atomics serialise at
+  // L2 (1125 blocks on one accumulator cost 23 us on an 18 MB tensor,
+  // profiles/round1_kernel_stats_v2.txt).  So: >= 4 row tiles per block, up to D3D_BN_BLOCKS (default
+  // 2048) blocks, and D3D_BN_COPIES replicated accumulators that the consumer kernel folds.
+  static int cap = 0;
+  if (!cap) {
+    const char *e = getenv("D3D_BN_BLOCKS");
+    cap = e ? atoi(e) : 2048;
+    if (cap < 1) cap = 2048;
+  }
+  nb = (nb + 3) / 4;
+  if (nb > cap) nb = cap;
   return nb < 1 ? 1 : nb;
 }
 
@@ -254,7 +348,7 @@ extern "C" int d3d_bn_relu_fwd(const void *x, int n, int c, int dtype, const flo
               "d3d_bn_relu_fwd: training needs stats_ws, eval needs running stats");
   const int nb = bn_grid(n, c, dtype);
   if (training) {
-    D3D_HIP_TRY(hipMemsetAsync(stats_ws, 0, (size_t)2 * c * sizeof(float), stream));
+    D3D_HIP_TRY(d3d_fill_async(stream, stats_ws, 0, (size_t)D3D_BN_COPIES * 2 * c * sizeof(float)));
     if (dtype == D3D_BF16)
       hipLaunchKernelGGL(bn_stats_kernel<true>, dim3(nb), dim3(256), 0, stream, x, n, c, stats_ws);
     else
@@ -276,29 +370,24 @@ extern "C" int d3d_bn_relu_fwd(const void *x, int n, int c, int dtype, const flo
 extern "C" int d3d_bn_relu_bwd(const void *x, const void *dy, int n, int c, int dtype,
                                const float *gamma, const float *beta, const float *save_mean,
                                const float *save_invstd, int relu, void *dx, float *dgamma,
-                               float *dbeta, d3d_stream_t stream_) {
+                               float *dbeta, float *partial_ws, d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = bn_check(n, c, dtype, "d3d_bn_relu_bwd");
   if (rc) return rc;
-  D3D_REQUIRE(x && dy && dx && dgamma && dbeta && save_mean && save_invstd,
+  D3D_REQUIRE(x && dy && dx && dgamma && dbeta && save_mean && save_invstd && partial_ws,
               "d3d_bn_relu_bwd: null pointer");
   const int nb = bn_grid(n, c, dtype);
-  if (dbeta == dgamma + c) {  // adjacent (the Python side allocates one [2, c] buffer): one fill
-    D3D_HIP_TRY(hipMemsetAsync(dgamma, 0, (size_t)2 * c * sizeof(float), stream));
-  } else {
-    D3D_HIP_TRY(hipMemsetAsync(dgamma, 0, (size_t)c * sizeof(float), stream));
-    D3D_HIP_TRY(hipMemsetAsync(dbeta, 0, (size_t)c * sizeof(float), stream));
-  }
+  D3D_HIP_TRY(d3d_fill_async(stream, partial_ws, 0, (size_t)D3D_BN_COPIES * 2 * c * sizeof(float)));
   if (dtype == D3D_BF16) {
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nb), dim3(256), 0, stream, x, dy, n, c,
-                       gamma, beta, save_mean, save_invstd, relu, dgamma, dbeta);
+                       gamma, beta, save_mean, save_invstd, relu, partial_ws);
     hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma,
-                       beta, save_mean, save_invstd, relu, dgamma, dbeta, dx);
+                       beta, save_mean, save_invstd, relu, partial_ws, dgamma, dbeta, dx);
   } else {
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nb), dim3(256), 0, stream, x, dy, n, c,
-                       gamma, beta, save_mean, save_invstd, relu, dgamma, dbeta);
+                       gamma, beta, save_mean, save_invstd, relu, partial_ws);
     hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(nb), dim3(256), 0, stream, x, dy, n, c,
-                       gamma, beta, save_mean, save_invstd, relu, dgamma, dbeta, dx);
+                       gamma, beta, save_mean, save_invstd, relu, partial_ws, dgamma, dbeta, dx);
   }
   D3D_LAUNCH_TRY("bn_bwd kernels");
   return D3D_OK;

@@ -2,6 +2,7 @@
 // n*c elements scattered into a zeroed [B, C, D, H, W] tensor, HBM-bound on the
 // zero fill of the dense tensor (the occupied fraction is ~19 % on KITTI).
 #include "d3d_common.h"
+#include "d3d_fill.h"
 
 // channels_last = 1 addresses the dense tensor as [B, H, W, C*D] (channel = c*D + z): the
 // memory layout of a channels-last [B, C*D, H, W] tensor, which MIOpen's NHWC conv kernels
@@ -46,7 +47,7 @@ extern "C" int d3d_dense_scatter(const void *feat, const int32_t *coords, int n,
   if (rc) return rc;
   const size_t esz = dtype == D3D_BF16 ? 2 : 4;
   const size_t bytes = (size_t)batch * c * shape[0] * shape[1] * shape[2] * esz;
-  D3D_HIP_TRY(hipMemsetAsync(dense, 0, bytes, stream));
+  D3D_HIP_TRY(d3d_fill_async(stream, dense, 0, bytes));
   if (n == 0) return D3D_OK;
   int64_t items = (int64_t)n * c;
   int nb = (int)((items + 255) / 256);

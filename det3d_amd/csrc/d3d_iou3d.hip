@@ -13,6 +13,7 @@
 // scheme as d3d_nms.hip (one wave per 64x64 tile, column boxes in LDS, one 64-bit word per lane, upper
 // triangle only), keep pass on the device (d3d_nms_reduce.h) instead of on the host.
 #include "d3d_common.h"
+#include "d3d_fill.h"
 #include "d3d_nms_reduce.h"
 
 #define IOU3D_EPS 1e-8f
@@ -232,7 +233,7 @@ extern "C" int d3d_iou3d_nms(const float *boxes, int n, float thresh, int normal
   D3D_REQUIRE(thresh >= 0.f, "d3d_iou3d_nms: negative threshold");
   D3D_REQUIRE(keep && n_keep, "d3d_iou3d_nms: null output");
   if (n == 0) {
-    D3D_HIP_TRY(hipMemsetAsync(n_keep, 0, 4, stream));
+    D3D_HIP_TRY(d3d_fill_async(stream, n_keep, 0, 4));
     return D3D_OK;
   }
   const int nblk = (n + 63) / 64;

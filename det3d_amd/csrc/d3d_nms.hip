@@ -12,6 +12,7 @@
 // Semantics follow the CPU rule the shipped configs execute: skip a pair when the
 // stand-up IoU <= 0 (nms_cpu.h:105), suppress when polygon IoU >= thresh (:157).
 #include "d3d_common.h"
+#include "d3d_fill.h"
 #include "d3d_nms_reduce.h"
 
 struct Quad {
@@ -223,7 +224,7 @@ static int nms_common(const float *boxes, int n, float thresh, int max_keep, int
   D3D_REQUIRE(n >= 0 && max_keep >= 0, "d3d_nms: n/max_keep");
   D3D_REQUIRE(keep && n_keep, "d3d_nms: null output");
   if (n == 0 || max_keep == 0) {
-    D3D_HIP_TRY(hipMemsetAsync(n_keep, 0, 4, stream));
+    D3D_HIP_TRY(d3d_fill_async(stream, n_keep, 0, 4));
     return D3D_OK;
   }
   const int nblk = (n + 63) / 64;

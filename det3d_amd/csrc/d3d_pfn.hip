@@ -11,6 +11,7 @@
 //   bwd  : pfn_bwd_reduce (dbeta, dgamma from the argmax rows)  ->  pfn_bwd_weight (dW)
 // All f32 (the reader runs before any bf16 cast); HBM-bound on reading the voxel rows once per pass.
 #include "d3d_common.h"
+#include "d3d_fill.h"
 
 #define PFN_MAXK 16
 
@@ -313,7 +314,7 @@ extern "C" int d3d_pfn_fwd(const float *voxels, const int32_t *num_points, const
               "d3d_pfn_fwd: training needs stats_ws, eval needs running stats");
   const int nb = pfn_blocks(m);
   if (training) {
-    D3D_HIP_TRY(hipMemsetAsync(stats_ws, 0, (size_t)2 * f * sizeof(float), stream));
+    D3D_HIP_TRY(d3d_fill_async(stream, stats_ws, 0, (size_t)2 * f * sizeof(float)));
     PFN_DISPATCH(pfn_stats_kernel, G, voxels, num_points, (const int4 *)coors, weight, stats_ws);
     D3D_LAUNCH_TRY("pfn_stats_kernel");
   }
@@ -338,9 +339,12 @@ extern "C" int d3d_pfn_bwd(const float *voxels, const int32_t *num_points, const
                   argmax && dweight && dgamma && dbeta,
               "d3d_pfn_bwd: null pointer");
   const int nb = pfn_blocks(m);
-  D3D_HIP_TRY(hipMemsetAsync(dweight, 0, (size_t)f * G.k * sizeof(float), stream));
-  D3D_HIP_TRY(hipMemsetAsync(dgamma, 0, (size_t)f * sizeof(float), stream));
-  D3D_HIP_TRY(hipMemsetAsync(dbeta, 0, (size_t)f * sizeof(float), stream));
+  {
+    const D3dFillSeg segs[3] = {{dweight, 0, (size_t)f * G.k * sizeof(float)},
+                                {dgamma, 0, (size_t)f * sizeof(float)},
+                                {dbeta, 0, (size_t)f * sizeof(float)}};
+    D3D_HIP_TRY(d3d_fill_async(stream, segs, 3));
+  }
   PFN_DISPATCH(pfn_bwd_reduce_kernel, G, voxels, num_points, (const int4 *)coors, weight, save_mean,
                save_invstd, out, dout, argmax, dgamma, dbeta);
   D3D_LAUNCH_TRY("pfn_bwd_reduce_kernel");

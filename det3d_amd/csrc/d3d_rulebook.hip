@@ -17,6 +17,7 @@
 // Input counts are read from device memory so voxelize -> rulebooks -> next level
 // chains on one stream with no host round trip.  All of it is integer, HBM/L2-bound.
 #include "d3d_scan.h"
+#include "d3d_fill.h"
 
 struct RbGeom {
   int batch;
@@ -136,11 +137,13 @@ extern "C" int d3d_subm_rulebook(const int32_t *coords, const int32_t *n_dev, in
   D3dArena A(workspace, workspace_bytes);
   unsigned long long *tab = A.take<unsigned long long>(hsize);
   const int half = G.kvol / 2;
-  D3D_HIP_TRY(hipMemsetAsync(tab, 0xFF, (size_t)hsize * 8, stream));
-  if (pair_count) D3D_HIP_TRY(hipMemsetAsync(pair_count, 0, (size_t)G.kvol * 4, stream));
-  // offsets above the centre are only written through the mirror rule: default them to -1
-  if (G.kvol > 1)
-    D3D_HIP_TRY(hipMemsetAsync(nbr + (size_t)(half + 1) * cap, 0xFF, (size_t)half * cap * 4, stream));
+  {
+    // offsets above the centre are only written through the mirror rule: default them to -1
+    const D3dFillSeg segs[3] = {{tab, 0xFF, (size_t)hsize * 8},
+                                {pair_count, 0, pair_count ? (size_t)G.kvol * 4 : 0},
+                                {nbr + (size_t)(half + 1) * cap, 0xFF, G.kvol > 1 ? (size_t)half * cap * 4 : 0}};
+    D3D_HIP_TRY(d3d_fill_async(stream, segs, 3));
+  }
   int nb = (cap + 255) / 256;
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(rb_hash_build_kernel, dim3(nb), dim3(256), 0, stream, (const int4 *)coords,
@@ -315,8 +318,10 @@ extern "C" int d3d_conv_rulebook(const int32_t *coords_in, const int32_t *n_in_d
   int *tiles = A.take<int>((size_t)d3d_scan_num_tiles(words) + 1);
   if (!tiles) return d3d_set_error(D3D_ECAPACITY, "d3d_conv_rulebook: workspace carve failed");
 
-  D3D_HIP_TRY(hipMemsetAsync(bitmap, 0, words * 4, stream));
-  if (pair_count) D3D_HIP_TRY(hipMemsetAsync(pair_count, 0, (size_t)G.kvol * 4, stream));
+  {
+    const D3dFillSeg segs[2] = {{bitmap, 0, (size_t)words * 4}, {pair_count, 0, pair_count ? (size_t)G.kvol * 4 : 0}};
+    D3D_HIP_TRY(d3d_fill_async(stream, segs, 2));
+  }
   int64_t items = (int64_t)cap_in * G.kvol;
   int nb = (int)((items + 255) / 256);
   if (nb > 2048) nb = 2048;

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "d3d_common.h"
+#include "d3d_fill.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -612,7 +613,7 @@ extern "C" int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const i
               "d3d_sparse_conv_wgrad: bad sizes");
   D3D_REQUIRE(cin * cout <= 16384, "d3d_sparse_conv_wgrad: cin*cout=%d > 16384", cin * cout);
   D3D_REQUIRE(dw, "d3d_sparse_conv_wgrad: null dw");
-  D3D_HIP_TRY(hipMemsetAsync(dw, 0, (size_t)kvol * cin * cout * sizeof(float), stream));
+  D3D_HIP_TRY(d3d_fill_async(stream, dw, 0, (size_t)kvol * cin * cout * sizeof(float)));
   if (n_out == 0) return D3D_OK;
   D3D_REQUIRE(feat && dout && nbr, "d3d_sparse_conv_wgrad: null pointer");
   // enough blocks to fill 256 CUs a few times over, but >= 1024 sites per split
@@ -650,5 +651,55 @@ extern "C" int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const i
     hipLaunchKernelGGL(spconv_wgrad_generic_kernel<false>, dim3(kvol, splits), dim3(256), smem,
                        stream, feat, dout, nbr, cap, n_out, rows_per_split, cin, cout, dw);
   D3D_LAUNCH_TRY("spconv_wgrad_generic_kernel");
+  return D3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight repack: the parameter keeps spconv's layout [kvol][cin][cout] f32 (checkpoint compatible);
+// the conv kernels want W[k] with the contraction dimension contiguous, in the feature dtype:
+//   forward  wpack_fwd  [kvol][cout][cin] = W[k]^T
+//   dgrad    wpack_dgrad[kvol][cin][cout] = W[k] (k mirrored for submanifold layers)
+// One launch writes both (the PyTorch-op version was transpose-copy + cast + flip-copy + cast = 4
+// launches per layer and step).
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+    spconv_pack_weights_kernel(const float *__restrict__ w, int kvol, int cin, int cout, int flip,
+                               void *__restrict__ fwd_, void *__restrict__ dgrad_) {
+  const int per_k = cin * cout;
+  const int total = kvol * per_k;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int k = t / per_k, rem = t - k * per_k;
+    const int ci = rem / cout, co = rem - ci * cout;
+    const float v = w[t];
+    const int tf = (k * cout + co) * cin + ci;
+    const int td = ((flip ? kvol - 1 - k : k) * cin + ci) * cout + co;
+    if (BF16) {
+      const uint16_t h = f32_to_bf16(v);
+      if (fwd_) ((uint16_t *)fwd_)[tf] = h;
+      if (dgrad_) ((uint16_t *)dgrad_)[td] = h;
+    } else {
+      if (fwd_) ((float *)fwd_)[tf] = v;
+      if (dgrad_) ((float *)dgrad_)[td] = v;
+    }
+  }
+}
+
+extern "C" int d3d_pack_conv_weights(const float *weight, int kvol, int cin, int cout, int dtype,
+                                     int flip_dgrad, void *wpack_fwd, void *wpack_dgrad,
+                                     d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  D3D_REQUIRE(kvol >= 1 && cin >= 1 && cout >= 1, "d3d_pack_conv_weights: sizes");
+  D3D_REQUIRE(dtype == D3D_F32 || dtype == D3D_BF16, "d3d_pack_conv_weights: dtype %d", dtype);
+  D3D_REQUIRE(weight && (wpack_fwd || wpack_dgrad), "d3d_pack_conv_weights: null pointer");
+  const int total = kvol * cin * cout;
+  int nb = (total + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  if (dtype == D3D_BF16)
+    hipLaunchKernelGGL(spconv_pack_weights_kernel<true>, dim3(nb), dim3(256), 0, stream, weight, kvol, cin,
+                       cout, flip_dgrad, wpack_fwd, wpack_dgrad);
+  else
+    hipLaunchKernelGGL(spconv_pack_weights_kernel<false>, dim3(nb), dim3(256), 0, stream, weight, kvol, cin,
+                       cout, flip_dgrad, wpack_fwd, wpack_dgrad);
+  D3D_LAUNCH_TRY("spconv_pack_weights_kernel");
   return D3D_OK;
 }

@@ -15,6 +15,7 @@
 // All passes are HBM/L2-bound integer work: one coalesced read of the points
 // per pass, 4-byte atomics into tables that fit L2.
 #include "d3d_scan.h"
+#include "d3d_fill.h"
 
 #define VOX_SLOT_EMPTY 0x7f7f7f7f  // memset(0x7f) pattern, larger than any point index
 #define VOX_MAX_BATCH 1024
@@ -272,10 +273,13 @@ extern "C" int d3d_voxelize(const float *points, int64_t n_points, int point_str
   P.T = max_points;
   P.M = max_voxels;
 
-  D3D_HIP_TRY(hipMemsetAsync(hkeys, 0xFF, (size_t)L.hsize * 4, stream));
-  D3D_HIP_TRY(hipMemsetAsync(hfirst, 0x7f, (size_t)L.hsize * 4, stream));
-  D3D_HIP_TRY(hipMemsetAsync(count, 0, rows * 4, stream));
-  D3D_HIP_TRY(hipMemsetAsync(slots, 0x7f, rows * (size_t)max_points * 4, stream));
+  {
+    const D3dFillSeg segs[4] = {{hkeys, 0xFF, (size_t)L.hsize * 4},
+                                {hfirst, 0x7f, (size_t)L.hsize * 4},
+                                {count, 0, rows * 4},
+                                {slots, 0x7f, rows * (size_t)max_points * 4}};
+    D3D_HIP_TRY(d3d_fill_async(stream, segs, 4));  // one launch instead of four hipMemsetAsync
+  }
 
   const int nb = (int)((n_points + 255) / 256);
   if (nb > 0) {

@@ -3,6 +3,7 @@
   Sequential (.add), Empty        det3d/models/utils/misc.py:40-113
   get_paddings_indicator          det3d/models/utils/misc.py:180-202
 """
+import os
 import sys
 from collections import OrderedDict
 
@@ -42,6 +43,13 @@ def build_norm_layer(cfg, num_features, postfix=""):
     return name, layer
 
 
+# Optional: route the RPN's Conv2d -> BatchNorm2d -> ReLU triples (channels-last maps) through the fused
+# HIP BatchNorm+ReLU passes of the sparse layers.  OFF by default: on the 36 MB KITTI maps MIOpen's NHWC
+# batch norm + clamp is faster (438 vs 398 frames/s end to end, MI355X, round 1); the sparse-layer kernels
+# are tuned for 1-10 MB tensors.  D3D_FUSE_BN2D=1 turns it on.
+FUSE_BN2D_RELU = os.environ.get("D3D_FUSE_BN2D", "0") == "1"
+
+
 class Sequential(nn.Module):
     """nn.Sequential with `.add()`; children are named "0", "1", ... so state-dict keys
     match the reference (`neck.blocks.0.1.weight`, ...)."""
@@ -77,8 +85,20 @@ class Sequential(nn.Module):
         self.add_module(name, module)
 
     def forward(self, input):
-        for module in self._modules.values():
-            input = module(input)
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if FUSE_BN2D_RELU and type(m) is nn.BatchNorm2d and torch.is_tensor(input) and input.is_cuda:
+                from . import spconv  # the fused [N, C] BatchNorm(+ReLU) kernels (d3d_bn_relu_*)
+
+                if spconv.fusable_bn2d(m, input):
+                    relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+                    input = spconv.bn_relu_2d(m, input, relu)
+                    i += 2 if relu else 1
+                    continue
+            input = m(input)
+            i += 1
         return input
 
 

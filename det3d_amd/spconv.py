@@ -177,7 +177,15 @@ class _SparseConvFn(torch.autograd.Function):
         feats = feats.contiguous()
         kvol, cin, cout = rb.kvol, weight.shape[-2], weight.shape[-1]
         assert feats.shape[0] == rb.n_in and feats.shape[1] == cin, (feats.shape, rb.n_in, cin)
-        wpack = weight.detach().reshape(kvol, cin, cout).transpose(1, 2).contiguous().to(feats.dtype)
+        # one launch repacks the [kD,kH,kW,Cin,Cout] f32 parameter for the forward and (kept for the
+        # backward) the data gradient; W itself is not saved in packed form anywhere else
+        w32 = weight.detach().float().contiguous()
+        wpack = torch.empty((kvol, cout, cin), dtype=feats.dtype, device=feats.device)
+        wd = torch.empty((kvol, cin, cout), dtype=feats.dtype, device=feats.device) \
+            if ctx.needs_input_grad[0] else None
+        rc = L.d3d_pack_conv_weights(w32.data_ptr(), kvol, cin, cout, _DT[feats.dtype], int(rb.subm),
+                                     wpack.data_ptr(), _lib.ptr(wd), _lib.stream_ptr(feats.device))
+        _lib.check(rc, "d3d_pack_conv_weights")
         out = torch.empty((rb.n_out, cout), dtype=feats.dtype, device=feats.device)
         b = bias.detach().float().contiguous() if bias is not None else None
         rc = _timed("fwd", cin, cout, rb.n_out, rb, feats.device, lambda: L.d3d_sparse_conv_fwd(
@@ -185,6 +193,7 @@ class _SparseConvFn(torch.autograd.Function):
             rb.n_out, kvol, cin, cout, _DT[feats.dtype], out.data_ptr(), _lib.stream_ptr(feats.device)))
         _lib.check(rc, "d3d_sparse_conv_fwd")
         ctx.save_for_backward(feats, weight)
+        ctx.wd = wd
         ctx.rb = rb
         ctx.has_bias = bias is not None
         return out
@@ -200,13 +209,11 @@ class _SparseConvFn(torch.autograd.Function):
         stream = _lib.stream_ptr(feats.device)
         gin = gw = gb = None
         if ctx.needs_input_grad[0]:
-            w3 = weight.detach().reshape(kvol, cin, cout)
+            wd = ctx.wd  # packed in the forward: W[k] as is; k mirrored for submanifold layers because
+            #              (j -> i at offset k)  <=>  (i -> j at offset kvol-1-k) on the same table
             if rb.subm:
-                # (j -> i at offset k)  <=>  (i -> j at offset kvol-1-k): same table, W flipped
-                wd = w3.flip(0).contiguous().to(feats.dtype)
                 nbr, cap = rb.nbr_out, rb.cap_out
             else:
-                wd = w3.contiguous().to(feats.dtype)
                 nbr, cap = rb.nbr_in, rb.cap_in
             gin = torch.empty((rb.n_in, cin), dtype=feats.dtype, device=feats.device)
             rc = _timed("dgrad", cout, cin, rb.n_in, rb, feats.device, lambda: L.d3d_sparse_conv_fwd(
@@ -235,7 +242,7 @@ class _BNReLUFn(torch.autograd.Function):
         n, c = x.shape
         dev = x.device
         y = torch.empty_like(x)
-        save = torch.empty((4, c), dtype=torch.float32, device=dev)  # mean, invstd, stats scratch
+        save = torch.empty((2 + 2 * _lib.D3D_BN_COPIES, c), dtype=torch.float32, device=dev)  # mean, invstd, scratch
         rc = L.d3d_bn_relu_fwd(x.data_ptr(), n, c, _DT[x.dtype], _lib.ptr(weight), _lib.ptr(bias),
                                _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum),
                                float(eps), int(training), int(relu), y.data_ptr(),
@@ -259,8 +266,8 @@ class _BNReLUFn(torch.autograd.Function):
         g = torch.empty((2, c), dtype=torch.float32, device=x.device)
         rc = L.d3d_bn_relu_bwd(x.data_ptr(), dy.data_ptr(), n, c, _DT[x.dtype], _lib.ptr(weight),
                                _lib.ptr(bias), save[0].data_ptr(), save[1].data_ptr(), int(ctx.relu),
-                               dx.data_ptr(), g[0].data_ptr(), g[1].data_ptr(),
-                               _lib.stream_ptr(x.device))
+                               dx.data_ptr(), g[0].data_ptr(), g[1].data_ptr(), save[2].data_ptr(),
+                               _lib.stream_ptr(x.device))  # the forward's stats scratch is free again
         _lib.check(rc, "d3d_bn_relu_bwd")
         gw = g[0].to(weight.dtype) if weight is not None else None
         gb = g[1].to(bias.dtype) if bias is not None else None
@@ -286,6 +293,31 @@ def bn_relu(bn, feats, relu):
     kernels; state (running stats) lives in the module exactly as with F.batch_norm."""
     return _BNReLUFn.apply(feats, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                            bn.momentum, bn.eps, bn.training, relu)
+
+
+def fusable_bn2d(bn, x):
+    """plain affine nn.BatchNorm2d with running stats on a CUDA f32/bf16 feature map stored channels-last,
+    i.e. a row-major [B*H*W, C] matrix in memory -- exactly what d3d_bn_relu_* sweeps."""
+    if type(bn) is not nn.BatchNorm2d or not x.is_cuda or x.dtype not in _DT or x.dim() != 4:
+        return False
+    if bn.momentum is None or not bn.track_running_stats or bn.weight is None or not bn.training:
+        return False
+    if x.shape[1] == 1 or not x.is_contiguous(memory_format=torch.channels_last):
+        return False
+    c = x.shape[1]
+    epv = 8 if x.dtype == torch.bfloat16 else 4
+    return c % epv == 0 and c <= 256 and 256 % (c // epv) == 0 and x.numel() // c >= 2
+
+
+def bn_relu_2d(bn, x, relu):
+    """BatchNorm2d (+ReLU) of a channels-last [B, C, H, W] map through the sparse-feature kernels."""
+    b, c, h, w = x.shape
+    rows = x.permute(0, 2, 3, 1).reshape(b * h * w, c)  # a view: channels-last memory is [B,H,W,C]
+    y = _BNReLUFn.apply(rows, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                        bn.training, relu)
+    # like bn_relu(): num_batches_tracked is not advanced (one launch per layer for a counter that
+    # momentum-based running statistics never read)
+    return y.view(b, h, w, c).permute(0, 3, 1, 2)
 
 
 class _DenseFn(torch.autograd.Function):

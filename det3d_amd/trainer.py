@@ -7,12 +7,24 @@ det3d/solver/fastai_optim.py:155-171 (p *= 1 - wd*lr, then Adam with weight_deca
 det3d/solver/learning_schedules_fastai.py:68-95 (OneCycle, cosine annealing).
 """
 import contextlib
+import gc
 import math
 
 import numpy as np
 import torch
 
 from . import dist as d3d_dist
+
+
+def freeze_gc():
+    """Call once after the warm-up steps of a training loop.  One step creates a few thousand short-lived
+    Python containers, so CPython runs a full generational collection every few steps, and a full collection
+    walks every tracked object of the process (torch + numpy: ~10^6 objects, 40-80 ms) -- measured on MI355X
+    as a bimodal 8.5 / 12.5 ms step (bench.py --no-gc-freeze).  gc.freeze() moves everything alive now into
+    the permanent generation; the collector stays enabled and later collections only scan what the loop
+    itself creates."""
+    gc.collect()
+    gc.freeze()
 
 
 def annealing_cos(start, end, pct):

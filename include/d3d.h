@@ -126,6 +126,13 @@ int d3d_conv_rulebook(const int32_t *coords_in, const int32_t *n_in_dev, int cap
  * The same entry point computes the data gradient: pass grad_out as `feat`,
  * nbr_in (strided) or nbr with flipped k (submanifold) and W[k] untransposed.
  */
+/* spconv's parameter layout [kvol][cin][cout] f32 (det3d checkpoints) -> the two
+ * packed forms the kernels read, in the feature dtype, one launch:
+ *   wpack_fwd   dev [kvol][cout][cin]  (or NULL)           for d3d_sparse_conv_fwd
+ *   wpack_dgrad dev [kvol][cin][cout]  (or NULL), k -> kvol-1-k when flip_dgrad (submanifold layers) */
+int d3d_pack_conv_weights(const float *weight, int kvol, int cin, int cout, int dtype, int flip_dgrad,
+                          void *wpack_fwd, void *wpack_dgrad, d3d_stream_t stream);
+
 int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const float *bias,
                         const int32_t *nbr, int cap, int n_out, int kvol, int cin, int cout,
                         int dtype, void *out, d3d_stream_t stream);
@@ -142,19 +149,23 @@ int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const int32_t *nbr
  * (det3d/models/backbones/scn.py:106-157; residual blocks :76-87), F.batch_norm semantics
  * (biased variance to normalise, unbiased into running_var, eps, momentum).
  *  x, y, dy, dx dev [n,c] dtype; gamma/beta/running_* dev [c] f32 (gamma/beta may be NULL)
- *  training=1: batch statistics (stats_ws dev [2c] f32 scratch), running stats updated in
- *              place, save_mean/save_invstd dev [c] written for the backward
+ *  training=1: batch statistics (stats_ws dev [D3D_BN_COPIES * 2c] f32 scratch: the per-channel
+ *              sums are accumulated into D3D_BN_COPIES replicas to spread same-address atomics),
+ *              running stats updated in place, save_mean/save_invstd dev [c] written for the backward
  *  training=0: running statistics, stats_ws unused
  *  relu=1 fuses max(0, .) into the apply pass (and its mask into the backward).
- *  bwd overwrites dgamma/dbeta dev [c] f32 and dx.
+ *  bwd overwrites dgamma/dbeta dev [c] f32 and dx; partial_ws dev [D3D_BN_COPIES * 2c] f32 scratch.
+ *  Works on any row-major [n,c] matrix, e.g. the [B*H*W, C] view of a channels-last feature map
+ *  (the RPN's BatchNorm2d + ReLU pairs, det3d/models/necks/rpn.py:124-142).
  */
+#define D3D_BN_COPIES 8
 int d3d_bn_relu_fwd(const void *x, int n, int c, int dtype, const float *gamma, const float *beta,
                     float *running_mean, float *running_var, float momentum, float eps,
                     int training, int relu, void *y, float *save_mean, float *save_invstd,
                     float *stats_ws, d3d_stream_t stream);
 int d3d_bn_relu_bwd(const void *x, const void *dy, int n, int c, int dtype, const float *gamma,
                     const float *beta, const float *save_mean, const float *save_invstd, int relu,
-                    void *dx, float *dgamma, float *dbeta, d3d_stream_t stream);
+                    void *dx, float *dgamma, float *dbeta, float *partial_ws, d3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * PillarFeatureNet with one (last) PFNLayer: det3d/models/readers/pillar_encoder.py:115-155

@@ -277,6 +277,75 @@ def test_fused_bn_relu_vs_torch(c, dtype, relu):
     assert torch.allclose(ye.float().cpu(), yre, **tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 128, 50, 44), (1, 64, 31, 17), (4, 256, 25, 22)])
+def test_fused_bn2d_relu_channels_last_vs_torch(shape, dtype):
+    """The RPN's Conv2d -> BatchNorm2d -> ReLU triples on channels-last maps (necks.py through
+    nn_utils.Sequential) use d3d_bn_relu_* on the [B*H*W, C] view: same outputs, running statistics and
+    gradients as the stock modules; non-channels-last input keeps the stock path."""
+    from det3d_amd import nn_utils, spconv
+
+    torch.manual_seed(shape[1])
+    b, c, h, w = shape
+    x0 = (torch.randn(shape) * torch.linspace(0.5, 2.0, c).view(1, c, 1, 1)
+          + torch.linspace(-1, 1, c).view(1, c, 1, 1)).to(dtype)
+    g = torch.randn(shape).to(dtype)
+    ref = torch.nn.Sequential(torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.01), torch.nn.ReLU())
+    with torch.no_grad():
+        ref[0].weight.uniform_(0.5, 1.5)
+        ref[0].bias.uniform_(-0.5, 0.5)
+    mine = nn_utils.Sequential(torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.01), torch.nn.ReLU()).cuda()
+    mine.load_state_dict(ref.state_dict())
+    xr = x0.float().clone().requires_grad_(True)
+    yr = ref(xr)
+    (yr * g.float()).sum().backward()
+    xm = x0.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert spconv.fusable_bn2d(mine[0], xm) and not spconv.fusable_bn2d(mine[0], x0.cuda())
+    nn_utils.FUSE_BN2D_RELU = True  # opt-in path (default off: MIOpen's NHWC batch norm is faster on big maps)
+    try:
+        ym = mine(xm)
+    finally:
+        nn_utils.FUSE_BN2D_RELU = False
+    assert ym.dtype == dtype and ym.shape == shape and ym.is_contiguous(memory_format=torch.channels_last)
+    (ym.float() * g.cuda().float()).sum().backward()
+    tol = dict(atol=1e-4, rtol=1e-4) if dtype == torch.float32 else dict(atol=3e-2, rtol=2e-2)
+    assert torch.allclose(ym.float().cpu(), yr.detach(), **tol)
+    assert torch.allclose(mine[0].running_mean.cpu(), ref[0].running_mean, atol=1e-5, rtol=1e-4)
+    assert torch.allclose(mine[0].running_var.cpu(), ref[0].running_var, atol=1e-5, rtol=1e-4)
+    gtol = dict(atol=2e-3, rtol=2e-3) if dtype == torch.float32 else dict(atol=6e-2, rtol=5e-2)
+    assert torch.allclose(xm.grad.float().cpu(), xr.grad, **gtol)
+    rel = 2e-3 if dtype == torch.float32 else 2e-2
+    assert torch.allclose(mine[0].weight.grad.cpu(), ref[0].weight.grad, atol=rel * float(ref[0].weight.grad.abs().max()))
+    assert torch.allclose(mine[0].bias.grad.cpu(), ref[0].bias.grad, atol=rel * float(ref[0].bias.grad.abs().max()))
+    # default: the stock modules
+    with torch.no_grad():
+        y2 = mine(xm.detach())
+    assert torch.allclose(y2.float(), ym.detach().float(), **tol)
+
+
+def test_fused_bn_large_row_count_matches_torch():
+    """140 800 x 128 rows (the KITTI RPN map): exercises the 2048-block grid, the 4x unrolled sweeps
+    and the replicated accumulators."""
+    from det3d_amd import spconv
+
+    torch.manual_seed(5)
+    n, c = 140800, 128
+    x = (torch.randn(n, c, device="cuda") * 1.5 + 0.25)
+    g = torch.randn(n, c, device="cuda")
+    ref = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).cuda()
+    mine = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).cuda()
+    xr = x.clone().requires_grad_(True)
+    xm = x.clone().requires_grad_(True)
+    yr = torch.relu(ref(xr))
+    (yr * g).sum().backward()
+    ym = spconv.bn_relu(mine, xm, True)
+    (ym * g).sum().backward()
+    assert torch.allclose(ym, yr.detach(), atol=1e-4, rtol=1e-4)
+    assert torch.allclose(xm.grad, xr.grad, atol=2e-3, rtol=2e-3)
+    assert torch.allclose(mine.weight.grad, ref.weight.grad, rtol=1e-3, atol=1e-3 * float(ref.weight.grad.abs().max()))
+    assert torch.allclose(mine.running_var, ref.running_var, rtol=1e-4)
+
+
 def test_sequential_fuses_bn_relu_transparently():
     from det3d_amd import spconv
 

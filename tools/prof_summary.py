@@ -1,6 +1,7 @@
 """Summarise rocprofv3 rocpd sqlite output on the GPU box (the .db files exceed what gpurun
 copies back).  usage:
     prof_summary.py kernels <db> <window_ms> <steps> <out.txt> [header...]
+    prof_summary.py gaps <db> <window_ms> <steps> <out.txt>      (appends)
     prof_summary.py pmc <db> <counter> <out.txt>
 """
 import sqlite3
@@ -26,6 +27,35 @@ def kernels(db, window_ms, steps, out, header):
             f.write("%12.1f %12.1f %10.2f %6.1f%%  %s\n" % (r[2] / steps, r[1] / steps, r[3], 100 * r[2] / tot, r[0][:130]))
 
 
+def gaps(db, window_ms, steps, out):
+    """idle time on the device between consecutive kernels, attributed to the kernel that FOLLOWS the gap
+    and to the one that precedes it -- shows which launches the stream waits for."""
+    cur = sqlite3.connect(db).cursor()
+    t1 = cur.execute("select max(end) from kernels").fetchone()[0]
+    w0 = t1 - int(float(window_ms) * 1e6)
+    rows = cur.execute("select name, start, end from kernels where start > ? order by start", (w0,)).fetchall()
+    steps = float(steps)
+    after, before = {}, {}
+    tot = 0.0
+    for (n0, s0, e0), (n1, s1, e1) in zip(rows[:-1], rows[1:]):
+        g = max(0, s1 - e0) / 1e3
+        tot += g
+        a = after.setdefault(n1[:90], [0, 0.0])
+        a[0] += 1
+        a[1] += g
+        b = before.setdefault(n0[:90], [0, 0.0])
+        b[0] += 1
+        b[1] += g
+    busy = sum(e - s for _, s, e in rows) / 1e3
+    with open(out, "a") as f:
+        f.write("\n# gaps: window %.1f ms, busy %.2f ms/step, idle between kernels %.2f ms/step\n"
+                % (float(window_ms), busy / 1e3 / steps, tot / 1e3 / steps))
+        for title, d in (("gap BEFORE this kernel (it waited)", after), ("gap AFTER this kernel", before)):
+            f.write("# %s\n%12s %10s %10s  kernel\n" % (title, "us/step", "n/step", "avg_us"))
+            for k, (c, g) in sorted(d.items(), key=lambda kv: -kv[1][1])[:25]:
+                f.write("%12.1f %10.1f %10.2f  %s\n" % (g / steps, c / steps, g / c, k))
+
+
 def pmc(db, counter, out):
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select name, count(*), avg(counter_value), sum(counter_value), avg(duration)/1e3 from pmc_events "
@@ -42,5 +72,7 @@ def pmc(db, counter, out):
 if __name__ == "__main__":
     if sys.argv[1] == "kernels":
         kernels(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6:])
+    elif sys.argv[1] == "gaps":
+        gaps(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
