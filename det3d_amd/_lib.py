@@ -46,6 +46,9 @@ SIGNATURES = {
     "d3d_assign_targets_workspace_bytes": (sz, [i32, i32, i32]),
     "d3d_assign_targets": (i32, [vp, i32, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, sz, vp]),
     "d3d_assign_targets_task": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp]),
+    "d3d_head_loss_workspace_bytes": (sz, [i32]),
+    "d3d_head_loss": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, f32, f32, f32,
+                            f32, f32, f32, f32, vp, vp, vp, vp, vp, sz, vp]),
     "d3d_rotate_nms_workspace_bytes": (sz, [i32]),
     "d3d_rotate_nms": (i32, [vp, i32, f32, i32, vp, vp, vp, sz, vp]),
     "d3d_rotate_iou": (i32, [vp, i32, vp, i32, vp, vp]),
@@ -59,6 +62,7 @@ SIGNATURES = {
 D3D_F32 = 0
 D3D_BF16 = 1
 D3D_BN_COPIES = 8
+D3D_LOSS_SCALARS = 18
 D3D_IOU3D_OVERLAP, D3D_IOU3D_IOU_BEV, D3D_IOU3D_IOU_NORMAL = 0, 1, 2
 
 
@@ -107,7 +111,21 @@ def ptr(t):
     return t.data_ptr()
 
 
+_RAW_STREAM = None
+
+
 def stream_ptr(device=None):
+    """hipStream_t of torch's current stream on `device` as an int.  Called once per kernel launch (~60
+    times per training step), so it goes through the raw C accessor (0.3 us) rather than building a
+    torch.cuda.Stream object each time (5 us)."""
+    global _RAW_STREAM
     import torch
 
+    if _RAW_STREAM is None:
+        _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _RAW_STREAM:
+        idx = device.index if isinstance(device, torch.device) else device
+        if idx is None:
+            idx = torch.cuda.current_device()
+        return _RAW_STREAM(idx)
     return torch.cuda.current_stream(device).cuda_stream

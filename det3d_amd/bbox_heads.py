@@ -11,6 +11,7 @@ reference references undefined attributes (:911-913) and is not reachable from a
 config, so it raises here.
 """
 import logging
+import os
 from collections import defaultdict
 
 import numpy as np
@@ -21,6 +22,55 @@ from . import box_ops
 from . import losses  # noqa: F401  (registers the loss classes)
 from .builder import build_loss
 from .registry import HEADS
+
+
+# MultiGroupHead.loss through d3d_head_loss (one fused forward+gradient kernel per task group instead of
+# ~200 element-wise launches).  D3D_FUSE_LOSS=0 keeps the PyTorch-op formulation (also the CPU path).
+FUSE_LOSS = os.environ.get("D3D_FUSE_LOSS", "1") != "0"
+
+
+class _HeadLossFn(torch.autograd.Function):
+    """loss of one task group; returns the [D3D_LOSS_SCALARS] vector (element 0 is the loss)."""
+
+    @staticmethod
+    def forward(ctx, box_preds, cls_preds, dir_preds, labels, reg_targets, anchors, cfg):
+        from . import _lib
+
+        L = _lib.lib()
+        dev = box_preds.device
+        dt = box_preds.dtype
+        cls_preds = cls_preds.to(dt).contiguous()
+        box_preds = box_preds.contiguous()
+        if dir_preds is not None:
+            dir_preds = dir_preds.to(dt).contiguous()
+        b, a, code = box_preds.shape
+        nc = cls_preds.shape[-1]
+        g_box, g_cls = torch.empty_like(box_preds), torch.empty_like(cls_preds)
+        g_dir = torch.empty_like(dir_preds) if dir_preds is not None else None
+        scalars = torch.empty((_lib.D3D_LOSS_SCALARS,), dtype=torch.float32, device=dev)
+        wsb = L.d3d_head_loss_workspace_bytes(b)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        per_batch = anchors is not None and anchors.dim() == 3
+        rc = L.d3d_head_loss(
+            box_preds.data_ptr(), cls_preds.data_ptr(), _lib.ptr(dir_preds),
+            _lib.D3D_BF16 if dt == torch.bfloat16 else _lib.D3D_F32, labels.data_ptr(), reg_targets.data_ptr(),
+            _lib.ptr(anchors), int(per_batch), b, a, code, nc, anchors.shape[-1] if anchors is not None else 0,
+            int(cfg["sin_diff"]), float(cfg["dir_offset"]), float(cfg["pos_w"]), float(cfg["neg_w"]),
+            float(cfg["alpha"]), float(cfg["gamma"]), float(cfg["sigma"]), float(cfg["w_loc"]),
+            float(cfg["w_cls"]), float(cfg["w_dir"]), g_box.data_ptr(), g_cls.data_ptr(), _lib.ptr(g_dir),
+            scalars.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
+        _lib.check(rc, "d3d_head_loss")
+        ctx.save_for_backward(g_box, g_cls, *([g_dir] if g_dir is not None else []))
+        ctx.has_dir = g_dir is not None
+        return scalars
+
+    @staticmethod
+    def backward(ctx, gs):
+        saved = ctx.saved_tensors
+        g = gs[0]  # only element 0 (the loss) is differentiable; the rest are logging sums
+        g_box, g_cls = saved[0] * g.to(saved[0].dtype), saved[1] * g.to(saved[1].dtype)
+        g_dir = saved[2] * g.to(saved[2].dtype) if ctx.has_dir else None
+        return g_box, g_cls, g_dir, None, None, None, None
 
 
 def one_hot_f(tensor, depth, dim=-1, on_value=1.0, dtype=torch.float32):
@@ -185,11 +235,58 @@ class MultiGroupHead(nn.Module):
             raise ValueError("unknown loss norm type %s" % kind)
         return cls_weights, reg_weights, cared
 
+    def _fused_loss_ok(self, preds_dict, labels):
+        """the configuration d3d_head_loss implements (every shipped config), on device tensors"""
+        from . import losses as L
+
+        box = preds_dict["box_preds"]
+        if not (FUSE_LOSS and box.is_cuda and box.dtype in (torch.float32, torch.bfloat16)):
+            return False
+        if labels.dtype != torch.int32 or self.bev_only or not self.encode_background_as_zeros:
+            return False
+        if self.loss_norm["type"] != "NormByNumPositives":
+            return False
+        if type(self.loss_reg) is not L.WeightedSmoothL1Loss or not self.loss_reg._codewise:
+            return False
+        if type(self.loss_cls) is not L.SigmoidFocalLoss or self.loss_cls._alpha is None:
+            return False
+        if self.use_direction_classifier and (type(self.loss_aux) is not L.WeightedSoftmaxClassificationLoss
+                                              or self.loss_aux._logit_scale != 1.0):
+            return False
+        return self.box_n_dim <= 10
+
+    def _loss_fused(self, example, preds_dict, task_id, batch_size):
+        num_class = self.num_classes[task_id]
+        labels = example["labels"][task_id].contiguous()
+        reg_targets = example["reg_targets"][task_id].float().contiguous()
+        box_preds = preds_dict["box_preds"].view(batch_size, -1, self.box_n_dim)
+        cls_preds = preds_dict["cls_preds"].view(batch_size, -1, num_class)
+        dir_preds = anchors = None
+        if self.use_direction_classifier:
+            dir_preds = preds_dict["dir_cls_preds"].view(batch_size, -1, 2)
+            anchors = example["anchors"][task_id].float().contiguous()
+            anchors = anchors.view(batch_size, -1, anchors.shape[-1])
+        cfg = dict(sin_diff=self.encode_rad_error_by_sin, dir_offset=getattr(self, "direction_offset", 0.0) or 0.0,
+                   pos_w=self.loss_norm["pos_cls_weight"], neg_w=self.loss_norm["neg_cls_weight"],
+                   alpha=self.loss_cls._alpha, gamma=self.loss_cls._gamma or 0.0, sigma=self.loss_reg._sigma,
+                   w_loc=self.loss_reg._loss_weight, w_cls=self.loss_cls._loss_weight,
+                   w_dir=self.loss_aux._loss_weight if self.use_direction_classifier else 0.0)
+        s = _HeadLossFn.apply(box_preds, cls_preds, dir_preds, labels, reg_targets, anchors, cfg)
+        d = s.detach()
+        return {"loss": s[0], "cls_pos_loss": d[4], "cls_neg_loss": d[5],
+                "dir_loss_reduced": d[3] if self.use_direction_classifier else torch.tensor(0),
+                "cls_loss_reduced": d[2], "loc_loss_reduced": d[1],
+                "loc_loss_elem": list(d[8: 8 + self.box_n_dim].unbind(0)),
+                "num_pos": d[6].long(), "num_neg": d[7].long()}
+
     def loss(self, example, preds_dicts, **kwargs):
         batch_anchors = example["anchors"]
         batch_size_device = batch_anchors[0].shape[0]
         rets = []
         for task_id, preds_dict in enumerate(preds_dicts):
+            if self._fused_loss_ok(preds_dict, example["labels"][task_id]):
+                rets.append(self._loss_fused(example, preds_dict, task_id, batch_size_device))
+                continue
             num_class = self.num_classes[task_id]
             box_preds = preds_dict["box_preds"].float()
             cls_preds = preds_dict["cls_preds"].float()

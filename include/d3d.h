@@ -237,6 +237,31 @@ int d3d_assign_targets_task(const float *anchors, int num_anchors, int box_dim, 
                             size_t workspace_bytes, d3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Loss of one MultiGroupHead task group, forward and gradient w.r.t. the predictions in two launches.
+ * Replaces MultiGroupHead.loss (det3d/models/bbox_heads/mg_head.py:580-695: prepare_loss_weights :147-188
+ * with NormByNumPositives, create_loss :535-578, add_sin_difference :29-34, get_direction_target :54-63,
+ * _get_pos_neg_loss :36-52) with SigmoidFocalLoss, WeightedSmoothL1Loss (codewise; code_weights ignored as in
+ * losses.py:173) and WeightedSoftmaxClassificationLoss (losses.py:146-446), encode_background_as_zeros.
+ *  box_preds [B,A,code], cls_preds [B,A,nc], dir_preds [B,A,2] or NULL: dev, dtype (D3D_F32 | D3D_BF16)
+ *  labels dev [B,A] i32 (class / 0 / -1), reg_targets dev [B,A,code] f32
+ *  anchors dev [B,A,box_dim] f32 (anchors_per_batch = 1) or [A,box_dim] (0); only read with dir_preds
+ *  grad_box / grad_cls / grad_dir: dev, same shape and dtype as the predictions: d(loss)/d(prediction)
+ *  scalars dev [D3D_LOSS_SCALARS] f32: [0] loss = loc + cls + dir_weight * dir   [1] loc_loss_reduced
+ *    [2] cls_loss_reduced  [3] dir_loss (unweighted)  [4] cls_pos_loss  [5] cls_neg_loss
+ *    [6] num_pos of frame 0  [7] num_neg of frame 0  [8 .. 8+code) loc_loss_elem
+ *  code <= 10, nc <= 8.  workspace: d3d_head_loss_workspace_bytes(batch). */
+#define D3D_LOSS_SCALARS 18
+size_t d3d_head_loss_workspace_bytes(int batch);
+int d3d_head_loss(const void *box_preds, const void *cls_preds, const void *dir_preds, int dtype,
+                  const int32_t *labels, const float *reg_targets, const float *anchors,
+                  int anchors_per_batch, int batch, int num_anchors, int code_size, int num_class,
+                  int box_dim, int sin_difference, float dir_offset, float pos_cls_weight,
+                  float neg_cls_weight, float focal_alpha, float focal_gamma, float smooth_l1_sigma,
+                  float loc_weight, float cls_weight, float dir_weight, void *grad_box, void *grad_cls,
+                  void *grad_dir, float *scalars, void *workspace, size_t workspace_bytes,
+                  d3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Rotated NMS.  Replaces rotate_nms_cc (det3d/ops/nms/nms_cpu.py:34-45) +
  * rotate_non_max_suppression_cpu (det3d/ops/nms/nms_cpu.h:73-169), as driven
  * by box_torch_ops.rotate_nms (det3d/core/bbox/box_torch_ops.py:528-549).
