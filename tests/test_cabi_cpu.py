@@ -47,6 +47,32 @@ def test_argument_validation_without_gpu(hip_lib):
     assert hip_lib.d3d_subm_rulebook(1, 1, 10, 1, big, k3, 1, 1, None, 0, None) == -2
 
 
+def test_argument_validation_of_the_round1_additions(hip_lib):
+    """iou3d / evaluation IoU / task-group AssignTarget / head loss / weight repack / BN: every argument check
+    runs before the first HIP call."""
+    err = hip_lib.d3d_last_error
+    assert hip_lib.d3d_iou3d_pairwise(1, 3, 1, 3, 7, 1, None) == -1 and b"mode" in err()
+    assert hip_lib.d3d_iou3d_pairwise(None, 0, None, 5, 1, None, None) == 0          # empty: nothing to do
+    assert hip_lib.d3d_iou3d_nms(1, 5, -0.5, 0, 1, 1, 1, 1 << 20, None) == -1 and b"threshold" in err()
+    assert hip_lib.d3d_iou3d_nms(1, 20000, 0.1, 0, 1, 1, 1, 1 << 30, None) == -2     # > 16384 boxes
+    assert hip_lib.d3d_iou3d_nms(1, 100, 0.1, 0, 1, 1, 1, 8, None) == -2 and b"workspace" in err()
+    assert hip_lib.d3d_rotate_iou_eval(1, 3, 1, 3, 5, 1, None) == -1 and b"criterion" in err()
+    thr = (ctypes.c_float * 2)(0.5, 0.5)
+    args = lambda box_dim, k, per, a: (1, a, box_dim, k, per, thr, thr, 1, 1, 1, 1, 1, 4, 1, 1, 1, 1, 1 << 20, None)
+    assert hip_lib.d3d_assign_targets_task(*args(8, 2, 2, 16)) == -1 and b"box_dim" in err()
+    assert hip_lib.d3d_assign_targets_task(*args(9, 9, 2, 36)) == -1 and b"num_classes" in err()
+    assert hip_lib.d3d_assign_targets_task(*args(9, 2, 2, 18)) == -1 and b"multiple" in err()
+    assert hip_lib.d3d_pack_conv_weights(1, 27, 16, 16, 5, 0, 1, 1, None) == -1 and b"dtype" in err()
+    assert hip_lib.d3d_pack_conv_weights(1, 27, 16, 16, 0, 0, None, None, None) == -1
+    loss = lambda code, nc: hip_lib.d3d_head_loss(1, 1, None, 0, 1, 1, None, 0, 2, 100, code, nc, 7, 1, 0.0, 1.0, 2.0,
+                                                  0.25, 2.0, 3.0, 1.0, 1.0, 0.2, 1, 1, None, 1, 1, 1 << 10, None)
+    assert loss(11, 1) == -1 and b"code_size" in err()
+    assert loss(7, 9) == -1 and b"num_class" in err()
+    assert hip_lib.d3d_head_loss_workspace_bytes(4) >= 16
+    assert hip_lib.d3d_bn_relu_fwd(1, 100, 24, 1, None, None, None, None, 0.01, 1e-3, 1, 1, 1, None, None, 1, None) == -1
+    assert b"unsupported" in err()
+
+
 def test_workspace_queries(hip_lib):
     assert hip_lib.d3d_voxelize_workspace_bytes(60000, 4, 5, 20000) > 60000 * 4
     assert hip_lib.d3d_rotate_nms_workspace_bytes(1000) >= 1000 * 16 * 8

@@ -248,3 +248,18 @@ def test_task_group_anchors_and_targets_vs_reference_assign_v2(tag):
         assert np.array_equal(w, z["%s_f%d_weights" % (tag, f)])
         assert tgt.shape == z["%s_f%d_targets" % (tag, f)].shape
         assert np.allclose(tgt, z["%s_f%d_targets" % (tag, f)], atol=1e-6)
+
+
+def test_numpy_assign_restatement_vs_reference_randomised():
+    """tests/golden/crosscheck_assign.py: 40 random task groups (1-3 classes, 7/9-dim boxes, both coders, NaN
+    velocities, gt boxes on anchor centres) through the reference's own TargetAssigner and through
+    synthetic.assign_targets_task.  Runs where /root/reference exists (its own process: ref_loader stubs modules)."""
+    import subprocess
+    import sys
+
+    if not os.path.isdir("/root/reference/det3d"):
+        pytest.skip("/root/reference not present on this box")
+    script = os.path.join(GOLDEN, "crosscheck_assign.py")
+    out = subprocess.run([sys.executable, script, "40"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "identical to the reference" in out.stdout
