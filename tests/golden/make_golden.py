@@ -14,6 +14,8 @@ committed; tests never import the reference.  What each file pins:
                     (devRotateIoUEval) run as plain Python, criteria -1 / 0 / 1 / 2
   task_targets.npz  TargetAssigner.assign_v2 (core/anchor/target_assigner.py:68-142) on two-class task
                     groups: nuScenes 9-dim boxes + angle-vector coder, Lyft 7-dim boxes
+  augment.npz       random_flip(_both) + global_rotation + global_scaling_v2 (core/sampler/preprocess.py:796-861)
+                    with a seeded NumPy stream, 7-dim (KITTI) and 9-dim (nuScenes) boxes
   vfe_pfn.pt        VoxelFeatureExtractorV3 (voxel_encoder.py:197-211), PillarFeatureNet +
                     PointPillarsScatter (pillar_encoder.py:17-211)
   rpn.pt            RPN (necks/rpn.py:22-159) in three stride configurations
@@ -404,13 +406,42 @@ def task_targets():
     np.savez_compressed(os.path.join(HERE, "task_targets.npz"), **out)
 
 
+def augment_cases():
+    """random_flip / random_flip_both + global_rotation + global_scaling_v2 (core/sampler/preprocess.py:796-861)
+    exactly as Preprocess.__call__ chains them (pipelines/preprocess.py:197-212), seeded NumPy stream."""
+    prep = ref_loader.ref("det3d.core.sampler.preprocess")
+    out = {}
+    for tag, nd, both in (("kitti", 7, False), ("nusc", 9, True)):
+        for frame in range(4):
+            rng = np.random.default_rng(100 + frame + (10 if both else 0))
+            pts = rng.uniform(-30, 30, (500, 5 if both else 4)).astype(np.float32)
+            gt = rng.uniform(-20, 20, (6, nd)).astype(np.float32)
+            gt[:, 3:6] = rng.uniform(0.5, 5, (6, 3))
+            gt[:, -1] = rng.uniform(-3.1, 3.1, 6)
+            out["%s_f%d_points_in" % (tag, frame)] = pts.copy()
+            out["%s_f%d_gt_in" % (tag, frame)] = gt.copy()
+            np.random.seed(7 + frame)
+            if both:
+                gt, pts = prep.random_flip_both(gt, pts)
+            else:
+                gt, pts = prep.random_flip(gt, pts)
+            gt, pts = prep.global_rotation(gt, pts, rotation=[-0.3925, 0.3925] if both else [-0.78539816, 0.78539816])
+            gt, pts = prep.global_scaling_v2(gt, pts, 0.95, 1.05)
+            out["%s_f%d_points_out" % (tag, frame)] = pts
+            out["%s_f%d_gt_out" % (tag, frame)] = gt
+    np.savez_compressed(os.path.join(HERE, "augment.npz"), **out)
+    print("augment:", sorted(out)[:4], "...")
+
+
 def main():
     ref_loader.install()
-    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks"]
+    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment"]
     if "anchors" in which:
         anchors_targets()
     if "tasks" in which:
         task_targets()
+    if "augment" in which:
+        augment_cases()
     if "voxel" in which:
         voxel_cases()
     if "iou" in which:
