@@ -6,7 +6,7 @@
 
 // channels_last = 1 addresses the dense tensor as [B, H, W, C*D] (channel = c*D + z): the
 // memory layout of a channels-last [B, C*D, H, W] tensor, which MIOpen's NHWC conv kernels
-// consume without the NCHW<->NHWC transposes (0.63 ms/step in profiles/round1_kernel_stats_v2).
+// consume without the NCHW<->NHWC transposes (0.63 ms/step in profiles/round1_kernel_stats_v2.txt).
 template <typename T, bool GATHER>
 __global__ void __launch_bounds__(256)
     dense_move_kernel(T *__restrict__ feat, const int4 *__restrict__ coords, int n, int c, int D,

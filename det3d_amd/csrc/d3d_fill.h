@@ -1,8 +1,8 @@
 // Byte-pattern fills as ordinary kernel dispatches.
 //
 // hipMemsetAsync goes through ROCclr's blit path (`__amd_rocclr_fillBufferAligned`); between two kernels
-// on the same stream it costs a 13-16 us bubble on the MI355X (profiles/round1_gaps_v5.txt: ~100 fills
-// per training step = 1.2-1.6 ms of idle GPU, and the latency is bimodal).  A plain kernel keeps the
+// on the same stream it costs a 13-16 us bubble on the MI355X (profiles/round1_gaps_v5_memset.txt: ~90 fills
+// per training step = 1.1-1.6 ms of idle GPU under the profiler, and the latency is bimodal).  A plain kernel keeps the
 // queue in dispatch mode (2-3 us), and up to four regions with different byte values go in ONE launch
 // (the voxelizer's hash keys / first indices / counters / slots, a rulebook's table + counters, ...).
 #pragma once

@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t rb_lin(int b, int z, int y, int x, const int
 
 // wave-aggregated pair counting: one atomic per wave when the wave shares one k.  Optional
 // (pair_count == NULL skips it): kvol hot addresses serialise ~30k same-address atomics per
-// launch at L2, which was >50 % of the rulebook kernels' time (profiles/round1_kernel_stats_v1).
+// launch at L2, which was >50 % of the rulebook kernels' time (profiles/round1_kernel_stats_v1.txt).
 __device__ __forceinline__ void rb_count_pairs(int32_t *pair_count, int k, bool found) {
   if (pair_count == nullptr) return;
   unsigned long long m = __ballot(found);
