@@ -16,6 +16,7 @@ committed; tests never import the reference.  What each file pins:
                     groups: nuScenes 9-dim boxes + angle-vector coder, Lyft 7-dim boxes
   augment.npz       random_flip(_both) + global_rotation + global_scaling_v2 (core/sampler/preprocess.py:796-861)
                     with a seeded NumPy stream, 7-dim (KITTI) and 9-dim (nuScenes) boxes
+  sampler.npz       DistributedGroupSampler (datasets/loader/sampler.py:138-224): per-rank indices, two epochs
   vfe_pfn.pt        VoxelFeatureExtractorV3 (voxel_encoder.py:197-211), PillarFeatureNet +
                     PointPillarsScatter (pillar_encoder.py:17-211)
   rpn.pt            RPN (necks/rpn.py:22-159) in three stride configurations
@@ -433,15 +434,43 @@ def augment_cases():
     print("augment:", sorted(out)[:4], "...")
 
 
+def sampler_cases():
+    """DistributedGroupSampler (datasets/loader/sampler.py:138-224): indices per rank and epoch."""
+    sm = ref_loader.ref("det3d.datasets.loader.sampler")
+
+    class _DS:
+        def __init__(self, flag):
+            self.flag = flag
+
+        def __len__(self):
+            return len(self.flag)
+
+    out = {}
+    rng = np.random.default_rng(4)
+    for tag, n, spg, world in (("a", 37, 4, 3), ("b", 64, 4, 8), ("c", 53, 6, 2)):
+        flag = (rng.random(n) < 0.3).astype(np.uint8) if tag != "b" else np.zeros(n, np.uint8)
+        out[tag + "_flag"] = flag
+        out[tag + "_cfg"] = np.array([spg, world])
+        for epoch in (0, 3):
+            for rank in range(world):
+                s = sm.DistributedGroupSampler(_DS(flag), samples_per_gpu=spg, num_replicas=world, rank=rank)
+                s.set_epoch(epoch)
+                out["%s_e%d_r%d" % (tag, epoch, rank)] = np.array(list(iter(s)), np.int64)
+    np.savez_compressed(os.path.join(HERE, "sampler.npz"), **out)
+    print("sampler:", {k: v.shape for k, v in out.items() if k.endswith("_r0")})
+
+
 def main():
     ref_loader.install()
-    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment"]
+    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "sampler"]
     if "anchors" in which:
         anchors_targets()
     if "tasks" in which:
         task_targets()
     if "augment" in which:
         augment_cases()
+    if "sampler" in which:
+        sampler_cases()
     if "voxel" in which:
         voxel_cases()
     if "iou" in which:
