@@ -16,6 +16,7 @@ committed; tests never import the reference.  What each file pins:
                     groups: nuScenes 9-dim boxes + angle-vector coder, Lyft 7-dim boxes
   augment.npz       random_flip(_both) + global_rotation + global_scaling_v2 (core/sampler/preprocess.py:796-861)
                     with a seeded NumPy stream, 7-dim (KITTI) and 9-dim (nuScenes) boxes
+  collate.pt        collate_kitti (torchie/parallel/collate.py:90-150) on ragged frames, every key class
   sampler.npz       DistributedGroupSampler (datasets/loader/sampler.py:138-224): per-rank indices, two epochs
   vfe_pfn.pt        VoxelFeatureExtractorV3 (voxel_encoder.py:197-211), PillarFeatureNet +
                     PointPillarsScatter (pillar_encoder.py:17-211)
@@ -460,9 +461,31 @@ def sampler_cases():
     print("sampler:", {k: v.shape for k, v in out.items() if k.endswith("_r0")})
 
 
+def collate_cases():
+    """collate_kitti (torchie/parallel/collate.py:90-150) on three ragged frames with every key class."""
+    col = ref_loader.ref("det3d.torchie.parallel.collate")
+    rng = np.random.default_rng(8)
+    batch = []
+    for i, (m, n, g) in enumerate([(5, 40, 2), (3, 25, 0), (7, 33, 4)]):
+        batch.append(dict(
+            voxels=rng.random((m, 4, 4)).astype(np.float32), num_points=rng.integers(1, 5, m).astype(np.int32),
+            num_voxels=np.array([m], np.int64), coordinates=rng.integers(0, 30, (m, 3)).astype(np.int32),
+            points=rng.random((n, 4)).astype(np.float32), shape=np.array([70, 80, 10], np.int64),
+            anchors=[rng.random((12, 7)).astype(np.float32), rng.random((6, 7)).astype(np.float32)],
+            labels=[rng.integers(-1, 2, 12).astype(np.int32), rng.integers(-1, 3, 6).astype(np.int32)],
+            reg_targets=[rng.random((12, 7)).astype(np.float32), rng.random((6, 7)).astype(np.float32)],
+            reg_weights=[rng.random(12).astype(np.float32), rng.random(6).astype(np.float32)],
+            gt_boxes=[rng.random((g, 7)), rng.random((max(g - 1, 0), 7))],
+            calib=dict(rect=rng.random((4, 4)).astype(np.float32), P2=rng.random((4, 4)).astype(np.float32)),
+            metadata=dict(token="frame%d" % i, num_point_features=4)))
+    out = col.collate_kitti(batch)
+    torch.save(dict(batch=batch, out=out), os.path.join(HERE, "collate.pt"))
+    print("collate:", {k: (tuple(v.shape) if hasattr(v, "shape") else type(v).__name__) for k, v in out.items()})
+
+
 def main():
     ref_loader.install()
-    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "sampler"]
+    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "sampler", "collate"]
     if "anchors" in which:
         anchors_targets()
     if "tasks" in which:
@@ -471,6 +494,8 @@ def main():
         augment_cases()
     if "sampler" in which:
         sampler_cases()
+    if "collate" in which:
+        collate_cases()
     if "voxel" in which:
         voxel_cases()
     if "iou" in which:

@@ -263,3 +263,39 @@ def test_numpy_assign_restatement_vs_reference_randomised():
     out = subprocess.run([sys.executable, script, "40"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "identical to the reference" in out.stdout
+
+
+def test_collate_kitti_and_example_to_device_vs_reference_golden():
+    """det3d_amd.collate vs the reference's collate_kitti output (tests/golden/collate.pt): keys, dtypes, values;
+    then the adapter that turns the collated points into the device voxelizer's input."""
+    import numpy as np
+
+    from det3d_amd import collate
+
+    g = _load("collate.pt")
+    mine, ref = collate.collate_kitti(g["batch"]), g["out"]
+    assert list(mine) == list(ref)
+
+    def same(a, b, path):
+        assert type(a) is type(b), path
+        if isinstance(a, dict):
+            assert list(a) == list(b), path
+            for k in a:
+                same(a[k], b[k], path + "." + str(k))
+        elif isinstance(a, (list, tuple)):
+            assert len(a) == len(b), path
+            for i, (x, y) in enumerate(zip(a, b)):
+                same(x, y, "%s[%d]" % (path, i))
+        elif torch.is_tensor(a):
+            assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b), path
+        elif isinstance(a, np.ndarray):
+            assert a.dtype == b.dtype and np.array_equal(a, b), path
+        else:
+            assert a == b, path
+
+    same(mine, ref, "example")
+    dev = collate.example_to_device(mine, torch.device("cpu"))
+    assert set(dev) == set(mine) and dev["shape"] is mine["shape"] and torch.equal(dev["labels"][1], mine["labels"][1])
+    pts, off = collate.points_for_device_voxelizer(mine)
+    assert off.tolist() == [0, 40, 65, 98] and pts.shape == (98, 4) and pts.dtype == torch.float32
+    assert torch.equal(pts[40:65], torch.from_numpy(g["batch"][1]["points"]))
