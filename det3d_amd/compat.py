@@ -40,7 +40,7 @@ def install(force=False):
     global _DONE
     if _DONE and not force:
         return
-    from . import box_ops, builder, checkpoint, config, iou3d_utils, point_cloud_ops, registry
+    from . import box_ops, builder, checkpoint, collate, config, iou3d_utils, point_cloud_ops, registry
     from . import spconv as sp
 
     if force or not _real_module_available("det3d"):
@@ -52,6 +52,7 @@ def install(force=False):
         _alias("det3d.torchie", Config=config.Config, ConfigDict=config.ConfigDict).__path__ = []
         _alias("det3d.torchie.trainer", load_checkpoint=checkpoint.load_checkpoint,
                save_checkpoint=checkpoint.save_checkpoint, load_state_dict=checkpoint.load_state_dict)
+        _alias("det3d.torchie.parallel", collate_kitti=collate.collate_kitti)
         _alias("det3d.models", build_detector=builder.build_detector, build_reader=builder.build_reader,
                build_backbone=builder.build_backbone, build_neck=builder.build_neck,
                build_head=builder.build_head, build_loss=builder.build_loss,
