@@ -1,0 +1,55 @@
+"""bench.py contract pieces that do not need a GPU: the algorithmic-bytes formula of SURVEY.md 8(d), the flags the
+driver passes, the recorded bench line's schema, and that the script refuses to run without a GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+
+
+def test_algorithmic_bytes_formula():
+    import bench
+
+    # B_alg = P*Cin*e + P*8 + Nout*Cout*e + kvol*Cin*Cout*e
+    assert bench.b_alg("fwd", 64, 64, 1000, 13000, 27, 2) == 13000 * 64 * 2 + 13000 * 8 + 1000 * 64 * 2 + 27 * 64 * 64 * 2
+    assert bench.b_alg("dgrad", 32, 64, 10, 20, 27, 4) == 20 * 32 * 4 + 20 * 8 + 10 * 64 * 4 + 27 * 32 * 64 * 4
+    assert bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_driver_flags_parse(monkeypatch):
+    import bench
+
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "7", "--warmup", "3"])
+    a = bench.parse()
+    assert (a.gpus, a.steps, a.warmup, a.batch, a.points, a.dtype) == (8, 7, 3, 4, 20000, "bf16")
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert a.gpus == 1 and a.steps >= 10 and a.warmup >= 1 and not a.no_gc_freeze
+
+
+def test_recorded_bench_line_has_the_contract_fields():
+    d = json.load(open(os.path.join(ROOT, "profiles", "round1_bench_v5.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert abs(d["value"] - d["config"]["frames_per_gpu"] * d["n_gpus"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-2
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
+def test_bench_refuses_to_run_without_gpu():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "no CPU fallback" in (out.stderr + out.stdout)
