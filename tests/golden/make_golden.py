@@ -16,6 +16,8 @@ committed; tests never import the reference.  What each file pins:
                     groups: nuScenes 9-dim boxes + angle-vector coder, Lyft 7-dim boxes
   augment.npz       random_flip(_both) + global_rotation + global_scaling_v2 (core/sampler/preprocess.py:796-861)
                     with a seeded NumPy stream, 7-dim (KITTI) and 9-dim (nuScenes) boxes
+  assign_pipeline.npz  the AssignTarget pipeline step (datasets/pipelines/preprocess.py:306-483) built from the
+                    nuScenes-CBGS and Lyft assigner configs: per-task labels / positive targets / anchor checksums
   collate.pt        collate_kitti (torchie/parallel/collate.py:90-150) on ragged frames, every key class
   sampler.npz       DistributedGroupSampler (datasets/loader/sampler.py:138-224): per-rank indices, two epochs
   vfe_pfn.pt        VoxelFeatureExtractorV3 (voxel_encoder.py:197-211), PillarFeatureNet +
@@ -483,9 +485,64 @@ def collate_cases():
     print("collate:", {k: (tuple(v.shape) if hasattr(v, "shape") else type(v).__name__) for k, v in out.items()})
 
 
+def assign_pipeline():
+    """The reference's AssignTarget pipeline step itself (datasets/pipelines/preprocess.py:306-483) built from the
+    nuScenes CBGS assigner config (6 task groups, 10 classes, 128x128 feature map) and from the Lyft one, on
+    synthetic annotations.  Anchors are 12 MB per config, so the golden keeps labels (int8), the positive rows of
+    the regression targets and a checksum + samples of the anchors."""
+    pp = ref_loader.ref("det3d.datasets.pipelines.preprocess")
+    from det3d_amd import Config
+
+    root = os.path.dirname(os.path.dirname(HERE))
+    _mg = np.meshgrid
+    np.meshgrid = lambda *a, **k: list(_mg(*a, **k))
+    out = {}
+    try:
+        for tag, cfg_name, grid, nd in (("nusc", "nusc_cbgs.py", [1024, 1024, 40], 9), ("lyft", "lyft_cbgs.py", [2016, 2016, 40], 7)):
+            cfg = Config.fromfile(os.path.join(root, "det3d_amd", "configs", cfg_name))
+            at = pp.AssignTarget(cfg=cfg.assigner)
+            names_all = list(cfg.class_names)
+            gens = {g.class_name: g for g in cfg.target_assigner.anchor_generators}
+            rng = np.random.default_rng(31 if nd == 9 else 32)
+            n = 24
+            cls = rng.integers(1, len(names_all) + 1, n).astype(np.int32)
+            cls[:2] = [1, len(names_all)]
+            gt = np.zeros((n, nd), np.float32)
+            lim = 45.0 if nd == 9 else 90.0
+            gt[:, :2] = rng.uniform(-lim, lim, (n, 2))
+            for i in range(n):
+                g = gens[names_all[cls[i] - 1]]
+                gt[i, 2] = g.anchor_ranges[2]
+                gt[i, 3:6] = np.array(g.sizes) * rng.uniform(0.85, 1.2, 3)
+            gt[:, -1] = rng.uniform(-6.0, 6.0, n)             # outside [-pi, pi]: exercises limit_period
+            if nd == 9:
+                gt[:, 6:8] = rng.normal(0, 2, (n, 2))
+                gt[3, 6:8] = np.nan
+            res = dict(mode="train", lidar=dict(voxels=dict(shape=np.array(grid)),
+                                                annotations=dict(gt_boxes=gt.copy(), gt_classes=cls.copy(),
+                                                                 gt_names=np.array([names_all[c - 1] for c in cls]))))
+            res, _ = at(res, {})
+            ex = res["lidar"]["targets"]
+            out[tag + "_gt"], out[tag + "_cls"], out[tag + "_grid"] = gt, cls, np.array(grid)
+            out[tag + "_ntask"] = np.array(len(ex["anchors"]))
+            for t in range(len(ex["anchors"])):
+                a, lab, tgt, w = ex["anchors"][t], ex["labels"][t], ex["reg_targets"][t], ex["reg_weights"][t]
+                pos = np.where(lab > 0)[0]
+                assert np.array_equal(np.where(w > 0)[0], pos) and not tgt[lab <= 0].any()
+                out["%s_t%d_labels" % (tag, t)] = lab.astype(np.int8)
+                out["%s_t%d_pos_targets" % (tag, t)] = tgt[pos]
+                out["%s_t%d_anchor_sum" % (tag, t)] = a.astype(np.float64).sum(0)
+                out["%s_t%d_anchor_rows" % (tag, t)] = a[:: max(len(a) // 64, 1)]
+                out["%s_t%d_task_gt" % (tag, t)] = res["lidar"]["annotations"]["gt_boxes"][t]
+                print("assign_pipeline", tag, t, a.shape, "pos", len(pos), "ignored", int((lab < 0).sum()))
+    finally:
+        np.meshgrid = _mg
+    np.savez_compressed(os.path.join(HERE, "assign_pipeline.npz"), **out)
+
+
 def main():
     ref_loader.install()
-    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "sampler", "collate"]
+    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "sampler", "collate", "pipeline"]
     if "anchors" in which:
         anchors_targets()
     if "tasks" in which:
@@ -496,6 +553,8 @@ def main():
         sampler_cases()
     if "collate" in which:
         collate_cases()
+    if "pipeline" in which:
+        assign_pipeline()
     if "voxel" in which:
         voxel_cases()
     if "iou" in which:

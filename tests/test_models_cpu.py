@@ -299,3 +299,94 @@ def test_collate_kitti_and_example_to_device_vs_reference_golden():
     pts, off = collate.points_for_device_voxelizer(mine)
     assert off.tolist() == [0, 40, 65, 98] and pts.shape == (98, 4) and pts.dtype == torch.float32
     assert torch.equal(pts[40:65], torch.from_numpy(g["batch"][1]["points"]))
+
+
+@pytest.mark.parametrize("tag,cfg_name", [("nusc", "nusc_cbgs.py"), ("lyft", "lyft_cbgs.py")])
+def test_assign_target_pipeline_step_vs_reference(tag, cfg_name):
+    """det3d_amd.target_assigner.AssignTarget (reference constructor / __call__ interface) vs the output of the
+    reference's own AssignTarget built from the same assigner config (tests/golden/assign_pipeline.npz): all task
+    groups, class re-basing, yaw wrapping, NaN velocities, labels bit-exact, positive targets within 1e-6."""
+    import numpy as np
+
+    from det3d_amd import Config
+    from det3d_amd.target_assigner import AssignTarget
+
+    z = np.load(os.path.join(GOLDEN, "assign_pipeline.npz"))
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(here, "det3d_amd", "configs", cfg_name))
+    at = AssignTarget(cfg=cfg.assigner)
+    names = list(cfg.class_names)
+    cls = z[tag + "_cls"]
+    res = dict(mode="train", lidar=dict(voxels=dict(shape=z[tag + "_grid"]), annotations=dict(
+        gt_boxes=z[tag + "_gt"].copy(), gt_classes=cls.copy(), gt_names=np.array([names[c - 1] for c in cls]))))
+    res, _ = at(res, {})
+    ex = res["lidar"]["targets"]
+    assert len(ex["anchors"]) == int(z[tag + "_ntask"]) == len(cfg.tasks)
+    for t in range(len(ex["anchors"])):
+        a, lab, tgt, w = ex["anchors"][t], ex["labels"][t], ex["reg_targets"][t], ex["reg_weights"][t]
+        # the reference pipeline hands np.int64 feature-map sizes to create_anchors_3d_range, so NumPy promotes
+        # its anchor centres (and everything downstream) to float64; ours stay float32: 1 ulp of float32 apart
+        assert z["%s_t%d_anchor_rows" % (tag, t)].dtype == np.float64 and a.dtype == np.float32
+        assert np.allclose(a[:: max(len(a) // 64, 1)], z["%s_t%d_anchor_rows" % (tag, t)], atol=4e-6, rtol=0)
+        assert np.allclose(a.astype(np.float64).sum(0), z["%s_t%d_anchor_sum" % (tag, t)], rtol=1e-6, atol=2.0)
+        assert np.array_equal(lab.astype(np.int8), z["%s_t%d_labels" % (tag, t)]), t
+        pos = np.where(lab > 0)[0]
+        assert np.allclose(tgt[pos], z["%s_t%d_pos_targets" % (tag, t)], atol=2e-5), t
+        assert np.array_equal(np.where(w > 0)[0], pos) and not tgt[lab <= 0].any()
+        assert np.allclose(res["lidar"]["annotations"]["gt_boxes"][t], z["%s_t%d_task_gt" % (tag, t)], atol=1e-6,
+                           equal_nan=True)
+
+
+def test_assign_target_batch_path_prepares_tasks_like_the_frame_path(monkeypatch):
+    """AssignTarget.assign_batch (device path) differs from __call__ only in how it hands each task group its boxes
+    (class masking on the padded batch, compaction for single-class groups, yaw wrapping in the wrapper).  With the
+    device launch replaced by a NumPy shim that has the KERNEL's semantics (first `count` boxes; class filter only
+    for multi-class groups) both paths must give identical targets."""
+    import numpy as np
+
+    from det3d_amd import Config, synthetic
+    from det3d_amd.target_assigner import AssignTarget
+
+    def shim(anchors, k, r, hi, lo, gt, gt_classes, gt_count, encode_angle_vector=False, limit_gt_angle=False):
+        anc = anchors.numpy()
+        labs, tgts, ws = [], [], []
+        for b in range(gt.shape[0]):
+            n = int(gt_count[b])
+            boxes, cls = gt[b, :n].numpy().copy(), gt_classes[b, :n].numpy().copy()
+            if limit_gt_angle:
+                boxes[:, -1] = boxes[:, -1] - np.floor(boxes[:, -1] / (2 * np.pi) + 0.5) * (2 * np.pi)
+            if k == 1:
+                cls = np.ones_like(cls)          # the single-class kernel path takes every listed box
+            else:
+                boxes, cls = boxes[cls > 0], cls[cls > 0]
+            l, t, w = synthetic.assign_targets_task(anc, k, r, hi, lo, boxes, cls, encode_angle_vector)
+            labs.append(torch.from_numpy(l))
+            tgts.append(torch.from_numpy(t))
+            ws.append(torch.from_numpy(w))
+        return torch.stack(labs), torch.stack(tgts), torch.stack(ws)
+
+    monkeypatch.setattr(synthetic, "assign_targets_task_device", shim)
+    z = np.load(os.path.join(GOLDEN, "assign_pipeline.npz"))
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(here, "det3d_amd", "configs", "nusc_cbgs.py"))
+    at = AssignTarget(cfg=cfg.assigner)
+    names = list(cfg.class_names)
+    grid = z["nusc_grid"]
+    frames = [(z["nusc_gt"], z["nusc_cls"]), (z["nusc_gt"][5:9], z["nusc_cls"][5:9]),
+              (np.zeros((0, 9), np.float32), np.zeros((0,), np.int32))]
+    gmax = max(len(c) for _, c in frames)
+    gt = np.zeros((3, gmax, 9), np.float32)
+    cls = np.zeros((3, gmax), np.int64)
+    for i, (g, c) in enumerate(frames):
+        gt[i, : len(g)], cls[i, : len(c)] = g, c
+    cnt = torch.tensor([len(c) for _, c in frames], dtype=torch.int32)
+    batch = at.assign_batch(grid, torch.from_numpy(gt), torch.from_numpy(cls), cnt)
+    for i, (g, c) in enumerate(frames):
+        res = dict(mode="train", lidar=dict(voxels=dict(shape=grid), annotations=dict(
+            gt_boxes=g.copy(), gt_classes=c.copy(), gt_names=np.array([names[k - 1] for k in c]))))
+        ex = at(res, {})[0]["lidar"]["targets"]
+        for t in range(len(cfg.tasks)):
+            assert np.array_equal(batch["labels"][t][i].numpy(), ex["labels"][t]), (i, t)
+            assert np.allclose(batch["reg_targets"][t][i].numpy(), ex["reg_targets"][t], atol=1e-6, equal_nan=True)
+            assert np.array_equal(batch["reg_weights"][t][i].numpy(), ex["reg_weights"][t])
+            assert batch["anchors"][t].shape == (3,) + ex["anchors"][t].shape
