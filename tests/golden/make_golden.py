@@ -18,6 +18,7 @@ committed; tests never import the reference.  What each file pins:
                     with a seeded NumPy stream, 7-dim (KITTI) and 9-dim (nuScenes) boxes
   assign_pipeline.npz  the AssignTarget pipeline step (datasets/pipelines/preprocess.py:306-483) built from the
                     nuScenes-CBGS and Lyft assigner configs: per-task labels / positive targets / anchor checksums
+  range_filter.npz  filter_gt_box_outside_range (core/sampler/preprocess.py:133-147)
   collate.pt        collate_kitti (torchie/parallel/collate.py:90-150) on ragged frames, every key class
   sampler.npz       DistributedGroupSampler (datasets/loader/sampler.py:138-224): per-rank indices, two epochs
   vfe_pfn.pt        VoxelFeatureExtractorV3 (voxel_encoder.py:197-211), PillarFeatureNet +
@@ -540,9 +541,26 @@ def assign_pipeline():
     np.savez_compressed(os.path.join(HERE, "assign_pipeline.npz"), **out)
 
 
+def range_filter_cases():
+    """filter_gt_box_outside_range (core/sampler/preprocess.py:133-147) incl. boxes touching / straddling the border."""
+    prep = ref_loader.ref("det3d.core.sampler.preprocess")
+    rng = np.random.default_rng(12)
+    n = 200
+    gt = np.zeros((n, 7), np.float32)
+    gt[:, 0] = rng.uniform(-10, 80, n)
+    gt[:, 1] = rng.uniform(-50, 50, n)
+    gt[:, 3:6] = rng.uniform(0.5, 5, (n, 3))
+    gt[:, 6] = rng.uniform(-3.2, 3.2, n)
+    gt[:4] = [[0, 0, 0, 2, 2, 1, 0], [-1, 0, 0, 2, 2, 1, 0], [70.4, 40, 0, 2, 4, 1, 0.3], [71.5, 0, 0, 2, 2, 1, 0]]
+    lim = np.array([0, -40.0, 70.4, 40.0], np.float32)
+    mask = prep.filter_gt_box_outside_range(gt, lim)
+    np.savez_compressed(os.path.join(HERE, "range_filter.npz"), gt=gt, limit=lim, mask=mask)
+    print("range_filter:", int(mask.sum()), "of", n, mask[:4])
+
+
 def main():
     ref_loader.install()
-    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "sampler", "collate", "pipeline"]
+    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "sampler", "collate", "pipeline", "rangefilter"]
     if "anchors" in which:
         anchors_targets()
     if "tasks" in which:
@@ -555,6 +573,8 @@ def main():
         collate_cases()
     if "pipeline" in which:
         assign_pipeline()
+    if "rangefilter" in which:
+        range_filter_cases()
     if "voxel" in which:
         voxel_cases()
     if "iou" in which:
