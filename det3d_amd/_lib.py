@@ -59,6 +59,7 @@ SIGNATURES = {
     "d3d_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
 }
 
+ABI_VERSION = 2  # include/d3d.h D3D_ABI_VERSION
 D3D_F32 = 0
 D3D_BF16 = 1
 D3D_BN_COPIES = 8
@@ -83,7 +84,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.d3d_abi_version() != 1:
+        if L.d3d_abi_version() != ABI_VERSION:
             raise D3dError("libd3d_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 1
+#define D3D_ABI_VERSION 2 /* 2: d3d_bn_relu_bwd takes partial_ws; BN scratch is D3D_BN_COPIES * 2c; round-1 additions */
 
 #define D3D_OK 0
 #define D3D_EINVAL -1    /* bad argument / unsupported shape           */
