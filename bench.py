@@ -27,7 +27,6 @@ if "--no-channels-last" not in sys.argv:
     os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
     os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC_BATCHNORM", "1")
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

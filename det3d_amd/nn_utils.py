@@ -4,7 +4,6 @@
   get_paddings_indicator          det3d/models/utils/misc.py:180-202
 """
 import os
-import sys
 from collections import OrderedDict
 
 import torch

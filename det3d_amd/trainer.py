@@ -10,7 +10,6 @@ import contextlib
 import gc
 import math
 
-import numpy as np
 import torch
 
 from . import dist as d3d_dist
