@@ -68,6 +68,15 @@ class TrainStep:
         self.global_step = 0
         self.last = {}
 
+    # ---- resume (the reference keeps epoch / iter / optimizer in the checkpoint: trainer.py save_checkpoint,
+    # resume :470-499); here the schedule position is the global step
+    def state_dict(self):
+        return dict(global_step=self.global_step, optimizer=self.opt.state_dict())
+
+    def load_state_dict(self, state):
+        self.global_step = int(state["global_step"])
+        self.opt.load_state_dict(state["optimizer"])
+
     def _ctx(self):
         if self.autocast_dtype is None:
             return contextlib.nullcontext()

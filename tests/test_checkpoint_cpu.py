@@ -125,3 +125,47 @@ def test_fold_bn_sparse_layers_matches_oracle_conv_plus_bn():
         want = nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
         got = spconv_ref.indice_conv(feats, conv.weight.detach(), pr, n_out, bias=conv.bias.detach())
         assert torch.allclose(got, want, atol=2e-5, rtol=1e-4)
+
+
+class _ToyDetector(nn.Module):
+    """losses-dict interface of the detectors (forward(example, return_loss=True) -> {"loss": [...]})"""
+
+    def __init__(self):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 3))
+
+    def forward(self, example, return_loss=True):
+        return {"loss": [(self.net(example["x"]) - example["y"]).pow(2).mean()]}
+
+
+def test_train_step_resume_continues_the_same_trajectory(tmp_path):
+    """save after 3 steps (model + optimizer + schedule position), resume in fresh objects, 2 more steps ==
+    5 uninterrupted steps: one-cycle lr / momentum, true weight decay and Adam moments all carry over."""
+    from det3d_amd.trainer import TrainStep
+
+    torch.manual_seed(0)
+    data = [dict(x=torch.randn(8, 6), y=torch.randn(8, 3)) for _ in range(5)]
+
+    def fresh():
+        torch.manual_seed(1)
+        m = _ToyDetector()
+        return m, TrainStep(m, total_steps=5, lr_max=1e-2, wd=0.01, grad_clip=35.0)
+
+    m_ref, t_ref = fresh()
+    ref_losses = [float(t_ref(d)) for d in data]
+    m_a, t_a = fresh()
+    for d in data[:3]:
+        t_a(d)
+    f = str(tmp_path / "resume.pth")
+    checkpoint.save_checkpoint(m_a, f, meta=dict(train_step=t_a.state_dict()))
+    m_b, t_b = fresh()
+    with torch.no_grad():
+        for p in m_b.parameters():
+            p.add_(1.0)  # make sure the loaded state is what counts
+    ck = checkpoint.load_checkpoint(m_b, f, map_location="cpu", strict=True)
+    t_b.load_state_dict(ck["meta"]["train_step"])
+    assert t_b.global_step == 3
+    resumed = [float(t_b(d)) for d in data[3:]]
+    assert resumed == pytest.approx(ref_losses[3:], rel=1e-6)
+    for p, q in zip(m_ref.parameters(), m_b.parameters()):
+        assert torch.allclose(p, q, atol=1e-7)
