@@ -33,6 +33,18 @@ def build_oracle(force=False):
     return LIB
 
 
+def build_oracle_sanitized(force=False):
+    """AddressSanitizer + UBSan build of the same C restatements (oracle/libd3d_oracle_asan.so): the checker the
+    GPU parity tests trust is itself run under sanitizers by tests/test_oracle_sanitizers_cpu.py."""
+    out = os.path.join(HERE, "libd3d_oracle_asan.so")
+    srcs = [os.path.join(HERE, s) for s in C_SOURCES]
+    if force or _stale(out, srcs):
+        cmd = ["gcc", "-O1", "-g", "-std=c11", "-ffp-contract=off", "-fPIC", "-shared", "-fsanitize=address,undefined",
+               "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-o", out] + srcs + ["-lm"]
+        subprocess.run(cmd, check=True)
+    return out
+
+
 def ref_module_path():
     suffix = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
     return os.path.join(REF_DIR, "d3d_ref" + suffix)
