@@ -7,12 +7,17 @@ on the host cores).
 Follows, with the same module nesting so a det3d_amd state_dict loads unchanged:
   reader    det3d/models/readers/voxel_encoder.py:206-211      mean VFE
   backbone  det3d/models/backbones/scn.py:92-197               SpMiddleFHD (layer list :106-157)
+            det3d/models/backbones/scn.py:46-89,308-370        SparseBasicBlock, SpMiddleResNetFHD
+            det3d/models/readers/pillar_encoder.py:17-211      PFNLayer, PillarFeatureNet, PointPillarsScatter
   neck      det3d/models/necks/rpn.py:70-159                   RPN blocks / deblocks / concat
   head      det3d/models/bbox_heads/mg_head.py:215-230,528-533 1x1 convs, NHWC permute
   loss      mg_head.py:535-695 + losses/losses.py:146-336,407-446
   predict   mg_head.py:697-1085 + core/bbox/box_torch_ops.py:80-148,528-549
 The RPN/head/loss restatements are pinned by tests/golden/{rpn,head}.pt (outputs of the
 reference's own modules); the sparse part inherits spconv_ref's "parity unpinned" status.
+Whole detectors (KITTI SECOND, nuScenes CBGS, Lyft CBGS, nuScenes PointPillars) are pinned by
+tests/golden/detectors.pt: the reference's own VoxelNet / PointPillars classes -- scn.py executed over
+oracle/spconv_shim.py -- run in the build container on cropped ranges (tests/golden/make_golden.py).
 """
 import math
 
@@ -63,6 +68,106 @@ class SpMiddleFHDRef(nn.Module):
         d = dense(feats, idx, batch, shape)
         n, c, dd, h, w = d.shape
         return d.view(n, c * dd, h, w)
+
+
+class SparseBasicBlockRef(nn.Module):
+    """scn.py:46-89 -- conv1 -> bn1 -> relu -> conv2 -> bn2 -> (+ identity) -> relu; both convs carry a bias
+    (`bias = norm_cfg is not None` after the default was filled in, :60-63)."""
+
+    def __init__(self, c, key):
+        super().__init__()
+        self.conv1 = SparseConvRef(c, c, 3, subm=True, bias=True, indice_key=key)
+        self.bn1 = nn.BatchNorm1d(c, **BN)
+        self.conv2 = SparseConvRef(c, c, 3, subm=True, bias=True, indice_key=key)
+        self.bn2 = nn.BatchNorm1d(c, **BN)
+
+    def forward(self, st):
+        identity = st[0]
+        out = self.conv1(st)
+        out = (F.relu(self.bn1(out[0])),) + out[1:]
+        out = self.conv2(out)
+        return (F.relu(self.bn2(out[0]) + identity),) + out[1:]
+
+
+def _run_sparse_stack(seq, feats, coors, batch_size, input_shape):
+    shape = (np.array(input_shape[::-1]) + [1, 0, 0]).tolist()
+    st = (feats, np.asarray(coors).astype(np.int32), shape, batch_size, {})
+    for m in seq:
+        if isinstance(m, (SparseConvRef, SparseBasicBlockRef)):
+            st = m(st)
+        else:
+            st = (m(st[0]),) + st[1:]
+    feats, idx, shape, batch, cache = st
+    d = dense(feats, idx, batch, shape)
+    n, c, dd, h, w = d.shape
+    return st, d.view(n, c * dd, h, w)
+
+
+class SpMiddleResNetFHDRef(nn.Module):
+    """scn.py:308-370; child indices of `middle_conv` equal the reference's SparseSequential."""
+
+    def __init__(self, cin=5):
+        super().__init__()
+        L = [SparseConvRef(cin, 16, 3, subm=True, indice_key="res0"), nn.BatchNorm1d(16, **BN), nn.ReLU(),
+             SparseBasicBlockRef(16, "res0"), SparseBasicBlockRef(16, "res0")]
+        for i, (ci, co, pad) in enumerate([(16, 32, 1), (32, 64, 1), (64, 128, [0, 1, 1])]):
+            L += [SparseConvRef(ci, co, 3, 2, pad), nn.BatchNorm1d(co, **BN), nn.ReLU(),
+                  SparseBasicBlockRef(co, "res%d" % (i + 1)), SparseBasicBlockRef(co, "res%d" % (i + 1))]
+        L += [SparseConvRef(128, 128, (3, 1, 1), (2, 1, 1), 0), nn.BatchNorm1d(128, **BN), nn.ReLU()]
+        self.middle_conv = nn.Sequential(*L)
+
+    def forward(self, feats, coors, batch_size, input_shape):
+        self.last, out = _run_sparse_stack(self.middle_conv, feats, coors, batch_size, input_shape)
+        return out
+
+
+class _PFNLayerRef(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.linear = nn.Linear(cin, cout, bias=False)
+        self.norm = nn.BatchNorm1d(cout, **BN)
+
+
+class PillarFeatureNetRef(nn.Module):
+    """pillar_encoder.py:60-155 with a single (last) PFNLayer, as every shipped config has."""
+
+    def __init__(self, num_input_features, num_filters, voxel_size, pc_range):
+        super().__init__()
+        assert len(num_filters) == 1
+        self.pfn_layers = nn.ModuleList([_PFNLayerRef(num_input_features + 5, num_filters[0])])
+        self.vx, self.vy = voxel_size[0], voxel_size[1]
+        self.x_offset = self.vx / 2 + pc_range[0]
+        self.y_offset = self.vy / 2 + pc_range[1]
+
+    def forward(self, features, num_voxels, coors):
+        mean = features[:, :, :3].sum(1, keepdim=True) / num_voxels.type_as(features).view(-1, 1, 1)
+        f_cluster = features[:, :, :3] - mean
+        f_center = torch.zeros_like(features[:, :, :2])
+        f_center[:, :, 0] = features[:, :, 0] - (coors[:, 3].to(features.dtype).unsqueeze(1) * self.vx + self.x_offset)
+        f_center[:, :, 1] = features[:, :, 1] - (coors[:, 2].to(features.dtype).unsqueeze(1) * self.vy + self.y_offset)
+        x = torch.cat([features, f_cluster, f_center], -1)
+        T = x.shape[1]
+        mask = (torch.arange(T)[None, :] < num_voxels.view(-1, 1)).type_as(x).unsqueeze(-1)
+        x = x * mask
+        layer = self.pfn_layers[0]
+        x = layer.linear(x)
+        x = layer.norm(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+        return F.relu(x).max(1)[0]
+
+
+class PointPillarsScatterRef(nn.Module):
+    """pillar_encoder.py:158-211"""
+
+    def __init__(self, c):
+        super().__init__()
+        self.c = c
+
+    def forward(self, feats, coors, batch_size, input_shape):
+        nx, ny = int(input_shape[0]), int(input_shape[1])
+        coors = torch.as_tensor(np.asarray(coors)).long()
+        canvas = feats.new_zeros((batch_size, self.c, ny * nx))
+        canvas[coors[:, 0], :, coors[:, 2] * nx + coors[:, 3]] = feats
+        return canvas.view(batch_size, self.c, ny, nx)
 
 
 def _rpn_block(cin, cout, n, stride):
@@ -140,41 +245,76 @@ def _smooth_l1(pred, tgt, weights, sigma=3.0):
     return loss * weights.unsqueeze(-1)
 
 
-def _decode(enc, anchors):
-    xa, ya, za, wa, la, ha, ra = anchors.unbind(-1)
-    xt, yt, zt, wt, lt, ht, rt = enc.unbind(-1)
+def _decode(enc, anchors, vec=False):
+    """second_box_decode, core/bbox/box_torch_ops.py:80-148 (7- and 9-dim anchors, optional angle vector)"""
+    if anchors.shape[-1] == 9:
+        xa, ya, za, wa, la, ha, vxa, vya, ra = anchors.unbind(-1)
+    else:
+        xa, ya, za, wa, la, ha, ra = anchors.unbind(-1)
+    t = enc.unbind(-1)
+    xt, yt, zt, wt, lt, ht = t[:6]
     diag = torch.sqrt(la ** 2 + wa ** 2)
-    return torch.stack([xt * diag + xa, yt * diag + ya, zt * ha + za, torch.exp(wt) * wa,
-                        torch.exp(lt) * la, torch.exp(ht) * ha, rt + ra], -1)
+    out = [xt * diag + xa, yt * diag + ya, zt * ha + za, torch.exp(wt) * wa, torch.exp(lt) * la, torch.exp(ht) * ha]
+    rest = t[6:]
+    if anchors.shape[-1] == 9:
+        out += [rest[0] + vxa, rest[1] + vya]
+        rest = rest[2:]
+    if vec:
+        out.append(torch.atan2(rest[1] + torch.sin(ra), rest[0] + torch.cos(ra)))
+    else:
+        out.append(rest[0] + ra)
+    return torch.stack(out, -1)
 
 
-class SecondRef(nn.Module):
-    """KITTI-car SECOND on the CPU.  `example` uses the collate_kitti keys with CPU tensors."""
+class DetectorRef(nn.Module):
+    """VoxelNet (detectors/voxelnet.py:22-59) / PointPillars (detectors/point_pillars.py:22-59) on the CPU,
+    any of the shipped model configs.  `example` uses the collate_kitti keys with CPU tensors."""
 
     def __init__(self, cfg):
         super().__init__()
-        m = cfg["model"] if isinstance(cfg, dict) else cfg.model
+        g = (lambda o, k: o[k]) if isinstance(cfg, dict) else (lambda o, k: getattr(o, k))
+        m = g(cfg, "model")
         neck = m["neck"]
-        self.n_in = m["reader"]["num_input_features"]
-        self.backbone = SpMiddleFHDRef(m["backbone"]["num_input_features"])
+        rd, bb = m["reader"], m["backbone"]
+        self.reader_type = rd["type"]
+        self.n_in = rd["num_input_features"]
+        if rd["type"] == "PillarFeatureNet":
+            self.reader = PillarFeatureNetRef(rd["num_input_features"], list(rd["num_filters"]), rd["voxel_size"],
+                                              rd["pc_range"])
+        if bb["type"] == "SpMiddleFHD":
+            self.backbone = SpMiddleFHDRef(bb["num_input_features"])
+        elif bb["type"] == "SpMiddleResNetFHD":
+            self.backbone = SpMiddleResNetFHDRef(bb["num_input_features"])
+        elif bb["type"] == "PointPillarsScatter":
+            self.backbone = PointPillarsScatterRef(bb.get("num_input_features", 64))
+        else:
+            raise ValueError(bb["type"])
         self.neck = RPNRef(neck["layer_nums"], neck["ds_layer_strides"], neck["ds_num_filters"],
                            neck["us_layer_strides"], neck["us_num_filters"], neck["num_input_features"])
         h = m["bbox_head"]
+        coder = h["box_coder"]
+        self.code_size, self.n_dim, self.vec = coder.code_size, coder.n_dim, bool(coder.vec_encode)
         self.num_classes = [len(t["class_names"]) for t in h["tasks"]]
         self.use_dir = h.get("loss_aux") is not None
+        self.sin_diff = bool(h.get("encode_rad_error_by_sin", True))
         self.dir_offset = h.get("direction_offset", 0.0)
-        self.bbox_head = _HeadRef(h["in_channels"], self.num_classes, 7, self.use_dir)
+        in_ch = h["in_channels"]
+        self.bbox_head = _HeadRef(in_ch[0] if isinstance(in_ch, (list, tuple)) else in_ch, self.num_classes,
+                                  self.code_size, self.use_dir)
         self.w_loc, self.w_cls = h["loss_bbox"]["loss_weight"], h["loss_cls"]["loss_weight"]
         self.w_dir = h["loss_aux"]["loss_weight"] if self.use_dir else 0.0
         self.pos_w = h["loss_norm"].get("pos_cls_weight", 1.0)
         self.neg_w = h["loss_norm"].get("neg_cls_weight", 1.0)
-        self.test_cfg = cfg["test_cfg"] if isinstance(cfg, dict) else cfg.test_cfg
+        self.test_cfg = g(cfg, "test_cfg")
 
     def features(self, example):
         v, n = example["voxels"], example["num_points"]
-        mean = v[:, :, : self.n_in].sum(1) / n.type_as(v).view(-1, 1)
-        x = self.backbone(mean, example["coordinates"].numpy(), len(example["num_voxels"]),
-                          [int(s) for s in example["shape"][0]])
+        coors = example["coordinates"]
+        if self.reader_type == "PillarFeatureNet":
+            f = self.reader(v, n, coors)
+        else:  # VoxelFeatureExtractorV3, voxel_encoder.py:206-211
+            f = v[:, :, : self.n_in].sum(1) / n.type_as(v).view(-1, 1)
+        x = self.backbone(f, coors.numpy(), len(example["num_voxels"]), [int(s) for s in example["shape"][0]])
         return self.neck(x)
 
     def forward(self, example, return_loss=True):
@@ -184,11 +324,12 @@ class SecondRef(nn.Module):
 
     def loss(self, example, preds):
         out = []
+        cs = self.code_size
         for ti, p in enumerate(preds):
             nc = self.num_classes[ti]
             labels = example["labels"][ti]
             B = labels.shape[0]
-            box = p["box_preds"].view(B, -1, 7)
+            box = p["box_preds"].view(B, -1, cs)
             cls = p["cls_preds"].view(B, -1, nc)
             tgt = example["reg_targets"][ti]
             pos, neg = labels > 0, labels == 0
@@ -197,11 +338,16 @@ class SecondRef(nn.Module):
             reg_w = pos.float() / norm
             ct = (labels * (labels >= 0).type_as(labels)).long()
             onehot = F.one_hot(ct, nc + 1)[..., 1:].float()
-            b1 = torch.cat([box[..., :-1], torch.sin(box[..., -1:]) * torch.cos(tgt[..., -1:])], -1)
-            b2 = torch.cat([tgt[..., :-1], torch.cos(box[..., -1:]) * torch.sin(tgt[..., -1:])], -1)
+            if self.sin_diff:
+                b1 = torch.cat([box[..., :-1], torch.sin(box[..., -1:]) * torch.cos(tgt[..., -1:])], -1)
+                b2 = torch.cat([tgt[..., :-1], torch.cos(box[..., -1:]) * torch.sin(tgt[..., -1:])], -1)
+            else:
+                b1, b2 = box, tgt
+            # WeightedSmoothL1Loss never applies its code_weights (losses.py:173: the attribute is read
+            # before it is set), so all code dimensions weigh 1
             loss = _smooth_l1(b1, b2, reg_w).sum() / B * self.w_loc + _focal(cls, onehot, cls_w).sum() / B * self.w_cls
             if self.use_dir:
-                an = example["anchors"][ti].view(B, -1, 7)
+                an = example["anchors"][ti].view(B, -1, self.n_dim)
                 rot = tgt[..., -1] + an[..., -1] - self.dir_offset
                 rot = rot - torch.floor(rot / (2 * math.pi) + 0.5) * 2 * math.pi
                 dt = (rot > 0).long()
@@ -224,8 +370,8 @@ class SecondRef(nn.Module):
             off = 0
             for ti, p in enumerate(preds):
                 nc = self.num_classes[ti]
-                an = example["anchors"][ti][b].view(-1, 7)
-                box = _decode(p["box_preds"][b].reshape(-1, 7).float(), an)
+                an = example["anchors"][ti][b].view(-1, self.n_dim)
+                box = _decode(p["box_preds"][b].reshape(-1, self.code_size).float(), an, self.vec)
                 sc_all = torch.sigmoid(p["cls_preds"][b].reshape(-1, nc).float())
                 sc, lab = (sc_all.squeeze(-1), torch.zeros(len(sc_all), dtype=torch.long)) if nc == 1 else sc_all.max(-1)
                 keep = sc >= tc["score_threshold"]
@@ -234,7 +380,7 @@ class SecondRef(nn.Module):
                 if len(sc):
                     k = min(len(sc), nms["nms_pre_max_size"])
                     sc_k, idx = torch.topk(sc, k)
-                    d6 = torch.cat([box[idx][:, [0, 1, 3, 4, 6]], sc_k[:, None]], 1).numpy()
+                    d6 = torch.cat([box[idx][:, [0, 1, 3, 4, -1]], sc_k[:, None]], 1).numpy()
                     sel = clib.rotate_nms_cc(d6, nms["nms_iou_threshold"])[: nms["nms_post_max_size"]]
                     sel = idx[torch.as_tensor(sel, dtype=torch.long)]
                 else:
@@ -249,6 +395,37 @@ class SecondRef(nn.Module):
             dets.append(dict(box3d_lidar=torch.cat(boxes_all), scores=torch.cat(scores_all),
                              label_preds=torch.cat(labels_all)))
         return dets
+
+
+SecondRef = DetectorRef  # the KITTI-car SECOND instance (bench.py's cpu_baseline, tests/test_e2e_gpu.py)
+
+
+def fill_deterministic(module, seed=0):
+    """Give `module` weights that depend only on (state-dict key, shape, seed) -- the golden script fills the
+    REFERENCE's model and the tests fill the product / oracle models with the same values without a 30 MB
+    weight fixture.  Conv / linear weights ~ N(0, 2 / fan_in); BatchNorm gamma ~ U(0.5, 1.5); biases and running
+    means ~ N(0, 0.1); running variances ~ U(0.5, 1.5)."""
+    import zlib
+
+    sd = module.state_dict()
+    with torch.no_grad():
+        for name in sorted(sd):
+            t = sd[name]
+            if not t.is_floating_point():
+                continue
+            g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + 7919 * seed) % (2 ** 31))
+            shape = tuple(t.shape)
+            if name.endswith("running_var"):
+                v = torch.rand(shape, generator=g) + 0.5
+            elif name.endswith("running_mean") or name.endswith("bias"):
+                v = torch.randn(shape, generator=g) * 0.1
+            elif t.dim() == 1:  # BatchNorm weight
+                v = torch.rand(shape, generator=g) + 0.5
+            else:
+                fan_in = (t.numel() // shape[-1]) if t.dim() == 5 else (t.numel() // shape[0])
+                v = torch.randn(shape, generator=g) * math.sqrt(2.0 / max(fan_in, 1))
+            t.copy_(v.to(t.dtype))
+    return module
 
 
 def cpu_example(host_batch, cfg_vox):

@@ -30,6 +30,15 @@ committed; tests never import the reference.  What each file pins:
                     it is replaced by this repo's oracle NMS, so head.pt pins everything
                     in predict() EXCEPT the polygon step.
   anchors_targets.npz  AnchorGeneratorRange + create_target_np (core/anchor/*)
+  detectors.pt      the reference's WHOLE detectors -- VoxelNet (detectors/voxelnet.py) / PointPillars
+                    (detectors/point_pillars.py) built by the reference's own registries from the four
+                    shipped model configs (KITTI SECOND, nuScenes CBGS, Lyft CBGS, nuScenes PointPillars):
+                    readers, scn.py (SpMiddleFHD / SpMiddleResNetFHD + SparseBasicBlock), PointPillarsScatter,
+                    RPN, MultiGroupHead forward / loss / predict -- on cropped ranges (detector_specs.py).
+                    scn.py runs over oracle/spconv_shim.py (spconv is un-vendored; its arithmetic is the
+                    oracle's, pinned to F.conv3d) and rotate_nms_cc is the oracle NMS (boost absent).
+  nms_gpu.npz       det3d/ops/nms/nms_gpu.py:22-126 (iou_device, nms_kernel, nms_postprocess: the +1-pixel
+                    axis-aligned NMS) run as plain Python through the numba stub
 """
 import collections
 import collections.abc
@@ -558,9 +567,160 @@ def range_filter_cases():
     print("range_filter:", int(mask.sum()), "of", n, mask[:4])
 
 
+def _dump_specs(path):
+    """the in-repo configs are loaded in a CHILD process (they import through det3d_amd's `det3d.*` aliases,
+    which must not coexist with ref_loader's real `det3d.*` modules here)."""
+    import subprocess
+
+    code = r"""
+import pickle, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import detector_specs as S
+out = {}
+for name in S.CASES:
+    cfg = S.load_cfg(name)
+    m = cfg.model.to_dict()
+    coder = cfg.model.bbox_head.box_coder
+    m["bbox_head"]["box_coder"] = dict(linear_dim=bool(coder.linear_dim), vec=bool(coder.vec_encode), n_dim=int(coder.n_dim))
+    m["neck"].pop("logger", None); m["bbox_head"].pop("logger", None)
+    out[name] = dict(model=m, test_cfg=cfg.test_cfg.to_dict())
+pickle.dump(out, open(%r, "wb"))
+""" % (HERE, os.path.dirname(os.path.dirname(HERE)), path)
+    subprocess.run([sys.executable, "-c", code], check=True)
+
+
+def detector_cases():
+    import pickle
+    import tempfile
+
+    import detector_specs as S
+    from oracle import clib, model_ref, spconv_shim
+
+    with tempfile.TemporaryDirectory() as td:
+        _dump_specs(os.path.join(td, "specs.pkl"))
+        specs = pickle.load(open(os.path.join(td, "specs.pkl"), "rb"))
+    sys.modules["spconv"] = spconv_shim  # scn.py: `import spconv; from spconv import SparseConv3d, SubMConv3d`
+    _patch_nms()
+    for mod in ("backbones.scn", "readers.voxel_encoder", "readers.pillar_encoder", "necks.rpn",
+                "bbox_heads.mg_head", "losses.losses"):
+        ref_loader.ref("det3d.models." + mod)
+    assert sys.modules["det3d.models.backbones.scn"].spconv is spconv_shim
+    dets_mod = {"VoxelNet": ref_loader.ref("det3d.models.detectors.voxelnet").VoxelNet,
+                "PointPillars": ref_loader.ref("det3d.models.detectors.point_pillars").PointPillars}
+    coders = ref_loader.ref("det3d.core.bbox.box_coders")
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+
+    out = {}
+    for name, case in S.CASES.items():
+        spec = specs[name]
+        m = spec["model"]
+        c = m["bbox_head"]["box_coder"]
+        m["bbox_head"]["box_coder"] = coders.GroundBox3dCoderTorch(c["linear_dim"], c["vec"], n_dim=c["n_dim"])
+        m["bbox_head"]["logger"] = logging.getLogger("head")
+        m["neck"]["logger"] = logging.getLogger("RPN")
+        tc = spec["test_cfg"]
+        test_cfg = Cfg(tc, nms=Cfg(tc["nms"]))
+        kind = m.pop("type")
+        m.pop("pretrained", None)
+        torch.manual_seed(0)
+        net = dets_mod[kind](train_cfg=None, test_cfg=test_cfg, **m)
+        model_ref.fill_deterministic(net)
+        code_size = m["bbox_head"]["box_coder"].code_size
+        ex, fmap, nv = S.make_example(name, m["bbox_head"]["tasks"], c["n_dim"], code_size)
+        anchors, labels, reg_targets = ex["anchors"], ex["labels"], ex["reg_targets"]
+        # ---- eval: raw predictions, neck input, detections
+        net.eval()
+        with torch.no_grad():
+            data = dict(features=ex["voxels"], num_voxels=ex["num_points"], coors=ex["coordinates"],
+                        batch_size=S.BATCH, input_shape=ex["shape"][0])
+            if kind == "PointPillars":
+                f = net.reader(data["features"], data["num_voxels"], data["coors"])
+            else:
+                f = net.reader(data["features"], data["num_voxels"])
+            bev = net.backbone(f, data["coors"], data["batch_size"], data["input_shape"])
+            preds = net.bbox_head(net.neck(bev))
+            dets = net.bbox_head.predict(ex, preds, test_cfg)
+        assert preds[0]["box_preds"].shape[1:3] == fmap, (preds[0]["box_preds"].shape, fmap)
+        # ---- train: loss per task group, all gradients (norms) + a few whole gradient tensors
+        net.train()
+        losses = net(ex, return_loss=True)
+        total = sum(losses["loss"])
+        params = dict(net.named_parameters())
+        grads = torch.autograd.grad(total, list(params.values()), allow_unused=True)
+        gnorm = {k: (float(g.norm()) if g is not None else 0.0) for k, g in zip(params, grads)}
+        small = {k: g.clone() for k, g in zip(params, grads) if g is not None and g.numel() <= 7000}
+        # the inputs are NOT stored (12k padded voxels + anchors would be 20 MB): the tests regenerate them with
+        # detector_specs.make_example (seeded) and check these sums first
+        sums = dict(voxels=float(ex["voxels"].double().sum()), coordinates=int(ex["coordinates"].long().sum()),
+                    num_points=int(ex["num_points"].long().sum()), num_voxels=[int(v) for v in nv],
+                    anchors=[float(a.double().sum()) for a in anchors], labels=[int(l.long().sum()) for l in labels],
+                    reg_targets=[float(t.double().abs().sum()) for t in reg_targets])
+        out[name] = dict(
+            fingerprint=S.param_fingerprint(net), input_sums=sums,
+            bev_shape=tuple(bev.shape), bev_sample=bev[:, :, 1::4, ::8].clone(), bev_abs_mean=float(bev.abs().mean()),
+            # raw head outputs [B, H, W, ch] on a quarter of the cells (every cell feeds `dets` anyway)
+            preds=[{k: v[:, ::2, 1::2].clone() for k, v in p.items()} for p in preds],
+            dets=[{k: v.clone() for k, v in d.items() if torch.is_tensor(v)} for d in dets],
+            loss=[l.detach().clone() for l in losses["loss"]], grad_norms=gnorm, grads=small)
+        print("detector", name, "voxels", nv, "bev", tuple(bev.shape), "loss", [round(float(l), 4) for l in losses["loss"]],
+              "dets", [d["scores"].shape[0] for d in dets], "small grads", len(small))
+    torch.save(out, os.path.join(HERE, "detectors.pt"))
+
+
+def nms_gpu_cases():
+    """det3d/ops/nms/nms_gpu.py: iou_device (:22-33, +1 pixel convention), nms_kernel (:67-101, one CUDA block
+    per 64x64 tile, `>` threshold), nms_postprocess (:109-126) -- executed as plain Python: the kernel body is
+    called once per (block, thread) with a fake numba.cuda context."""
+    ng = ref_loader.ref("det3d.ops.nms.nms_gpu")
+    rng = np.random.default_rng(11)
+    out = {}
+    for name, n, thr in (("dense", 150, 0.5), ("sparse", 130, 0.3), ("tiny", 3, 0.5), ("dupes", 70, 0.7)):
+        xy = rng.uniform(0, 60 if name != "sparse" else 400, (n, 2))
+        wh = rng.uniform(4, 30, (n, 2))
+        dets = np.concatenate([xy, xy + wh, rng.uniform(0, 1, (n, 1))], 1).astype(np.float32)
+        if name == "dupes":
+            dets[n // 2:, :4] = dets[: n - n // 2, :4]  # exact duplicates and
+            dets[n // 2:: 3, 2] += 1.0                     # near duplicates
+        if name == "tiny":
+            dets = np.array([[0, 0, 9, 9, 0.9], [1, 1, 10, 10, 0.8], [20, 20, 29, 29, 0.7]], np.float32)
+        order = dets[:, 4].argsort()[::-1]
+        boxes = np.ascontiguousarray(dets[order])
+        nb = -(-n // 64)
+        mask = np.zeros((n * nb,), dtype=np.uint64)
+        cuda = sys.modules["numba.cuda"]
+
+        class _Idx:
+            pass
+
+        for by in range(nb):
+            for bx in range(nb):
+                shared = {}
+                cuda.shared = type("S", (), {"array": staticmethod(
+                    lambda shape, dtype=None, _s=shared: _s.setdefault("a", np.zeros(shape, np.float32)))})
+                cuda.syncthreads = lambda: None
+                # phase 1 for all threads (shared-memory fill), then phase 2: the kernel has one barrier, so
+                # running every thread to completion in order with a persistent shared array is equivalent
+                for tx in range(64):
+                    cuda.threadIdx = _Idx(); cuda.threadIdx.x = tx
+                    cuda.blockIdx = _Idx(); cuda.blockIdx.x = bx; cuda.blockIdx.y = by
+                    ng.nms_kernel(n, np.float32(thr), boxes.reshape(-1), mask)
+                for tx in range(64):
+                    cuda.threadIdx.x = tx
+                    ng.nms_kernel(n, np.float32(thr), boxes.reshape(-1), mask)
+        keep = np.zeros((n,), np.int32)
+        num = ng.nms_postprocess(keep, mask, n)
+        out[name + "_dets"] = dets
+        out[name + "_thr"] = np.float32(thr)
+        out[name + "_keep"] = order[keep[:num]].astype(np.int64)
+        print("nms_gpu", name, n, "->", num)
+    np.savez_compressed(os.path.join(HERE, "nms_gpu.npz"), **out)
+
+
 def main():
     ref_loader.install()
-    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "sampler", "collate", "pipeline", "rangefilter"]
+    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "sampler", "collate", "pipeline", "rangefilter", "nmsgpu", "detectors"]
     if "anchors" in which:
         anchors_targets()
     if "tasks" in which:
@@ -587,6 +747,10 @@ def main():
         rpn_cases()
     if "head" in which:
         head_cases()
+    if "nmsgpu" in which:
+        nms_gpu_cases()
+    if "detectors" in which:
+        detector_cases()
 
 
 if __name__ == "__main__":

@@ -89,7 +89,7 @@ class _AddictDict(dict):
 
 
 STUBS = ["spconv", "spconv.utils", "torchvision", "torchvision.models", "torchvision.models.resnet",
-         "cv2", "fire", "pycocotools", "terminaltables", "tensorboardX", "shapely",
+         "cv2", "fire", "pycocotools", "pycocotools.mask", "terminaltables", "tensorboardX", "shapely",
          "shapely.geometry", "nuscenes", "IPython", "skimage", "PIL", "matplotlib",
          "matplotlib.pyplot", "open3d", "vtk", "pyquaternion", "lyft_dataset_sdk"]
 

@@ -302,3 +302,135 @@ def test_nuscenes_cbgs_six_group_model_trains_and_predicts():
         assert d["box3d_lidar"].shape == (n, 9) and d["scores"].shape == (n,) and n <= 6 * cfg.test_cfg.nms.nms_post_max_size
         if n:
             assert int(d["label_preds"].max()) < 10 and float(d["scores"].min()) >= cfg.test_cfg.score_threshold
+
+
+# ------------------------------------------------ whole detectors vs the REFERENCE's own detector classes
+def _golden_case(name):
+    import sys
+
+    gdir = os.path.join(ROOT, "tests", "golden")
+    if gdir not in sys.path:
+        sys.path.insert(0, gdir)
+    import detector_specs as S
+
+    g = torch.load(os.path.join(gdir, "detectors.pt"), weights_only=False)[name]
+    cfg = S.load_cfg(name)
+    coder = cfg.model.bbox_head.box_coder
+    ex, fmap, nv = S.make_example(name, cfg.model.bbox_head.tasks, coder.n_dim, coder.code_size)
+    S.check_input_sums(ex, g["input_sums"])
+    return S, g, cfg, ex
+
+
+def _to_gpu(ex):
+    out = {}
+    for k, v in ex.items():
+        if torch.is_tensor(v):
+            out[k] = v.cuda()
+        elif isinstance(v, list) and v and torch.is_tensor(v[0]):
+            out[k] = [t.cuda() for t in v]
+        else:
+            out[k] = v
+    return out
+
+
+@pytest.mark.parametrize("name", ["kitti_second", "nusc_cbgs", "lyft_cbgs", "nusc_pp"])
+def test_detector_matches_reference_detector_golden_fp32(name):
+    """BASELINE.json configs[1..4] on cropped ranges: the HIP product (fp32 mode) against tests/golden/detectors.pt,
+    i.e. the reference's OWN VoxelNet / PointPillars + scn.py (SpMiddleFHD, SpMiddleResNetFHD with its residual
+    blocks and biased convs) + RPN + MultiGroupHead run in the build container.  north_star tolerance: raw box
+    regressions within 1e-3; per-task losses 2e-4; gradient norms 1 % and whole small gradient tensors 2 %."""
+    from det3d_amd import build_detector
+    from oracle import model_ref as M
+
+    S, g, cfg, ex = _golden_case(name)
+    m = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg)
+    assert S.param_fingerprint(m) == [(k, tuple(s)) for k, s in g["fingerprint"]]
+    M.fill_deterministic(m)
+    m = m.cuda().eval()
+    exg = _to_gpu(ex)
+    with torch.no_grad():
+        data = dict(features=exg["voxels"], num_voxels=exg["num_points"], coors=exg["coordinates"],
+                    batch_size=S.BATCH, input_shape=exg["shape"][0])
+        preds = m.bbox_head(m.extract_feat(data))
+        dets = m.bbox_head.predict(exg, preds, m.test_cfg)
+    worst = 0.0
+    for p, gp in zip(preds, g["preds"]):
+        for k in gp:
+            worst = max(worst, float((p[k][:, ::2, 1::2].float().cpu() - gp[k]).abs().max()))
+    print("%s: max |pred - reference| = %.2e (max |ref box| %.2f)" % (
+        name, worst, max(float(gp["box_preds"].abs().max()) for gp in g["preds"])))
+    assert worst < 1e-3
+    # detections: NMS decisions may flip for IoUs within rounding of the threshold -> nearest-centre matching,
+    # all but a few boxes must have a reference twin within 1e-3
+    for d, gd in zip(dets, g["dets"]):
+        a, b = d["box3d_lidar"].cpu(), gd["box3d_lidar"]
+        assert abs(a.shape[0] - b.shape[0]) <= 3, (a.shape, b.shape)
+        nn = torch.cdist(a[:, :2], b[:, :2]).argmin(1)
+        err = (a - b[nn]).abs().max(1)[0]
+        assert int((err >= 1e-3).sum()) <= 3, err[err >= 1e-3]
+    m.train()
+    losses = m(exg, return_loss=True)["loss"]
+    for a, b in zip(losses, g["loss"]):
+        assert float(a.detach()) == pytest.approx(float(b), rel=2e-4)
+    params = dict(m.named_parameters())
+    grads = dict(zip(params, torch.autograd.grad(sum(losses), list(params.values()), allow_unused=True)))
+    worst_t, worst_n = 0.0, 0.0
+    for k, gn in g["grad_norms"].items():
+        got = grads[k]
+        n = float(got.float().norm()) if got is not None else 0.0
+        if gn < 1e-4:  # conv bias in front of a train-mode BN: exactly-zero true gradient, rounding noise only
+            assert n < 1e-3, k
+            continue
+        worst_n = max(worst_n, abs(n - gn) / gn)
+        if k in g["grads"]:
+            ref = g["grads"][k]
+            worst_t = max(worst_t, float((got.float().cpu() - ref).abs().max()) / float(ref.abs().max()))
+    print("%s: worst gradient-norm rel err %.2e, worst small-tensor rel err %.2e" % (name, worst_n, worst_t))
+    assert worst_n < 1e-2 and worst_t < 2e-2
+
+
+@pytest.mark.parametrize("name", ["nusc_cbgs", "lyft_cbgs"])
+def test_resnet_fhd_backbone_vs_oracle_on_a_larger_cloud(name):
+    """SpMiddleResNetFHD alone, 3x the golden's voxel count: HIP fp32 vs oracle/model_ref.SpMiddleResNetFHDRef
+    (pinned to the reference's scn.py by the detector golden) -- dense output, input gradient, all parameter
+    gradients."""
+    from det3d_amd.backbones import SpMiddleResNetFHD
+    from oracle import clib
+    from oracle import model_ref as M
+
+    S, g, cfg, _ = _golden_case(name)
+    case = dict(S.CASES[name], points=18000)
+    cin = cfg.model.backbone.num_input_features
+    vox, coors, nums = [], [], []
+    for b in range(2):
+        v, cc, n = clib.points_to_voxel(S.synth_points(case, seed=7 + b), case["voxel"], case["range"], case["T"], True, 60000)
+        vox.append(v); nums.append(n)
+        coors.append(np.pad(cc, ((0, 0), (1, 0)), mode="constant", constant_values=b))
+    v, n = torch.from_numpy(np.concatenate(vox)), torch.from_numpy(np.concatenate(nums))
+    coors = torch.from_numpy(np.concatenate(coors))
+    feats = v[:, :, :cin].sum(1) / n.float().view(-1, 1)
+    grid = [int(s) for s in S.grid_of(case)]
+    torch.manual_seed(0)
+    ref = M.SpMiddleResNetFHDRef(cin).train()
+    M.fill_deterministic(ref)
+    prod = SpMiddleResNetFHD(num_input_features=cin)
+    prod.load_state_dict(ref.state_dict())
+    prod = prod.cuda().train()
+    f_ref = feats.clone().requires_grad_(True)
+    out_ref = ref(f_ref, coors.numpy(), 2, grid)
+    gout = torch.randn(out_ref.shape, generator=torch.Generator().manual_seed(1))
+    out_ref.backward(gout)
+    f_gpu = feats.cuda().requires_grad_(True)
+    out = prod(f_gpu, coors.cuda(), 2, grid)
+    out.backward(gout.cuda())
+    scale = float(out_ref.abs().max())
+    assert float((out.cpu() - out_ref).abs().max()) < 1e-3 * max(scale, 1.0)
+    gi = float((f_gpu.grad.cpu() - f_ref.grad).abs().max()) / float(f_ref.grad.abs().max())
+    assert gi < 2e-2, gi
+    worst = 0.0
+    for (k, p), (_, q) in zip(prod.named_parameters(), ref.named_parameters()):
+        if float(q.grad.abs().max()) < 1e-5:
+            continue
+        worst = max(worst, float((p.grad.cpu() - q.grad).abs().max()) / float(q.grad.abs().max()))
+    print("%s ResNetFHD %d voxels: input-grad rel err %.2e, worst param-grad rel err %.2e" % (name, len(feats), gi, worst))
+    assert worst < 2e-2

@@ -91,6 +91,19 @@ def test_axis_aligned_nms(oracle_lib):
     assert keep.cpu().tolist() == ref
 
 
+@pytest.mark.parametrize("case", ["dense", "sparse", "tiny", "dupes"])
+def test_axis_aligned_nms_vs_reference_nms_gpu_golden(case):
+    """a12: d3d_nms (through box_ops.nms) == the reference's nms_gpu.py run as plain Python (nms_gpu.npz)."""
+    from det3d_amd.box_ops import nms
+
+    g = np.load(os.path.join(GOLDEN, "nms_gpu.npz"))
+    dets, thr, ref = g[case + "_dets"], float(g[case + "_thr"]), g[case + "_keep"]
+    n = len(dets)
+    keep = nms(torch.from_numpy(dets[:, :4]).cuda(), torch.from_numpy(dets[:, 4]).cuda(), n, n, thr)
+    # score ties (the duplicated boxes keep distinct random scores) do not occur: exact order equality
+    assert keep.cpu().tolist() == ref.tolist()
+
+
 @pytest.mark.parametrize("name", ["kitti", "nusc", "lyft"])
 def test_head_predict_matches_reference_golden(name):
     """MultiGroupHead.predict on the GPU (decode, score filter, top-k, HIP rotated NMS, direction

@@ -74,3 +74,15 @@ def test_axis_aligned_nms_plus_one_convention(oracle_lib):
     # IoU(+1) of box0/box1 = 50/100 = 0.5 -> strict `>` keeps both at thr 0.5
     assert oracle_lib.nms_sorted(boxes, 0.5) == [0, 1, 2]
     assert oracle_lib.nms_sorted(boxes, 0.49) == [0, 2]
+
+
+@pytest.mark.parametrize("case", ["dense", "sparse", "tiny", "dupes"])
+def test_axis_aligned_nms_vs_reference_nms_gpu_golden(oracle_lib, case):
+    """a12: oracle nms_sorted == the reference's own nms_gpu.py (iou_device :22-33 with the +1-pixel
+    convention, nms_kernel :67-101 `>` threshold, nms_postprocess :109-126) executed as plain Python
+    (tests/golden/make_golden.py::nms_gpu_cases) -- kept indices in order, incl. exact duplicates."""
+    g = np.load(os.path.join(GOLDEN, "nms_gpu.npz"))
+    dets, thr, keep = g[case + "_dets"], float(g[case + "_thr"]), g[case + "_keep"]
+    order = dets[:, 4].argsort()[::-1]  # nms_gpu(): `order = dets[:, 4].argsort()[::-1]`
+    got = [int(order[i]) for i in oracle_lib.nms_sorted(dets[order, :4], thr)]
+    assert got == keep.tolist()
