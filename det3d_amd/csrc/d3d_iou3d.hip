@@ -87,19 +87,19 @@ __device__ float i3_overlap(const I3Box &A, const I3Box &B) {
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) {
       P2 x;
-      if (i3_seg(A.c[i + 1], A.c[i], B.c[j + 1], B.c[j], x)) {
+      if (cnt < 16 && i3_seg(A.c[i + 1], A.c[i], B.c[j + 1], B.c[j], x)) {
         sx += x.x;
         sy += x.y;
         pts[cnt++] = x;
       }
     }
   for (int k = 0; k < 4; ++k) {
-    if (i3_inside(A, B.c[k])) {
+    if (cnt < 16 && i3_inside(A, B.c[k])) {
       sx += B.c[k].x;
       sy += B.c[k].y;
       pts[cnt++] = B.c[k];
     }
-    if (i3_inside(B, A.c[k])) {
+    if (cnt < 16 && i3_inside(B, A.c[k])) {
       sx += A.c[k].x;
       sy += A.c[k].y;
       pts[cnt++] = A.c[k];

@@ -47,7 +47,10 @@ __device__ __forceinline__ float quad_area(const Quad &q) {
 
 // area of A n B by Sutherland-Hodgman clipping of A against B's four half-planes
 __device__ float quad_intersection(const Quad &A, const Quad &B) {
-  float px[8], py[8], tx[8], ty[8];
+  // 8 vertices is the bound for exactly convex input; after rounding, near-collinear / duplicated boxes can
+  // produce extra sign changes per clip edge, so the scratch holds 16 and appends stop there
+  constexpr int MAXV = 16;
+  float px[MAXV], py[MAXV], tx[MAXV], ty[MAXV];
   int ns = 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -69,12 +72,12 @@ __device__ float quad_intersection(const Quad &A, const Quad &B) {
       int j = (i + 1 == ns) ? 0 : i + 1;
       float dp = orient * ((bx - ax) * (py[i] - ay) - (by - ay) * (px[i] - ax));
       float dq = orient * ((bx - ax) * (py[j] - ay) - (by - ay) * (px[j] - ax));
-      if (dp >= 0.f) {
+      if (dp >= 0.f && nt < MAXV) {
         tx[nt] = px[i];
         ty[nt] = py[i];
         ++nt;
       }
-      if ((dp >= 0.f) != (dq >= 0.f)) {
+      if ((dp >= 0.f) != (dq >= 0.f) && nt < MAXV) {
         float t = dp / (dp - dq);
         tx[nt] = px[i] + t * (px[j] - px[i]);
         ty[nt] = py[i] + t * (py[j] - py[i]);

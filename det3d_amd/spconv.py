@@ -177,6 +177,11 @@ class _SparseConvFn(torch.autograd.Function):
         feats = feats.contiguous()
         kvol, cin, cout = rb.kvol, weight.shape[-2], weight.shape[-1]
         assert feats.shape[0] == rb.n_in and feats.shape[1] == cin, (feats.shape, rb.n_in, cin)
+        if weight.numel() != kvol * cin * cout:
+            # e.g. two convs of different kernel size sharing one indice_key: the packer would read
+            # kvol*cin*cout floats from a smaller weight
+            raise _lib.D3dError("sparse conv: weight %s does not match the rulebook's kernel volume %d "
+                                "(indice_key shared between different kernel sizes?)" % (tuple(weight.shape), kvol))
         # one launch repacks the [kD,kH,kW,Cin,Cout] f32 parameter for the forward and (kept for the
         # backward) the data gradient; W itself is not saved in packed form anywhere else
         w32 = weight.detach().float().contiguous()
@@ -281,6 +286,9 @@ def _fusable_bn(bn, feats):
         return False
     if bn.momentum is None or not bn.track_running_stats or bn.weight is None:
         return False
+    # the kernels read gamma / beta / running statistics as float32 (after model.bfloat16() they are not)
+    if any(t is not None and t.dtype != torch.float32 for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)):
+        return False
     if feats.shape[0] < 2 or (not bn.training and torch.is_grad_enabled() and feats.requires_grad):
         return False
     c = feats.shape[1]
@@ -301,6 +309,8 @@ def fusable_bn2d(bn, x):
     if type(bn) is not nn.BatchNorm2d or not x.is_cuda or x.dtype not in _DT or x.dim() != 4:
         return False
     if bn.momentum is None or not bn.track_running_stats or bn.weight is None or not bn.training:
+        return False
+    if any(t is not None and t.dtype != torch.float32 for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)):
         return False
     if x.shape[1] == 1 or not x.is_contiguous(memory_format=torch.channels_last):
         return False
@@ -463,6 +473,8 @@ class SparseConvolution(SparseModule):
     def forward(self, x):
         assert isinstance(x, SparseConvTensor)
         rb = self._get_rulebook(x)
+        if rb.subm != self.subm:
+            raise _lib.D3dError("indice_key %r is shared between a submanifold and a strided convolution" % (self.indice_key,))
         out_feats = _SparseConvFn.apply(x.features, self.weight, self.bias, rb)
         out = SparseConvTensor(out_feats, rb.out_indices if not self.subm else x.indices,
                                self.out_spatial_shape(x.spatial_shape), x.batch_size, x.grid)

@@ -99,12 +99,12 @@ double d3d_oracle_quad_intersection(const float *ca, const float *cb) {
       double qx = subj[2 * ((i + 1) % ns)], qy = subj[2 * ((i + 1) % ns) + 1];
       double dp = orient * ((bx - ax) * (py - ay) - (by - ay) * (px - ax));
       double dq = orient * ((bx - ax) * (qy - ay) - (by - ay) * (qx - ax));
-      if (dp >= 0) {
+      if (dp >= 0 && nt < 16) {
         tmp[2 * nt] = px;
         tmp[2 * nt + 1] = py;
         ++nt;
       }
-      if ((dp >= 0) != (dq >= 0)) {
+      if ((dp >= 0) != (dq >= 0) && nt < 16) {
         double t = dp / (dp - dq);
         tmp[2 * nt] = px + t * (qx - px);
         tmp[2 * nt + 1] = py + t * (qy - py);

@@ -76,6 +76,36 @@ def test_rotate_nms_adversarial(oracle_lib):
         assert keep.cpu().tolist() == ref
 
 
+def test_rotate_nms_and_iou3d_on_duplicated_and_nearly_duplicated_boxes(oracle_lib):
+    """clip-scratch overflow regression: many exact duplicates and boxes that differ by a few ulps /
+    micro-rotations -- near-collinear edges make Sutherland-Hodgman emit extra vertices after rounding."""
+    from det3d_amd.box_ops import rotate_nms
+    from det3d_amd import iou3d_utils
+
+    rng = np.random.default_rng(3)
+    base = np.concatenate([rng.uniform(-20, 20, (40, 2)), rng.uniform(0.5, 5, (40, 2)), rng.uniform(-3.2, 3.2, (40, 1))], 1)
+    rep = np.repeat(base, 6, axis=0)
+    rep[1::6] = np.nextafter(rep[1::6].astype(np.float32), np.float32(np.inf))       # 1 ulp off
+    rep[2::6, 4] += 1e-6                                                             # micro rotation
+    rep[3::6, :2] += 1e-5                                                            # micro shift
+    rep[4::6, 4] += np.pi / 2 + 1e-6                                                 # ~90 degrees, same centre
+    rep[5::6, 2:4] *= 1 + 1e-6                                                       # micro scale
+    boxes = rep.astype(np.float32)
+    scores = (rng.permutation(len(boxes)) / len(boxes)).astype(np.float32)
+    dets = np.concatenate([boxes, scores[:, None]], 1)
+    for thr in (0.1, 0.5, 0.9):
+        (ref, margin) = oracle_lib.rotate_nms_cc(dets, thr, return_margin=True)
+        keep = rotate_nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), 1000, 1000, thr).cpu().tolist()
+        if keep != ref:
+            assert margin < 1e-5, (thr, margin)  # an IoU sat within rounding of the threshold
+    # iou3d overlap on the same set: finite, symmetric-ish and equal to the oracle
+    b5 = np.stack([boxes[:, 0] - boxes[:, 2] / 2, boxes[:, 1] - boxes[:, 3] / 2, boxes[:, 0] + boxes[:, 2] / 2,
+                   boxes[:, 1] + boxes[:, 3] / 2, boxes[:, 4]], 1).astype(np.float32)
+    got = iou3d_utils.boxes_iou_bev(torch.from_numpy(b5).cuda(), torch.from_numpy(b5).cuda()).cpu().numpy()
+    ref = oracle_lib.iou3d_pairwise(b5, b5, "iou_bev")
+    assert np.isfinite(got).all() and np.abs(got - ref).max() < 1e-4
+
+
 def test_axis_aligned_nms(oracle_lib):
     from det3d_amd.box_ops import nms
 
