@@ -34,9 +34,17 @@ SIGNATURES = {
                                 vp, vp, vp, vp, sz, vp]),
     "d3d_pack_conv_weights": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "d3d_sparse_conv_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
-    "d3d_sparse_conv_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "d3d_sparse_conv_fwd_ex": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "d3d_sparse_conv_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "d3d_sparse_conv_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
     "d3d_bn_relu_fwd": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp, vp, vp, vp]),
     "d3d_bn_relu_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "d3d_bn_stats": (i32, [vp, i32, i32, i32, vp, vp]),
+    "d3d_bn_apply": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp, vp, vp, vp]),
+    "d3d_bn_bwd_reduce": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]),
+    "d3d_bn_bwd_dx": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "d3d_channel_affine": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp]),
+    "d3d_channel_affine_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]),
     "d3d_pfn_fwd": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp, vp, vp, vp, f32, f32,
                           i32, vp, vp, vp, vp, vp, vp]),
     "d3d_pfn_bwd": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp, vp, vp, vp, vp, vp,
@@ -59,7 +67,7 @@ SIGNATURES = {
     "d3d_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
 }
 
-ABI_VERSION = 2  # include/d3d.h D3D_ABI_VERSION
+ABI_VERSION = 3  # include/d3d.h D3D_ABI_VERSION
 D3D_F32 = 0
 D3D_BF16 = 1
 D3D_BN_COPIES = 8
@@ -69,6 +77,12 @@ D3D_IOU3D_OVERLAP, D3D_IOU3D_IOU_BEV, D3D_IOU3D_IOU_NORMAL = 0, 1, 2
 
 class D3dError(RuntimeError):
     pass
+
+
+class ConvEpilogue(ctypes.Structure):
+    """D3dConvEpilogue of include/d3d.h (device pointers as integers)"""
+    _fields_ = [("stats", vp), ("bn_x", vp), ("bn_mean", vp), ("bn_invstd", vp), ("bn_gamma", vp),
+                ("bn_beta", vp), ("bn_relu", i32), ("bn_partial", vp)]
 
 
 def lib():

@@ -49,15 +49,18 @@ class SparseBasicBlock(spconv.SparseModule):
 
     def forward(self, x):
         identity = x
-        out = self.conv1(x)
-        if spconv.FUSE_BN_RELU and spconv._fusable_bn(self.bn1, out.features):
-            out.features = spconv.bn_relu(self.bn1, out.features, relu=True)
+        n = x.indices.shape[0]
+        if spconv.FUSE_BN_RELU and n != 0 and spconv._fusable_bn(self.bn1, x.features, channels=self.conv1.out_channels):
+            # statistics of bn1 / bn2 from the conv epilogues; conv2 is the only consumer of bn1's output, so
+            # its data-gradient launch also reduces bn1's backward sums
+            out, link = spconv.conv_bn_relu(self.conv1, self.bn1, True, x, want_link=True)
         else:
+            out, link = self.conv1(x), None
             out.features = self.relu(self.bn1(out.features))
-        out = self.conv2(out)
-        if spconv.FUSE_BN_RELU and spconv._fusable_bn(self.bn2, out.features):
-            out.features = spconv.bn_relu(self.bn2, out.features, relu=False)
+        if spconv.FUSE_BN_RELU and n != 0 and spconv._fusable_bn(self.bn2, out.features, channels=self.conv2.out_channels):
+            out, _ = spconv.conv_bn_relu(self.conv2, self.bn2, False, out, link_in=link)
         else:
+            out = self.conv2(out)
             out.features = self.bn2(out.features)
         if self.downsample is not None:
             identity = self.downsample(x)
@@ -76,6 +79,7 @@ class _SparseMiddle(nn.Module):
             voxel_features = voxel_features.to(torch.get_autocast_dtype("cuda"))
         ret = spconv.SparseConvTensor(voxel_features, coors, sparse_shape.tolist(), batch_size)
         self.middle_conv.plan(ret)  # every rulebook of the stack, one host sync
+        spconv.ARENA.reset(voxel_features.device)  # one launch zeroes every conv-epilogue accumulator of this pass
         ret = self.middle_conv(ret)
         self.last_indice_dict = ret.indice_dict
         # [B, C, D, H, W] -> [B, C*D, H, W]; optionally channels-last for MIOpen's NHWC kernels

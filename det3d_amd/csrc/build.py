@@ -20,6 +20,7 @@ SOURCES = [
     "d3d_voxelize.hip",
     "d3d_rulebook.hip",
     "d3d_spconv.hip",
+    "d3d_wgrad.hip",
     "d3d_bn.hip",
     "d3d_pfn.hip",
     "d3d_dense.hip",

@@ -335,6 +335,163 @@ static int bn_grid(int n, int c, int dtype) {
   return nb < 1 ? 1 : nb;
 }
 
+// ---- the two halves of each direction as separate entry points: the conv epilogues (d3d_sparse_conv_fwd_ex)
+// can produce the reductions, and cross-rank BatchNorm puts an all-reduce between the halves
+extern "C" int d3d_bn_stats(const void *x, int n, int c, int dtype, float *stats_ws, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = bn_check(n, c, dtype, "d3d_bn_stats");
+  if (rc) return rc;
+  D3D_REQUIRE(x && stats_ws, "d3d_bn_stats: null pointer");
+  const int nb = bn_grid(n, c, dtype);
+  D3D_HIP_TRY(d3d_fill_async(stream, stats_ws, 0, (size_t)D3D_BN_COPIES * 2 * c * sizeof(float)));
+  if (dtype == D3D_BF16)
+    hipLaunchKernelGGL(bn_stats_kernel<true>, dim3(nb), dim3(256), 0, stream, x, n, c, stats_ws);
+  else
+    hipLaunchKernelGGL(bn_stats_kernel<false>, dim3(nb), dim3(256), 0, stream, x, n, c, stats_ws);
+  D3D_LAUNCH_TRY("bn_stats_kernel");
+  return D3D_OK;
+}
+
+extern "C" int d3d_bn_apply(const void *x, int n, int c, int dtype, const float *gamma, const float *beta,
+                            float *running_mean, float *running_var, float momentum, float eps, int training,
+                            int relu, const float *stats_ws, void *y, float *save_mean, float *save_invstd,
+                            d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = bn_check(n, c, dtype, "d3d_bn_apply");
+  if (rc) return rc;
+  D3D_REQUIRE(x && y, "d3d_bn_apply: null pointer");
+  D3D_REQUIRE(training ? stats_ws != nullptr : (running_mean && running_var),
+              "d3d_bn_apply: training needs stats_ws, eval needs running stats");
+  const int nb = bn_grid(n, c, dtype);
+  if (dtype == D3D_BF16)
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(nb), dim3(256), 0, stream, x, n, c, gamma, beta,
+                       running_mean, running_var, momentum, eps, training, relu, stats_ws, y,
+                       save_mean, save_invstd);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(nb), dim3(256), 0, stream, x, n, c, gamma, beta,
+                       running_mean, running_var, momentum, eps, training, relu, stats_ws, y,
+                       save_mean, save_invstd);
+  D3D_LAUNCH_TRY("bn_apply_kernel");
+  return D3D_OK;
+}
+
+extern "C" int d3d_bn_bwd_reduce(const void *x, const void *dy, int n, int c, int dtype, const float *gamma,
+                                 const float *beta, const float *save_mean, const float *save_invstd, int relu,
+                                 float *partial_ws, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = bn_check(n, c, dtype, "d3d_bn_bwd_reduce");
+  if (rc) return rc;
+  D3D_REQUIRE(x && dy && save_mean && save_invstd && partial_ws, "d3d_bn_bwd_reduce: null pointer");
+  const int nb = bn_grid(n, c, dtype);
+  D3D_HIP_TRY(d3d_fill_async(stream, partial_ws, 0, (size_t)D3D_BN_COPIES * 2 * c * sizeof(float)));
+  if (dtype == D3D_BF16)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma, beta,
+                       save_mean, save_invstd, relu, partial_ws);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma, beta,
+                       save_mean, save_invstd, relu, partial_ws);
+  D3D_LAUNCH_TRY("bn_bwd_reduce_kernel");
+  return D3D_OK;
+}
+
+extern "C" int d3d_bn_bwd_dx(const void *x, const void *dy, int n, int c, int dtype, const float *gamma,
+                             const float *beta, const float *save_mean, const float *save_invstd, int relu,
+                             const float *partial_ws, void *dx, float *dgamma, float *dbeta, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = bn_check(n, c, dtype, "d3d_bn_bwd_dx");
+  if (rc) return rc;
+  D3D_REQUIRE(x && dy && dx && dgamma && dbeta && save_mean && save_invstd && partial_ws,
+              "d3d_bn_bwd_dx: null pointer");
+  const int nb = bn_grid(n, c, dtype);
+  if (dtype == D3D_BF16)
+    hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma, beta,
+                       save_mean, save_invstd, relu, partial_ws, dgamma, dbeta, dx);
+  else
+    hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma, beta,
+                       save_mean, save_invstd, relu, partial_ws, dgamma, dbeta, dx);
+  D3D_LAUNCH_TRY("bn_bwd_dx_kernel");
+  return D3D_OK;
+}
+
+// ---- per-channel affine sweeps for cross-rank BatchNorm (det3d/ops/syncbn): the statistics travel through an
+// all-reduce between the reduction and these passes, so the coefficients arrive as [c] vectors
+//   fwd: y  = relu?(x * scale + shift)                                  (syncbn_cuda_kernel.cu:166-198)
+//   bwd: dx = ca * dz + cb * x + cc,  dz = dy * [x * scale + shift > 0]  (:595-640 with the ReLU mask folded in)
+template <bool BF16, bool BWD>
+__global__ void __launch_bounds__(256)
+    bn_affine_kernel(const void *__restrict__ x, const void *__restrict__ dy, int n, int c,
+                     const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                     const float *__restrict__ ca, const float *__restrict__ cb, const float *__restrict__ cc,
+                     void *__restrict__ out) {
+  constexpr int EPV = BnVec<BF16>::EPV;
+  const int segs = c / EPV;
+  const int seg = threadIdx.x % segs, rl = threadIdx.x / segs, rp = 256 / segs;
+  float sc[EPV], sh[EPV], a[EPV], b[EPV], d[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    const int ch = seg * EPV + j;
+    sc[j] = scale[ch];
+    sh[j] = shift[ch];
+    if (BWD) {
+      a[j] = ca[ch];
+      b[j] = cb[ch];
+      d[j] = cc[ch];
+    }
+  }
+  const int64_t step = (int64_t)gridDim.x * rp;
+  for (int64_t r = (int64_t)blockIdx.x * rp + rl; r < n; r += step) {
+    float v[EPV], g[EPV];
+    BnVec<BF16>::load(x, r * segs + seg, v);
+    if (BWD) BnVec<BF16>::load(dy, r * segs + seg, g);
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      const float z = fmaf(v[j], sc[j], sh[j]);
+      if (BWD) {
+        const float dz = (relu && z <= 0.f) ? 0.f : g[j];
+        v[j] = fmaf(a[j], dz, fmaf(b[j], v[j], d[j]));
+      } else {
+        v[j] = relu ? fmaxf(z, 0.f) : z;
+      }
+    }
+    BnVec<BF16>::store(out, r * segs + seg, v);
+  }
+}
+
+extern "C" int d3d_channel_affine(const void *x, int n, int c, int dtype, const float *scale, const float *shift,
+                                  int relu, void *y, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = bn_check(n, c, dtype, "d3d_channel_affine");
+  if (rc) return rc;
+  D3D_REQUIRE(x && y && scale && shift, "d3d_channel_affine: null pointer");
+  const int nb = bn_grid(n, c, dtype);
+  if (dtype == D3D_BF16)
+    hipLaunchKernelGGL((bn_affine_kernel<true, false>), dim3(nb), dim3(256), 0, stream, x, nullptr, n, c, scale,
+                       shift, relu, nullptr, nullptr, nullptr, y);
+  else
+    hipLaunchKernelGGL((bn_affine_kernel<false, false>), dim3(nb), dim3(256), 0, stream, x, nullptr, n, c, scale,
+                       shift, relu, nullptr, nullptr, nullptr, y);
+  D3D_LAUNCH_TRY("bn_affine_kernel");
+  return D3D_OK;
+}
+
+extern "C" int d3d_channel_affine_bwd(const void *x, const void *dy, int n, int c, int dtype, const float *scale,
+                                      const float *shift, int relu, const float *coef_dz, const float *coef_x,
+                                      const float *coef_1, void *dx, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = bn_check(n, c, dtype, "d3d_channel_affine_bwd");
+  if (rc) return rc;
+  D3D_REQUIRE(x && dy && dx && scale && shift && coef_dz && coef_x && coef_1, "d3d_channel_affine_bwd: null pointer");
+  const int nb = bn_grid(n, c, dtype);
+  if (dtype == D3D_BF16)
+    hipLaunchKernelGGL((bn_affine_kernel<true, true>), dim3(nb), dim3(256), 0, stream, x, dy, n, c, scale, shift,
+                       relu, coef_dz, coef_x, coef_1, dx);
+  else
+    hipLaunchKernelGGL((bn_affine_kernel<false, true>), dim3(nb), dim3(256), 0, stream, x, dy, n, c, scale, shift,
+                       relu, coef_dz, coef_x, coef_1, dx);
+  D3D_LAUNCH_TRY("bn_affine_kernel");
+  return D3D_OK;
+}
+
 extern "C" int d3d_bn_relu_fwd(const void *x, int n, int c, int dtype, const float *gamma,
                                const float *beta, float *running_mean, float *running_var,
                                float momentum, float eps, int training, int relu, void *y,

@@ -22,6 +22,7 @@
 
 #include "d3d_common.h"
 #include "d3d_fill.h"
+#include "d3d_spconv_internal.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -45,10 +46,10 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round to nearest 
 // launch bound: a 16-wave block puts 4 waves on every SIMD, so two resident blocks per CU need
 // <= 64 VGPRs (8 waves/SIMD); at 66 VGPRs only one block fits and the kernel is 45 % slower
 template <int CIN, int COUT, int MT, int WAVES, bool BF16>
-__global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 8 : 4))
+__global__ void __launch_bounds__(WAVES * 64, ((WAVES >= 16 && CIN * COUT <= 4096 && BF16) ? 8 : 4))
     spconv_fwd_mfma_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
                            const float *__restrict__ bias, const int32_t *__restrict__ nbr,
-                           int cap, int n_out, int kvol, void *__restrict__ out_) {
+                           int cap, int n_out, int kvol, void *__restrict__ out_, D3dConvEpilogue ep) {
   constexpr int NT = COUT / 16;
   constexpr int ESZ = BF16 ? 2 : 4;
   constexpr int KW = BF16 ? ((CIN % 32 == 0) ? 32 : 16) : 16;  // channels per k-step
@@ -82,16 +83,24 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 8 : 4))
   }
   // gathered-row fragment of one (tile, k-step): 16 B (8 bf16 | 4 f32) or 8 B (4 bf16, Cin = 16)
   using FragT = typename std::conditional<(BF16 && KW == 16), uint2, uint4>::type;
+  // addresses are (uniform 64-bit base in SGPRs) + (32-bit byte offset in one VGPR): the host side checks that
+  // the feature matrix and the neighbour table stay below 4 GB.  With 64-bit per-lane addresses the three
+  // address pairs pushed the kernel past its 64-VGPR budget and the spill reload sat in front of the gather.
   const unsigned char *fbase = (const unsigned char *)feat_;
+  const uint32_t lane_off = (uint32_t)(lg * EPL * ESZ);
   auto gather = [&](const int(&ix)[MT], FragT(&f)[MT][KS]) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         FragT z = {};
-        f[m][ks] = ix[m] >= 0 ? *(const FragT *)(fbase + ((int64_t)ix[m] * CIN + ks * KW + lg * EPL) * ESZ)
-                              : z;
+        const uint32_t off = (uint32_t)ix[m] * (uint32_t)(CIN * ESZ) + lane_off + (uint32_t)(ks * KW * ESZ);
+        f[m][ks] = ix[m] >= 0 ? *(const FragT *)(fbase + off) : z;
       }
+  };
+  auto nbr_at = [&](int k, int s) -> int {  // nbr[k * cap + s]
+    const int32_t *nk = nbr + (int64_t)k * cap;  // uniform
+    return nk[(uint32_t)s];
   };
 
   // software pipeline over kernel offsets: indices two offsets ahead, gathered rows one offset
@@ -100,8 +109,8 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 8 : 4))
   int idx0[MT], idx1[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    idx0[m] = live[m] ? nbr[site[m]] : -1;
-    idx1[m] = (kvol > 1 && live[m]) ? nbr[(int64_t)cap + site[m]] : -1;
+    idx0[m] = live[m] ? nbr_at(0, site[m]) : -1;
+    idx1[m] = (kvol > 1 && live[m]) ? nbr_at(1, site[m]) : -1;
   }
   FragT fcur[MT][KS];
   gather(idx0, fcur);
@@ -112,7 +121,7 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 8 : 4))
 #pragma unroll
   for (int j = 0; j < WPT; ++j) {
     int e = threadIdx.x + j * NTHREADS;
-    if (e < WVEC) wreg[j] = *(const uint4 *)(wg + (size_t)e * 16);
+    if (e < WVEC) wreg[j] = *(const uint4 *)(wg + (uint32_t)(e * 16));
   }
 #pragma unroll
   for (int j = 0; j < WPT; ++j) {
@@ -126,7 +135,7 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 8 : 4))
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
       int e = threadIdx.x + j * NTHREADS;
-      if (e < WVEC) wreg[j] = *(const uint4 *)(wg + ((size_t)WVEC + e) * 16);
+      if (e < WVEC) wreg[j] = *(const uint4 *)(wg + (size_t)WVEC * 16 + (uint32_t)(e * 16));
     }
   }
   __syncthreads();
@@ -138,13 +147,13 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 8 : 4))
 #pragma unroll
       for (int j = 0; j < WPT; ++j) {
         int e = threadIdx.x + j * NTHREADS;
-        if (e < WVEC) wfar[j] = *(const uint4 *)(wg + ((size_t)(k + 2) * WVEC + e) * 16);
+        if (e < WVEC) wfar[j] = *(const uint4 *)(wg + (size_t)(k + 2) * (WVEC * 16) + (uint32_t)(e * 16));
       }
     }
     int idx2[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
-      idx2[m] = (k + 2 < kvol && live[m]) ? nbr[(int64_t)(k + 2) * cap + site[m]] : -1;
+      idx2[m] = (k + 2 < kvol && live[m]) ? nbr_at(k + 2, site[m]) : -1;
     FragT fnxt[MT][KS];
     gather(idx1, fnxt);  // offset k+1 (all -1 past the end: no loads issued)
     bool any = false;
@@ -203,13 +212,33 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 8 : 4))
     }
   }
 
-  // epilogue: lane holds couts [n*16 + lg*4, +4) of site[m]
+  // epilogue: lane holds couts [n*16 + lg*4, +4) of site[m].  Optional per-channel reductions ride along
+  // (each saves one full sweep over the activations, see D3dConvEpilogue in include/d3d.h):
+  //   ep.stats      forward : sum / sum of squares of the rows just produced (BatchNorm batch statistics)
+  //   ep.bn_partial dgrad   : sum dz * xhat | sum dz of the BatchNorm(+ReLU) that produced this conv's input
+  const bool want_stats = ep.stats != nullptr, want_bnb = ep.bn_partial != nullptr;
+  float *red = (float *)wlds;  // [2 * COUT]; every wave is past the last barrier of the offset loop
+  if (want_stats || want_bnb) {
+    for (int i = threadIdx.x; i < 2 * COUT; i += NTHREADS) red[i] = 0.f;
+    __syncthreads();
+  }
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    if (!live[m]) continue;
+  for (int n = 0; n < NT; ++n) {
+    const int co = n * 16 + lg * 4;
+    float r0[4] = {0.f, 0.f, 0.f, 0.f}, r1[4] = {0.f, 0.f, 0.f, 0.f};
+    float bmu[4], bis[4], bga[4], bbe[4];
+    if (want_bnb) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int co = n * 16 + lg * 4;
+      for (int j = 0; j < 4; ++j) {
+        bmu[j] = ep.bn_mean[co + j];
+        bis[j] = ep.bn_invstd[co + j];
+        bga[j] = ep.bn_gamma ? ep.bn_gamma[co + j] : 1.f;
+        bbe[j] = ep.bn_beta ? ep.bn_beta[co + j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (!live[m]) continue;
       f32x4_t v = acc[m][n];
       if (bias) {
         v[0] += bias[co + 0];
@@ -217,17 +246,67 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 8 : 4))
         v[2] += bias[co + 2];
         v[3] += bias[co + 3];
       }
+      float w[4];  // the values as stored (rounded to the feature dtype): what the next pass will read
       if constexpr (BF16) {
         uint16_t *o = (uint16_t *)out_ + (int64_t)site[m] * COUT + co;
+        const uint16_t h0 = f32_to_bf16(v[0]), h1 = f32_to_bf16(v[1]), h2 = f32_to_bf16(v[2]), h3 = f32_to_bf16(v[3]);
         uint2 pk;
-        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        pk.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        pk.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
         *(uint2 *)o = pk;
+        w[0] = bf16_to_f32(h0); w[1] = bf16_to_f32(h1); w[2] = bf16_to_f32(h2); w[3] = bf16_to_f32(h3);
       } else {
         float *o = (float *)out_ + (int64_t)site[m] * COUT + co;
         *(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);
+        w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3];
+      }
+      if (want_stats) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          r0[j] += w[j];
+          r1[j] = fmaf(w[j], w[j], r1[j]);
+        }
+      }
+      if (want_bnb) {
+        float x[4];
+        if constexpr (BF16) {
+          const uint2 xr = *(const uint2 *)((const uint16_t *)ep.bn_x + (int64_t)site[m] * COUT + co);
+          x[0] = bf16_to_f32((uint16_t)(xr.x & 0xffffu)); x[1] = bf16_to_f32((uint16_t)(xr.x >> 16));
+          x[2] = bf16_to_f32((uint16_t)(xr.y & 0xffffu)); x[3] = bf16_to_f32((uint16_t)(xr.y >> 16));
+        } else {
+          const float4 xr = *(const float4 *)((const float *)ep.bn_x + (int64_t)site[m] * COUT + co);
+          x[0] = xr.x; x[1] = xr.y; x[2] = xr.z; x[3] = xr.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // same arithmetic as bn_bwd_reduce_kernel (d3d_bn.hip)
+          const float xh = (x[j] - bmu[j]) * bis[j];
+          const float dz = (ep.bn_relu && fmaf(xh, bga[j], bbe[j]) <= 0.f) ? 0.f : w[j];
+          r0[j] = fmaf(dz, xh, r0[j]);
+          r1[j] += dz;
+        }
       }
     }
+    if (want_stats || want_bnb) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a0 = r0[j], a1 = r1[j];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {  // the 16 sites of a tile sit in lanes lr = 0..15
+          a0 += __shfl_xor(a0, o, 64);
+          a1 += __shfl_xor(a1, o, 64);
+        }
+        if (lr == 0) {
+          atomicAdd(&red[co + j], a0);
+          atomicAdd(&red[COUT + co + j], a1);
+        }
+      }
+    }
+  }
+  if (want_stats || want_bnb) {
+    __syncthreads();
+    // [copy][2 * COUT]: (sum | sum sq) or (dgamma | dbeta), replicated to spread same-address atomics
+    float *dst = (want_stats ? ep.stats : ep.bn_partial) + (size_t)(blockIdx.x % D3D_BN_COPIES) * 2 * COUT;
+    for (int i = threadIdx.x; i < 2 * COUT; i += NTHREADS) atomicAdd(&dst[i], red[i]);
   }
 }
 
@@ -267,11 +346,11 @@ __global__ void __launch_bounds__(256)
 
 template <int CIN, int COUT, int MT, int WAVES, bool BF16>
 static int launch_fwd(const void *feat, const void *wpack, const float *bias, const int32_t *nbr,
-                      int cap, int n_out, int kvol, void *out, hipStream_t stream) {
+                      int cap, int n_out, int kvol, void *out, const D3dConvEpilogue &ep, hipStream_t stream) {
   const int rows_per_block = WAVES * MT * 16;
   const int nb = (n_out + rows_per_block - 1) / rows_per_block;
   hipLaunchKernelGGL((spconv_fwd_mfma_kernel<CIN, COUT, MT, WAVES, BF16>), dim3(nb),
-                     dim3(WAVES * 64), 0, stream, feat, wpack, bias, nbr, cap, n_out, kvol, out);
+                     dim3(WAVES * 64), 0, stream, feat, wpack, bias, nbr, cap, n_out, kvol, out, ep);
   D3D_LAUNCH_TRY("spconv_fwd_mfma_kernel");
   return D3D_OK;
 }
@@ -279,30 +358,47 @@ static int launch_fwd(const void *feat, const void *wpack, const float *bias, co
 #define FWD_CASE(CI, CO, MT, WV)                                                                \
   if (cin == CI && cout == CO) {                                                                \
     return dtype == D3D_BF16 ? launch_fwd<CI, CO, MT, WV, true>(feat, wpack, bias, nbr, cap,    \
-                                                                n_out, kvol, out, stream)       \
+                                                                n_out, kvol, out, ep, stream)   \
                              : launch_fwd<CI, CO, MT, WV, false>(feat, wpack, bias, nbr, cap,   \
-                                                                 n_out, kvol, out, stream);     \
+                                                                 n_out, kvol, out, ep, stream); \
   }
 
 extern "C" int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const float *bias,
                                    const int32_t *nbr, int cap, int n_out, int kvol, int cin,
                                    int cout, int dtype, void *out, d3d_stream_t stream_) {
+  return d3d_sparse_conv_fwd_ex(feat, wpack, bias, nbr, cap, n_out, kvol, cin, cout, dtype, out, nullptr, stream_);
+}
+
+extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const float *bias,
+                                      const int32_t *nbr, int cap, int n_out, int kvol, int cin,
+                                      int cout, int dtype, void *out, const D3dConvEpilogue *epilogue,
+                                      d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  D3dConvEpilogue ep = {};
+  if (epilogue) ep = *epilogue;
+  D3D_REQUIRE(!(ep.stats && ep.bn_partial), "d3d_sparse_conv_fwd_ex: one reduction per launch (stats or bn_partial)");
+  D3D_REQUIRE(!ep.bn_partial || (ep.bn_x && ep.bn_mean && ep.bn_invstd),
+              "d3d_sparse_conv_fwd_ex: bn_partial needs bn_x, bn_mean, bn_invstd");
+  D3D_REQUIRE(!(ep.stats || ep.bn_partial) || (cin % 16 == 0 && cout % 16 == 0 && cin <= 128 && cout <= 128),
+              "d3d_sparse_conv_fwd_ex: the fused reductions exist on the MFMA path only (channels %d -> %d)", cin, cout);
   D3D_REQUIRE(dtype == D3D_F32 || dtype == D3D_BF16, "d3d_sparse_conv_fwd: dtype %d", dtype);
   D3D_REQUIRE(n_out >= 0 && n_out <= cap && kvol >= 1 && cin >= 1 && cout >= 1,
               "d3d_sparse_conv_fwd: n_out=%d cap=%d kvol=%d cin=%d cout=%d", n_out, cap, kvol, cin,
               cout);
   if (n_out == 0) return D3D_OK;
   D3D_REQUIRE(feat && wpack && nbr && out, "d3d_sparse_conv_fwd: null pointer");
+  D3D_REQUIRE((int64_t)cap * (int64_t)(cin > cout ? cin : cout) * 4 < ((int64_t)1 << 32),
+              "d3d_sparse_conv_fwd: cap=%d rows x %d channels exceed the 4 GB the kernels' 32-bit row offsets address",
+              cap, cin > cout ? cin : cout);
   // tuning knob (tools/tune_fwd.py): alternative (MT, WAVES) tilings of the dominant 64->64 layer
   static const int fwd_variant = getenv("D3D_FWD_VARIANT") ? atoi(getenv("D3D_FWD_VARIANT")) : 0;
   if (fwd_variant && cin == 64 && cout == 64 && dtype == D3D_BF16) {
-    if (fwd_variant == 1) return launch_fwd<64, 64, 4, 4, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, stream);
-    if (fwd_variant == 2) return launch_fwd<64, 64, 4, 8, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, stream);
-    if (fwd_variant == 3) return launch_fwd<64, 64, 2, 4, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, stream);
-    if (fwd_variant == 4) return launch_fwd<64, 64, 1, 8, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, stream);
-    if (fwd_variant == 5) return launch_fwd<64, 64, 2, 16, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, stream);
-    if (fwd_variant == 6) return launch_fwd<64, 64, 2, 8, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, stream);
+    if (fwd_variant == 1) return launch_fwd<64, 64, 4, 4, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    if (fwd_variant == 2) return launch_fwd<64, 64, 4, 8, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    if (fwd_variant == 3) return launch_fwd<64, 64, 2, 4, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    if (fwd_variant == 4) return launch_fwd<64, 64, 1, 8, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    if (fwd_variant == 5) return launch_fwd<64, 64, 2, 16, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    if (fwd_variant == 6) return launch_fwd<64, 64, 2, 8, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
   }
   FWD_CASE(16, 16, 2, 4)
   FWD_CASE(16, 32, 2, 4)
@@ -311,9 +407,11 @@ extern "C" int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const fl
   FWD_CASE(32, 64, 2, 8)
   FWD_CASE(64, 32, 2, 8)
   FWD_CASE(64, 64, 1, 16)  // sweep (tools/tune_fwd.py): MT1x16 53.5 us, MT2x8 56.9, MT4x8 66.8, MT2x4 97.3
-  FWD_CASE(64, 128, 1, 8)
-  FWD_CASE(128, 64, 2, 8)
-  FWD_CASE(128, 128, 1, 8)
+  // 128-channel layers (nuScenes / Lyft ResNetFHD): 16-wave blocks halve the weight-staging registers per
+  // thread; with 8 waves the W[k] prefetch registers were spilled to scratch inside the offset loop
+  FWD_CASE(64, 128, 1, 16)
+  FWD_CASE(128, 64, 1, 16)
+  FWD_CASE(128, 128, 1, 16)
   int64_t items = (int64_t)n_out * cout;
   int nb = (int)((items + 255) / 256);
   if (nb > 4096) nb = 4096;
@@ -604,15 +702,8 @@ static int launch_wgrad(const void *feat, const void *dout, const int32_t *nbr, 
     return launch_wgrad<CI, CO, 1, 64, true>(WGRAD_ARGS);                                 \
   }
 
-extern "C" int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const int32_t *nbr,
-                                     int cap, int n_out, int kvol, int cin, int cout, int dtype,
-                                     float *dw, d3d_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  D3D_REQUIRE(dtype == D3D_F32 || dtype == D3D_BF16, "d3d_sparse_conv_wgrad: dtype %d", dtype);
-  D3D_REQUIRE(n_out >= 0 && n_out <= cap && kvol >= 1 && cin >= 1 && cout >= 1,
-              "d3d_sparse_conv_wgrad: bad sizes");
-  D3D_REQUIRE(cin * cout <= 16384, "d3d_sparse_conv_wgrad: cin*cout=%d > 16384", cin * cout);
-  D3D_REQUIRE(dw, "d3d_sparse_conv_wgrad: null dw");
+int d3d_wgrad_legacy(const void *feat, const void *dout, const int32_t *nbr, int cap, int n_out, int kvol,
+                     int cin, int cout, int dtype, float *dw, hipStream_t stream) {
   D3D_HIP_TRY(d3d_fill_async(stream, dw, 0, (size_t)kvol * cin * cout * sizeof(float)));
   if (n_out == 0) return D3D_OK;
   D3D_REQUIRE(feat && dout && nbr, "d3d_sparse_conv_wgrad: null pointer");
@@ -622,7 +713,7 @@ extern "C" int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const i
   // defaults from the sweep on a KITTI batch (126k sites, 1.67M pairs, 64x64): KG=1 pipelined
   // 64-site tiles 138 us, KG=3 pipelined 141 us, v1 (unpipelined) 149 us, 128-site tiles 199 us
   static const int knob_kg = getenv("D3D_WGRAD_KG") ? atoi(getenv("D3D_WGRAD_KG")) : 1;
-  static const int knob_blocks = getenv("D3D_WGRAD_BLOCKS") ? atoi(getenv("D3D_WGRAD_BLOCKS")) : 1024;
+  static const int knob_blocks = getenv("D3D_WGRAD_LEGACY_BLOCKS") ? atoi(getenv("D3D_WGRAD_LEGACY_BLOCKS")) : 1024;
   static const int variant = getenv("D3D_WGRAD_VARIANT") ? atoi(getenv("D3D_WGRAD_VARIANT")) : 1;
   const int kgroups =
       (knob_kg == 3 && kvol % 3 == 0 && cin * cout <= 4096 && cin >= 16) ? kvol / 3 : kvol;

@@ -1,0 +1,299 @@
+// Sparse-conv weight gradient for gfx950, site-tile stationary (round 2):
+//
+//   dW[k][ci][co] = sum_o  feat[nbr[k][o]][ci] * dout[o][co]
+//
+// Round 1 ran one block per (kernel offset, site split): every dout tile was fetched once per offset
+// (27x) and 1024 blocks x 4096 float atomics were folded into one 216 KB dW (99 us for 64->64, 3-6x the
+// compulsory HBM traffic, profiles/round1_pmc_fetch_size.txt).  Here a 16-wave block owns a contiguous
+// range of output sites and a GROUP of KG kernel offsets whose [Cin x Cout] accumulators all live in
+// registers (64->64: 9 offsets x 16 MFMA tiles = one tile per wave and offset, 36 VGPRs):
+//   * a dout tile of STEP sites is staged in LDS ONCE and reused for the KG offsets (27 / KG reads of dout
+//     per launch instead of 27; KG = 27 for Cin*Cout <= 2048, i.e. dout is read exactly once);
+//   * the gathered feature rows of one (tile, offset) stage are 16 KB = one 16-byte vector per thread;
+//     they are prefetched DEPTH stages ahead in registers (DEPTH x 16 KB in flight per CU) with their
+//     neighbour indices prefetched a further DEPTH stages ahead, so the two dependent L2 round trips
+//     (index, then row) of the gather overlap ~2*DEPTH stages of LDS + MFMA work;
+//   * sites become the MFMA k dimension through ds_read_b64_tr_b16 on [16 sites][16 ch] LDS tiles;
+//   * no atomics: every block stores its partial dW to a workspace slice and a second, streaming kernel
+//     sums the splits in a fixed order => the weight gradient is bit-reproducible run to run.
+// Traffic per launch: P*Cin*e gathered (L2) + (27/KG)*N*Cout*e + 27*N*4 (table) + 2 * splits*|dW|*4.
+#include <stdlib.h>
+
+#include "d3d_common.h"
+#include "d3d_fill.h"
+#include "d3d_spconv_internal.h"
+
+typedef __attribute__((ext_vector_type(4))) short wg_s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float wg_f32x4_t;
+
+#define WG_WAVES 16
+#define WG_THREADS (WG_WAVES * 64)
+
+template <int CIN, int COUT, int KG, int DEPTH>
+__global__ void __launch_bounds__(WG_THREADS)
+    spconv_wgrad_tile_kernel(const uint16_t *__restrict__ feat, const uint16_t *__restrict__ dout,
+                             const int32_t *__restrict__ nbr, int cap, int n_out, int rows_per_split,
+                             int kvol, float *__restrict__ part) {
+  constexpr int CIT = CIN / 16, COT = COUT / 16, TILES = CIT * COT;
+  constexpr int TPW = TILES >= WG_WAVES ? TILES / WG_WAVES : 1;     // MFMA tiles per wave and offset
+  constexpr int KSPLIT = TILES >= WG_WAVES ? 1 : WG_WAVES / TILES;  // wave groups sharing the offsets
+  constexpr int NACC = (KG + KSPLIT - 1) / KSPLIT;                  // offsets accumulated per wave
+  constexpr int FSEG = CIN / 8, DSEG = COUT / 8;                    // 16-byte segments per row
+  constexpr int STEP = WG_THREADS / FSEG;                           // sites per stage (1 vector / thread)
+  constexpr int CHUNKS = STEP / 16;
+  constexpr int DN = STEP * DSEG;
+  constexpr int DV = (DN + WG_THREADS - 1) / WG_THREADS;            // dout vectors per thread and tile
+  constexpr int FBUF = CHUNKS * CIT * 256, DBUF = CHUNKS * COT * 256;  // bf16 elements per LDS buffer
+  static_assert(DEPTH <= KG || KG == 1, "one dout register set: the next tile's rows must not be issued twice");
+  // [buffer][chunk][ch tile][16 sites][16 ch] bf16
+  __shared__ __attribute__((aligned(16))) uint16_t lds_f[2 * FBUF];
+  __shared__ __attribute__((aligned(16))) uint16_t lds_d[2 * DBUF];
+
+  const int k0 = blockIdx.x * KG;
+  const int s0 = blockIdx.y * rows_per_split;
+  int s1 = s0 + rows_per_split;
+  if (s1 > n_out) s1 = n_out;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int my_tile = wave % TILES;    // first (only, if TILES <= 16) MFMA tile of this wave
+  const int my_kgrp = wave / TILES;    // 0 when KSPLIT == 1
+
+  wg_f32x4_t acc[NACC][TPW];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[a][t] = wg_f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int ntiles = (s1 - s0 + STEP - 1) / STEP;
+  const int nstages = ntiles * KG;
+  const int frow = threadIdx.x / FSEG, fseg = threadIdx.x - frow * FSEG;
+
+  auto load_index = [&](int st) -> int {
+    const int tile = st / KG, kk = st - tile * KG;
+    const int site = s0 + tile * STEP + frow;
+    return site < s1 ? nbr[(int64_t)(k0 + kk) * cap + site] : -1;
+  };
+  auto load_feat = [&](int i) -> uint4 {
+    return i >= 0 ? *(const uint4 *)(feat + (int64_t)i * CIN + fseg * 8) : make_uint4(0, 0, 0, 0);
+  };
+  uint4 dr[DV];
+  auto load_dout = [&](int tile) {
+    const int base = s0 + tile * STEP;
+#pragma unroll
+    for (int j = 0; j < DV; ++j) {
+      const int e = threadIdx.x + j * WG_THREADS;
+      if (DN % WG_THREADS != 0 && e >= DN) break;
+      const int r = e / DSEG, seg = e - r * DSEG;
+      const int site = base + r;
+      dr[j] = site < s1 ? *(const uint4 *)(dout + (int64_t)site * COUT + seg * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
+
+  uint4 fr[DEPTH];
+  int ix[DEPTH];
+  if (nstages > 0) {
+    load_dout(0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) ix[d] = d < nstages ? load_index(d) : -1;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      fr[d] = load_feat(ix[d]);
+      ix[d] = d + DEPTH < nstages ? load_index(d + DEPTH) : -1;
+    }
+  }
+
+  for (int sb = 0; sb < nstages; sb += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int st = sb + d;
+      if (st >= nstages) break;
+      const int tile = st / KG, kk = st - tile * KG;
+      uint16_t *bf = lds_f + (st & 1) * FBUF;
+      uint16_t *bd = lds_d + (tile & 1) * DBUF;
+      // stage `st` -> LDS ([16 sites][16 ch] tiles).  The buffer's previous readers (stage st-2) all
+      // passed the barrier of stage st-1 after finishing their MFMAs, so one barrier per stage suffices
+      *(uint4 *)(bf + ((frow >> 4) * CIT + (fseg >> 1)) * 256 + (frow & 15) * 16 + (fseg & 1) * 8) = fr[d];
+      if (kk == 0) {
+#pragma unroll
+        for (int j = 0; j < DV; ++j) {
+          const int e = threadIdx.x + j * WG_THREADS;
+          if (DN % WG_THREADS != 0 && e >= DN) break;
+          const int r = e / DSEG, seg = e - r * DSEG;
+          *(uint4 *)(bd + ((r >> 4) * COT + (seg >> 1)) * 256 + (r & 15) * 16 + (seg & 1) * 8) = dr[j];
+        }
+      }
+      __syncthreads();
+      // refill the pipeline: rows of stage st+DEPTH (their indices arrived DEPTH stages ago), indices of
+      // stage st+2*DEPTH, and -- once per tile -- the next tile's dout rows
+      fr[d] = st + DEPTH < nstages ? load_feat(ix[d]) : make_uint4(0, 0, 0, 0);
+      ix[d] = st + 2 * DEPTH < nstages ? load_index(st + 2 * DEPTH) : -1;
+      if (kk == 0 && tile + 1 < ntiles) load_dout(tile + 1);
+      if ((kk % KSPLIT) == my_kgrp) {
+        const int aidx = kk / KSPLIT;
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+          if (a != aidx) continue;  // keeps acc[] statically indexed (uniform branch)
+#pragma unroll 4
+          for (int chunk = 0; chunk < CHUNKS; ++chunk) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+              const int tl = my_tile + t * WG_WAVES;
+              const int cit = tl / COT, cot = tl - cit * COT;
+              // each lane passes the address of ITS 8 bytes in the row-major 4x16 block of sites
+              // [lg*4, lg*4+4); the hardware returns the transposed column lr
+              wg_s16x4_t av = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (__attribute__((address_space(3))) wg_s16x4_t *)(bf + (chunk * CIT + cit) * 256 + lg * 64 + lr * 4));
+              wg_s16x4_t bv = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (__attribute__((address_space(3))) wg_s16x4_t *)(bd + (chunk * COT + cot) * 256 + lg * 64 + lr * 4));
+              acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, acc[a][t], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // partial dW of this (offset group, site split): plain stores, summed by wgrad_reduce_kernel
+  float *pbase = part + (int64_t)blockIdx.y * kvol * (CIN * COUT);
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    const int kk = a * KSPLIT + my_kgrp;
+    if (kk >= KG) continue;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tl = my_tile + t * WG_WAVES;
+      const int cit = tl / COT, cot = tl - cit * COT;
+      float *o = pbase + ((int64_t)(k0 + kk) * CIN + cit * 16 + lg * 4) * COUT + cot * 16 + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r * COUT] = acc[a][t][r];
+    }
+  }
+}
+
+// dw[e] = sum over splits of part[s][e] in a fixed order (4 elements per thread, two independent chains)
+__global__ void __launch_bounds__(256)
+    wgrad_reduce_kernel(const float4 *__restrict__ part, int splits, int64_t total4, float4 *__restrict__ dw) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    int s = 0;
+    for (; s + 1 < splits; s += 2) {
+      const float4 u = part[(int64_t)s * total4 + e], v = part[(int64_t)(s + 1) * total4 + e];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+      b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+    if (s < splits) {
+      const float4 u = part[(int64_t)s * total4 + e];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+    }
+    dw[e] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+
+struct WgPlan {
+  int kg, step, splits, rows_per_split;
+};
+
+static int wg_target_blocks() {
+  static const int v = getenv("D3D_WGRAD_BLOCKS") ? atoi(getenv("D3D_WGRAD_BLOCKS")) : 256;  // one per CU
+  return v < 1 ? 256 : v;
+}
+
+// offsets per block: all of them while the accumulators of a wave stay <= ~56 registers
+static int wg_kgroup(int kvol, int cin, int cout) {
+  const int tiles = (cin / 16) * (cout / 16);
+  const int kg = tiles <= 8 ? 27 : (tiles <= 32 ? 9 : 3);
+  if (kvol % kg == 0 && kvol >= kg) return kg;
+  return kvol % 3 == 0 ? 3 : 1;
+}
+
+static bool wg_supported(int cin, int cout) {
+  return (cin == 16 && (cout == 16 || cout == 32)) || (cin == 32 && (cout == 32 || cout == 64)) ||
+         (cin == 64 && (cout == 64 || cout == 128)) || (cin == 128 && cout == 128);
+}
+
+static WgPlan wg_plan(int n_out, int kvol, int cin, int cout) {
+  WgPlan p;
+  p.kg = wg_kgroup(kvol, cin, cout);
+  p.step = WG_THREADS / (cin / 8);
+  const int kgroups = kvol / p.kg;
+  const int tiles = (n_out + p.step - 1) / p.step;
+  int splits = (wg_target_blocks() + kgroups - 1) / kgroups;
+  int max_splits = (tiles + 1) / 2;  // >= 2 tiles per block
+  if (max_splits < 1) max_splits = 1;
+  if (splits > max_splits) splits = max_splits;
+  int tiles_per_split = (tiles + splits - 1) / splits;
+  p.rows_per_split = tiles_per_split * p.step;
+  p.splits = (n_out + p.rows_per_split - 1) / p.rows_per_split;
+  if (p.splits < 1) p.splits = 1;
+  return p;
+}
+
+extern "C" size_t d3d_sparse_conv_wgrad_workspace_bytes(int n_out, int kvol, int cin, int cout, int dtype) {
+  if (dtype != D3D_BF16 || !wg_supported(cin, cout) || n_out <= 0) return 256;
+  WgPlan p = wg_plan(n_out, kvol, cin, cout);
+  return (size_t)p.splits * kvol * cin * cout * sizeof(float) + 256;
+}
+
+template <int CI, int CO, int KG, int DEPTH>
+static int wg_launch(const void *feat, const void *dout, const int32_t *nbr, int cap, int n_out, int kvol,
+                     const WgPlan &p, float *part, hipStream_t stream) {
+  hipLaunchKernelGGL((spconv_wgrad_tile_kernel<CI, CO, KG, DEPTH>), dim3(kvol / KG, p.splits),
+                     dim3(WG_THREADS), 0, stream, (const uint16_t *)feat, (const uint16_t *)dout, nbr, cap,
+                     n_out, p.rows_per_split, kvol, part);
+  D3D_LAUNCH_TRY("spconv_wgrad_tile_kernel");
+  return D3D_OK;
+}
+
+#define WG_ARGS feat, dout, nbr, cap, n_out, kvol, p, part, stream
+// (channels) -> the offset group wg_kgroup() picks for a 27-offset kernel with its prefetch depth, plus the
+// 3-offset ((3,1,1) kernels) and 1-offset fallbacks
+#define WG_CASE(CI, CO, KGMAIN, DMAIN)                                                        \
+  if (cin == CI && cout == CO) {                                                              \
+    if (p.kg == KGMAIN) return wg_launch<CI, CO, KGMAIN, DMAIN>(WG_ARGS);                     \
+    if (p.kg == 3) return wg_launch<CI, CO, 3, 3>(WG_ARGS);                                   \
+    if (p.kg == 1) return wg_launch<CI, CO, 1, 4>(WG_ARGS);                                   \
+  }
+
+static int wg_dispatch(const void *feat, const void *dout, const int32_t *nbr, int cap, int n_out, int kvol,
+                       int cin, int cout, const WgPlan &p, float *part, hipStream_t stream) {
+  // prefetch depth: DEPTH stages x 16 KB of gathered rows in flight per CU, bounded by the 128 VGPRs a
+  // 16-wave block leaves each lane (accumulators: 4 * NACC * TPW)
+  WG_CASE(16, 16, 27, 8)
+  WG_CASE(16, 32, 27, 8)
+  WG_CASE(32, 32, 27, 8)
+  WG_CASE(32, 64, 27, 6)
+  WG_CASE(64, 64, 9, 8)
+  WG_CASE(64, 128, 9, 4)
+  WG_CASE(128, 128, 3, 3)
+  return d3d_set_error(D3D_EINVAL, "wgrad tile kernel: unsupported channels %d -> %d (kg %d)", cin, cout, p.kg);
+}
+
+extern "C" int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const int32_t *nbr, int cap,
+                                     int n_out, int kvol, int cin, int cout, int dtype, float *dw,
+                                     void *workspace, size_t workspace_bytes, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  D3D_REQUIRE(dtype == D3D_F32 || dtype == D3D_BF16, "d3d_sparse_conv_wgrad: dtype %d", dtype);
+  D3D_REQUIRE(n_out >= 0 && n_out <= cap && kvol >= 1 && cin >= 1 && cout >= 1,
+              "d3d_sparse_conv_wgrad: bad sizes");
+  D3D_REQUIRE(cin * cout <= 16384, "d3d_sparse_conv_wgrad: cin*cout=%d > 16384", cin * cout);
+  D3D_REQUIRE(dw, "d3d_sparse_conv_wgrad: null dw");
+  // D3D_WGRAD_LEGACY=1: the round-1 kernels (one block per offset, float atomics) for A/B timing
+  static const int legacy = getenv("D3D_WGRAD_LEGACY") ? atoi(getenv("D3D_WGRAD_LEGACY")) : 0;
+  const bool tile_path = !legacy && dtype == D3D_BF16 && wg_supported(cin, cout) && n_out > 0;
+  if (!tile_path) return d3d_wgrad_legacy(feat, dout, nbr, cap, n_out, kvol, cin, cout, dtype, dw, stream);
+  D3D_REQUIRE(feat && dout && nbr, "d3d_sparse_conv_wgrad: null pointer");
+  const size_t need = d3d_sparse_conv_wgrad_workspace_bytes(n_out, kvol, cin, cout, dtype);
+  if (!workspace || workspace_bytes < need)
+    return d3d_set_error(D3D_ECAPACITY, "d3d_sparse_conv_wgrad: workspace %zu B < %zu B", workspace_bytes, need);
+  WgPlan p = wg_plan(n_out, kvol, cin, cout);
+  float *part = (float *)workspace;
+  int rc = wg_dispatch(feat, dout, nbr, cap, n_out, kvol, cin, cout, p, part, stream);
+  if (rc) return rc;
+  const int64_t total4 = (int64_t)kvol * cin * cout / 4;
+  int nb = (int)((total4 + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, stream, (const float4 *)part, p.splits, total4,
+                     (float4 *)dw);
+  D3D_LAUNCH_TRY("wgrad_reduce_kernel");
+  return D3D_OK;
+}

@@ -16,6 +16,7 @@ MI355X-native differences under the hood:
   * conv fwd / dgrad / wgrad are single launches per layer (d3d_sparse_conv_*).
 There is no CPU implementation here: tensors must live on the GPU.
 """
+import ctypes
 import math
 
 import numpy as np
@@ -47,6 +48,88 @@ def _timed(kind, cin, cout, n_out, rb, dev, fn):
     e1.record(st)
     LAUNCH_LOG.append((kind, cin, cout, n_out, rb, e0, e1))
     return rc
+
+
+FUSE_BN_STATS = True  # BN batch statistics from the producing conv's epilogue, BN-backward reductions from the
+#                       consuming conv's dgrad epilogue (d3d_sparse_conv_fwd_ex): 2 instead of 4 BN sweeps per layer
+
+
+class _ZeroArena:
+    """One flat f32 buffer per device handing out ZEROED per-channel accumulators (BN statistics / backward
+    partial sums written by conv epilogues).  `reset()` -- called by the backbones right before they run their
+    sparse stack, on the compute stream -- re-zeroes the whole buffer with ONE launch and bumps `generation`;
+    views handed out before a reset must not be accumulated into afterwards (the users compare generations).
+    Without resets (layers used on their own) the arena simply runs out and hands out private zeroed buffers."""
+
+    def __init__(self):
+        self.buf = {}
+        self.off = {}
+        self.generation = 0
+
+    def reset(self, dev):
+        b = self.buf.get(dev)
+        if b is not None:
+            b.zero_()
+        self.off[dev] = 0
+        self.generation += 1
+
+    def take(self, dev, n):
+        b = self.buf.get(dev)
+        off = self.off.get(dev, 0)
+        if b is None or off + n > b.numel():
+            if b is None and off == 0:
+                b = self.buf[dev] = torch.zeros((1 << 18,), dtype=torch.float32, device=dev)  # 1 MB
+            else:  # arena exhausted (very deep stack): a private zeroed buffer, still correct
+                return torch.zeros((n,), dtype=torch.float32, device=dev)
+        self.off[dev] = off + n
+        return b[off: off + n]
+
+
+ARENA = _ZeroArena()
+
+
+class _BnLink:
+    """Shared between a fused BN(+ReLU) op and the ONE sparse conv that consumes its output: lets the conv's data
+    gradient launch accumulate the BN-backward reductions (sum dz*xhat, sum dz) in its epilogue."""
+
+    __slots__ = ("x", "save", "gamma", "beta", "relu", "partial", "generation", "reduced")
+
+    def __init__(self):
+        self.x = self.save = self.gamma = self.beta = self.partial = None
+        self.relu = False
+        self.generation = -1
+        self.reduced = False
+
+
+_PACK_CACHE = {}  # id(weight) -> (weakref, version, dtype, flip, pad, wpack, wdgrad)
+
+
+def _packed_weights(weight, kvol, cin, cout, dtype, subm, need_dgrad, pad_cin):
+    """[kD,kH,kW,Cin,Cout] f32 parameter -> the kernels' packed forms (one launch), cached until the parameter
+    changes (optimizer steps bump `weight._version`): repeated forwards -- evaluation, several micro-batches per
+    step -- do not repack."""
+    import weakref
+
+    key = id(weight)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == dtype and \
+            hit[3] == subm and hit[4] == pad_cin and (hit[6] is not None or not need_dgrad):
+        return hit[5], hit[6]
+    L = _lib.lib()
+    w32 = weight.detach().float().reshape(kvol, cin, cout)
+    if pad_cin != cin:
+        w32 = torch.nn.functional.pad(w32, (0, 0, 0, pad_cin - cin))
+    w32 = w32.contiguous()
+    wpack = torch.empty((kvol, cout, pad_cin), dtype=dtype, device=weight.device)
+    wd = torch.empty((kvol, pad_cin, cout), dtype=dtype, device=weight.device) if need_dgrad else None
+    rc = L.d3d_pack_conv_weights(w32.data_ptr(), kvol, pad_cin, cout, _DT[dtype], int(subm), wpack.data_ptr(),
+                                 _lib.ptr(wd), _lib.stream_ptr(weight.device))
+    _lib.check(rc, "d3d_pack_conv_weights")
+    if len(_PACK_CACHE) > 512:
+        for k in [k for k, v in _PACK_CACHE.items() if v[0]() is None]:
+            del _PACK_CACHE[k]
+    _PACK_CACHE[key] = (weakref.ref(weight), weight._version, dtype, subm, pad_cin, wpack, wd)
+    return wpack, wd
 
 
 def _triple(v):
@@ -169,7 +252,10 @@ def finalize_conv_rulebook(rb, n_in, n_out):
 # --------------------------------------------------------------------- autograd
 class _SparseConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, weight, bias, rb):
+    def forward(ctx, feats, weight, bias, rb, stats, link):
+        """stats: zeroed f32 [D3D_BN_COPIES * 2 * cout] or None -- the launch adds sum / sum-of-squares of its
+        output rows (the batch statistics of the BatchNorm that follows).  link: _BnLink of the fused BN(+ReLU)
+        that produced `feats`, or None -- the backward's dgrad launch then also reduces that BN's gradient sums."""
         _need_cuda(feats, "sparse conv")
         L = _lib.lib()
         if feats.dtype not in _DT:
@@ -182,25 +268,33 @@ class _SparseConvFn(torch.autograd.Function):
             # kvol*cin*cout floats from a smaller weight
             raise _lib.D3dError("sparse conv: weight %s does not match the rulebook's kernel volume %d "
                                 "(indice_key shared between different kernel sizes?)" % (tuple(weight.shape), kvol))
-        # one launch repacks the [kD,kH,kW,Cin,Cout] f32 parameter for the forward and (kept for the
-        # backward) the data gradient; W itself is not saved in packed form anywhere else
-        w32 = weight.detach().float().contiguous()
-        wpack = torch.empty((kvol, cout, cin), dtype=feats.dtype, device=feats.device)
-        wd = torch.empty((kvol, cin, cout), dtype=feats.dtype, device=feats.device) \
-            if ctx.needs_input_grad[0] else None
-        rc = L.d3d_pack_conv_weights(w32.data_ptr(), kvol, cin, cout, _DT[feats.dtype], int(rb.subm),
-                                     wpack.data_ptr(), _lib.ptr(wd), _lib.stream_ptr(feats.device))
-        _lib.check(rc, "d3d_pack_conv_weights")
+        # stem layers (3..5 input channels, scn.py:106-107 / :324): zero-pad the rows to 16 channels so the layer
+        # runs on the MFMA kernels like every other one (the VALU fallbacks were the slowest launches of the
+        # step for the smallest layer: 41 us forward, 105 us weight gradient)
+        pad_cin = 16 if (cin < 16 and cout % 16 == 0) else cin
+        if pad_cin != cin:
+            feats = torch.nn.functional.pad(feats, (0, pad_cin - cin))
+        need_dgrad = ctx.needs_input_grad[0]
+        wpack, wd = _packed_weights(weight, kvol, cin, cout, feats.dtype, rb.subm, need_dgrad, pad_cin)
         out = torch.empty((rb.n_out, cout), dtype=feats.dtype, device=feats.device)
         b = bias.detach().float().contiguous() if bias is not None else None
-        rc = _timed("fwd", cin, cout, rb.n_out, rb, feats.device, lambda: L.d3d_sparse_conv_fwd(
+        mfma = pad_cin % 16 == 0 and cout % 16 == 0 and pad_cin <= 128 and cout <= 128
+        ep = None
+        if stats is not None and mfma and rb.n_out > 0:
+            ep = _lib.ConvEpilogue(stats=stats.data_ptr())
+        rc = _timed("fwd", pad_cin, cout, rb.n_out, rb, feats.device, lambda: L.d3d_sparse_conv_fwd_ex(
             feats.data_ptr(), wpack.data_ptr(), _lib.ptr(b), rb.nbr_out.data_ptr(), rb.cap_out,
-            rb.n_out, kvol, cin, cout, _DT[feats.dtype], out.data_ptr(), _lib.stream_ptr(feats.device)))
+            rb.n_out, kvol, pad_cin, cout, _DT[feats.dtype], out.data_ptr(),
+            ctypes.byref(ep) if ep is not None else None, _lib.stream_ptr(feats.device)))
         _lib.check(rc, "d3d_sparse_conv_fwd")
+        ctx.stats_done = ep is not None
         ctx.save_for_backward(feats, weight)
         ctx.wd = wd
         ctx.rb = rb
         ctx.has_bias = bias is not None
+        ctx.pad = (cin, pad_cin)
+        ctx.link = link
+        ctx.mfma = mfma
         return out
 
     @staticmethod
@@ -208,7 +302,8 @@ class _SparseConvFn(torch.autograd.Function):
         L = _lib.lib()
         feats, weight = ctx.saved_tensors
         rb = ctx.rb
-        kvol, cin, cout = rb.kvol, weight.shape[-2], weight.shape[-1]
+        kvol, cout = rb.kvol, weight.shape[-1]
+        cin, pad_cin = ctx.pad
         gout = gout.contiguous().to(feats.dtype)
         dt = _DT[feats.dtype]
         stream = _lib.stream_ptr(feats.device)
@@ -220,43 +315,71 @@ class _SparseConvFn(torch.autograd.Function):
                 nbr, cap = rb.nbr_out, rb.cap_out
             else:
                 nbr, cap = rb.nbr_in, rb.cap_in
-            gin = torch.empty((rb.n_in, cin), dtype=feats.dtype, device=feats.device)
-            rc = _timed("dgrad", cout, cin, rb.n_in, rb, feats.device, lambda: L.d3d_sparse_conv_fwd(
-                gout.data_ptr(), wd.data_ptr(), None, nbr.data_ptr(), cap, rb.n_in, kvol, cout, cin,
-                dt, gin.data_ptr(), stream))
+            gin = torch.empty((rb.n_in, pad_cin), dtype=feats.dtype, device=feats.device)
+            ep = None
+            link = ctx.link
+            if link is not None and ctx.mfma and pad_cin == cin and rb.n_in > 0 and \
+                    link.generation == ARENA.generation and not link.reduced:
+                # gin is dL/dy of the BN(+ReLU) that produced `feats`: reduce its gradient sums here
+                ep = _lib.ConvEpilogue(bn_x=link.x.data_ptr(), bn_mean=link.save[0].data_ptr(),
+                                       bn_invstd=link.save[1].data_ptr(), bn_gamma=_lib.ptr(link.gamma),
+                                       bn_beta=_lib.ptr(link.beta), bn_relu=int(link.relu),
+                                       bn_partial=link.partial.data_ptr())
+            rc = _timed("dgrad", cout, pad_cin, rb.n_in, rb, feats.device, lambda: L.d3d_sparse_conv_fwd_ex(
+                gout.data_ptr(), wd.data_ptr(), None, nbr.data_ptr(), cap, rb.n_in, kvol, cout, pad_cin,
+                dt, gin.data_ptr(), ctypes.byref(ep) if ep is not None else None, stream))
             _lib.check(rc, "d3d_sparse_conv_fwd(dgrad)")
+            if ep is not None:
+                link.reduced = True
+            if pad_cin != cin:
+                gin = gin[:, :cin].contiguous()
         if ctx.needs_input_grad[1]:
-            gw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=feats.device)
-            rc = _timed("wgrad", cin, cout, rb.n_out, rb, feats.device, lambda: L.d3d_sparse_conv_wgrad(
+            gw = torch.empty((kvol, pad_cin, cout), dtype=torch.float32, device=feats.device)
+            wsb = L.d3d_sparse_conv_wgrad_workspace_bytes(rb.n_out, kvol, pad_cin, cout, dt)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=feats.device)
+            rc = _timed("wgrad", pad_cin, cout, rb.n_out, rb, feats.device, lambda: L.d3d_sparse_conv_wgrad(
                 feats.data_ptr(), gout.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, rb.n_out, kvol,
-                cin, cout, dt, gw.data_ptr(), stream))
+                pad_cin, cout, dt, gw.data_ptr(), ws.data_ptr(), wsb, stream))
             _lib.check(rc, "d3d_sparse_conv_wgrad")
+            if pad_cin != cin:
+                gw = gw[:, :cin]
             gw = gw.reshape(weight.shape).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gout.float().sum(0)
-        return gin, gw, gb, None
+        return gin, gw, gb, None, None, None
 
 
 class _BNReLUFn(torch.autograd.Function):
-    """BatchNorm1d (+ReLU) on [N, C] features through d3d_bn_relu_fwd / _bwd."""
+    """BatchNorm1d (+ReLU) on [N, C] features through the d3d_bn_* kernels.  `stats` (optional): the batch sums
+    already accumulated by the producing conv's epilogue -> only the apply pass runs.  `link` (optional): filled
+    for the single conv consuming the output, whose dgrad epilogue then does this op's backward reduction."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, training, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, training, relu, stats, link):
         L = _lib.lib()
         x = x.contiguous()
         n, c = x.shape
         dev = x.device
         y = torch.empty_like(x)
-        save = torch.empty((2 + 2 * _lib.D3D_BN_COPIES, c), dtype=torch.float32, device=dev)  # mean, invstd, scratch
-        rc = L.d3d_bn_relu_fwd(x.data_ptr(), n, c, _DT[x.dtype], _lib.ptr(weight), _lib.ptr(bias),
-                               _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum),
-                               float(eps), int(training), int(relu), y.data_ptr(),
-                               save[0].data_ptr(), save[1].data_ptr(), save[2].data_ptr(),
-                               _lib.stream_ptr(dev))
-        _lib.check(rc, "d3d_bn_relu_fwd")
+        save = torch.empty((2, c), dtype=torch.float32, device=dev)  # mean, invstd
+        st = _lib.stream_ptr(dev)
+        if training and stats is None:
+            stats = torch.empty((2 * _lib.D3D_BN_COPIES * c,), dtype=torch.float32, device=dev)
+            _lib.check(L.d3d_bn_stats(x.data_ptr(), n, c, _DT[x.dtype], stats.data_ptr(), st), "d3d_bn_stats")
+        rc = L.d3d_bn_apply(x.data_ptr(), n, c, _DT[x.dtype], _lib.ptr(weight), _lib.ptr(bias),
+                            _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum), float(eps),
+                            int(training), int(relu), _lib.ptr(stats) if training else None, y.data_ptr(),
+                            save[0].data_ptr(), save[1].data_ptr(), st)
+        _lib.check(rc, "d3d_bn_apply")
         ctx.save_for_backward(x, weight, bias, save)
         ctx.relu = relu
         ctx.training = training
+        ctx.link = link
+        if link is not None and training:
+            link.x, link.save, link.gamma, link.beta, link.relu = x, save, weight, bias, bool(relu)
+            link.partial = ARENA.take(dev, 2 * _lib.D3D_BN_COPIES * c)
+            link.generation = ARENA.generation
+            link.reduced = False
         return y
 
     @staticmethod
@@ -269,19 +392,31 @@ class _BNReLUFn(torch.autograd.Function):
         dy = dy.contiguous().to(x.dtype)
         dx = torch.empty_like(x)
         g = torch.empty((2, c), dtype=torch.float32, device=x.device)
-        rc = L.d3d_bn_relu_bwd(x.data_ptr(), dy.data_ptr(), n, c, _DT[x.dtype], _lib.ptr(weight),
-                               _lib.ptr(bias), save[0].data_ptr(), save[1].data_ptr(), int(ctx.relu),
-                               dx.data_ptr(), g[0].data_ptr(), g[1].data_ptr(), save[2].data_ptr(),
-                               _lib.stream_ptr(x.device))  # the forward's stats scratch is free again
-        _lib.check(rc, "d3d_bn_relu_bwd")
+        st = _lib.stream_ptr(x.device)
+        link = ctx.link
+        if link is not None and link.reduced and link.generation == ARENA.generation:
+            partial = link.partial  # reduced by the consuming conv's dgrad epilogue
+        else:
+            partial = torch.empty((2 * _lib.D3D_BN_COPIES * c,), dtype=torch.float32, device=x.device)
+            rc = L.d3d_bn_bwd_reduce(x.data_ptr(), dy.data_ptr(), n, c, _DT[x.dtype], _lib.ptr(weight),
+                                     _lib.ptr(bias), save[0].data_ptr(), save[1].data_ptr(), int(ctx.relu),
+                                     partial.data_ptr(), st)
+            _lib.check(rc, "d3d_bn_bwd_reduce")
+        rc = L.d3d_bn_bwd_dx(x.data_ptr(), dy.data_ptr(), n, c, _DT[x.dtype], _lib.ptr(weight), _lib.ptr(bias),
+                             save[0].data_ptr(), save[1].data_ptr(), int(ctx.relu), partial.data_ptr(),
+                             dx.data_ptr(), g[0].data_ptr(), g[1].data_ptr(), st)
+        _lib.check(rc, "d3d_bn_bwd_dx")
+        if link is not None:
+            link.x = link.save = link.partial = None  # drop the references held for the epilogue
         gw = g[0].to(weight.dtype) if weight is not None else None
         gb = g[1].to(bias.dtype) if bias is not None else None
-        return dx, gw, gb, None, None, None, None, None, None
+        return dx, gw, gb, None, None, None, None, None, None, None, None
 
 
-def _fusable_bn(bn, feats):
+def _fusable_bn(bn, feats, channels=None):
     """plain affine nn.BatchNorm1d with running stats, on CUDA f32/bf16 features whose channel
-    count the kernel supports (c/8 | 256 for bf16, c/4 | 256 for f32)."""
+    count the kernel supports (c/8 | 256 for bf16, c/4 | 256 for f32).  `channels`: judge a BN that will see
+    `channels`-wide rows of the same dtype / row count class as `feats` (the output of a conv not yet run)."""
     if type(bn) is not nn.BatchNorm1d or not feats.is_cuda or feats.dtype not in _DT or feats.dim() != 2:
         return False
     if bn.momentum is None or not bn.track_running_stats or bn.weight is None:
@@ -291,16 +426,34 @@ def _fusable_bn(bn, feats):
         return False
     if feats.shape[0] < 2 or (not bn.training and torch.is_grad_enabled() and feats.requires_grad):
         return False
-    c = feats.shape[1]
+    c = feats.shape[1] if channels is None else channels
+    if bn.num_features != c:
+        return False
     epv = 8 if feats.dtype == torch.bfloat16 else 4
     return c % epv == 0 and c <= 256 and 256 % (c // epv) == 0
 
 
-def bn_relu(bn, feats, relu):
+def bn_relu(bn, feats, relu, stats=None, link=None):
     """apply `bn` (an nn.BatchNorm1d) and optionally ReLU to sparse features with the fused HIP
     kernels; state (running stats) lives in the module exactly as with F.batch_norm."""
     return _BNReLUFn.apply(feats, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                           bn.momentum, bn.eps, bn.training, relu)
+                           bn.momentum, bn.eps, bn.training, relu, stats, link)
+
+
+def conv_bn_relu(conv, bn, relu, x, link_in=None, want_link=False):
+    """conv -> BatchNorm1d [-> ReLU] on a SparseConvTensor with the BN batch statistics taken from the conv's
+    epilogue.  link_in: _BnLink of the fused BN that produced x.features (this conv being its only consumer).
+    want_link: return a _BnLink for the single conv that will consume the result.  Returns (tensor, link)."""
+    fuse = FUSE_BN_STATS and bn.training and x.features.is_cuda and x.features.shape[0] > 0
+    stats = None
+    if fuse:
+        stats = ARENA.take(x.features.device, 2 * _lib.D3D_BN_COPIES * conv.out_channels)
+    out = conv(x, stats=stats, link=link_in if FUSE_BN_STATS else None)
+    if not getattr(out, "_stats_done", False):
+        stats = None
+    link = _BnLink() if (want_link and fuse) else None
+    out.features = bn_relu(bn, out.features, relu, stats, link)
+    return out, link
 
 
 def fusable_bn2d(bn, x):
@@ -324,7 +477,7 @@ def bn_relu_2d(bn, x, relu):
     b, c, h, w = x.shape
     rows = x.permute(0, 2, 3, 1).reshape(b * h * w, c)  # a view: channels-last memory is [B,H,W,C]
     y = _BNReLUFn.apply(rows, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                        bn.training, relu)
+                        bn.training, relu, None, None)
     # like bn_relu(): num_batches_tracked is not advanced (one launch per layer for a counter that
     # momentum-based running statistics never read)
     return y.view(b, h, w, c).permute(0, 3, 1, 2)
@@ -470,15 +623,21 @@ class SparseConvolution(SparseModule):
         x.indice_dict[key] = rb
         return rb
 
-    def forward(self, x):
+    def forward(self, x, stats=None, link=None):
         assert isinstance(x, SparseConvTensor)
         rb = self._get_rulebook(x)
         if rb.subm != self.subm:
             raise _lib.D3dError("indice_key %r is shared between a submanifold and a strided convolution" % (self.indice_key,))
-        out_feats = _SparseConvFn.apply(x.features, self.weight, self.bias, rb)
+        cin = self.in_channels
+        pad_cin = 16 if (cin < 16 and self.out_channels % 16 == 0) else cin
+        mfma = pad_cin % 16 == 0 and self.out_channels % 16 == 0 and pad_cin <= 128 and self.out_channels <= 128
+        if not mfma or rb.n_out == 0:
+            stats = None
+        out_feats = _SparseConvFn.apply(x.features, self.weight, self.bias, rb, stats, link)
         out = SparseConvTensor(out_feats, rb.out_indices if not self.subm else x.indices,
                                self.out_spatial_shape(x.spatial_shape), x.batch_size, x.grid)
         out.indice_dict = x.indice_dict
+        out._stats_done = stats is not None
         return out
 
 
@@ -543,11 +702,28 @@ class SparseSequential(SparseModule):
     def forward(self, input):
         mods = list(self._modules.values())
         i = 0
+        link = None  # _BnLink of the fused BN whose output is `input.features` (if this stack produced it)
         while i < len(mods):
             module = mods[i]
+            if isinstance(module, SparseConvolution) and FUSE_BN_RELU and i + 1 < len(mods) and \
+                    isinstance(input, SparseConvTensor) and input.indices.shape[0] != 0 and \
+                    _fusable_bn(mods[i + 1], input.features, channels=module.out_channels):
+                # conv -> BatchNorm1d [-> ReLU]: statistics from the conv epilogue, one apply pass; if the next
+                # module is again a conv it is the only consumer and reduces this BN's backward sums
+                relu = i + 2 < len(mods) and type(mods[i + 2]) is nn.ReLU
+                nxt = i + (3 if relu else 2)
+                want_link = nxt < len(mods) and isinstance(mods[nxt], SparseConvolution)
+                input, link = conv_bn_relu(module, mods[i + 1], relu, input, link_in=link, want_link=want_link)
+                i = nxt
+                continue
             if is_spconv_module(module):
-                input = module(input)
+                if isinstance(module, SparseConvolution):
+                    input = module(input, link=link if FUSE_BN_STATS else None)
+                else:
+                    input = module(input)
+                link = None
             elif isinstance(input, SparseConvTensor):
+                link = None
                 if input.indices.shape[0] != 0:
                     # BatchNorm1d [+ ReLU] on the active sites -> one fused HIP op
                     if FUSE_BN_RELU and _fusable_bn(module, input.features):
@@ -557,6 +733,7 @@ class SparseSequential(SparseModule):
                         continue
                     input.features = module(input.features)
             else:
+                link = None
                 input = module(input)
             i += 1
         return input

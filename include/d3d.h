@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 2 /* 2: d3d_bn_relu_bwd takes partial_ws; BN scratch is D3D_BN_COPIES * 2c; round-1 additions */
+#define D3D_ABI_VERSION 3 /* 3: d3d_sparse_conv_wgrad takes a workspace (two-pass deterministic weight gradient); round-2 additions */
 
 #define D3D_OK 0
 #define D3D_EINVAL -1    /* bad argument / unsupported shape           */
@@ -137,11 +137,36 @@ int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const float *bias,
                         const int32_t *nbr, int cap, int n_out, int kvol, int cin, int cout,
                         int dtype, void *out, d3d_stream_t stream);
 
+/* The same launch with a per-channel reduction folded into its epilogue -- each replaces one full sweep over
+ * the activations that the reference pays as a separate BatchNorm kernel (scn.py:106-157 applies
+ * nn.BatchNorm1d + nn.ReLU modules to `.features` after every conv):
+ *   forward: stats != NULL       -> sum / sum-of-squares of the produced rows (as stored, i.e. rounded to
+ *            dtype) are ADDED to stats [D3D_BN_COPIES][2*cout] f32 = what d3d_bn_stats computes;
+ *   dgrad  : bn_partial != NULL  -> the rows produced are dL/dy of the BatchNorm(+ReLU) whose output was this
+ *            conv's input; with that layer's pre-BN activations bn_x [n_out, cout] (dtype), saved mean /
+ *            invstd and gamma / beta (NULL = 1 / 0), sum dz*xhat | sum dz (dz = dy masked by the ReLU) are
+ *            ADDED to bn_partial [D3D_BN_COPIES][2*cout] f32 = what d3d_bn_bwd_reduce computes.
+ * The caller zeroes the accumulators.  Channel counts must be multiples of 16 (MFMA path). */
+typedef struct D3dConvEpilogue {
+  float *stats;
+  const void *bn_x;
+  const float *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;
+  int bn_relu;
+  float *bn_partial;
+} D3dConvEpilogue;
+int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const float *bias,
+                           const int32_t *nbr, int cap, int n_out, int kvol, int cin, int cout,
+                           int dtype, void *out, const D3dConvEpilogue *epilogue, d3d_stream_t stream);
+
 /* weight gradient: dw[k][ci][co] = sum_o feat[nbr[k][o]][ci] * dout[o][co]
- *  dw dev [kvol, cin, cout] f32, overwritten. */
+ *  dw dev [kvol, cin, cout] f32, overwritten.
+ *  workspace: device scratch of d3d_sparse_conv_wgrad_workspace_bytes(...) bytes holding the per-split
+ *  partial sums of the two-pass (atomic-free, bit-reproducible) bf16 path; f32 and channel counts outside
+ *  {16,32,64,128} take the one-pass kernels and ignore it. */
+size_t d3d_sparse_conv_wgrad_workspace_bytes(int n_out, int kvol, int cin, int cout, int dtype);
 int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const int32_t *nbr, int cap,
                           int n_out, int kvol, int cin, int cout, int dtype, float *dw,
-                          d3d_stream_t stream);
+                          void *workspace, size_t workspace_bytes, d3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * BatchNorm1d (+ReLU) over the active sites: replaces the nn.BatchNorm1d / nn.ReLU module
@@ -166,6 +191,30 @@ int d3d_bn_relu_fwd(const void *x, int n, int c, int dtype, const float *gamma, 
 int d3d_bn_relu_bwd(const void *x, const void *dy, int n, int c, int dtype, const float *gamma,
                     const float *beta, const float *save_mean, const float *save_invstd, int relu,
                     void *dx, float *dgamma, float *dbeta, float *partial_ws, d3d_stream_t stream);
+/* The halves of the two calls above as separate entry points (d3d_bn_relu_fwd = d3d_bn_stats + d3d_bn_apply,
+ * d3d_bn_relu_bwd = d3d_bn_bwd_reduce + d3d_bn_bwd_dx; same buffers).  The reductions can then come from a
+ * convolution epilogue (d3d_sparse_conv_fwd_ex) instead of their own sweep; d3d_bn_stats / d3d_bn_bwd_reduce
+ * zero their accumulator first, the apply / dx halves only read it. */
+int d3d_bn_stats(const void *x, int n, int c, int dtype, float *stats_ws, d3d_stream_t stream);
+int d3d_bn_apply(const void *x, int n, int c, int dtype, const float *gamma, const float *beta,
+                 float *running_mean, float *running_var, float momentum, float eps, int training, int relu,
+                 const float *stats_ws, void *y, float *save_mean, float *save_invstd, d3d_stream_t stream);
+int d3d_bn_bwd_reduce(const void *x, const void *dy, int n, int c, int dtype, const float *gamma,
+                      const float *beta, const float *save_mean, const float *save_invstd, int relu,
+                      float *partial_ws, d3d_stream_t stream);
+int d3d_bn_bwd_dx(const void *x, const void *dy, int n, int c, int dtype, const float *gamma, const float *beta,
+                  const float *save_mean, const float *save_invstd, int relu, const float *partial_ws, void *dx,
+                  float *dgamma, float *dbeta, d3d_stream_t stream);
+/* Per-channel affine sweeps for the reference's cross-rank BatchNorm (det3d/ops/syncbn/syncbn.py:15-118,
+ * src/syncbn_cuda_kernel.cu:166-198 transform_input, :595-640 input_backward): the all-reduced statistics
+ * arrive as [c] f32 vectors, so the passes take ready coefficients:
+ *   d3d_channel_affine      y  = relu ? max(0, x*scale + shift) : x*scale + shift
+ *   d3d_channel_affine_bwd  dx = coef_dz*dz + coef_x*x + coef_1,  dz = dy masked by [x*scale + shift > 0] if relu */
+int d3d_channel_affine(const void *x, int n, int c, int dtype, const float *scale, const float *shift, int relu,
+                       void *y, d3d_stream_t stream);
+int d3d_channel_affine_bwd(const void *x, const void *dy, int n, int c, int dtype, const float *scale,
+                           const float *shift, int relu, const float *coef_dz, const float *coef_x,
+                           const float *coef_1, void *dx, d3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * PillarFeatureNet with one (last) PFNLayer: det3d/models/readers/pillar_encoder.py:115-155

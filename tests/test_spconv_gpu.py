@@ -369,3 +369,142 @@ def test_sequential_fuses_bn_relu_transparently():
         spconv.FUSE_BN_RELU = True
     assert torch.allclose(a, b, atol=1e-4, rtol=1e-4)
     assert torch.allclose(net[1].running_var, net2[1].running_var, atol=1e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,gi,n_per", [(64, 64, 0, 30000), (32, 64, 1, 24000), (128, 128, 0, 9000),
+                                               (16, 16, 0, 30000), (64, 64, 3, 20000)])
+def test_wgrad_dgrad_at_kitti_scale_vs_oracle_and_bit_reproducible(cin, cout, gi, n_per):
+    """weight / data gradients pinned at toy sizes only.  ~60 k active sites (a KITTI batch level),
+    bf16: the two-pass tile kernel (many site splits, all offset groups, deep prefetch pipeline) against the
+    oracle's gather-mm-scatter, and the weight gradient must be bit-identical between two launches (no atomics)."""
+    from det3d_amd import spconv
+
+    ksize, stride, padding, subm = GEOMS[gi]
+    rng = np.random.default_rng(cin + cout + gi)
+    shape = [21, 200, 176]
+    idx, feats = _random_sparse(rng, 2, shape, n_per, cin)
+    w = (rng.standard_normal((*ksize, cin, cout)) / np.sqrt(cin * 9)).astype(np.float32)
+    out_idx, out_shape, pairs = R.get_indice_pairs(idx, 2, shape, ksize, stride, padding, subm)
+    g = rng.standard_normal((len(out_idx), cout)).astype(np.float32)
+    q = lambda a: torch.from_numpy(a).to(torch.bfloat16).float()
+    f_ref = q(feats).clone().requires_grad_(True)
+    w_ref = q(w).clone().requires_grad_(True)
+    out_ref = R.indice_conv(f_ref, w_ref, pairs, len(out_idx))
+    (out_ref * q(g)).sum().backward()
+
+    cls = spconv.SubMConv3d if subm else spconv.SparseConv3d
+    m = cls(cin, cout, ksize, stride=stride, padding=padding, bias=False).cuda()
+    with torch.no_grad():
+        m.weight.copy_(q(w))
+    grads = []
+    for _ in range(2):
+        m.weight.grad = None
+        f = q(feats).cuda().to(torch.bfloat16).requires_grad_(True)
+        y = m(spconv.SparseConvTensor(f, torch.from_numpy(idx).cuda(), shape, 2))
+        (y.features.float() * q(g).cuda()).sum().backward()
+        grads.append(m.weight.grad.clone())
+    assert torch.equal(grads[0], grads[1]), "weight gradient differs between two identical launches"
+    gw, gw_ref = grads[0].cpu(), w_ref.grad
+    # sums of up to ~6e4 products of bf16-rounded factors accumulated in f32: compare against the tensor scale
+    assert float((gw - gw_ref).abs().max()) < 2e-3 * float(gw_ref.abs().max()) + 1e-3
+    assert torch.allclose(y.features.float().cpu(), out_ref.detach(), atol=3e-2, rtol=2e-2)
+    assert torch.allclose(f.grad.float().cpu(), f_ref.grad, atol=6e-2, rtol=3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin0", [4, 16])
+def test_conv_epilogue_bn_fusions_match_the_separate_sweeps(dtype, cin0):
+    """d3d_sparse_conv_fwd_ex: BN batch statistics from the forward epilogue and BN-backward sums from the dgrad
+    epilogue (spconv.FUSE_BN_STATS) vs the same stack with separate bn_stats / bn_bwd_reduce sweeps: activations,
+    running statistics, input gradient and every parameter gradient.  cin0 = 4 also exercises the zero-padded
+    stem layer."""
+    import copy
+
+    from det3d_amd import spconv
+
+    rng = np.random.default_rng(9)
+    shape = [11, 60, 56]
+    idx, feats = _random_sparse(rng, 2, shape, 5000, cin0)
+    torch.manual_seed(2)
+    bn = lambda c: torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)
+    net = spconv.SparseSequential(
+        spconv.SubMConv3d(cin0, 16, 3, bias=False, indice_key="a"), bn(16), torch.nn.ReLU(),
+        spconv.SubMConv3d(16, 32, 3, bias=False, indice_key="a"), bn(32), torch.nn.ReLU(),
+        spconv.SparseConv3d(32, 64, 3, 2, padding=1, bias=False), bn(64), torch.nn.ReLU(),
+        spconv.SubMConv3d(64, 64, 3, bias=True, indice_key="b"), bn(64),
+        spconv.SubMConv3d(64, 64, 3, bias=False, indice_key="b"), bn(64), torch.nn.ReLU()).cuda()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            torch.nn.init.uniform_(m.weight, 0.5, 1.5)
+            torch.nn.init.normal_(m.bias, 0, 0.2)
+    net2 = copy.deepcopy(net)
+    gout = None
+    res = []
+    for fused, model in ((True, net), (False, net2)):
+        spconv.FUSE_BN_STATS = fused
+        try:
+            spconv.ARENA.reset(torch.device("cuda", 0))
+            f = torch.from_numpy(feats).cuda().to(dtype).requires_grad_(True)
+            y = model(spconv.SparseConvTensor(f, torch.from_numpy(idx).cuda(), shape, 2)).features
+            if gout is None:
+                gout = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).cuda().to(dtype)
+            y.backward(gout)
+            res.append((y.detach().float(), f.grad.float(), [p.grad.float() for p in model.parameters()],
+                        [b.clone() for b in model.buffers()]))
+        finally:
+            spconv.FUSE_BN_STATS = True
+    (ya, ga, pa, ba), (yb, gb, pb, bb) = res
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    rel = lambda a, b: float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+    assert rel(ya, yb) < tol
+    assert rel(ga, gb) < 5 * tol
+    for a, b in zip(pa, pb):
+        if float(b.abs().max()) < 1e-6:
+            continue
+        assert rel(a, b) < 5 * tol
+    for a, b in zip(ba, bb):
+        if a.is_floating_point():
+            assert torch.allclose(a, b, rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_split_bn_entry_points_and_channel_affine_sweeps(dtype):
+    """d3d_bn_stats + d3d_bn_apply == d3d_bn_relu_fwd; d3d_channel_affine(_bwd) against their formulas."""
+    from det3d_amd import _lib
+
+    L = _lib.lib()
+    dt = _lib.D3D_BF16 if dtype == torch.bfloat16 else _lib.D3D_F32
+    n, c = 12345, 64
+    torch.manual_seed(4)
+    x = (torch.randn(n, c, device="cuda") * 2 + 0.5).to(dtype)
+    dy = torch.randn(n, c, device="cuda").to(dtype)
+    gamma, beta = torch.rand(c, device="cuda") + 0.5, torch.randn(c, device="cuda") * 0.1
+    st = _lib.stream_ptr(x.device)
+    rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    rm2, rv2 = rm.clone(), rv.clone()
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    save1, save2 = torch.empty(2, c, device="cuda"), torch.empty(2, c, device="cuda")
+    ws1 = torch.empty(2 * _lib.D3D_BN_COPIES * c, device="cuda")
+    ws2 = torch.empty_like(ws1)
+    _lib.check(L.d3d_bn_relu_fwd(x.data_ptr(), n, c, dt, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                                 0.01, 1e-3, 1, 1, y1.data_ptr(), save1[0].data_ptr(), save1[1].data_ptr(),
+                                 ws1.data_ptr(), st), "fwd")
+    _lib.check(L.d3d_bn_stats(x.data_ptr(), n, c, dt, ws2.data_ptr(), st), "stats")
+    _lib.check(L.d3d_bn_apply(x.data_ptr(), n, c, dt, gamma.data_ptr(), beta.data_ptr(), rm2.data_ptr(), rv2.data_ptr(),
+                              0.01, 1e-3, 1, 1, ws2.data_ptr(), y2.data_ptr(), save2[0].data_ptr(),
+                              save2[1].data_ptr(), st), "apply")
+    assert torch.allclose(y1.float(), y2.float(), atol=1e-2 if dtype == torch.bfloat16 else 1e-5)
+    assert torch.allclose(save1, save2, rtol=1e-4, atol=1e-6) and torch.allclose(rv, rv2, rtol=1e-5)
+    # channel affine forward / backward
+    scale, shift = gamma * save1[1], beta - save1[0] * gamma * save1[1]
+    y3 = torch.empty_like(x)
+    _lib.check(L.d3d_channel_affine(x.data_ptr(), n, c, dt, scale.data_ptr(), shift.data_ptr(), 1, y3.data_ptr(), st), "aff")
+    ref = torch.relu(x.float() * scale + shift)
+    assert torch.allclose(y3.float(), ref, atol=2e-2 if dtype == torch.bfloat16 else 1e-5, rtol=1e-2 if dtype == torch.bfloat16 else 1e-5)
+    ca, cb, cc = torch.rand(c, device="cuda"), torch.randn(c, device="cuda") * 0.01, torch.randn(c, device="cuda") * 0.01
+    dx = torch.empty_like(x)
+    _lib.check(L.d3d_channel_affine_bwd(x.data_ptr(), dy.data_ptr(), n, c, dt, scale.data_ptr(), shift.data_ptr(), 1,
+                                        ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), dx.data_ptr(), st), "affb")
+    dz = dy.float() * ((x.float() * scale + shift) > 0)
+    ref = ca * dz + cb * x.float() + cc
+    assert torch.allclose(dx.float(), ref, atol=2e-2 if dtype == torch.bfloat16 else 1e-5, rtol=1e-2 if dtype == torch.bfloat16 else 1e-5)
