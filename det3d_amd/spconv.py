@@ -18,6 +18,7 @@ There is no CPU implementation here: tensors must live on the GPU.
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -50,7 +51,7 @@ def _timed(kind, cin, cout, n_out, rb, dev, fn):
     return rc
 
 
-FUSE_BN_STATS = True  # BN batch statistics from the producing conv's epilogue, BN-backward reductions from the
+FUSE_BN_STATS = os.environ.get("D3D_FUSE_BN_STATS", "1") != "0"  # BN batch statistics from the producing conv's epilogue, BN-backward reductions from the
 #                       consuming conv's dgrad epilogue (d3d_sparse_conv_fwd_ex): 2 instead of 4 BN sweeps per layer
 
 
