@@ -6,18 +6,28 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the whole hot path over one batch of synthetic KITTI-range clouds that
-are already resident in HBM: device voxelizer + fused mean VFE -> anchor target assignment (HIP) -> SpMiddleFHD (HIP rulebooks,
-sparse conv fwd) -> RPN / head (MIOpen via PyTorch-ROCm, bf16 autocast) -> losses -> backward
-(HIP dgrad / wgrad) -> gradient mean over ranks (RCCL) -> clip -> true-WD Adam.  Rank 0 prints
-ONE JSON line; `roofline` describes the hand-written sparse-conv gather kernel
-(spconv_fwd_mfma_kernel, timed with HIP events on its launch stream inside the timed region),
-`cpu_baseline` is the CPU oracle port (reference CPU voxelizer + PyTorch-CPU model) timed on
-this box's host cores on a bounded sample.
+One step = one pass of the whole hot path over one batch of synthetic clouds that are already resident in
+HBM: device voxelizer + fused mean VFE -> anchor target assignment (HIP) -> sparse backbone (HIP rulebooks,
+sparse conv fwd with the BN statistics in its epilogue) -> RPN / head (MIOpen via PyTorch-ROCm) -> fused loss
+-> backward (HIP dgrad with the BN-backward sums in its epilogue / two-pass wgrad) -> gradient mean over ranks
+(RCCL) -> clip -> true-WD Adam.  Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      the hand-written sparse-conv gather kernel (spconv_fwd_mfma_kernel<64,64>), HIP events on the
+                launch stream inside the timed region; `frac` is the SURVEY.md 8(d) algorithmic-bytes figure
+                against the HBM peak, `hbm_frac_true` prices the measured HBM traffic (rocprofv3 PMC passes,
+                profiles/) the same way -- the kernel is bound by L2 gather latency, not by HBM bytes
+  fp32          the same workload without autocast: the precision that meets north_star's 1e-3 box tolerance
+  precision     max |box regression - CPU oracle| of both dtypes on one frame with O(1)-scale outputs
+  rpn_mfma      the dense RPN convolutions alone (MIOpen / CK): FLOPs per step / time / 2.5 PFLOP/s
+  predict       inference frames/s (forward + decode + rotated NMS on the device) and NMS microseconds
+  stages        voxelizer / rulebooks / sparse BN sweeps: ms per step and algorithmic GB/s
+  workloads     (--workload all, N = 1) the other BASELINE configurations that fit one GPU
+  cpu_baseline  the CPU oracle port (compiled reference voxelizer + PyTorch-CPU model) on this box's host cores
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -32,19 +42,38 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity)
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+# name -> config file, frames per GPU, points per frame, generator settings
+WORKLOADS = {
+    "c2-20k": dict(config="kitti_car_second.py", kind="kitti", batch=4, points=20000,
+                   note="KITTI-car SECOND, ~16k voxels/frame"),
+    "c2-60k": dict(config="kitti_car_second.py", kind="kitti", batch=4, points=60000,
+                   note="KITTI-car SECOND, 60k points: hits the 20000-voxel cap"),
+    "c4": dict(config="nusc_cbgs.py", kind="tasks", batch=4, points=250000, beams=32, sweeps=10,
+               note="nuScenes CBGS ResNetFHD, 10-sweep clouds (batch 4 of the config's 16 per GPU)"),
+    "c5": dict(config="lyft_cbgs.py", kind="tasks", batch=2, points=200000, beams=64, sweeps=1,
+               note="Lyft CBGS ResNetFHD, 2016x2016x40 grid (batch 2 of the config's 6 per GPU)"),
+    "c3": dict(config="nusc_point_pillars.py", kind="tasks", batch=4, points=250000, beams=32, sweeps=10,
+               note="nuScenes PointPillars"),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (default: a > 2 s timed region)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU (config samples_per_gpu)")
     ap.add_argument("--points", type=int, default=20000, help="points per synthetic frame")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default="c2-20k", choices=sorted(WORKLOADS) + ["all"],
+                    help="headline workload; `all` also runs the other single-GPU configurations briefly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-log", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip fp32 / precision / rpn / predict / stage probes")
     ap.add_argument("--cached-targets", action="store_true",
                     help="use the host-precomputed anchor targets instead of d3d_assign_targets in the step")
     ap.add_argument("--no-gc-freeze", action="store_true",
@@ -61,51 +90,129 @@ def b_alg(kind, cin, cout, n_out, pairs, kvol, esz):
     return pairs * cin * esz + pairs * 8 + n_out * cout * esz + kvol * cin * cout * esz
 
 
-def _cpu_threads():
+def _cpu_threads(limit=None):
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    # the reference's CPU path is DataLoader workers + a PyTorch-CPU model; past ~16 threads the
-    # small per-offset mm / index_add_ ops of the sparse layers only lose to OpenMP barriers
-    return max(1, min(avail, int(os.environ.get("D3D_CPU_THREADS", "16"))))
+    return max(1, min(avail, int(limit or os.environ.get("D3D_CPU_THREADS", "16"))))
 
 
+# --------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline_worker(batch, points):
-    """runs in a child process (bench.py --cpu-baseline-only): reference CPU path (oracle port)
-    on the host cores, 1 one-frame warm-up + 1 timed step of `batch` frames."""
+    """child process (bench.py --cpu-baseline-only): the reference CPU path on the host cores --
+    voxelizer = the reference's own C++ point_cloud_ops.h compiled into oracle/_ref (falls back to the oracle's
+    C restatement if that module was not built), model = oracle/model_ref (PyTorch-CPU fp32 SECOND
+    fwd/bwd/clip/Adam).  Protocol (bounded to ~30 s): per thread count one warm-up step, then
+    the median of the timed steps; plus the C1 plumbing case (KITTI PointPillars, batch 2, product modules on CPU)."""
+    import numpy as np
+
     from det3d_amd import Config, synthetic
+    from oracle import clib
     from oracle import model_ref as M
 
-    cores = _cpu_threads()
-    torch.set_num_threads(cores)
     cfg = Config.fromfile(os.path.join(ROOT, "det3d_amd", "configs", "kitti_car_second.py"))
     torch.manual_seed(0)
     m = M.SecondRef(cfg)
     m.train()
     ds = synthetic.KittiCarSynthetic(n_points=points, n_seeds=batch + 1)
     opt = torch.optim.Adam(m.parameters(), lr=3e-4, betas=(0.9, 0.99))
+    # the per-frame voxelizer of cpu_example: the reference's own C++ twin (point_cloud_ops.h, compiled into
+    # oracle/_ref with its dense -1 grid of 360 MB per frame, exactly what a DataLoader worker pays) if present
+    vox_kind = "port"
+    if clib.ref_module() is not None:
+        try:
+            clib.ref_points_to_voxel(ds.frames[0]["points"][:100], synthetic.KITTI_CAR["voxel_size"],
+                                     synthetic.KITTI_CAR["pc_range"], 5, 100)
+            clib.points_to_voxel = lambda pts, vs, rg, T, rev, M_: clib.ref_points_to_voxel(pts, vs, rg, T, M_)
+            vox_kind = "reference"
+        except Exception:
+            pass
 
     def one(step, bsz):
         hb = ds.host_batch(step, bsz)
+        t0 = time.perf_counter()
         ex = M.cpu_example(hb, synthetic.KITTI_CAR)
+        t1 = time.perf_counter()
         loss = sum(m(ex)["loss"])
+        t2 = time.perf_counter()
         opt.zero_grad()
         loss.backward()
         torch.nn.utils.clip_grad_norm_(m.parameters(), 35)
         opt.step()
+        t3 = time.perf_counter()
+        return dict(data=t1 - t0, forward=t2 - t1, backward_step=t3 - t2, total=t3 - t0)
 
-    one(0, 1)  # primitive creation / page faults, untimed
-    t0 = time.perf_counter()
-    one(1, batch)
-    dt = time.perf_counter() - t0
-    print(json.dumps(dict(value=round(batch / dt, 4), unit="frames/s", cores=cores, kind="port",
-                          sample="1 training step of %d frames x %d pts (oracle CPU voxelizer + "
-                                 "PyTorch-CPU fp32 SECOND fwd/bwd/clip/Adam) after a 1-frame warm-up: "
-                                 "%.1f s on %d threads" % (batch, points, dt, cores))))
+    runs = {}
+    budget_t0 = time.perf_counter()
+    for cores, n_timed in ((8, 3), (16, 2)):
+        cores = _cpu_threads(cores)
+        if cores in runs:
+            continue
+        torch.set_num_threads(cores)
+        one(0, 1)  # primitive creation / page faults, untimed
+        rec = []
+        for i in range(n_timed):
+            rec.append(one(1 + i, batch))
+            if time.perf_counter() - budget_t0 > 40:
+                break
+        med = statistics.median(r["total"] for r in rec)
+        mid = sorted(rec, key=lambda r: r["total"])[len(rec) // 2]
+        runs[cores] = dict(frames_per_s=round(batch / med, 4), median_step_s=round(med, 3), steps=len(rec),
+                           buckets_s={k: round(v, 3) for k, v in mid.items()})
+    best = max(runs, key=lambda c: runs[c]["frames_per_s"])
+    out = dict(value=runs[best]["frames_per_s"], unit="frames/s", cores=best, kind="port", voxelizer=vox_kind,
+               runs={str(c): r for c, r in runs.items()},
+               sample="median of %d training steps of %d frames x %d pts after a warm-up step, per thread count "
+                      "(%s): CPU voxelizer (%s) + PyTorch-CPU fp32 SECOND fwd/bwd/clip/Adam; best = %d threads"
+                      % (runs[best]["steps"], batch, points, ", ".join("%s threads" % c for c in runs),
+                         "compiled reference point_cloud_ops.h" if vox_kind == "reference" else "oracle C port", best))
+    # C1 plumbing (BASELINE configs[0]): KITTI PointPillars on the CPU-only PyTorch path, batch 2, 16k points
+    try:
+        from det3d_amd import build_detector
+        from det3d_amd.point_cloud_ops import grid_size_of
+
+        cfg1 = Config.fromfile(os.path.join(ROOT, "det3d_amd", "configs", "kitti_point_pillars.py"))
+        torch.manual_seed(0)
+        pp = build_detector(cfg1.model, cfg1.train_cfg, cfg1.test_cfg).train()
+        vg = cfg1.voxel_generator
+        grid = grid_size_of(vg.voxel_size, vg.range)
+        f1 = int(cfg1.assigner.out_size_factor)
+        fmap = [1, int(grid[1]) // f1, int(grid[0]) // f1]
+        gen = cfg1.assigner.target_assigner.anchor_generators[0]
+        anchors = synthetic.create_anchors_3d_range(fmap, gen.anchor_ranges, gen.sizes, gen.rotations).reshape(-1, 7)
+        torch.set_num_threads(best)
+
+        def c1_step(seed0):
+            vox, coors, nums, nv, labs, tgts = [], [], [], [], [], []
+            for b in range(2):
+                pts, gt = synthetic.kitti_like_cloud(seed0 + b, 16384)
+                v, c, n = clib.points_to_voxel(pts, vg.voxel_size, vg.range, vg.max_points_in_voxel, True, vg.max_voxel_num)
+                vox.append(v); nums.append(n); nv.append(len(c))
+                coors.append(np.pad(c, ((0, 0), (1, 0)), constant_values=b))
+                lab, tgt, _ = synthetic.assign_targets(anchors, gt, gen.matched_threshold, gen.unmatched_threshold)
+                labs.append(lab); tgts.append(tgt)
+            t = torch.from_numpy
+            ex = dict(voxels=t(np.concatenate(vox)), coordinates=t(np.concatenate(coors)), num_points=t(np.concatenate(nums)),
+                      num_voxels=np.array(nv), shape=np.stack([grid] * 2), anchors=[t(np.stack([anchors] * 2))],
+                      labels=[t(np.stack(labs))], reg_targets=[t(np.stack(tgts))])
+            loss = sum(pp(ex, return_loss=True)["loss"])
+            pp.zero_grad()
+            loss.backward()
+
+        c1_step(0)
+        t0 = time.perf_counter()
+        c1_step(2)
+        dt = time.perf_counter() - t0
+        out["c1_plumbing"] = dict(frames_per_s=round(2 / dt, 3), cores=best,
+                                  sample="kitti_point_pillars, 2 frames x 16384 pts, CPU voxelizer + target assignment + "
+                                         "product modules on CPU fwd+bwd, 1 timed step after 1 warm-up")
+    except Exception as e:  # the plumbing number is a side note: never fail the baseline over it
+        out["c1_plumbing"] = dict(error=repr(e)[:200])
+    print(json.dumps(out))
 
 
-def cpu_baseline(batch, points, budget_s=240):
+def cpu_baseline(batch, points, budget_s=300):
     import subprocess
 
     try:
@@ -120,15 +227,380 @@ def cpu_baseline(batch, points, budget_s=240):
         return {"error": "cpu baseline exceeded its %d s budget" % budget_s}
 
 
+# ------------------------------------------------------------------------------------------------ workloads
+class Workload:
+    """model + data + train step of one BASELINE configuration, inputs resident in HBM."""
+
+    def __init__(self, name, args, dev, rank, world, dtype, total_steps, batch=None, points=None):
+        from det3d_amd import Config, build_detector, synthetic
+        from det3d_amd import dist as D
+        from det3d_amd.trainer import TrainStep
+
+        spec = dict(WORKLOADS[name])
+        self.name, self.spec, self.dtype = name, spec, dtype
+        self.batch = batch or spec["batch"]
+        self.points = points or spec["points"]
+        self.cfg = cfg = Config.fromfile(os.path.join(ROOT, "det3d_amd", "configs", spec["config"]))
+        torch.manual_seed(0)
+        model = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(dev).train()
+        if hasattr(model.backbone, "middle_conv"):
+            model.backbone.dense_channels_last = not args.no_channels_last
+        D.broadcast_params(model)
+        self.model = model
+        self.cached_targets = args.cached_targets
+        if spec["kind"] == "kitti":
+            n_seeds = 16
+            self.ds = synthetic.KittiCarSynthetic(n_points=self.points, n_seeds=n_seeds)
+            self.vox_cfg = synthetic.KITTI_CAR
+        else:
+            n_seeds = 8
+            self.ds = synthetic.TaskGroupSynthetic(cfg, self.points, n_seeds=n_seeds, beams=spec["beams"],
+                                                   sweeps=spec["sweeps"])
+        self.n_batches = max(n_seeds // self.batch, 1)
+        self.batches = [self.ds.device_batch(i, self.batch, dev, rank, world) for i in range(self.n_batches)]
+        self.step_fn = TrainStep(model, total_steps=max(total_steps, 100), lr_max=cfg.lr_config.lr_max,
+                                 wd=cfg.optimizer.VALUE.wd, moms=cfg.lr_config.moms,
+                                 div_factor=cfg.lr_config.div_factor, pct_start=cfg.lr_config.pct_start,
+                                 grad_clip=cfg.optimizer_config.grad_clip.max_norm,
+                                 autocast_dtype=torch.bfloat16 if dtype == "bf16" else None)
+
+    def example(self, i, targets=True):
+        from det3d_amd import synthetic
+
+        b = self.batches[i % self.n_batches]
+        if self.spec["kind"] == "kitti":
+            return synthetic.make_example(b, self.vox_cfg, fused_mean=True, device_targets=targets and not self.cached_targets)
+        return self.ds.make_example(b, targets=targets)
+
+    def describe(self):
+        return "%s: %d frames/GPU x %d pts (%s), fwd+bwd+Adam" % (
+            self.spec["config"].replace(".py", ""), self.batch, self.points, self.spec["note"])
+
+
+def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, freeze=True):
+    """W untimed warm-up steps, then exactly `steps` steps bracketed by barrier + synchronize; returns
+    (max-over-ranks elapsed seconds, launch records of the sampled steps, final loss)."""
+    from det3d_amd import dist as D
+    from det3d_amd import spconv, trainer
+
+    records = []
+
+    def drain():
+        if spconv.LAUNCH_LOG:
+            for kind, cin, cout, n_out, rb, e0, e1 in spconv.LAUNCH_LOG:
+                records.append((kind, cin, cout, n_out, rb, e0.elapsed_time(e1)))
+            spconv.LAUNCH_LOG.clear()
+
+    def one(i):
+        ex = wl.example(i)
+        drain()  # events of the previous step are complete: make_example just synced
+        return wl.step_fn(ex)
+
+    for i in range(warmup):
+        one(i)
+        torch.cuda.synchronize()
+        note("%s %s warmup step %d done" % (wl.name, wl.dtype, i))
+    torch.cuda.synchronize()
+    # CPython's full collections walk ~10^6 tracked objects (40-80 ms) every few steps: freeze what exists
+    if freeze:
+        trainer.freeze_gc()
+    D.barrier()
+    # HIP-event timing of individual launches perturbs the stream (~0.4 ms per event pair on ROCm), so inside
+    # the timed region only the dominant kernel of the LAST TWO steps is timed
+    sample_from = max(steps - 2, 0)
+    spconv.LAUNCH_FILTER = launch_filter
+    torch.cuda.synchronize()
+    ms0 = torch.cuda.memory_stats(dev)
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(steps):
+        if i == sample_from and launch_filter is not None:
+            spconv.LAUNCH_LOG = []
+        loss = one(warmup + i)
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats(dev)
+    alloc = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
+    alloc["reserved_MB"] = int(ms1.get("reserved_bytes.all.current", 0) >> 20)
+    note("%s %s timed region done: %.3f s for %d steps; allocator during it: %s" % (wl.name, wl.dtype, elapsed, steps, alloc))
+    drain()
+    spconv.LAUNCH_LOG = None
+    spconv.LAUNCH_FILTER = None
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(t.item()), records, loss
+
+
+def kernel_table(wl, step_index, rank, esz):
+    """one extra untimed step with every sparse-conv launch event-timed (rank 0); all ranks run it (collective)."""
+    from det3d_amd import spconv
+
+    spconv.LAUNCH_FILTER = None
+    spconv.LAUNCH_LOG = [] if rank == 0 else None
+    spconv.LAUNCH_LOG_LIMIT = 1024
+    ex = wl.example(step_index)
+    wl.step_fn(ex)
+    torch.cuda.synchronize()
+    recs = [(k, ci, co, n, rb, e0.elapsed_time(e1)) for k, ci, co, n, rb, e0, e1 in (spconv.LAUNCH_LOG or [])]
+    spconv.LAUNCH_LOG = None
+    return group_launches(recs, esz)
+
+
+_PAIRS = {}
+
+
+def group_launches(entries, esz):
+    groups = {}
+    for kind, cin, cout, n_out, rb, ms in entries:
+        P = _PAIRS.get(id(rb))
+        if P is None:
+            P = _PAIRS[id(rb)] = (rb, rb.pairs())  # keep rb alive: id() must stay unique
+        P = P[1]
+        if kind == "wgrad":
+            key, byts = "spconv_wgrad_tile %dx%d" % (cin, cout), P * (cin + cout) * esz
+        else:
+            mfma = cin % 16 == 0 and cout % 16 == 0
+            key = ("spconv_fwd_mfma_kernel<%d,%d>" if mfma else "spconv_fwd_generic<%d,%d>") % (cin, cout)
+            byts = b_alg(kind, cin, cout, n_out, P, rb.kvol, esz)
+        g = groups.setdefault(key, dict(ms=0.0, bytes=0.0, launches=0))
+        g["ms"] += ms
+        g["launches"] += 1
+        g["bytes"] += byts
+    return groups
+
+
+def roofline_object(groups, key, dtype):
+    g = groups.get(key)
+    if not g:
+        return None
+    ach = g["bytes"] / (g["ms"] * 1e-3) / 1e9
+    out = {"kernel": key, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+           "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
+           "alg_bytes_per_launch": int(g["bytes"] / g["launches"]), "launches_timed": g["launches"],
+           "limiter": "L2 gather latency / occupancy: measured HBM traffic is ~1/3 of the algorithmic bytes (each "
+                      "row is gathered ~13x, served by L2 / Infinity Cache), see hbm_frac_true",
+           "note": "HIP events on the launch stream, fwd+dgrad launches of the last 2 timed steps; B_alg per "
+                   "SURVEY.md 8(d)"}
+    return out
+
+
+def attach_pmc_traffic(roof, wl):
+    """HBM traffic needs PMC passes (rocprofv3 --pmc cannot run inside this process): take the committed
+    measurement (tools/pmc_spconv.sh) only if it was taken on THIS kernel source and workload."""
+    path = os.path.join(ROOT, "profiles", "round2_pmc_spconv.json")
+    src = os.path.join(ROOT, "det3d_amd", "csrc", "d3d_spconv.hip")
+    try:
+        pmc = json.load(open(path))
+        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+        w = pmc["workload"]
+        if pmc.get("kernel_source_sha16") != sha:
+            roof["traffic_source"] = "profiles/round2_pmc_spconv.json is stale (kernel source changed): not used"
+            return
+        if (w["name"], w["frames_per_gpu"], w["points_per_frame"], w["dtype"]) != (wl.name, wl.batch, wl.points, wl.dtype):
+            return
+        roof["traffic"] = pmc["traffic_bytes_per_launch"]
+        roof["traffic_measured_in_run"] = False
+        roof["traffic_source"] = "profiles/round2_pmc_spconv.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " \
+                                 "tools/pmc_spconv.sh; kernel source sha %s)" % sha
+        if roof.get("avg_launch_us"):
+            roof["hbm_frac_true"] = round(pmc["traffic_bytes_per_launch"] / (roof["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    except (OSError, KeyError, ValueError):
+        pass
+
+
+# --------------------------------------------------------------------------------------------------- probes
+def _ev():
+    return torch.cuda.Event(enable_timing=True)
+
+
+def stage_probe(wl, dev):
+    """voxelizer / target assignment / rulebooks / whole step phases of ONE extra step, HIP events."""
+    from det3d_amd import spconv
+
+    out = {}
+    b = wl.batches[0]
+    e = [_ev() for _ in range(4)]
+    torch.cuda.synchronize()
+    e[0].record()
+    ex = wl.example(0, targets=False)
+    e[1].record()
+    ex_t = wl.example(0, targets=True)
+    e[2].record()
+    torch.cuda.synchronize()
+    vox_ms = e[0].elapsed_time(e[1])
+    n_pts, c = b["points"].shape
+    m = int(ex["coordinates"].shape[0])
+    mean_c = ex["voxel_mean"].shape[1] if "voxel_mean" in ex else 0
+    vbytes = n_pts * c * 4 + m * 16 + m * mean_c * 4 + (ex["voxels"].numel() * 4 if "voxels" in ex else 0)
+    out["voxelize"] = dict(ms=round(vox_ms, 4), voxels=m, alg_MB=round(vbytes / 1e6, 2),
+                           achieved_GBs=round(vbytes / (vox_ms * 1e-3) / 1e9, 1),
+                           note="includes the host sync that reads the voxel counts")
+    out["voxelize_plus_assign_ms"] = round(e[1].elapsed_time(e[2]), 4)
+    bb = wl.model.backbone
+    if hasattr(bb, "middle_conv"):
+        feats = ex_t["voxel_mean"]
+        shape = [int(s) for s in ex_t["shape"][0]]
+        st = spconv.SparseConvTensor(feats, ex_t["coordinates"], [shape[2] + 1, shape[1], shape[0]], wl.batch)
+        torch.cuda.synchronize()
+        e[0].record()
+        d = bb.middle_conv.plan(st)
+        e[1].record()
+        torch.cuda.synchronize()
+        rbs = {id(r): r for r in d.values()}.values()
+        rb_bytes = 0
+        for r in rbs:
+            rb_bytes += r.n_in * 16 + r.kvol * r.n_out * 4 + (0 if r.subm else r.n_out * 16 + r.kvol * r.n_in * 4)
+        ms = e[0].elapsed_time(e[1])
+        out["rulebooks"] = dict(ms=round(ms, 4), tables=len(rbs), alg_MB=round(rb_bytes / 1e6, 2),
+                                achieved_GBs=round(rb_bytes / (ms * 1e-3) / 1e9, 1),
+                                note="all rulebooks of the backbone incl. the one host sync; bytes = coords in + "
+                                     "neighbour tables out")
+    return out
+
+
+def rpn_mfma_probe(wl, dev, dtype):
+    """The dense RPN / head convolutions alone (north_star: MFMA utilisation against the gfx950 peak): every
+    Conv2d / ConvTranspose2d of the neck + head is run fwd + bwd (data and weight gradients) on tensors of the
+    shapes the workload produces; FLOPs = 2*Cout*Cin*k*k*Hout*Wout*B per pass, x3 for training."""
+    from torch import nn
+
+    convs = [m for m in list(wl.model.neck.modules()) + list(wl.model.bbox_head.modules())
+             if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))]
+    shapes = {}
+    hooks = [m.register_forward_hook(lambda mod, inp, out: shapes.__setitem__(mod, (tuple(inp[0].shape), tuple(out.shape))))
+             for m in convs]
+    ex = wl.example(0)
+    with torch.no_grad(), wl.step_fn._ctx():
+        wl.model(ex, return_loss=True)
+    for h in hooks:
+        h.remove()
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    total_flops, total_ms = 0.0, 0.0
+    for m in convs:
+        if m not in shapes:
+            continue
+        ishape, oshape = shapes[m]
+        x = torch.randn(ishape, device=dev, dtype=tdt).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        w = m.weight.detach().to(tdt).requires_grad_(True)
+        kk = m.kernel_size[0] * m.kernel_size[1]
+        if isinstance(m, nn.ConvTranspose2d):
+            f = lambda: torch.nn.functional.conv_transpose2d(x, w, None, m.stride, m.padding)
+            flops = 2.0 * ishape[0] * ishape[1] * oshape[1] * kk * ishape[2] * ishape[3]
+        else:
+            f = lambda: torch.nn.functional.conv2d(x, w, None, m.stride, m.padding)
+            flops = 2.0 * oshape[0] * oshape[1] * ishape[1] * kk * oshape[2] * oshape[3]
+        y = f()
+        g = torch.randn_like(y)
+        for _ in range(2):
+            torch.autograd.grad(f(), (x, w), g)
+        e0, e1 = _ev(), _ev()
+        reps = 5
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            torch.autograd.grad(f(), (x, w), g)
+        e1.record()
+        torch.cuda.synchronize()
+        total_ms += e0.elapsed_time(e1) / reps
+        total_flops += 3 * flops
+    peak = MFMA_BF16_PEAK_TFLOPS if dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+    ach = total_flops / (total_ms * 1e-3) / 1e12 if total_ms else 0.0
+    return dict(convs=len(shapes), gflop_per_step=round(total_flops / 1e9, 1), conv_ms_per_step=round(total_ms, 3),
+                achieved_TFLOPs=round(ach, 1), peak_TFLOPs=peak, frac=round(ach / peak, 4), dtype=dtype,
+                note="MIOpen / CK kernels through PyTorch-ROCm (north_star: RPN via rocBLAS/MIOpen), fwd + dgrad + wgrad "
+                     "of every neck / head conv at the workload's shapes, HIP events; SQ MFMA counters: profiles/")
+
+
+def predict_probe(wl, dev, dtype, iters=20):
+    """inference frames/s (the reference's only speed probe is inference, tools/dist_test.py:178-193):
+    voxelize -> backbone -> RPN -> head -> decode -> rotated NMS, eval mode; NMS time by HIP events."""
+    from det3d_amd import box_ops
+
+    model = wl.model
+    model.eval()
+    nms_ms = []
+    orig = box_ops.rotate_nms
+
+    def timed_nms(*a, **k):
+        e0, e1 = _ev(), _ev()
+        e0.record()
+        r = orig(*a, **k)
+        e1.record()
+        nms_ms.append((e0, e1))
+        return r
+
+    try:
+        with torch.no_grad(), wl.step_fn._ctx():
+            for i in range(3):
+                model(wl.example(i, targets=False), return_loss=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_det = 0
+            for i in range(iters):
+                dets = model(wl.example(i, targets=False), return_loss=False)
+                n_det += sum(int(d["scores"].shape[0]) for d in dets)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            box_ops.rotate_nms = timed_nms
+            import det3d_amd.bbox_heads as BH
+            BH.box_ops.rotate_nms = timed_nms
+            model(wl.example(0, targets=False), return_loss=False)
+            torch.cuda.synchronize()
+    finally:
+        box_ops.rotate_nms = orig
+        model.train()
+    us = [1e3 * a.elapsed_time(b) for a, b in nms_ms]
+    return dict(frames_per_s=round(iters * wl.batch / dt, 1), ms_per_batch=round(1e3 * dt / iters, 3),
+                detections_per_frame=round(n_det / (iters * wl.batch), 1), dtype=dtype,
+                nms_calls_per_batch=len(us), nms_us_avg=round(sum(us) / max(len(us), 1), 1),
+                note="random-init weights: the score threshold passes few boxes, so NMS sees small inputs")
+
+
+def precision_probe(dev):
+    """north_star: boxes within 1e-3 of the reference.  One KITTI frame, weights from fill_deterministic (raw box
+    regressions of O(1), like a trained net), eval mode: max |GPU - CPU oracle| over all raw box regressions for
+    fp32 and for bf16 autocast."""
+    import numpy as np
+
+    from det3d_amd import Config, build_detector, synthetic
+    from oracle import model_ref as M
+
+    cfg = Config.fromfile(os.path.join(ROOT, "det3d_amd", "configs", "kitti_car_second.py"))
+    prod = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg)
+    M.fill_deterministic(prod)
+    ref = M.SecondRef(cfg)
+    ref.load_state_dict(prod.state_dict())
+    prod = prod.to(dev).eval()
+    ref.eval()
+    ds = synthetic.KittiCarSynthetic(n_points=12000, n_seeds=1)
+    ex_cpu = M.cpu_example(ds.host_batch(0, 1), synthetic.KITTI_CAR)
+    ex = synthetic.make_example(ds.device_batch(0, 1, dev), synthetic.KITTI_CAR)
+    with torch.no_grad():
+        rb = ref.bbox_head.tasks[0](ref.features(ex_cpu))["box_preds"]
+        data = dict(features=ex["voxel_mean"], num_voxels=ex["num_points"], coors=ex["coordinates"], batch_size=1,
+                    input_shape=ex["shape"][0])
+        b32 = prod.bbox_head(prod.extract_feat(data))[0]["box_preds"].float().cpu()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            b16 = prod.bbox_head(prod.extract_feat(data))[0]["box_preds"].float().cpu()
+    scale = float(rb.abs().max())
+    e32, e16 = float((b32 - rb).abs().max()), float((b16 - rb).abs().max())
+    return dict(ref_max_abs=round(scale, 3), tolerance=1e-3, fp32_max_abs_err=float(np.format_float_scientific(e32, 2)),
+                bf16_max_abs_err=float(np.format_float_scientific(e16, 2)), fp32_within_tolerance=bool(e32 < 1e-3),
+                bf16_within_tolerance=bool(e16 < 1e-3),
+                note="raw box regressions of one 12k-point frame vs the CPU oracle (oracle/model_ref, fp32), "
+                     "deterministic O(1)-scale weights; bf16 activations carry 2^-9 relative rounding per layer, "
+                     "so only the fp32 line meets the 1e-3 contract")
+
+
+# ----------------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
     if args.cpu_baseline_only:
         return cpu_baseline_worker(args.batch, args.points)
-    from det3d_amd import Config, build_detector, synthetic
     from det3d_amd import dist as D
-    from det3d_amd import spconv
-    from det3d_amd import trainer
-    from det3d_amd.trainer import TrainStep
 
     t_start = time.perf_counter()
     rank, local_rank, world = D.init_dist()
@@ -140,174 +612,108 @@ def main():
     # perf-db cache); D3D_MIOPEN_FIND=0 falls back to immediate mode
     torch.backends.cudnn.benchmark = bool(int(os.environ.get("D3D_MIOPEN_FIND", "1")))
 
-    cfg = Config.fromfile(os.path.join(ROOT, "det3d_amd", "configs", "kitti_car_second.py"))
-    torch.manual_seed(0)
-    model = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg)
-    model = model.to(dev).train()
-    model.backbone.dense_channels_last = not args.no_channels_last
-    D.broadcast_params(model)
-
-    n_seeds = 16
-    ds = synthetic.KittiCarSynthetic(n_points=args.points, n_seeds=n_seeds)
-    n_batches = max(n_seeds // args.batch, 1)
-    # inputs resident in HBM before the timed region: distinct batches per rank, cycled
-    batches = [ds.device_batch(i, args.batch, dev, rank, world) for i in range(n_batches)]
-    vox_cfg = synthetic.KITTI_CAR
-
-    total_steps = args.steps + args.warmup
-    step_fn = TrainStep(model, total_steps=max(total_steps, 100), lr_max=cfg.lr_config.lr_max,
-                        wd=cfg.optimizer.VALUE.wd, moms=cfg.lr_config.moms,
-                        div_factor=cfg.lr_config.div_factor, pct_start=cfg.lr_config.pct_start,
-                        grad_clip=cfg.optimizer_config.grad_clip.max_norm,
-                        autocast_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
-
-    records = []  # (kind, cin, cout, n_out, rulebook, ms) of every timed sparse-conv launch
-
-    def drain_launch_log():
-        """resolve the HIP events of the previous step (complete: make_example just synced)"""
-        if spconv.LAUNCH_LOG:
-            for kind, cin, cout, n_out, rb, e0, e1 in spconv.LAUNCH_LOG:
-                records.append((kind, cin, cout, n_out, rb, e0.elapsed_time(e1)))
-            spconv.LAUNCH_LOG.clear()
-
-    def one_step(i):
-        ex = synthetic.make_example(batches[i % n_batches], vox_cfg, fused_mean=True,
-                                    device_targets=not args.cached_targets)
-        drain_launch_log()
-        return step_fn(ex)
-
     def note(msg):
         if rank == 0:
             print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
-    for i in range(args.warmup):
-        one_step(i)
-        torch.cuda.synchronize()
-        note("warmup step %d done" % i)
-    torch.cuda.synchronize()
-    # The step allocates a few thousand short-lived Python containers; CPython's generational collector
-    # then walks every tracked object of the process (torch + numpy: ~10^6) in a full collection every few
-    # steps, 40-80 ms each, which showed up as a bimodal 8.5 / 12.5 ms step.  Freezing what exists after
-    # warm-up (gc stays enabled) makes later collections scan only what the loop itself creates.
-    if not args.no_gc_freeze:
-        trainer.freeze_gc()
-    D.barrier()
-
-    # HIP-event timing of individual launches perturbs the stream (~0.4 ms per event pair on
-    # ROCm), so inside the timed region only the dominant kernel (64->64 fwd/dgrad) of the LAST
-    # TWO steps is timed; the full per-kernel table comes from one extra untimed step below.
-    sample_from = max(args.steps - 2, 0)
-    spconv.LAUNCH_FILTER = lambda kind, cin, cout: kind != "wgrad" and cin == 64 and cout == 64
-    torch.cuda.synchronize()
-    ms0 = torch.cuda.memory_stats(dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i == sample_from and not args.no_launch_log:
-            spconv.LAUNCH_LOG = []
-        loss = one_step(args.warmup + i)
-    torch.cuda.synchronize()
-    D.barrier()
-    elapsed = time.perf_counter() - t0
-    ms1 = torch.cuda.memory_stats(dev)
-    # hipMalloc / hipFree inside the timed region would stall the stream: report them
-    alloc_delta = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
-    alloc_delta["reserved_MB"] = int(ms1.get("reserved_bytes.all.current", 0) >> 20)
-    note("timed region done: %.3f s; allocator during it: %s" % (elapsed, alloc_delta))
-    drain_launch_log()
-    log = list(records)
-    table_log = []
-    if not args.no_launch_log:
-        spconv.LAUNCH_FILTER = None
-        spconv.LAUNCH_LOG = [] if rank == 0 else None
-        del records[:]
-        one_step(args.warmup + args.steps)  # untimed, all ranks (the step has a collective):
-        torch.cuda.synchronize()            # every sparse-conv launch event-timed on rank 0
-        drain_launch_log()
-        table_log = list(records)
-    spconv.LAUNCH_LOG = None
-    spconv.LAUNCH_FILTER = None
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(t.item())
-    frames = args.steps * args.batch * world
+    head = "c2-20k" if args.workload == "all" else args.workload
+    custom = head == "c2-20k"
+    wl = Workload(head, args, dev, rank, world, args.dtype, args.steps + args.warmup,
+                  batch=args.batch if custom else None, points=args.points if custom else None)
+    esz = 2 if args.dtype == "bf16" else 4
+    dominant = (lambda kind, cin, cout: kind != "wgrad" and cin == 64 and cout == 64) if not args.no_launch_log else None
+    elapsed, records, loss = timed_region(wl, args.steps, args.warmup, rank, world, dev, note, dominant,
+                                          freeze=not args.no_gc_freeze)
+    frames = args.steps * wl.batch * world
     value = frames / elapsed
-
     out = {
-        "metric": "training frames/sec (KITTI-car SECOND, voxelize->sparse conv->RPN->head->loss->bwd->step)",
+        "metric": "training frames/sec (%s, voxelize->sparse conv->RPN->head->loss->bwd->step)" % (
+            "KITTI-car SECOND" if wl.spec["kind"] == "kitti" else wl.spec["config"].replace(".py", "")),
         "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "kitti_car_vfev3_spmiddlefhd_rpn1_mghead: %d frames/GPU x %d pts "
-                               "(synthetic KITTI-car-range clouds, ~16k voxels/frame), fwd+bwd+Adam"
-                               % (args.batch, args.points),
-                   "frames_per_gpu": args.batch, "points_per_frame": args.points,
-                   "parallelism": "dp%d" % world, "final_loss": round(float(loss), 4)},
+        "config": {"workload": wl.describe(), "name": wl.name, "frames_per_gpu": wl.batch,
+                   "points_per_frame": wl.points, "parallelism": "dp%d" % world,
+                   "final_loss": round(float(loss), 4), "timed_region_s": round(elapsed, 3)},
     }
+    if rank == 0 and records:
+        roof = roofline_object(group_launches(records, esz), "spconv_fwd_mfma_kernel<64,64>", args.dtype)
+        if roof:
+            attach_pmc_traffic(roof, wl)
+            out["roofline"] = roof
+    if not args.no_launch_log:
+        groups = kernel_table(wl, args.warmup + args.steps, rank, esz)  # all ranks: the step has a collective
+        if rank == 0 and groups:
+            table = {}
+            for k, g in groups.items():
+                table[k] = dict(launches_per_step=g["launches"], avg_us=round(1e3 * g["ms"] / g["launches"], 2),
+                                ms_per_step=round(g["ms"], 4), achieved_GBs=round(g["bytes"] / (g["ms"] * 1e-3) / 1e9, 1),
+                                B_alg_MB_per_launch=round(g["bytes"] / g["launches"] / 1e6, 2))
+            out["kernels"] = table
+            out["sparse_conv_ms_per_step"] = round(sum(g["ms"] for g in groups.values()), 3)
 
-    def group(entries):
-        esz = 2 if args.dtype == "bf16" else 4
-        groups = {}
-        for kind, cin, cout, n_out, rb, ms in entries:
-            P = pair_cache.setdefault(id(rb), None)
-            if P is None:
-                P = pair_cache[id(rb)] = rb.pairs()
-            if kind == "wgrad":
-                key, byts = "spconv_wgrad %dx%d" % (cin, cout), 0.0
-            else:
-                mfma = cin % 16 == 0 and cout % 16 == 0
-                key = ("spconv_fwd_mfma_kernel<%d,%d>" if mfma else "spconv_fwd_generic<%d,%d>") % (cin, cout)
-                byts = b_alg(kind, cin, cout, n_out, P, rb.kvol, esz)
-            g = groups.setdefault(key, dict(ms=0.0, bytes=0.0, launches=0))
-            g["ms"] += ms
-            g["launches"] += 1
-            g["bytes"] += byts
-        return groups
-
-    pair_cache = {}
-    if rank == 0 and log:
-        g = group(log)["spconv_fwd_mfma_kernel<64,64>"]
-        ach = g["bytes"] / (g["ms"] * 1e-3) / 1e9
-        out["roofline"] = {"kernel": "spconv_fwd_mfma_kernel<64,64>", "bound": "hbm",
-                           "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                           "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
-                           "alg_bytes_per_launch": int(g["bytes"] / g["launches"]),
-                           "launches_timed": g["launches"],
-                           "traffic_source": None,
-                           "note": "HIP events on the launch stream, 64->64 fwd+dgrad launches of the "
-                                   "last 2 timed steps; B_alg per SURVEY.md 8(d)"}
-    if rank == 0 and "roofline" in out:
-        # HBM traffic needs PMC passes (rocprofv3 --pmc cannot run inside this process): take the
-        # committed measurement of the same workload if there is one
-        pmc_path = os.path.join(ROOT, "profiles", "round1_pmc_spconv.json")
+    extras = rank == 0 and world == 1 and not args.no_extras
+    if extras:
         try:
-            pmc = json.load(open(pmc_path))
-            w = pmc["workload"]
-            if (w["frames_per_gpu"], w["points_per_frame"], w["dtype"]) == (args.batch, args.points, args.dtype):
-                out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "profiles/round1_pmc_spconv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, read side x2 per MI355X_MICROARCH.md)"
-        except (OSError, KeyError, ValueError):
-            pass
-    if rank == 0 and table_log:
-        table = {}
-        groups = group(table_log)
-        for k, g in groups.items():
-            row = dict(launches_per_step=g["launches"], avg_us=round(1e3 * g["ms"] / g["launches"], 2),
-                       ms_per_step=round(g["ms"], 4))
-            if g["bytes"]:
-                row["achieved_GBs"] = round(g["bytes"] / (g["ms"] * 1e-3) / 1e9, 1)
-                row["B_alg_MB_per_launch"] = round(g["bytes"] / g["launches"] / 1e6, 2)
-            table[k] = row
-        out["kernels"] = table
-        out["sparse_conv_ms_per_step"] = round(sum(g["ms"] for g in groups.values()), 3)
+            note("stage / rpn / predict probes ...")
+            out["stages"] = stage_probe(wl, dev)
+            out["rpn_mfma"] = rpn_mfma_probe(wl, dev, args.dtype)
+            out["predict"] = predict_probe(wl, dev, args.dtype)
+        except Exception as e:
+            out["probe_error"] = repr(e)[:300]
+    if extras and args.dtype == "bf16" and wl.spec["kind"] == "kitti":
+        try:
+            note("precision probe (both dtypes vs the CPU oracle) ...")
+            out["precision"] = precision_probe(dev)
+            note("fp32 line ...")
+            k32 = max(min(args.steps, 60), 5)
+            wl32 = Workload(head, args, dev, rank, world, "fp32", k32 + 3, batch=wl.batch, points=wl.points)
+            el32, rec32, _ = timed_region(wl32, k32, 3, rank, world, dev, note, dominant, freeze=False)
+            o32 = {"value": round(k32 * wl.batch / el32, 2), "unit": "frames/s", "ms_per_step": round(1e3 * el32 / k32, 3),
+                   "steps": k32, "warmup": 3, "dtype": "fp32",
+                   "note": "same workload and step without autocast: exact-f32 MFMA in the sparse stack, fp32 MIOpen "
+                           "convolutions; this is the precision whose box regressions meet north_star's 1e-3"}
+            r32 = roofline_object(group_launches(rec32, 4), "spconv_fwd_mfma_kernel<64,64>", "fp32")
+            if r32:
+                o32["roofline_frac"] = r32["frac"]
+                o32["roofline_achieved_GBs"] = r32["achieved"]
+            out["fp32"] = o32
+            del wl32
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["fp32_error"] = repr(e)[:300]
+    if extras and args.workload == "all":
+        out["workloads"] = {}
+        for name in ("c2-60k", "c4", "c5", "c3"):
+            try:
+                note("workload %s ..." % name)
+                w2 = Workload(name, args, dev, rank, world, args.dtype, 40)
+                k2 = 12
+                flt = (lambda kind, cin, cout: kind != "wgrad" and cin == cout and cin in (64, 128))
+                el, rec, l2 = timed_region(w2, k2, 4, rank, world, dev, note, flt, freeze=False)
+                row = {"workload": w2.describe(), "value": round(k2 * w2.batch / el, 2), "unit": "frames/s",
+                       "ms_per_step": round(1e3 * el / k2, 3), "steps": k2, "dtype": args.dtype,
+                       "final_loss": round(float(l2), 4)}
+                g2 = group_launches(rec, esz)
+                for key in ("spconv_fwd_mfma_kernel<128,128>", "spconv_fwd_mfma_kernel<64,64>"):
+                    r2 = roofline_object(g2, key, args.dtype)
+                    if r2:
+                        row.setdefault("roofline", []).append({k: r2[k] for k in (
+                            "kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "alg_bytes_per_launch")})
+                out["workloads"][name] = row
+                del w2
+                torch.cuda.empty_cache()
+            except Exception as e:
+                out["workloads"][name] = {"error": repr(e)[:300]}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and wl.spec["kind"] == "kitti":
         note("cpu baseline (child process) ...")
-        out["cpu_baseline"] = cpu_baseline(args.batch, args.points)
+        out["cpu_baseline"] = cpu_baseline(wl.batch, wl.points)
         if "value" in out["cpu_baseline"]:
             out["config"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+            if "fp32" in out:
+                out["fp32"]["gpu_over_cpu"] = round(out["fp32"]["value"] / out["cpu_baseline"]["value"], 1)
         note("cpu baseline done")
 
     if rank == 0:

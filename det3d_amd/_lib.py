@@ -40,9 +40,9 @@ SIGNATURES = {
     "d3d_bn_relu_fwd": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp, vp, vp, vp]),
     "d3d_bn_relu_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "d3d_bn_stats": (i32, [vp, i32, i32, i32, vp, vp]),
-    "d3d_bn_apply": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp, vp, vp, vp]),
+    "d3d_bn_apply": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, i32, vp, i32, vp, vp, vp, vp]),
     "d3d_bn_bwd_reduce": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]),
-    "d3d_bn_bwd_dx": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "d3d_bn_bwd_dx": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]),
     "d3d_channel_affine": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp]),
     "d3d_channel_affine_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]),
     "d3d_pfn_fwd": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp, vp, vp, vp, f32, f32,
@@ -82,7 +82,7 @@ class D3dError(RuntimeError):
 class ConvEpilogue(ctypes.Structure):
     """D3dConvEpilogue of include/d3d.h (device pointers as integers)"""
     _fields_ = [("stats", vp), ("bn_x", vp), ("bn_mean", vp), ("bn_invstd", vp), ("bn_gamma", vp),
-                ("bn_beta", vp), ("bn_relu", i32), ("bn_partial", vp)]
+                ("bn_beta", vp), ("bn_relu", i32), ("bn_partial", vp), ("copies", i32)]
 
 
 def lib():

@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256)
     bn_apply_kernel(const void *__restrict__ x, int n, int c, const float *__restrict__ gamma,
                     const float *__restrict__ beta, float *running_mean, float *running_var,
                     float momentum, float eps, int training, int relu,
-                    const float *__restrict__ stats, void *__restrict__ y, float *save_mean,
+                    const float *__restrict__ stats, int copies, void *__restrict__ y, float *save_mean,
                     float *save_invstd) {
   constexpr int EPV = BnVec<BF16>::EPV;
   __shared__ float scale[BN_MAXC], shift[BN_MAXC];
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256)
     float mean, var;
     if (training) {
       float s1 = 0.f, s2 = 0.f;
-      for (int k = 0; k < D3D_BN_COPIES; ++k) {
+      for (int k = 0; k < copies; ++k) {
         s1 += stats[(size_t)k * 2 * c + ch];
         s2 += stats[(size_t)k * 2 * c + c + ch];
       }
@@ -244,13 +244,13 @@ __global__ void __launch_bounds__(256)
     bn_bwd_dx_kernel(const void *__restrict__ x, const void *__restrict__ dy, int n, int c,
                      const float *__restrict__ gamma, const float *__restrict__ beta,
                      const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
-                     const float *__restrict__ partial, float *__restrict__ dgamma,
+                     const float *__restrict__ partial, int copies, float *__restrict__ dgamma,
                      float *__restrict__ dbeta, void *__restrict__ dx) {
   constexpr int EPV = BnVec<BF16>::EPV;
   __shared__ float tot[2 * BN_MAXC];
   for (int i = threadIdx.x; i < 2 * c; i += 256) {  // fold the replicated partial sums
     float t = 0.f;
-    for (int k = 0; k < D3D_BN_COPIES; ++k) t += partial[(size_t)k * 2 * c + i];
+    for (int k = 0; k < copies; ++k) t += partial[(size_t)k * 2 * c + i];
     tot[i] = t;
     if (blockIdx.x == 0) {
       if (i < c) dgamma[i] = t;
@@ -354,22 +354,23 @@ extern "C" int d3d_bn_stats(const void *x, int n, int c, int dtype, float *stats
 
 extern "C" int d3d_bn_apply(const void *x, int n, int c, int dtype, const float *gamma, const float *beta,
                             float *running_mean, float *running_var, float momentum, float eps, int training,
-                            int relu, const float *stats_ws, void *y, float *save_mean, float *save_invstd,
-                            d3d_stream_t stream_) {
+                            int relu, const float *stats_ws, int copies, void *y, float *save_mean,
+                            float *save_invstd, d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = bn_check(n, c, dtype, "d3d_bn_apply");
   if (rc) return rc;
+  D3D_REQUIRE(copies >= 1 && copies <= 256, "d3d_bn_apply: copies=%d", copies);
   D3D_REQUIRE(x && y, "d3d_bn_apply: null pointer");
   D3D_REQUIRE(training ? stats_ws != nullptr : (running_mean && running_var),
               "d3d_bn_apply: training needs stats_ws, eval needs running stats");
   const int nb = bn_grid(n, c, dtype);
   if (dtype == D3D_BF16)
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(nb), dim3(256), 0, stream, x, n, c, gamma, beta,
-                       running_mean, running_var, momentum, eps, training, relu, stats_ws, y,
+                       running_mean, running_var, momentum, eps, training, relu, stats_ws, copies, y,
                        save_mean, save_invstd);
   else
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(nb), dim3(256), 0, stream, x, n, c, gamma, beta,
-                       running_mean, running_var, momentum, eps, training, relu, stats_ws, y,
+                       running_mean, running_var, momentum, eps, training, relu, stats_ws, copies, y,
                        save_mean, save_invstd);
   D3D_LAUNCH_TRY("bn_apply_kernel");
   return D3D_OK;
@@ -396,19 +397,21 @@ extern "C" int d3d_bn_bwd_reduce(const void *x, const void *dy, int n, int c, in
 
 extern "C" int d3d_bn_bwd_dx(const void *x, const void *dy, int n, int c, int dtype, const float *gamma,
                              const float *beta, const float *save_mean, const float *save_invstd, int relu,
-                             const float *partial_ws, void *dx, float *dgamma, float *dbeta, d3d_stream_t stream_) {
+                             const float *partial_ws, int copies, void *dx, float *dgamma, float *dbeta,
+                             d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = bn_check(n, c, dtype, "d3d_bn_bwd_dx");
   if (rc) return rc;
+  D3D_REQUIRE(copies >= 1 && copies <= 256, "d3d_bn_bwd_dx: copies=%d", copies);
   D3D_REQUIRE(x && dy && dx && dgamma && dbeta && save_mean && save_invstd && partial_ws,
               "d3d_bn_bwd_dx: null pointer");
   const int nb = bn_grid(n, c, dtype);
   if (dtype == D3D_BF16)
     hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma, beta,
-                       save_mean, save_invstd, relu, partial_ws, dgamma, dbeta, dx);
+                       save_mean, save_invstd, relu, partial_ws, copies, dgamma, dbeta, dx);
   else
     hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma, beta,
-                       save_mean, save_invstd, relu, partial_ws, dgamma, dbeta, dx);
+                       save_mean, save_invstd, relu, partial_ws, copies, dgamma, dbeta, dx);
   D3D_LAUNCH_TRY("bn_bwd_dx_kernel");
   return D3D_OK;
 }
@@ -498,6 +501,7 @@ extern "C" int d3d_bn_relu_fwd(const void *x, int n, int c, int dtype, const flo
                                float *save_mean, float *save_invstd, float *stats_ws,
                                d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const int copies = D3D_BN_COPIES;
   int rc = bn_check(n, c, dtype, "d3d_bn_relu_fwd");
   if (rc) return rc;
   D3D_REQUIRE(x && y, "d3d_bn_relu_fwd: null pointer");
@@ -514,11 +518,11 @@ extern "C" int d3d_bn_relu_fwd(const void *x, int n, int c, int dtype, const flo
   }
   if (dtype == D3D_BF16)
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(nb), dim3(256), 0, stream, x, n, c, gamma, beta,
-                       running_mean, running_var, momentum, eps, training, relu, stats_ws, y,
+                       running_mean, running_var, momentum, eps, training, relu, stats_ws, copies, y,
                        save_mean, save_invstd);
   else
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(nb), dim3(256), 0, stream, x, n, c, gamma, beta,
-                       running_mean, running_var, momentum, eps, training, relu, stats_ws, y,
+                       running_mean, running_var, momentum, eps, training, relu, stats_ws, copies, y,
                        save_mean, save_invstd);
   D3D_LAUNCH_TRY("bn_apply_kernel");
   return D3D_OK;
@@ -529,6 +533,7 @@ extern "C" int d3d_bn_relu_bwd(const void *x, const void *dy, int n, int c, int 
                                const float *save_invstd, int relu, void *dx, float *dgamma,
                                float *dbeta, float *partial_ws, d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const int copies = D3D_BN_COPIES;
   int rc = bn_check(n, c, dtype, "d3d_bn_relu_bwd");
   if (rc) return rc;
   D3D_REQUIRE(x && dy && dx && dgamma && dbeta && save_mean && save_invstd && partial_ws,
@@ -539,12 +544,12 @@ extern "C" int d3d_bn_relu_bwd(const void *x, const void *dy, int n, int c, int 
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nb), dim3(256), 0, stream, x, dy, n, c,
                        gamma, beta, save_mean, save_invstd, relu, partial_ws);
     hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma,
-                       beta, save_mean, save_invstd, relu, partial_ws, dgamma, dbeta, dx);
+                       beta, save_mean, save_invstd, relu, partial_ws, copies, dgamma, dbeta, dx);
   } else {
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nb), dim3(256), 0, stream, x, dy, n, c,
                        gamma, beta, save_mean, save_invstd, relu, partial_ws);
     hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(nb), dim3(256), 0, stream, x, dy, n, c,
-                       gamma, beta, save_mean, save_invstd, relu, partial_ws, dgamma, dbeta, dx);
+                       gamma, beta, save_mean, save_invstd, relu, partial_ws, copies, dgamma, dbeta, dx);
   }
   D3D_LAUNCH_TRY("bn_bwd kernels");
   return D3D_OK;

@@ -305,7 +305,10 @@ __global__ void __launch_bounds__(WAVES * 64, ((WAVES >= 16 && CIN * COUT <= 409
   if (want_stats || want_bnb) {
     __syncthreads();
     // [copy][2 * COUT]: (sum | sum sq) or (dgamma | dbeta), replicated to spread same-address atomics
-    float *dst = (want_stats ? ep.stats : ep.bn_partial) + (size_t)(blockIdx.x % D3D_BN_COPIES) * 2 * COUT;
+    // [copy][2 * COUT]: (sum | sum sq) or (dgamma | dbeta), replicated to spread same-address atomics.  (Agent-
+    // and workgroup-scope float adds lower to the same global_atomic_add_f32 on gfx950 and execute beyond the
+    // XCD's L2, so a per-XCD replica indexed by HW_REG_XCC_ID buys nothing over blockIdx % 8.)
+    float *dst = (want_stats ? ep.stats : ep.bn_partial) + (size_t)(blockIdx.x % (unsigned)ep.copies) * 2 * COUT;
     for (int i = threadIdx.x; i < 2 * COUT; i += NTHREADS) atomicAdd(&dst[i], red[i]);
   }
 }
@@ -377,6 +380,8 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
   D3dConvEpilogue ep = {};
   if (epilogue) ep = *epilogue;
   D3D_REQUIRE(!(ep.stats && ep.bn_partial), "d3d_sparse_conv_fwd_ex: one reduction per launch (stats or bn_partial)");
+  if (ep.copies <= 0) ep.copies = D3D_BN_COPIES;
+  D3D_REQUIRE(ep.copies <= 256, "d3d_sparse_conv_fwd_ex: copies=%d", ep.copies);
   D3D_REQUIRE(!ep.bn_partial || (ep.bn_x && ep.bn_mean && ep.bn_invstd),
               "d3d_sparse_conv_fwd_ex: bn_partial needs bn_x, bn_mean, bn_invstd");
   D3D_REQUIRE(!(ep.stats || ep.bn_partial) || (cin % 16 == 0 && cout % 16 == 0 && cin <= 128 && cout <= 128),

@@ -13,7 +13,10 @@
 //     they are prefetched DEPTH stages ahead in registers (DEPTH x 16 KB in flight per CU) with their
 //     neighbour indices prefetched a further DEPTH stages ahead, so the two dependent L2 round trips
 //     (index, then row) of the gather overlap ~2*DEPTH stages of LDS + MFMA work;
-//   * sites become the MFMA k dimension through ds_read_b64_tr_b16 on [16 sites][16 ch] LDS tiles;
+//   * sites become the MFMA k dimension through ds_read_b64_tr_b16 on [16 sites][16 ch] LDS tiles (32 sites per
+//     mfma_f32_16x16x32_bf16); when Cin*Cout has fewer than 16 MFMA tiles the waves sharing a tile split the sites
+//     of each stage and keep separate partial sums, so all 16 waves work in every stage;
+//   * f32 (parity mode) runs the same pipeline on mfma_f32_16x16x4f32 with plain [site][ch] LDS rows;
 //   * no atomics: every block stores its partial dW to a workspace slice and a second, streaming kernel
 //     sums the splits in a fixed order => the weight gradient is bit-reproducible run to run.
 // Traffic per launch: P*Cin*e gathered (L2) + (27/KG)*N*Cout*e + 27*N*4 (table) + 2 * splits*|dW|*4.
@@ -24,30 +27,50 @@
 #include "d3d_spconv_internal.h"
 
 typedef __attribute__((ext_vector_type(4))) short wg_s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short wg_s16x8_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 wg_bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float wg_f32x4_t;
 
 #define WG_WAVES 16
 #define WG_THREADS (WG_WAVES * 64)
 
-template <int CIN, int COUT, int KG, int DEPTH>
+// compile-time geometry shared by the kernel and the host-side planner
+template <int CIN, int COUT, bool BF16> struct WgGeom {
+  static constexpr int EPV = BF16 ? 8 : 4;                       // elements per 16-byte vector
+  static constexpr int CIT = CIN / 16, COT = COUT / 16, TILES = CIT * COT;
+  static constexpr int FSEG = CIN / EPV, DSEG = COUT / EPV;      // 16-byte segments per row
+  static constexpr int STEP = WG_THREADS / FSEG;                 // sites per stage (1 vector / thread)
+  static constexpr int TPW = TILES >= WG_WAVES ? TILES / WG_WAVES : 1;     // MFMA tiles per wave
+  static constexpr int CSPLIT = TILES >= WG_WAVES ? 1 : WG_WAVES / TILES;  // waves sharing one tile: they
+  //   split the sites of a stage and each keeps its own partial sum -> CSPLIT partial slabs per block
+};
+
+// One block = 16 waves, one group of KG kernel offsets, one contiguous range of output sites.
+//   bf16: LDS tiles [16 sites][16 ch], ds_read_b64_tr_b16 turns sites into the MFMA k dimension, two of them
+//         feed one mfma_f32_16x16x32_bf16 (32 sites per instruction)
+//   f32 : LDS rows [site][ch + 16 pad], one element per lane feeds mfma_f32_16x16x4f32 (4 sites per
+//         instruction, exact f32 products: the parity mode)
+template <int CIN, int COUT, int KG, int DEPTH, bool BF16>
 __global__ void __launch_bounds__(WG_THREADS)
-    spconv_wgrad_tile_kernel(const uint16_t *__restrict__ feat, const uint16_t *__restrict__ dout,
+    spconv_wgrad_tile_kernel(const void *__restrict__ feat_, const void *__restrict__ dout_,
                              const int32_t *__restrict__ nbr, int cap, int n_out, int rows_per_split,
                              int kvol, float *__restrict__ part) {
-  constexpr int CIT = CIN / 16, COT = COUT / 16, TILES = CIT * COT;
-  constexpr int TPW = TILES >= WG_WAVES ? TILES / WG_WAVES : 1;     // MFMA tiles per wave and offset
-  constexpr int KSPLIT = TILES >= WG_WAVES ? 1 : WG_WAVES / TILES;  // wave groups sharing the offsets
-  constexpr int NACC = (KG + KSPLIT - 1) / KSPLIT;                  // offsets accumulated per wave
-  constexpr int FSEG = CIN / 8, DSEG = COUT / 8;                    // 16-byte segments per row
-  constexpr int STEP = WG_THREADS / FSEG;                           // sites per stage (1 vector / thread)
-  constexpr int CHUNKS = STEP / 16;
+  using G = WgGeom<CIN, COUT, BF16>;
+  constexpr int CIT = G::CIT, COT = G::COT, TILES = G::TILES, TPW = G::TPW, CSPLIT = G::CSPLIT;
+  constexpr int FSEG = G::FSEG, DSEG = G::DSEG, STEP = G::STEP, EPV = G::EPV;
   constexpr int DN = STEP * DSEG;
-  constexpr int DV = (DN + WG_THREADS - 1) / WG_THREADS;            // dout vectors per thread and tile
-  constexpr int FBUF = CHUNKS * CIT * 256, DBUF = CHUNKS * COT * 256;  // bf16 elements per LDS buffer
+  constexpr int DV = (DN + WG_THREADS - 1) / WG_THREADS;  // dout vectors per thread and tile
+  // bf16: [chunk of 16 sites][ch tile][16 sites][16 ch]; f32: [site][ch + 16]  (elements)
+  constexpr int FROW = CIN + 16, DROW = COUT + 16;
+  constexpr int FBUF = BF16 ? STEP * CIN : STEP * FROW;
+  constexpr int DBUF = BF16 ? STEP * COUT : STEP * DROW;
+  constexpr int ESZ = BF16 ? 2 : 4;
+  // MFMA k-steps per stage and per wave: 32 sites (bf16) / 4 sites (f32) each, split over the CSPLIT waves
+  constexpr int KSTEPS = STEP / (BF16 ? 32 : 4);
+  static_assert(KSTEPS % CSPLIT == 0, "sites of a stage must split evenly over the waves sharing a tile");
   static_assert(DEPTH <= KG || KG == 1, "one dout register set: the next tile's rows must not be issued twice");
-  // [buffer][chunk][ch tile][16 sites][16 ch] bf16
-  __shared__ __attribute__((aligned(16))) uint16_t lds_f[2 * FBUF];
-  __shared__ __attribute__((aligned(16))) uint16_t lds_d[2 * DBUF];
+  __shared__ __attribute__((aligned(16))) unsigned char lds_f[2 * FBUF * ESZ];
+  __shared__ __attribute__((aligned(16))) unsigned char lds_d[2 * DBUF * ESZ];
 
   const int k0 = blockIdx.x * KG;
   const int s0 = blockIdx.y * rows_per_split;
@@ -55,26 +78,30 @@ __global__ void __launch_bounds__(WG_THREADS)
   if (s1 > n_out) s1 = n_out;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int my_tile = wave % TILES;    // first (only, if TILES <= 16) MFMA tile of this wave
-  const int my_kgrp = wave / TILES;    // 0 when KSPLIT == 1
+  const int my_tile = wave % TILES;  // first (only, if TILES <= 16) MFMA tile of this wave
+  const int my_part = wave / TILES;  // which share of a stage's sites (0 when CSPLIT == 1)
 
-  wg_f32x4_t acc[NACC][TPW];
+  wg_f32x4_t acc[KG][TPW];
 #pragma unroll
-  for (int a = 0; a < NACC; ++a)
+  for (int a = 0; a < KG; ++a)
 #pragma unroll
     for (int t = 0; t < TPW; ++t) acc[a][t] = wg_f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int ntiles = (s1 - s0 + STEP - 1) / STEP;
   const int nstages = ntiles * KG;
   const int frow = threadIdx.x / FSEG, fseg = threadIdx.x - frow * FSEG;
+  const unsigned char *feat = (const unsigned char *)feat_;
+  const unsigned char *dout = (const unsigned char *)dout_;
 
   auto load_index = [&](int st) -> int {
     const int tile = st / KG, kk = st - tile * KG;
     const int site = s0 + tile * STEP + frow;
-    return site < s1 ? nbr[(int64_t)(k0 + kk) * cap + site] : -1;
+    const int32_t *nk = nbr + (int64_t)(k0 + kk) * cap;  // uniform base, 32-bit lane offset
+    return site < s1 ? nk[(uint32_t)site] : -1;
   };
   auto load_feat = [&](int i) -> uint4 {
-    return i >= 0 ? *(const uint4 *)(feat + (int64_t)i * CIN + fseg * 8) : make_uint4(0, 0, 0, 0);
+    const uint32_t off = (uint32_t)i * (uint32_t)(CIN * ESZ) + (uint32_t)(fseg * 16);
+    return i >= 0 ? *(const uint4 *)(feat + off) : make_uint4(0, 0, 0, 0);
   };
   uint4 dr[DV];
   auto load_dout = [&](int tile) {
@@ -85,8 +112,14 @@ __global__ void __launch_bounds__(WG_THREADS)
       if (DN % WG_THREADS != 0 && e >= DN) break;
       const int r = e / DSEG, seg = e - r * DSEG;
       const int site = base + r;
-      dr[j] = site < s1 ? *(const uint4 *)(dout + (int64_t)site * COUT + seg * 8) : make_uint4(0, 0, 0, 0);
+      const uint32_t off = (uint32_t)site * (uint32_t)(COUT * ESZ) + (uint32_t)(seg * 16);
+      dr[j] = site < s1 ? *(const uint4 *)(dout + off) : make_uint4(0, 0, 0, 0);
     }
+  };
+  // LDS element offset of 16-byte segment `seg` of row r
+  auto lds_off = [&](int r, int seg, int ctiles, int rowlen) -> int {
+    if constexpr (BF16) return ((r >> 4) * ctiles + (seg >> 1)) * 256 + (r & 15) * 16 + (seg & 1) * 8;
+    else return r * rowlen + seg * 4;
   };
 
   uint4 fr[DEPTH];
@@ -108,18 +141,18 @@ __global__ void __launch_bounds__(WG_THREADS)
       const int st = sb + d;
       if (st >= nstages) break;
       const int tile = st / KG, kk = st - tile * KG;
-      uint16_t *bf = lds_f + (st & 1) * FBUF;
-      uint16_t *bd = lds_d + (tile & 1) * DBUF;
-      // stage `st` -> LDS ([16 sites][16 ch] tiles).  The buffer's previous readers (stage st-2) all
-      // passed the barrier of stage st-1 after finishing their MFMAs, so one barrier per stage suffices
-      *(uint4 *)(bf + ((frow >> 4) * CIT + (fseg >> 1)) * 256 + (frow & 15) * 16 + (fseg & 1) * 8) = fr[d];
+      unsigned char *bf = lds_f + (st & 1) * (FBUF * ESZ);
+      unsigned char *bd = lds_d + (tile & 1) * (DBUF * ESZ);
+      // stage `st` -> LDS.  The buffer's previous readers (stage st-2) all passed the barrier of stage st-1
+      // after finishing their MFMAs, so one barrier per stage suffices
+      *(uint4 *)(bf + lds_off(frow, fseg, CIT, FROW) * ESZ) = fr[d];
       if (kk == 0) {
 #pragma unroll
         for (int j = 0; j < DV; ++j) {
           const int e = threadIdx.x + j * WG_THREADS;
           if (DN % WG_THREADS != 0 && e >= DN) break;
           const int r = e / DSEG, seg = e - r * DSEG;
-          *(uint4 *)(bd + ((r >> 4) * COT + (seg >> 1)) * 256 + (r & 15) * 16 + (seg & 1) * 8) = dr[j];
+          *(uint4 *)(bd + lds_off(r, seg, COT, DROW) * ESZ) = dr[j];
         }
       }
       __syncthreads();
@@ -128,24 +161,39 @@ __global__ void __launch_bounds__(WG_THREADS)
       fr[d] = st + DEPTH < nstages ? load_feat(ix[d]) : make_uint4(0, 0, 0, 0);
       ix[d] = st + 2 * DEPTH < nstages ? load_index(st + 2 * DEPTH) : -1;
       if (kk == 0 && tile + 1 < ntiles) load_dout(tile + 1);
-      if ((kk % KSPLIT) == my_kgrp) {
-        const int aidx = kk / KSPLIT;
 #pragma unroll
-        for (int a = 0; a < NACC; ++a) {
-          if (a != aidx) continue;  // keeps acc[] statically indexed (uniform branch)
+      for (int a = 0; a < KG; ++a) {
+        if (a != kk) continue;  // keeps acc[] statically indexed (uniform branch)
 #pragma unroll 4
-          for (int chunk = 0; chunk < CHUNKS; ++chunk) {
+        for (int q = 0; q < KSTEPS / CSPLIT; ++q) {
+          const int ks = q * CSPLIT + my_part;  // this wave's k-steps of the stage
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-              const int tl = my_tile + t * WG_WAVES;
-              const int cit = tl / COT, cot = tl - cit * COT;
-              // each lane passes the address of ITS 8 bytes in the row-major 4x16 block of sites
-              // [lg*4, lg*4+4); the hardware returns the transposed column lr
-              wg_s16x4_t av = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                  (__attribute__((address_space(3))) wg_s16x4_t *)(bf + (chunk * CIT + cit) * 256 + lg * 64 + lr * 4));
-              wg_s16x4_t bv = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                  (__attribute__((address_space(3))) wg_s16x4_t *)(bd + (chunk * COT + cot) * 256 + lg * 64 + lr * 4));
-              acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, acc[a][t], 0, 0, 0);
+          for (int t = 0; t < TPW; ++t) {
+            const int tl = my_tile + t * WG_WAVES;
+            const int cit = tl / COT, cot = tl - cit * COT;
+            if constexpr (BF16) {
+              // 32 sites = LDS chunks 2*ks and 2*ks+1.  Each lane passes the address of ITS 8 bytes in the
+              // row-major 4x16 block of sites [lg*4, lg*4+4); the hardware returns the transposed column lr.
+              // A and B use the same site order, so any consistent k labelling is a valid sum.
+              const uint16_t *f16 = (const uint16_t *)bf, *d16 = (const uint16_t *)bd;
+              wg_s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (__attribute__((address_space(3))) wg_s16x4_t *)(f16 + ((2 * ks) * CIT + cit) * 256 + lg * 64 + lr * 4));
+              wg_s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (__attribute__((address_space(3))) wg_s16x4_t *)(f16 + ((2 * ks + 1) * CIT + cit) * 256 + lg * 64 + lr * 4));
+              wg_s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (__attribute__((address_space(3))) wg_s16x4_t *)(d16 + ((2 * ks) * COT + cot) * 256 + lg * 64 + lr * 4));
+              wg_s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (__attribute__((address_space(3))) wg_s16x4_t *)(d16 + ((2 * ks + 1) * COT + cot) * 256 + lg * 64 + lr * 4));
+              wg_s16x8_t av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+              wg_s16x8_t bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+              acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wg_bf16x8_t, av),
+                                                                  __builtin_bit_cast(wg_bf16x8_t, bv), acc[a][t], 0, 0, 0);
+            } else {
+              // 4 sites: lane group lg supplies k = lg, lane lr the channel
+              const float *f32p = (const float *)bf, *d32p = (const float *)bd;
+              const float av = f32p[(ks * 4 + lg) * FROW + cit * 16 + lr];
+              const float bv = d32p[(ks * 4 + lg) * DROW + cot * 16 + lr];
+              acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[a][t], 0, 0, 0);
             }
           }
         }
@@ -153,44 +201,55 @@ __global__ void __launch_bounds__(WG_THREADS)
     }
   }
 
-  // partial dW of this (offset group, site split): plain stores, summed by wgrad_reduce_kernel
-  float *pbase = part + (int64_t)blockIdx.y * kvol * (CIN * COUT);
+  // partial dW of this (offset group, site split, wave share): plain stores, summed by wgrad_reduce_kernel
+  float *pbase = part + ((int64_t)blockIdx.y * CSPLIT + my_part) * kvol * (CIN * COUT);
 #pragma unroll
-  for (int a = 0; a < NACC; ++a) {
-    const int kk = a * KSPLIT + my_kgrp;
-    if (kk >= KG) continue;
+  for (int a = 0; a < KG; ++a) {
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       const int tl = my_tile + t * WG_WAVES;
       const int cit = tl / COT, cot = tl - cit * COT;
-      float *o = pbase + ((int64_t)(k0 + kk) * CIN + cit * 16 + lg * 4) * COUT + cot * 16 + lr;
+      float *o = pbase + ((int64_t)(k0 + a) * CIN + cit * 16 + lg * 4) * COUT + cot * 16 + lr;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r * COUT] = acc[a][t][r];
     }
   }
 }
 
-// dw[e] = sum over splits of part[s][e] in a fixed order (4 elements per thread, two independent chains)
+// dw[e] = sum over slabs of part[s][e] in a fixed order.  Block = 32 float4 elements x 8 slab groups: every
+// thread walks slabs g, g+8, ... with two independent chains, the 8 groups are folded through LDS in order.
 __global__ void __launch_bounds__(256)
-    wgrad_reduce_kernel(const float4 *__restrict__ part, int splits, int64_t total4, float4 *__restrict__ dw) {
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    int s = 0;
-    for (; s + 1 < splits; s += 2) {
-      const float4 u = part[(int64_t)s * total4 + e], v = part[(int64_t)(s + 1) * total4 + e];
+    wgrad_reduce_kernel(const float4 *__restrict__ part, int slabs, int64_t total4, float4 *__restrict__ dw) {
+  __shared__ float4 red[8][32];
+  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int64_t e = (int64_t)blockIdx.x * 32 + el;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (e < total4) {
+    int s = g;
+    for (; s + 8 < slabs; s += 16) {
+      const float4 u = part[(int64_t)s * total4 + e], v = part[(int64_t)(s + 8) * total4 + e];
       a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
       b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
     }
-    if (s < splits) {
+    if (s < slabs) {
       const float4 u = part[(int64_t)s * total4 + e];
       a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
     }
-    dw[e] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+  red[g][el] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  __syncthreads();
+  if (g == 0 && e < total4) {
+    float4 r = red[0][el];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      r.x += red[j][el].x; r.y += red[j][el].y; r.z += red[j][el].z; r.w += red[j][el].w;
+    }
+    dw[e] = r;
   }
 }
 
 struct WgPlan {
-  int kg, step, splits, rows_per_split;
+  int kg, step, csplit, splits, rows_per_split;
 };
 
 static int wg_target_blocks() {
@@ -198,10 +257,10 @@ static int wg_target_blocks() {
   return v < 1 ? 256 : v;
 }
 
-// offsets per block: all of them while the accumulators of a wave stay <= ~56 registers
+// offsets per block: the accumulators of a wave are 4 * KG * TPW registers
 static int wg_kgroup(int kvol, int cin, int cout) {
   const int tiles = (cin / 16) * (cout / 16);
-  const int kg = tiles <= 8 ? 27 : (tiles <= 32 ? 9 : 3);
+  const int kg = tiles <= 32 ? 9 : 3;
   if (kvol % kg == 0 && kvol >= kg) return kg;
   return kvol % 3 == 0 ? 3 : 1;
 }
@@ -211,10 +270,13 @@ static bool wg_supported(int cin, int cout) {
          (cin == 64 && (cout == 64 || cout == 128)) || (cin == 128 && cout == 128);
 }
 
-static WgPlan wg_plan(int n_out, int kvol, int cin, int cout) {
+static WgPlan wg_plan(int n_out, int kvol, int cin, int cout, int dtype) {
   WgPlan p;
+  const int epv = dtype == D3D_BF16 ? 8 : 4;
+  const int tiles_mfma = (cin / 16) * (cout / 16);
   p.kg = wg_kgroup(kvol, cin, cout);
-  p.step = WG_THREADS / (cin / 8);
+  p.step = WG_THREADS / (cin / epv);
+  p.csplit = tiles_mfma >= WG_WAVES ? 1 : WG_WAVES / tiles_mfma;
   const int kgroups = kvol / p.kg;
   const int tiles = (n_out + p.step - 1) / p.step;
   int splits = (wg_target_blocks() + kgroups - 1) / kgroups;
@@ -229,17 +291,16 @@ static WgPlan wg_plan(int n_out, int kvol, int cin, int cout) {
 }
 
 extern "C" size_t d3d_sparse_conv_wgrad_workspace_bytes(int n_out, int kvol, int cin, int cout, int dtype) {
-  if (dtype != D3D_BF16 || !wg_supported(cin, cout) || n_out <= 0) return 256;
-  WgPlan p = wg_plan(n_out, kvol, cin, cout);
-  return (size_t)p.splits * kvol * cin * cout * sizeof(float) + 256;
+  if ((dtype != D3D_BF16 && dtype != D3D_F32) || !wg_supported(cin, cout) || n_out <= 0) return 256;
+  WgPlan p = wg_plan(n_out, kvol, cin, cout, dtype);
+  return (size_t)p.splits * p.csplit * kvol * cin * cout * sizeof(float) + 256;
 }
 
-template <int CI, int CO, int KG, int DEPTH>
+template <int CI, int CO, int KG, int DEPTH, bool BF16>
 static int wg_launch(const void *feat, const void *dout, const int32_t *nbr, int cap, int n_out, int kvol,
                      const WgPlan &p, float *part, hipStream_t stream) {
-  hipLaunchKernelGGL((spconv_wgrad_tile_kernel<CI, CO, KG, DEPTH>), dim3(kvol / KG, p.splits),
-                     dim3(WG_THREADS), 0, stream, (const uint16_t *)feat, (const uint16_t *)dout, nbr, cap,
-                     n_out, p.rows_per_split, kvol, part);
+  hipLaunchKernelGGL((spconv_wgrad_tile_kernel<CI, CO, KG, DEPTH, BF16>), dim3(kvol / KG, p.splits),
+                     dim3(WG_THREADS), 0, stream, feat, dout, nbr, cap, n_out, p.rows_per_split, kvol, part);
   D3D_LAUNCH_TRY("spconv_wgrad_tile_kernel");
   return D3D_OK;
 }
@@ -247,21 +308,27 @@ static int wg_launch(const void *feat, const void *dout, const int32_t *nbr, int
 #define WG_ARGS feat, dout, nbr, cap, n_out, kvol, p, part, stream
 // (channels) -> the offset group wg_kgroup() picks for a 27-offset kernel with its prefetch depth, plus the
 // 3-offset ((3,1,1) kernels) and 1-offset fallbacks
-#define WG_CASE(CI, CO, KGMAIN, DMAIN)                                                        \
-  if (cin == CI && cout == CO) {                                                              \
-    if (p.kg == KGMAIN) return wg_launch<CI, CO, KGMAIN, DMAIN>(WG_ARGS);                     \
-    if (p.kg == 3) return wg_launch<CI, CO, 3, 3>(WG_ARGS);                                   \
-    if (p.kg == 1) return wg_launch<CI, CO, 1, 4>(WG_ARGS);                                   \
+#define WG_CASE(CI, CO, KGMAIN, DMAIN)                                                                 \
+  if (cin == CI && cout == CO) {                                                                       \
+    if (bf16) {                                                                                        \
+      if (p.kg == KGMAIN) return wg_launch<CI, CO, KGMAIN, DMAIN, true>(WG_ARGS);                      \
+      if (p.kg == 3) return wg_launch<CI, CO, 3, 3, true>(WG_ARGS);                                    \
+      if (p.kg == 1) return wg_launch<CI, CO, 1, 4, true>(WG_ARGS);                                    \
+    } else {                                                                                           \
+      if (p.kg == KGMAIN) return wg_launch<CI, CO, KGMAIN, (DMAIN > 4 ? 4 : DMAIN), false>(WG_ARGS);   \
+      if (p.kg == 3) return wg_launch<CI, CO, 3, 3, false>(WG_ARGS);                                   \
+      if (p.kg == 1) return wg_launch<CI, CO, 1, 4, false>(WG_ARGS);                                   \
+    }                                                                                                  \
   }
 
 static int wg_dispatch(const void *feat, const void *dout, const int32_t *nbr, int cap, int n_out, int kvol,
-                       int cin, int cout, const WgPlan &p, float *part, hipStream_t stream) {
+                       int cin, int cout, bool bf16, const WgPlan &p, float *part, hipStream_t stream) {
   // prefetch depth: DEPTH stages x 16 KB of gathered rows in flight per CU, bounded by the 128 VGPRs a
-  // 16-wave block leaves each lane (accumulators: 4 * NACC * TPW)
-  WG_CASE(16, 16, 27, 8)
-  WG_CASE(16, 32, 27, 8)
-  WG_CASE(32, 32, 27, 8)
-  WG_CASE(32, 64, 27, 6)
+  // 16-wave block leaves each lane (accumulators: 4 * KG * TPW)
+  WG_CASE(16, 16, 9, 8)
+  WG_CASE(16, 32, 9, 6)
+  WG_CASE(32, 32, 9, 8)
+  WG_CASE(32, 64, 9, 4)
   WG_CASE(64, 64, 9, 8)
   WG_CASE(64, 128, 9, 4)
   WG_CASE(128, 128, 3, 3)
@@ -279,21 +346,21 @@ extern "C" int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const i
   D3D_REQUIRE(dw, "d3d_sparse_conv_wgrad: null dw");
   // D3D_WGRAD_LEGACY=1: the round-1 kernels (one block per offset, float atomics) for A/B timing
   static const int legacy = getenv("D3D_WGRAD_LEGACY") ? atoi(getenv("D3D_WGRAD_LEGACY")) : 0;
-  const bool tile_path = !legacy && dtype == D3D_BF16 && wg_supported(cin, cout) && n_out > 0;
+  const bool tile_path = !legacy && wg_supported(cin, cout) && n_out > 0 &&
+                         (int64_t)cap * (cin > cout ? cin : cout) * 4 < ((int64_t)1 << 32);  // 32-bit row offsets
   if (!tile_path) return d3d_wgrad_legacy(feat, dout, nbr, cap, n_out, kvol, cin, cout, dtype, dw, stream);
   D3D_REQUIRE(feat && dout && nbr, "d3d_sparse_conv_wgrad: null pointer");
   const size_t need = d3d_sparse_conv_wgrad_workspace_bytes(n_out, kvol, cin, cout, dtype);
   if (!workspace || workspace_bytes < need)
     return d3d_set_error(D3D_ECAPACITY, "d3d_sparse_conv_wgrad: workspace %zu B < %zu B", workspace_bytes, need);
-  WgPlan p = wg_plan(n_out, kvol, cin, cout);
+  WgPlan p = wg_plan(n_out, kvol, cin, cout, dtype);
   float *part = (float *)workspace;
-  int rc = wg_dispatch(feat, dout, nbr, cap, n_out, kvol, cin, cout, p, part, stream);
+  int rc = wg_dispatch(feat, dout, nbr, cap, n_out, kvol, cin, cout, dtype == D3D_BF16, p, part, stream);
   if (rc) return rc;
   const int64_t total4 = (int64_t)kvol * cin * cout / 4;
-  int nb = (int)((total4 + 255) / 256);
-  if (nb > 1024) nb = 1024;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, stream, (const float4 *)part, p.splits, total4,
-                     (float4 *)dw);
+  const int nb = (int)((total4 + 31) / 32);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, stream, (const float4 *)part,
+                     p.splits * p.csplit, total4, (float4 *)dw);
   D3D_LAUNCH_TRY("wgrad_reduce_kernel");
   return D3D_OK;
 }

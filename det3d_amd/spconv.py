@@ -30,6 +30,7 @@ _DT = {torch.float32: _lib.D3D_F32, torch.bfloat16: _lib.D3D_BF16}
 
 # bench.py sets this to a list to time every d3d_sparse_conv_fwd launch with HIP events
 # recorded on the launch stream: entries are (kind, cin, cout, n_out, rulebook, ev0, ev1)
+EPI_COPIES = int(os.environ.get("D3D_EPI_COPIES", "8"))  # replicas of a conv-epilogue accumulator (same-address atomics)
 FUSE_BN_RELU = True  # SparseSequential / SparseBasicBlock route BatchNorm1d(+ReLU) to d3d_bn_relu_*
 LAUNCH_LOG = None
 LAUNCH_LOG_LIMIT = 256
@@ -79,7 +80,7 @@ class _ZeroArena:
         off = self.off.get(dev, 0)
         if b is None or off + n > b.numel():
             if b is None and off == 0:
-                b = self.buf[dev] = torch.zeros((1 << 18,), dtype=torch.float32, device=dev)  # 1 MB
+                b = self.buf[dev] = torch.zeros((1 << 20,), dtype=torch.float32, device=dev)  # 4 MB
             else:  # arena exhausted (very deep stack): a private zeroed buffer, still correct
                 return torch.zeros((n,), dtype=torch.float32, device=dev)
         self.off[dev] = off + n
@@ -282,7 +283,7 @@ class _SparseConvFn(torch.autograd.Function):
         mfma = pad_cin % 16 == 0 and cout % 16 == 0 and pad_cin <= 128 and cout <= 128
         ep = None
         if stats is not None and mfma and rb.n_out > 0:
-            ep = _lib.ConvEpilogue(stats=stats.data_ptr())
+            ep = _lib.ConvEpilogue(stats=stats.data_ptr(), copies=EPI_COPIES)
         rc = _timed("fwd", pad_cin, cout, rb.n_out, rb, feats.device, lambda: L.d3d_sparse_conv_fwd_ex(
             feats.data_ptr(), wpack.data_ptr(), _lib.ptr(b), rb.nbr_out.data_ptr(), rb.cap_out,
             rb.n_out, kvol, pad_cin, cout, _DT[feats.dtype], out.data_ptr(),
@@ -325,7 +326,7 @@ class _SparseConvFn(torch.autograd.Function):
                 ep = _lib.ConvEpilogue(bn_x=link.x.data_ptr(), bn_mean=link.save[0].data_ptr(),
                                        bn_invstd=link.save[1].data_ptr(), bn_gamma=_lib.ptr(link.gamma),
                                        bn_beta=_lib.ptr(link.beta), bn_relu=int(link.relu),
-                                       bn_partial=link.partial.data_ptr())
+                                       bn_partial=link.partial.data_ptr(), copies=EPI_COPIES)
             rc = _timed("dgrad", cout, pad_cin, rb.n_in, rb, feats.device, lambda: L.d3d_sparse_conv_fwd_ex(
                 gout.data_ptr(), wd.data_ptr(), None, nbr.data_ptr(), cap, rb.n_in, kvol, cout, pad_cin,
                 dt, gin.data_ptr(), ctypes.byref(ep) if ep is not None else None, stream))
@@ -364,12 +365,14 @@ class _BNReLUFn(torch.autograd.Function):
         y = torch.empty_like(x)
         save = torch.empty((2, c), dtype=torch.float32, device=dev)  # mean, invstd
         st = _lib.stream_ptr(dev)
+        copies = EPI_COPIES  # stats from a conv epilogue
         if training and stats is None:
-            stats = torch.empty((2 * _lib.D3D_BN_COPIES * c,), dtype=torch.float32, device=dev)
+            copies = _lib.D3D_BN_COPIES
+            stats = torch.empty((2 * copies * c,), dtype=torch.float32, device=dev)
             _lib.check(L.d3d_bn_stats(x.data_ptr(), n, c, _DT[x.dtype], stats.data_ptr(), st), "d3d_bn_stats")
         rc = L.d3d_bn_apply(x.data_ptr(), n, c, _DT[x.dtype], _lib.ptr(weight), _lib.ptr(bias),
                             _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum), float(eps),
-                            int(training), int(relu), _lib.ptr(stats) if training else None, y.data_ptr(),
+                            int(training), int(relu), _lib.ptr(stats) if training else None, copies, y.data_ptr(),
                             save[0].data_ptr(), save[1].data_ptr(), st)
         _lib.check(rc, "d3d_bn_apply")
         ctx.save_for_backward(x, weight, bias, save)
@@ -378,7 +381,7 @@ class _BNReLUFn(torch.autograd.Function):
         ctx.link = link
         if link is not None and training:
             link.x, link.save, link.gamma, link.beta, link.relu = x, save, weight, bias, bool(relu)
-            link.partial = ARENA.take(dev, 2 * _lib.D3D_BN_COPIES * c)
+            link.partial = ARENA.take(dev, 2 * EPI_COPIES * c)
             link.generation = ARENA.generation
             link.reduced = False
         return y
@@ -396,15 +399,16 @@ class _BNReLUFn(torch.autograd.Function):
         st = _lib.stream_ptr(x.device)
         link = ctx.link
         if link is not None and link.reduced and link.generation == ARENA.generation:
-            partial = link.partial  # reduced by the consuming conv's dgrad epilogue
+            partial, copies = link.partial, EPI_COPIES  # reduced by the consuming conv's dgrad epilogue
         else:
-            partial = torch.empty((2 * _lib.D3D_BN_COPIES * c,), dtype=torch.float32, device=x.device)
+            copies = _lib.D3D_BN_COPIES
+            partial = torch.empty((2 * copies * c,), dtype=torch.float32, device=x.device)
             rc = L.d3d_bn_bwd_reduce(x.data_ptr(), dy.data_ptr(), n, c, _DT[x.dtype], _lib.ptr(weight),
                                      _lib.ptr(bias), save[0].data_ptr(), save[1].data_ptr(), int(ctx.relu),
                                      partial.data_ptr(), st)
             _lib.check(rc, "d3d_bn_bwd_reduce")
         rc = L.d3d_bn_bwd_dx(x.data_ptr(), dy.data_ptr(), n, c, _DT[x.dtype], _lib.ptr(weight), _lib.ptr(bias),
-                             save[0].data_ptr(), save[1].data_ptr(), int(ctx.relu), partial.data_ptr(),
+                             save[0].data_ptr(), save[1].data_ptr(), int(ctx.relu), partial.data_ptr(), copies,
                              dx.data_ptr(), g[0].data_ptr(), g[1].data_ptr(), st)
         _lib.check(rc, "d3d_bn_bwd_dx")
         if link is not None:
@@ -448,7 +452,7 @@ def conv_bn_relu(conv, bn, relu, x, link_in=None, want_link=False):
     fuse = FUSE_BN_STATS and bn.training and x.features.is_cuda and x.features.shape[0] > 0
     stats = None
     if fuse:
-        stats = ARENA.take(x.features.device, 2 * _lib.D3D_BN_COPIES * conv.out_channels)
+        stats = ARENA.take(x.features.device, 2 * EPI_COPIES * conv.out_channels)
     out = conv(x, stats=stats, link=link_in if FUSE_BN_STATS else None)
     if not getattr(out, "_stats_done", False):
         stats = None

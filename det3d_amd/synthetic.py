@@ -334,3 +334,148 @@ def make_example(batch, cfg, fused_mean=True, want_voxels=False, device_targets=
     if fused_mean:
         ex["voxel_mean"] = out["mean"]
     return ex
+
+
+# ------------------------------------------------------------------ multi-group workloads (BASELINE configs[2..4])
+def spinning_lidar_cloud(seed, n_points, pc_range, channels=5, beams=32, sweeps=10, sensor_h=1.84,
+                         boxes=None):
+    """360-degree spinning lidar: `beams` elevations between -30.7 and +10.7 degrees,
+    ground-plane hits at sensor height, exponential obstacles, clipped to the range; `sweeps` > 1 adds the
+    time-lag channel (0, 0.05, ... as in nuScenes' 10-sweep clouds, pipelines/loading.py:126).  Surface points
+    of the planted `boxes` [G, >=7] (x, y, z, w, l, h, ..., r) take 15 % of the budget.
+    Returns float32 [n_points, channels] (x, y, z, intensity[, dt])."""
+    rng = np.random.default_rng(seed)
+    lo, hi = np.array(pc_range[:3], np.float64), np.array(pc_range[3:], np.float64)
+    n_box = int(n_points * 0.15) if boxes is not None and len(boxes) else 0
+    n_bg = n_points - n_box
+    az = rng.uniform(-np.pi, np.pi, n_bg)
+    el = np.deg2rad(np.linspace(-30.7, 10.7, beams))[rng.integers(0, beams, n_bg)]
+    with np.errstate(divide="ignore"):
+        r_ground = np.where(el < 0, sensor_h / np.maximum(np.tan(-el), 1e-6), np.inf)
+    r = np.minimum(np.minimum(r_ground, 2.0 + rng.exponential(0.35 * hi[0], n_bg)), 1.4 * hi[0])
+    xyz = np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az),
+                    r * np.sin(el) + rng.normal(0, 0.02, n_bg)], 1)
+    parts = [xyz]
+    if n_box:
+        per = max(n_box // len(boxes), 1)
+        for b in boxes:
+            u = rng.uniform(-0.5, 0.5, (per, 3))
+            u[np.arange(per), rng.integers(0, 3, per)] = rng.choice([-0.5, 0.5], per)
+            loc = u * b[3:6]
+            c, s = np.cos(b[-1]), np.sin(b[-1])
+            parts.append(np.stack([loc[:, 0] * c + loc[:, 1] * s + b[0], -loc[:, 0] * s + loc[:, 1] * c + b[1],
+                                   loc[:, 2] + b[2]], 1))
+    xyz = np.concatenate(parts)[:n_points]
+    if len(xyz) < n_points:
+        xyz = np.concatenate([xyz, parts[0][: n_points - len(xyz)]])
+    xyz = np.clip(xyz, lo + 1e-3, hi - 1e-3)
+    cols = [xyz, rng.uniform(0, 1, (n_points, 1))]
+    if channels >= 5:
+        cols.append(rng.integers(0, sweeps, (n_points, 1)) * 0.05)
+    pts = np.concatenate(cols, 1).astype(np.float32)[:, :channels]
+    rng.shuffle(pts)
+    return pts
+
+
+class TaskGroupSynthetic:
+    """Seeded frames for a multi-group config (nuScenes CBGS / nuScenes PointPillars / Lyft CBGS): clouds from
+    spinning_lidar_cloud with planted boxes of every class, per-task anchors from the config's anchor
+    generators (target_assigner.py:144-166), padded per-task gt tensors for d3d_assign_targets_task."""
+
+    def __init__(self, cfg, n_points, n_seeds=8, channels=None, boxes_per_class=3, beams=32, sweeps=10):
+        from .point_cloud_ops import grid_size_of
+
+        self.cfg = cfg
+        vg = cfg.voxel_generator
+        self.vox = dict(voxel_size=list(vg.voxel_size), pc_range=list(vg.range), max_points=vg.max_points_in_voxel,
+                        max_voxels=vg.max_voxel_num)
+        self.grid = grid_size_of(vg.voxel_size, vg.range)
+        f = cfg.assigner.out_size_factor
+        self.feature_size = [1, int(self.grid[1]) // f, int(self.grid[0]) // f]
+        self.vec = bool(cfg.box_coder.encode_angle_vector)
+        self.nd = int(cfg.box_coder.n_dim)
+        self.channels = channels or (5 if self.nd == 9 else 4)
+        gens_all = {g.class_name: g for g in cfg.target_assigner.anchor_generators}
+        self.tasks = []
+        for task in cfg.tasks:
+            gens = [gens_all[c].to_dict() if hasattr(gens_all[c], "to_dict") else dict(gens_all[c])
+                    for c in task.class_names]
+            anchors, k, r, hi_t, lo_t = task_anchors(self.feature_size, gens)
+            self.tasks.append(dict(gens=gens, anchors=anchors, k=k, r=r, matched=hi_t, unmatched=lo_t))
+        lo, hi = np.array(vg.range[:3]), np.array(vg.range[3:])
+        self.frames = []
+        for s in range(n_seeds):
+            rng = np.random.default_rng(1000 + s)
+            per_task, all_boxes = [], []
+            for t in self.tasks:
+                g = np.zeros((t["k"] * boxes_per_class, self.nd), np.float32)
+                c = np.zeros((t["k"] * boxes_per_class,), np.int32)
+                for j in range(len(g)):
+                    ci = j % t["k"]
+                    gen = t["gens"][ci]
+                    c[j] = ci + 1
+                    g[j, :2] = rng.uniform(0.8 * lo[:2], 0.8 * hi[:2])
+                    g[j, 2] = gen["anchor_ranges"][2]
+                    g[j, 3:6] = np.array(gen["sizes"]) * rng.uniform(0.9, 1.1, 3)
+                    if self.nd == 9:
+                        g[j, 6:8] = rng.normal(0, 2, 2)
+                    g[j, -1] = rng.uniform(-np.pi, np.pi)
+                per_task.append((g, c))
+                all_boxes.append(g)
+            pts = spinning_lidar_cloud(s, n_points, vg.range, self.channels, beams, sweeps,
+                                       boxes=np.concatenate(all_boxes))
+            self.frames.append(dict(points=pts, gt=per_task))
+
+    def device_batch(self, step, batch_size, device, rank=0, world=1):
+        idx = [(step * batch_size * world + rank * batch_size + i) % len(self.frames) for i in range(batch_size)]
+        fr = [self.frames[i] for i in idx]
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=True)
+        off = np.cumsum([0] + [len(f["points"]) for f in fr]).astype(np.int32)
+        out = dict(points=t(np.concatenate([f["points"] for f in fr])), frame_offsets=t(off),
+                   metadata=[dict(token=int(i)) for i in idx], anchors=[], anchors_flat=[], gt_boxes=[],
+                   gt_classes=[], gt_count=[])
+        for ti, task in enumerate(self.tasks):
+            gmax = max(len(f["gt"][ti][0]) for f in fr)
+            gt = np.zeros((batch_size, gmax, self.nd), np.float32)
+            cls = np.zeros((batch_size, gmax), np.int32)
+            for b, f in enumerate(fr):
+                g, c = f["gt"][ti]
+                gt[b, : len(g)], cls[b, : len(g)] = g, c
+            a = t(task["anchors"])
+            out["anchors_flat"].append(a)
+            out["anchors"].append(a[None].expand(batch_size, -1, -1).contiguous())
+            out["gt_boxes"].append(t(gt))
+            out["gt_classes"].append(t(cls))
+            out["gt_count"].append(t(np.array([len(f["gt"][ti][0]) for f in fr], np.int32)))
+        return out
+
+    def make_example(self, batch, want_voxels=False, targets=True):
+        """device voxelizer (+ fused mean for VoxelNet readers) and one d3d_assign_targets_task call per task
+        group -> the collate_kitti-style `example`."""
+        from .point_cloud_ops import voxelize_batch
+
+        v = self.vox
+        pillars = self.cfg.model.reader.type == "PillarFeatureNet"
+        mean_c = 0 if pillars else int(self.cfg.model.reader.num_input_features)
+        vb = voxelize_batch(batch["points"], batch["frame_offsets"], v["voxel_size"], v["pc_range"],
+                            v["max_points"], v["max_voxels"], want_voxels=want_voxels or pillars,
+                            mean_channels=mean_c)
+        out = vb.sync()
+        bsz = batch["frame_offsets"].numel() - 1
+        ex = dict(coordinates=out["coordinates"], num_points=out["num_points"], num_voxels=out["num_voxels"],
+                  shape=np.stack([self.grid] * bsz), anchors=batch["anchors"], metadata=batch["metadata"])
+        if "voxels" in out:
+            ex["voxels"] = out["voxels"]
+        if mean_c:
+            ex["voxel_mean"] = out["mean"]
+        if targets:
+            ex["labels"], ex["reg_targets"], ex["reg_weights"] = [], [], []
+            for ti, task in enumerate(self.tasks):
+                lab, tgt, w = assign_targets_task_device(
+                    batch["anchors_flat"][ti], task["k"], task["r"], task["matched"], task["unmatched"],
+                    batch["gt_boxes"][ti], batch["gt_classes"][ti], batch["gt_count"][ti],
+                    encode_angle_vector=self.vec, limit_gt_angle=True)
+                ex["labels"].append(lab)
+                ex["reg_targets"].append(tgt)
+                ex["reg_weights"].append(w)
+        return ex

@@ -146,13 +146,15 @@ int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const float *bias,
  *            conv's input; with that layer's pre-BN activations bn_x [n_out, cout] (dtype), saved mean /
  *            invstd and gamma / beta (NULL = 1 / 0), sum dz*xhat | sum dz (dz = dy masked by the ReLU) are
  *            ADDED to bn_partial [D3D_BN_COPIES][2*cout] f32 = what d3d_bn_bwd_reduce computes.
- * The caller zeroes the accumulators.  Channel counts must be multiples of 16 (MFMA path). */
+ * The caller zeroes the accumulators.  Channel counts must be multiples of 16 (MFMA path).
+ * Which of the D3D_BN_COPIES replicas a block adds to is the kernel's business (consumers fold all of them). */
 typedef struct D3dConvEpilogue {
   float *stats;
   const void *bn_x;
   const float *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;
   int bn_relu;
   float *bn_partial;
+  int copies; /* replicas of the accumulator ([copies][2*cout]; 0 = D3D_BN_COPIES): block b adds to replica b % copies */
 } D3dConvEpilogue;
 int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const float *bias,
                            const int32_t *nbr, int cap, int n_out, int kvol, int cin, int cout,
@@ -194,17 +196,19 @@ int d3d_bn_relu_bwd(const void *x, const void *dy, int n, int c, int dtype, cons
 /* The halves of the two calls above as separate entry points (d3d_bn_relu_fwd = d3d_bn_stats + d3d_bn_apply,
  * d3d_bn_relu_bwd = d3d_bn_bwd_reduce + d3d_bn_bwd_dx; same buffers).  The reductions can then come from a
  * convolution epilogue (d3d_sparse_conv_fwd_ex) instead of their own sweep; d3d_bn_stats / d3d_bn_bwd_reduce
- * zero their accumulator first, the apply / dx halves only read it. */
+ * zero their accumulator first, the apply / dx halves only read it: [copies][2c] replicas (D3D_BN_COPIES from
+ * d3d_bn_stats / d3d_bn_bwd_reduce; a conv epilogue may have used more to thin out same-address atomics). */
 int d3d_bn_stats(const void *x, int n, int c, int dtype, float *stats_ws, d3d_stream_t stream);
 int d3d_bn_apply(const void *x, int n, int c, int dtype, const float *gamma, const float *beta,
                  float *running_mean, float *running_var, float momentum, float eps, int training, int relu,
-                 const float *stats_ws, void *y, float *save_mean, float *save_invstd, d3d_stream_t stream);
+                 const float *stats_ws, int copies, void *y, float *save_mean, float *save_invstd,
+                 d3d_stream_t stream);
 int d3d_bn_bwd_reduce(const void *x, const void *dy, int n, int c, int dtype, const float *gamma,
                       const float *beta, const float *save_mean, const float *save_invstd, int relu,
                       float *partial_ws, d3d_stream_t stream);
 int d3d_bn_bwd_dx(const void *x, const void *dy, int n, int c, int dtype, const float *gamma, const float *beta,
-                  const float *save_mean, const float *save_invstd, int relu, const float *partial_ws, void *dx,
-                  float *dgamma, float *dbeta, d3d_stream_t stream);
+                  const float *save_mean, const float *save_invstd, int relu, const float *partial_ws, int copies,
+                  void *dx, float *dgamma, float *dbeta, d3d_stream_t stream);
 /* Per-channel affine sweeps for the reference's cross-rank BatchNorm (det3d/ops/syncbn/syncbn.py:15-118,
  * src/syncbn_cuda_kernel.cu:166-198 transform_input, :595-640 input_backward): the all-reduced statistics
  * arrive as [c] f32 vectors, so the passes take ready coefficients:

@@ -321,6 +321,14 @@ def _golden_case(name):
     return S, g, cfg, ex
 
 
+def _bias_before_bn(name):
+    """SparseBasicBlock's convs carry a bias and feed a train-mode BatchNorm (scn.py:60-66): the batch mean removes
+    the bias, its true gradient is exactly zero and every implementation holds its own rounding noise there"""
+    import re
+
+    return re.search(r"middle_conv\.\d+\.conv[12]\.bias$", name) is not None
+
+
 def _to_gpu(ex):
     out = {}
     for k, v in ex.items():
@@ -375,11 +383,13 @@ def test_detector_matches_reference_detector_golden_fp32(name):
     params = dict(m.named_parameters())
     grads = dict(zip(params, torch.autograd.grad(sum(losses), list(params.values()), allow_unused=True)))
     worst_t, worst_n = 0.0, 0.0
+    gmax = max(g["grad_norms"].values())
     for k, gn in g["grad_norms"].items():
         got = grads[k]
         n = float(got.float().norm()) if got is not None else 0.0
-        if gn < 1e-4:  # conv bias in front of a train-mode BN: exactly-zero true gradient, rounding noise only
-            assert n < 1e-3, k
+        if gn < 1e-4 or _bias_before_bn(k):
+            # conv bias in front of a train-mode BN: exactly-zero true gradient, both sides hold rounding noise
+            assert n < 1e-2 * gmax, (k, n, gmax)
             continue
         worst_n = max(worst_n, abs(n - gn) / gn)
         if k in g["grads"]:
@@ -429,7 +439,7 @@ def test_resnet_fhd_backbone_vs_oracle_on_a_larger_cloud(name):
     assert gi < 2e-2, gi
     worst = 0.0
     for (k, p), (_, q) in zip(prod.named_parameters(), ref.named_parameters()):
-        if float(q.grad.abs().max()) < 1e-5:
+        if float(q.grad.abs().max()) < 1e-5 or _bias_before_bn(k):
             continue
         worst = max(worst, float((p.grad.cpu() - q.grad).abs().max()) / float(q.grad.abs().max()))
     print("%s ResNetFHD %d voxels: input-grad rel err %.2e, worst param-grad rel err %.2e" % (name, len(feats), gi, worst))

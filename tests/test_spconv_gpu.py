@@ -458,10 +458,11 @@ def test_conv_epilogue_bn_fusions_match_the_separate_sweeps(dtype, cin0):
     rel = lambda a, b: float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
     assert rel(ya, yb) < tol
     assert rel(ga, gb) < 5 * tol
-    for a, b in zip(pa, pb):
-        if float(b.abs().max()) < 1e-6:
+    names = [n for n, _ in net.named_parameters()]
+    for name, a, b in zip(names, pa, pb):
+        if name == "9.bias":  # conv bias in front of a train-mode BN: zero true gradient, rounding noise only
             continue
-        assert rel(a, b) < 5 * tol
+        assert rel(a, b) < 5 * tol, name
     for a, b in zip(ba, bb):
         if a.is_floating_point():
             assert torch.allclose(a, b, rtol=1e-3, atol=1e-5)
@@ -491,7 +492,7 @@ def test_split_bn_entry_points_and_channel_affine_sweeps(dtype):
                                  ws1.data_ptr(), st), "fwd")
     _lib.check(L.d3d_bn_stats(x.data_ptr(), n, c, dt, ws2.data_ptr(), st), "stats")
     _lib.check(L.d3d_bn_apply(x.data_ptr(), n, c, dt, gamma.data_ptr(), beta.data_ptr(), rm2.data_ptr(), rv2.data_ptr(),
-                              0.01, 1e-3, 1, 1, ws2.data_ptr(), y2.data_ptr(), save2[0].data_ptr(),
+                              0.01, 1e-3, 1, 1, ws2.data_ptr(), _lib.D3D_BN_COPIES, y2.data_ptr(), save2[0].data_ptr(),
                               save2[1].data_ptr(), st), "apply")
     assert torch.allclose(y1.float(), y2.float(), atol=1e-2 if dtype == torch.bfloat16 else 1e-5)
     assert torch.allclose(save1, save2, rtol=1e-4, atol=1e-6) and torch.allclose(rv, rv2, rtol=1e-5)
