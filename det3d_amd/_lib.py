@@ -59,6 +59,11 @@ SIGNATURES = {
                             f32, f32, f32, f32, vp, vp, vp, vp, vp, sz, vp]),
     "d3d_rotate_nms_workspace_bytes": (sz, [i32]),
     "d3d_rotate_nms": (i32, [vp, i32, f32, i32, vp, vp, vp, sz, vp]),
+    "d3d_decode_filter_topk_workspace_bytes": (sz, [i32, i32]),
+    "d3d_decode_filter_topk": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp,
+                                     vp, vp, sz, vp]),
+    "d3d_rotate_nms_batched_workspace_bytes": (sz, [i32, i32]),
+    "d3d_rotate_nms_batched": (i32, [vp, i32, vp, i32, i32, f32, i32, vp, vp, vp, sz, vp]),
     "d3d_rotate_iou": (i32, [vp, i32, vp, i32, vp, vp]),
     "d3d_nms": (i32, [vp, i32, f32, i32, vp, vp, vp, sz, vp]),
     "d3d_iou3d_pairwise": (i32, [vp, i32, vp, i32, i32, vp, vp]),

@@ -28,6 +28,19 @@ def conv1x1(in_planes, out_planes, stride=1, indice_key=None, bias=True):
                              bias=bias, indice_key=indice_key)
 
 
+def _bn_act(bn, feats, relu_module=None):
+    """norm [+ ReLU] on sparse features outside the fused BatchNorm1d path: the cross-rank SyncBN runs on its split
+    sweeps with the ReLU folded in, anything else is the plain module call"""
+    if type(bn).__name__ == "DistributedSyncBN" and feats.shape[0] > 0:
+        from .syncbn import sync_bn_relu
+
+        y = sync_bn_relu(bn, feats, relu_module is not None)
+        if y is not None:
+            return y
+    y = bn(feats)
+    return relu_module(y) if relu_module is not None else y
+
+
 class SparseBasicBlock(spconv.SparseModule):
     expansion = 1
 
@@ -56,7 +69,7 @@ class SparseBasicBlock(spconv.SparseModule):
             out, link = spconv.conv_bn_relu(self.conv1, self.bn1, True, x, want_link=True)
         else:
             out, link = self.conv1(x), None
-            out.features = self.relu(self.bn1(out.features))
+            out.features = _bn_act(self.bn1, out.features, self.relu)
         if spconv.FUSE_BN_RELU and n != 0 and spconv._fusable_bn(self.bn2, out.features, channels=self.conv2.out_channels):
             out, _ = spconv.conv_bn_relu(self.conv2, self.bn2, False, out, link_in=link)
         else:

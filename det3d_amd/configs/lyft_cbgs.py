@@ -47,3 +47,6 @@ test_cfg = dict(
     score_threshold=0.1, post_center_limit_range=[-110, -110, -6, 110, 110, 2], max_per_img=500)
 voxel_generator = dict(range=PC_RANGE, voxel_size=VOXEL, max_points_in_voxel=10, max_voxel_num=80000)
 data = dict(samples_per_gpu=6, workers_per_gpu=6)
+optimizer = dict(TYPE="adam", VALUE=dict(amsgrad=0.0, wd=0.01), FIXED_WD=True, MOVING_AVERAGE=False)
+optimizer_config = dict(grad_clip=dict(max_norm=35, norm_type=2))
+lr_config = dict(type="one_cycle", lr_max=0.01, moms=[0.95, 0.85], div_factor=10.0, pct_start=0.4)

@@ -37,3 +37,6 @@ assigner = dict(box_coder=box_coder, target_assigner=target_assigner,
 train_cfg = dict(assigner=assigner)
 voxel_generator = dict(range=PC_RANGE, voxel_size=VOXEL, max_points_in_voxel=20, max_voxel_num=30000)
 data = dict(samples_per_gpu=4, workers_per_gpu=8)
+optimizer = dict(TYPE="adam", VALUE=dict(amsgrad=0.0, wd=0.01), FIXED_WD=True, MOVING_AVERAGE=False)
+optimizer_config = dict(grad_clip=dict(max_norm=35, norm_type=2))
+lr_config = dict(type="one_cycle", lr_max=0.002, moms=[0.95, 0.85], div_factor=10.0, pct_start=0.4)

@@ -26,6 +26,7 @@ SOURCES = [
     "d3d_dense.hip",
     "d3d_assign.hip",
     "d3d_nms.hip",
+    "d3d_decode.hip",
     "d3d_iou3d.hip",
     "d3d_loss.hip",
 ]

@@ -54,6 +54,35 @@ static inline int d3d_next_pow2(int64_t x) {
 
 // ---------------------------------------------------------------- device side
 #define D3D_WAVE 64
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() makes hipcc drain EVERY outstanding global
+// load first (s_waitcnt vmcnt(0) before s_barrier), which serialises software-pipelined gathers; here the
+// in-flight global loads stay in flight and hipcc's own counted vmcnt(N) waits at their first use still apply.
+__device__ __forceinline__ void d3d_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Raw buffer descriptor over `p` for gathers whose INVALID lanes must read zeros without a branch and without a
+// select on the loaded data (either would make hipcc wait for the load right where it is issued): invalid lanes
+// pass D3D_OOB_OFFSET, the hardware's range check (offset >= num_records) returns 0 for them.  num_records is
+// fixed at 2 GB - 16: callers guarantee their tensors are smaller (checked on the host side).
+typedef __attribute__((ext_vector_type(4))) unsigned int d3d_u32x4;
+#define D3D_OOB_OFFSET 0xFFFFFFF0u
+#define D3D_RSRC_BYTES 0x7FFFFFF0
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t d3d_make_rsrc(const void *p) {
+  return __builtin_amdgcn_make_buffer_rsrc((void *)p, /*stride*/ 0, D3D_RSRC_BYTES, 0x00020000);
+}
+__device__ __forceinline__ uint4 d3d_buffer_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_offset) {
+  d3d_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_offset, 0, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ uint2 d3d_buffer_load8(__amdgpu_buffer_rsrc_t r, uint32_t byte_offset) {
+  __attribute__((ext_vector_type(2))) unsigned int v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_offset, 0, 0);
+  return make_uint2(v[0], v[1]);
+}
+__device__ __forceinline__ int d3d_buffer_load4(__amdgpu_buffer_rsrc_t r, uint32_t byte_offset) {
+  return (int)__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_offset, 0, 0);
+}
 #define D3D_EMPTY_KEY 0xFFFFFFFFu
 
 __device__ __forceinline__ uint32_t d3d_hash_u32(uint32_t k, uint32_t mask) {

@@ -269,6 +269,157 @@ extern "C" int d3d_nms(const float *boxes, int n, float thresh, int max_keep, in
                     (hipStream_t)stream, false);
 }
 
+// ---- batched rotated NMS: S independent box lists (frames x task groups) in one grid.
+//   boxes  dev [S, K, nd] f32, list s holds counts[s] <= K boxes SORTED by descending score; the BEV box is
+//          columns (0, 1, 3, 4, nd-1) = (x, y, w, l, r) as mg_head.py:1008 picks them
+//   keep   dev [S, max_keep] i32 (indices into the list), n_keep dev [S]
+__global__ void __launch_bounds__(256)
+    nms_prep_batched_kernel(const float *__restrict__ boxes, int nd, const int32_t *__restrict__ counts, int K,
+                            float *__restrict__ rec) {
+  const int s = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= counts[s]) return;
+  const float *bx = boxes + ((int64_t)s * K + i) * nd;
+  const float b5[5] = {bx[0], bx[1], bx[3], bx[4], bx[nd - 1]};
+  Quad q = box_quad(b5);
+  float x0 = q.x[0], x1 = q.x[0], y0 = q.y[0], y1 = q.y[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    x0 = fminf(x0, q.x[k]);
+    x1 = fmaxf(x1, q.x[k]);
+    y0 = fminf(y0, q.y[k]);
+    y1 = fmaxf(y1, q.y[k]);
+  }
+  float *r = rec + ((int64_t)s * K + i) * NMS_REC;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    r[2 * k] = q.x[k];
+    r[2 * k + 1] = q.y[k];
+  }
+  r[8] = x0;
+  r[9] = y0;
+  r[10] = x1;
+  r[11] = y1;
+}
+
+__global__ void __launch_bounds__(64)
+    nms_mask_batched_kernel(const float *__restrict__ rec_all, const int32_t *__restrict__ counts, int K,
+                            float thresh, int nblk_max, unsigned long long *__restrict__ mask_all) {
+  const int s = blockIdx.z;
+  const int n = counts[s];
+  const int nblk = (n + 63) / 64;
+  const int rb = blockIdx.y, cb = blockIdx.x;
+  if (rb >= nblk || cb >= nblk) return;
+  const float *rec = rec_all + (int64_t)s * K * NMS_REC;
+  unsigned long long *mask = mask_all + (int64_t)s * K * nblk_max;
+  const int tx = threadIdx.x;
+  if (cb < rb) {
+    int i = rb * 64 + tx;
+    if (i < n) mask[(int64_t)i * nblk_max + cb] = 0ull;
+    return;
+  }
+  __shared__ float col[64 * NMS_REC];
+  const int cj = cb * 64 + tx;
+  if (cj < n) {
+#pragma unroll
+    for (int k = 0; k < NMS_REC; ++k) col[tx * NMS_REC + k] = rec[(int64_t)cj * NMS_REC + k];
+  }
+  __syncthreads();
+  const int i = rb * 64 + tx;
+  if (i >= n) return;
+  const int ncol = min(64, n - cb * 64);
+  unsigned long long bits = 0ull;
+  float mine[NMS_REC];
+#pragma unroll
+  for (int k = 0; k < NMS_REC; ++k) mine[k] = rec[(int64_t)i * NMS_REC + k];
+  Quad A;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    A.x[k] = mine[2 * k];
+    A.y[k] = mine[2 * k + 1];
+  }
+  for (int j = (rb == cb) ? tx + 1 : 0; j < ncol; ++j) {
+    const float *o = col + j * NMS_REC;
+    if (standup_iou(mine + 8, o + 8) <= 0.f) continue;
+    Quad B;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      B.x[k] = o[2 * k];
+      B.y[k] = o[2 * k + 1];
+    }
+    float inter = quad_intersection(A, B);
+    if (!(inter > 0.f)) continue;
+    float uni = quad_area(A) + quad_area(B) - inter;
+    if (!(uni > 0.f)) continue;
+    if (inter / uni >= thresh) bits |= 1ull << j;
+  }
+  mask[(int64_t)i * nblk_max + cb] = bits;
+}
+
+__global__ void __launch_bounds__(64)
+    nms_reduce_batched_kernel(const unsigned long long *__restrict__ mask_all, const int32_t *__restrict__ counts,
+                              int K, int nblk_max, int max_keep, int32_t *__restrict__ keep_all,
+                              int32_t *__restrict__ n_keep) {
+  __shared__ unsigned long long remv[NMS_MAX_BLK];
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int n = counts[s];
+  const int nblk = (n + 63) / 64;
+  const unsigned long long *mask = mask_all + (int64_t)s * K * nblk_max;
+  int32_t *keep = keep_all + (int64_t)s * max_keep;
+  for (int w = lane; w < nblk; w += 64) remv[w] = 0ull;
+  __syncthreads();
+  int nk = 0;
+  for (int i = 0; i < n && nk < max_keep; ++i) {
+    const int blk = i >> 6;
+    const bool gone = (remv[blk] >> (i & 63)) & 1ull;
+    if (!gone) {
+      if (lane == 0) keep[nk] = i;
+      ++nk;
+      for (int w = blk + lane; w < nblk; w += 64) remv[w] |= mask[(int64_t)i * nblk_max + w];
+    }
+    __syncthreads();
+  }
+  for (int i = nk + lane; i < max_keep; i += 64) keep[i] = -1;
+  if (lane == 0) n_keep[s] = nk;
+}
+
+extern "C" size_t d3d_rotate_nms_batched_workspace_bytes(int lists, int k) {
+  size_t nblk = (size_t)(k + 63) / 64;
+  return d3d_align_up((size_t)lists * k * NMS_REC * 4) + d3d_align_up((size_t)lists * k * nblk * 8) + 256;
+}
+
+extern "C" int d3d_rotate_nms_batched(const float *boxes, int box_ndim, const int32_t *counts, int lists, int k,
+                                      float thresh, int max_keep, int32_t *keep, int32_t *n_keep,
+                                      void *workspace, size_t workspace_bytes, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  D3D_REQUIRE(lists >= 0 && k >= 0 && max_keep >= 0 && box_ndim >= 5, "d3d_rotate_nms_batched: sizes");
+  if (lists == 0) return D3D_OK;
+  D3D_REQUIRE(keep && n_keep && counts, "d3d_rotate_nms_batched: null pointer");
+  if (k == 0 || max_keep == 0) {
+    D3D_HIP_TRY(d3d_fill_async(stream, n_keep, 0, (size_t)lists * 4));
+    return D3D_OK;
+  }
+  const int nblk = (k + 63) / 64;
+  if (nblk > NMS_MAX_BLK)
+    return d3d_set_error(D3D_ECAPACITY, "d3d_rotate_nms_batched: k=%d exceeds %d boxes", k, NMS_MAX_BLK * 64);
+  if (workspace_bytes < d3d_rotate_nms_batched_workspace_bytes(lists, k))
+    return d3d_set_error(D3D_ECAPACITY, "d3d_rotate_nms_batched: workspace too small");
+  D3D_REQUIRE(boxes && workspace, "d3d_rotate_nms_batched: null pointer");
+  D3dArena A(workspace, workspace_bytes);
+  float *rec = A.take<float>((size_t)lists * k * NMS_REC);
+  unsigned long long *mask = A.take<unsigned long long>((size_t)lists * k * nblk);
+  hipLaunchKernelGGL(nms_prep_batched_kernel, dim3((k + 255) / 256, lists), dim3(256), 0, stream, boxes, box_ndim,
+                     counts, k, rec);
+  D3D_LAUNCH_TRY("nms_prep_batched_kernel");
+  hipLaunchKernelGGL(nms_mask_batched_kernel, dim3(nblk, nblk, lists), dim3(64), 0, stream, rec, counts, k, thresh,
+                     nblk, mask);
+  D3D_LAUNCH_TRY("nms_mask_batched_kernel");
+  hipLaunchKernelGGL(nms_reduce_batched_kernel, dim3(lists), dim3(64), 0, stream, mask, counts, k, nblk, max_keep,
+                     keep, n_keep);
+  D3D_LAUNCH_TRY("nms_reduce_batched_kernel");
+  return D3D_OK;
+}
+
 __global__ void __launch_bounds__(256)
     rotate_iou_kernel(const float *__restrict__ a, int m, const float *__restrict__ b, int n,
                       float *__restrict__ iou) {

@@ -37,16 +37,27 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round to nearest 
 }
 
 // ===================================================================== forward
-// One wave = MT tiles of 16 output sites x all COUT columns; a block is WAVES waves that
-// share W[k]: the block stages W[k] (COUT x CIN) in LDS once per kernel offset (double
-// buffered, +16 B row padding so ds_read_b128 of 16 rows is conflict-free) -- with per-wave
-// global loads the weight fragments were 4x the gather traffic through L1/TA
-// (profiles/round1_kernel_stats_v0.txt).  The gathered rows go straight from global memory
-// into MFMA B-operand registers, the next offset's indices are prefetched.
-// launch bound: a 16-wave block puts 4 waves on every SIMD, so two resident blocks per CU need
-// <= 64 VGPRs (8 waves/SIMD); at 66 VGPRs only one block fits and the kernel is 45 % slower
-template <int CIN, int COUT, int MT, int WAVES, bool BF16>
-__global__ void __launch_bounds__(WAVES * 64, ((WAVES >= 16 && CIN * COUT <= 4096 && BF16) ? 8 : 4))
+// One wave = MT tiles of 16 output sites x all COUT columns; a block is WAVES waves that share W[k]: the
+// block stages W[k] (COUT x CIN) in LDS once per kernel offset (double buffered, +16 B row padding so
+// ds_read_b128 of 16 rows is conflict-free).  The gathered rows go straight from global memory into MFMA
+// B-operand registers.
+//
+// Round 2: the offset loop is a DEPTH-stage software pipeline that really stays in flight.  Round 1 had the
+// structure (prefetch one offset ahead) but not the effect: (1) __syncthreads() makes hipcc drain every
+// outstanding global load before each barrier, (2) rotating the prefetch registers with copies (fcur = fnxt)
+// waits for the load that was just issued, (3) any conditional load gives the compiler a path with fewer
+// loads and its s_waitcnt falls back to vmcnt(0).  So the kernel was purely latency bound (41 us for 154 MB,
+// measured HBM traffic a third of that).  Now:
+//   * the loop is unrolled by DEPTH with statically indexed register slots (no copies);
+//   * every load is unconditional: invalid neighbours (index -1, rows past n_out) get an out-of-range buffer
+//     offset and the hardware returns zeros; indices / weights past the last offset re-read the last one;
+//   * the barrier orders LDS only (d3d_lds_barrier);
+//   * W[k] travels through the same vmcnt stream as the gathers (loads retire in order), so it is prefetched
+//     exactly as deep as they are: slot d holds gather(k+DEPTH), idx(k+2*DEPTH), W(k+1+DEPTH).
+// A 16-wave block with ~100 VGPRs runs once per CU with DEPTH x WAVES x MT x 16 rows in flight (64->64,
+// DEPTH 5: 160 KB per CU, against 64 KB for the 8-waves-per-SIMD / depth-1 version).
+template <int CIN, int COUT, int MT, int WAVES, int DEPTH, bool BF16>
+__global__ void __launch_bounds__(WAVES * 64, 4)
     spconv_fwd_mfma_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
                            const float *__restrict__ bias, const int32_t *__restrict__ nbr,
                            int cap, int n_out, int kvol, void *__restrict__ out_, D3dConvEpilogue ep) {
@@ -83,132 +94,112 @@ __global__ void __launch_bounds__(WAVES * 64, ((WAVES >= 16 && CIN * COUT <= 409
   }
   // gathered-row fragment of one (tile, k-step): 16 B (8 bf16 | 4 f32) or 8 B (4 bf16, Cin = 16)
   using FragT = typename std::conditional<(BF16 && KW == 16), uint2, uint4>::type;
-  // addresses are (uniform 64-bit base in SGPRs) + (32-bit byte offset in one VGPR): the host side checks that
-  // the feature matrix and the neighbour table stay below 4 GB.  With 64-bit per-lane addresses the three
-  // address pairs pushed the kernel past its 64-VGPR budget and the spill reload sat in front of the gather.
-  const unsigned char *fbase = (const unsigned char *)feat_;
+  const __amdgpu_buffer_rsrc_t feat_rs = d3d_make_rsrc(feat_);
   const uint32_t lane_off = (uint32_t)(lg * EPL * ESZ);
-  auto gather = [&](const int(&ix)[MT], FragT(&f)[MT][KS]) {
+  const int kmax = kvol - 1;
+  // neighbour index of this lane's sites at offset k (clamped: past the last offset / the last row it re-reads
+  // a valid entry; the value is then ignored through `live` or never used)
+  auto load_idx = [&](int k, int (&ix)[MT]) {
+    k = k < kmax ? k : kmax;
+    const int32_t *nk = nbr + (int64_t)k * cap;  // uniform base, 32-bit lane offset
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m) ix[m] = nk[(uint32_t)(live[m] ? site[m] : n_out - 1)];
+  };
+  auto gather = [&](const int (&ix)[MT], FragT (&f)[MT][KS]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const bool ok = live[m] && ix[m] >= 0;
+      const uint32_t base = ok ? (uint32_t)ix[m] * (uint32_t)(CIN * ESZ) + lane_off : D3D_OOB_OFFSET;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        FragT z = {};
-        const uint32_t off = (uint32_t)ix[m] * (uint32_t)(CIN * ESZ) + lane_off + (uint32_t)(ks * KW * ESZ);
-        f[m][ks] = ix[m] >= 0 ? *(const FragT *)(fbase + off) : z;
+        const uint32_t off = ok ? base + (uint32_t)(ks * KW * ESZ) : D3D_OOB_OFFSET;
+        if constexpr (sizeof(FragT) == 16) f[m][ks] = d3d_buffer_load16(feat_rs, off);
+        else f[m][ks] = d3d_buffer_load8(feat_rs, off);
       }
+    }
   };
-  auto nbr_at = [&](int k, int s) -> int {  // nbr[k * cap + s]
-    const int32_t *nk = nbr + (int64_t)k * cap;  // uniform
-    return nk[(uint32_t)s];
-  };
-
-  // software pipeline over kernel offsets: indices two offsets ahead, gathered rows one offset
-  // ahead (their L2 latency overlaps the previous offset's MFMAs, LDS traffic and barrier),
-  // weights one offset ahead through registers into the other LDS buffer
-  int idx0[MT], idx1[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    idx0[m] = live[m] ? nbr_at(0, site[m]) : -1;
-    idx1[m] = (kvol > 1 && live[m]) ? nbr_at(1, site[m]) : -1;
-  }
-  FragT fcur[MT][KS];
-  gather(idx0, fcur);
-
-  // stage W[0]
   const unsigned char *wg = (const unsigned char *)wpack_;
-  uint4 wreg[WPT];
-#pragma unroll
-  for (int j = 0; j < WPT; ++j) {
-    int e = threadIdx.x + j * NTHREADS;
-    if (e < WVEC) wreg[j] = *(const uint4 *)(wg + (uint32_t)(e * 16));
-  }
-#pragma unroll
-  for (int j = 0; j < WPT; ++j) {
-    int e = threadIdx.x + j * NTHREADS;
-    if (e < WVEC) *(uint4 *)(wlds + (e / SEGS) * ROWB + (e % SEGS) * 16) = wreg[j];
-  }
-  // W[1] starts its trip now: a weight tile is loaded TWO offsets before it is used, because
-  // the per-offset MFMA work of a wave (~50 ns) cannot cover an L2 round trip (~1 us) -- with a
-  // one-offset distance every iteration waited for its own weight load before the barrier
-  if (kvol > 1) {
+  auto load_w = [&](int k, d3d_u32x4 (&w)[WPT]) {  // first-class vectors: arrays of HIP's uint4 struct stay in scratch
+    k = k < kmax ? k : kmax;
+    const unsigned char *wk = wg + (size_t)k * (WVEC * 16);  // uniform
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
-      int e = threadIdx.x + j * NTHREADS;
-      if (e < WVEC) wreg[j] = *(const uint4 *)(wg + (size_t)WVEC * 16 + (uint32_t)(e * 16));
+      const int e = threadIdx.x + j * NTHREADS;
+      w[j] = *(const d3d_u32x4 *)(wk + (uint32_t)((e < WVEC ? e : WVEC - 1) * 16));
     }
-  }
-  __syncthreads();
+  };
+  auto publish_w = [&](int buf, const d3d_u32x4 (&w)[WPT]) {
+    unsigned char *dst = wlds + buf * WBYTES;
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+      const int e = threadIdx.x + j * NTHREADS;
+      if (WVEC % NTHREADS == 0 || e < WVEC) *(d3d_u32x4 *)(dst + (e / SEGS) * ROWB + (e % SEGS) * 16) = w[j];
+    }
+  };
 
-  for (int k = 0; k < kvol; ++k) {
-    const unsigned char *wcur = wlds + (k & 1) * WBYTES;
-    uint4 wfar[WPT];
-    if (k + 2 < kvol) {
+  // ---- prologue: W(0) -> LDS[0]; slots: fr[d] = gather(d), ix[d] = idx(d + DEPTH), wr[d] = W(d + 1)
+  FragT fr[DEPTH][MT][KS];
+  int ix[DEPTH][MT];
+  d3d_u32x4 wr[DEPTH][WPT];
+  {
+    d3d_u32x4 w0[WPT];
+    load_w(0, w0);
 #pragma unroll
-      for (int j = 0; j < WPT; ++j) {
-        int e = threadIdx.x + j * NTHREADS;
-        if (e < WVEC) wfar[j] = *(const uint4 *)(wg + (size_t)(k + 2) * (WVEC * 16) + (uint32_t)(e * 16));
-      }
+    for (int d = 0; d < DEPTH; ++d) load_idx(d, ix[d]);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_w(d + 1, wr[d]);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      gather(ix[d], fr[d]);
+      load_idx(d + DEPTH, ix[d]);
     }
-    int idx2[MT];
+    publish_w(0, w0);
+  }
+  d3d_lds_barrier();
+
+  for (int kb = 0; kb < kvol; kb += DEPTH) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-      idx2[m] = (k + 2 < kvol && live[m]) ? nbr_at(k + 2, site[m]) : -1;
-    FragT fnxt[MT][KS];
-    gather(idx1, fnxt);  // offset k+1 (all -1 past the end: no loads issued)
-    bool any = false;
+    for (int d = 0; d < DEPTH; ++d) {
+      const int k = kb + d;
+      const unsigned char *wcur = wlds + (k & 1) * WBYTES;
+      if (k < kvol) {  // uniform; the tail stages of the last group only keep the pipeline's load counts fixed
 #pragma unroll
-    for (int m = 0; m < MT; ++m) any |= idx0[m] >= 0;
-    if (__ballot(any) != 0ull) {
+        for (int ks = 0; ks < KS; ++ks) {
+          const int ch = ks * KW + lg * EPL;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int ch = ks * KW + lg * EPL;
+          for (int n = 0; n < NT; ++n) {
+            const FragT wa = *(const FragT *)(wcur + (n * 16 + lr) * ROWB + ch * ESZ);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const FragT wa = *(const FragT *)(wcur + (n * 16 + lr) * ROWB + ch * ESZ);
-#pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            if constexpr (BF16 && KW == 32) {
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                  __builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, fcur[m][ks]),
-                  acc[m][n], 0, 0, 0);
-            } else if constexpr (BF16) {
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
-                  __builtin_bit_cast(s16x4_t, wa), __builtin_bit_cast(s16x4_t, fcur[m][ks]),
-                  acc[m][n], 0, 0, 0);
-            } else {
-              // 16x16x4 f32 MFMA: lane group lg supplies k = lg; four of them walk the lane's 4
-              // consecutive channels (any consistent k labelling of A and B is a valid sum)
-              const float4 w4 = __builtin_bit_cast(float4, wa);
-              const float4 f4 = __builtin_bit_cast(float4, fcur[m][ks]);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, f4.x, acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, f4.y, acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, f4.z, acc[m][n], 0, 0, 0);
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, f4.w, acc[m][n], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) {
+              if constexpr (BF16 && KW == 32) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, fr[d][m][ks]),
+                    acc[m][n], 0, 0, 0);
+              } else if constexpr (BF16) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
+                    __builtin_bit_cast(s16x4_t, wa), __builtin_bit_cast(s16x4_t, fr[d][m][ks]),
+                    acc[m][n], 0, 0, 0);
+              } else {
+                // 16x16x4 f32 MFMA: lane group lg supplies k = lg; four of them walk the lane's 4
+                // consecutive channels (any consistent k labelling of A and B is a valid sum)
+                const float4 w4 = __builtin_bit_cast(float4, wa);
+                const float4 f4 = __builtin_bit_cast(float4, fr[d][m][ks]);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, f4.x, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, f4.y, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, f4.z, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, f4.w, acc[m][n], 0, 0, 0);
+              }
             }
           }
         }
       }
-    }
-    // publish W[k+1] into the other LDS buffer (its last readers finished at the previous
-    // barrier), then one barrier per offset
-    if (k + 1 < kvol) {
-      unsigned char *wnext = wlds + ((k + 1) & 1) * WBYTES;
-#pragma unroll
-      for (int j = 0; j < WPT; ++j) {
-        int e = threadIdx.x + j * NTHREADS;
-        if (e < WVEC) *(uint4 *)(wnext + (e / SEGS) * ROWB + (e % SEGS) * 16) = wreg[j];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < WPT; ++j) wreg[j] = wfar[j];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      idx0[m] = idx1[m];
-      idx1[m] = idx2[m];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) fcur[m][ks] = fnxt[m][ks];
+      // W(k+1) -> the other LDS buffer (its last readers finished before the previous barrier), then refill the
+      // three slots this stage freed; all loads unconditional, in consumption order
+      publish_w((k + 1) & 1, wr[d]);
+      load_w(k + 1 + DEPTH, wr[d]);
+      gather(ix[d], fr[d]);            // offset k + DEPTH (its indices arrived DEPTH stages ago)
+      load_idx(k + 2 * DEPTH, ix[d]);
+      d3d_lds_barrier();
     }
   }
 
@@ -347,23 +338,23 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-template <int CIN, int COUT, int MT, int WAVES, bool BF16>
+template <int CIN, int COUT, int MT, int WAVES, int DEPTH, bool BF16>
 static int launch_fwd(const void *feat, const void *wpack, const float *bias, const int32_t *nbr,
                       int cap, int n_out, int kvol, void *out, const D3dConvEpilogue &ep, hipStream_t stream) {
   const int rows_per_block = WAVES * MT * 16;
   const int nb = (n_out + rows_per_block - 1) / rows_per_block;
-  hipLaunchKernelGGL((spconv_fwd_mfma_kernel<CIN, COUT, MT, WAVES, BF16>), dim3(nb),
+  hipLaunchKernelGGL((spconv_fwd_mfma_kernel<CIN, COUT, MT, WAVES, DEPTH, BF16>), dim3(nb),
                      dim3(WAVES * 64), 0, stream, feat, wpack, bias, nbr, cap, n_out, kvol, out, ep);
   D3D_LAUNCH_TRY("spconv_fwd_mfma_kernel");
   return D3D_OK;
 }
 
-#define FWD_CASE(CI, CO, MT, WV)                                                                \
-  if (cin == CI && cout == CO) {                                                                \
-    return dtype == D3D_BF16 ? launch_fwd<CI, CO, MT, WV, true>(feat, wpack, bias, nbr, cap,    \
-                                                                n_out, kvol, out, ep, stream)   \
-                             : launch_fwd<CI, CO, MT, WV, false>(feat, wpack, bias, nbr, cap,   \
-                                                                 n_out, kvol, out, ep, stream); \
+#define FWD_CASE(CI, CO, MT, WV, DB, DF)                                                            \
+  if (cin == CI && cout == CO) {                                                                    \
+    return dtype == D3D_BF16 ? launch_fwd<CI, CO, MT, WV, DB, true>(feat, wpack, bias, nbr, cap,    \
+                                                                    n_out, kvol, out, ep, stream)   \
+                             : launch_fwd<CI, CO, MT, WV, DF, false>(feat, wpack, bias, nbr, cap,   \
+                                                                     n_out, kvol, out, ep, stream); \
   }
 
 extern "C" int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const float *bias,
@@ -392,31 +383,29 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
               cout);
   if (n_out == 0) return D3D_OK;
   D3D_REQUIRE(feat && wpack && nbr && out, "d3d_sparse_conv_fwd: null pointer");
-  D3D_REQUIRE((int64_t)cap * (int64_t)(cin > cout ? cin : cout) * 4 < ((int64_t)1 << 32),
-              "d3d_sparse_conv_fwd: cap=%d rows x %d channels exceed the 4 GB the kernels' 32-bit row offsets address",
+  D3D_REQUIRE((int64_t)cap * (int64_t)(cin > cout ? cin : cout) * 4 < (int64_t)D3D_RSRC_BYTES,
+              "d3d_sparse_conv_fwd: cap=%d rows x %d channels exceed the 2 GB the kernels' buffer descriptors address",
               cap, cin > cout ? cin : cout);
-  // tuning knob (tools/tune_fwd.py): alternative (MT, WAVES) tilings of the dominant 64->64 layer
+  // (Cin, Cout) -> tiles per wave, waves per block, pipeline depth for bf16 / f32.  Depth x gathered bytes per
+  // stage is what hides the L2 gather latency; it is bounded by the 128 VGPRs of a 4-waves-per-SIMD block.
+  // D3D_FWD_VARIANT (tools/tune_fwd.py) selects alternative 64->64 tilings.
   static const int fwd_variant = getenv("D3D_FWD_VARIANT") ? atoi(getenv("D3D_FWD_VARIANT")) : 0;
   if (fwd_variant && cin == 64 && cout == 64 && dtype == D3D_BF16) {
-    if (fwd_variant == 1) return launch_fwd<64, 64, 4, 4, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
-    if (fwd_variant == 2) return launch_fwd<64, 64, 4, 8, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
-    if (fwd_variant == 3) return launch_fwd<64, 64, 2, 4, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
-    if (fwd_variant == 4) return launch_fwd<64, 64, 1, 8, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
-    if (fwd_variant == 5) return launch_fwd<64, 64, 2, 16, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
-    if (fwd_variant == 6) return launch_fwd<64, 64, 2, 8, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    if (fwd_variant == 1) return launch_fwd<64, 64, 1, 16, 3, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    if (fwd_variant == 2) return launch_fwd<64, 64, 1, 16, 7, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    if (fwd_variant == 3) return launch_fwd<64, 64, 2, 8, 3, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    if (fwd_variant == 4) return launch_fwd<64, 64, 1, 8, 5, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
   }
-  FWD_CASE(16, 16, 2, 4)
-  FWD_CASE(16, 32, 2, 4)
-  FWD_CASE(32, 16, 2, 4)
-  FWD_CASE(32, 32, 2, 8)
-  FWD_CASE(32, 64, 2, 8)
-  FWD_CASE(64, 32, 2, 8)
-  FWD_CASE(64, 64, 1, 16)  // sweep (tools/tune_fwd.py): MT1x16 53.5 us, MT2x8 56.9, MT4x8 66.8, MT2x4 97.3
-  // 128-channel layers (nuScenes / Lyft ResNetFHD): 16-wave blocks halve the weight-staging registers per
-  // thread; with 8 waves the W[k] prefetch registers were spilled to scratch inside the offset loop
-  FWD_CASE(64, 128, 1, 16)
-  FWD_CASE(128, 64, 1, 16)
-  FWD_CASE(128, 128, 1, 16)
+  FWD_CASE(16, 16, 2, 8, 5, 4)
+  FWD_CASE(16, 32, 2, 8, 5, 4)
+  FWD_CASE(32, 16, 2, 8, 5, 3)
+  FWD_CASE(32, 32, 2, 8, 5, 3)
+  FWD_CASE(32, 64, 2, 8, 4, 2)
+  FWD_CASE(64, 32, 1, 16, 5, 2)
+  FWD_CASE(64, 64, 1, 16, 5, 2)
+  FWD_CASE(64, 128, 1, 16, 3, 1)
+  FWD_CASE(128, 64, 1, 16, 3, 1)
+  FWD_CASE(128, 128, 1, 16, 2, 1)
   int64_t items = (int64_t)n_out * cout;
   int nb = (int)((items + 255) / 256);
   if (nb > 4096) nb = 4096;

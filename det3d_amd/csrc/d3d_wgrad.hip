@@ -68,7 +68,6 @@ __global__ void __launch_bounds__(WG_THREADS)
   // MFMA k-steps per stage and per wave: 32 sites (bf16) / 4 sites (f32) each, split over the CSPLIT waves
   constexpr int KSTEPS = STEP / (BF16 ? 32 : 4);
   static_assert(KSTEPS % CSPLIT == 0, "sites of a stage must split evenly over the waves sharing a tile");
-  static_assert(DEPTH <= KG || KG == 1, "one dout register set: the next tile's rows must not be issued twice");
   __shared__ __attribute__((aligned(16))) unsigned char lds_f[2 * FBUF * ESZ];
   __shared__ __attribute__((aligned(16))) unsigned char lds_d[2 * DBUF * ESZ];
 
@@ -88,32 +87,44 @@ __global__ void __launch_bounds__(WG_THREADS)
     for (int t = 0; t < TPW; ++t) acc[a][t] = wg_f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int ntiles = (s1 - s0 + STEP - 1) / STEP;
-  const int nstages = ntiles * KG;
   const int frow = threadIdx.x / FSEG, fseg = threadIdx.x - frow * FSEG;
-  const unsigned char *feat = (const unsigned char *)feat_;
-  const unsigned char *dout = (const unsigned char *)dout_;
 
-  auto load_index = [&](int st) -> int {
-    const int tile = st / KG, kk = st - tile * KG;
-    const int site = s0 + tile * STEP + frow;
-    const int32_t *nk = nbr + (int64_t)(k0 + kk) * cap;  // uniform base, 32-bit lane offset
-    return site < s1 ? nk[(uint32_t)site] : -1;
+  // Every load below is UNCONDITIONAL (clamped address, result masked afterwards) and the KG stages of a tile are
+  // fully unrolled: the loop body is straight-line code with a fixed number of loads per stage, so hipcc's
+  // s_waitcnt bookkeeping can emit exact counted vmcnt(N) waits and DEPTH stages really stay in flight (a
+  // conditional load anywhere gives the compiler a path with fewer loads and it falls back to vmcnt(0)).  The
+  // barrier is the LDS-only one: __syncthreads() would drain the whole pipeline every stage.
+  // Masking happens on the ADDRESS side (buffer loads return 0 past the descriptor's range), never on the
+  // loaded data, and the neighbour index is masked where it is consumed, DEPTH stages after its load.
+  const int last_tile = ntiles - 1;
+  const __amdgpu_buffer_rsrc_t feat_rs = d3d_make_rsrc(feat_), dout_rs = d3d_make_rsrc(dout_);
+  auto index_site = [&](int tile) -> int {
+    tile = tile < last_tile ? tile : last_tile;  // uniform clamp: tail stages re-load valid rows
+    return s0 + tile * STEP + frow;
   };
-  auto load_feat = [&](int i) -> uint4 {
-    const uint32_t off = (uint32_t)i * (uint32_t)(CIN * ESZ) + (uint32_t)(fseg * 16);
-    return i >= 0 ? *(const uint4 *)(feat + off) : make_uint4(0, 0, 0, 0);
+  auto load_index = [&](int tile, int kk) -> int {  // raw value; garbage-free: the address is clamped
+    const int site = index_site(tile);
+    const int sc = site < s1 ? site : s1 - 1;
+    const int32_t *nk = nbr + (int64_t)(k0 + kk) * cap;  // uniform base, 32-bit lane offset
+    return nk[(uint32_t)sc];
+  };
+  auto load_feat = [&](int i, int tile) -> uint4 {  // i: raw index of a stage of `tile`
+    const bool ok = i >= 0 && index_site(tile) < s1;
+    const uint32_t off = ok ? (uint32_t)i * (uint32_t)(CIN * ESZ) + (uint32_t)(fseg * 16) : D3D_OOB_OFFSET;
+    return d3d_buffer_load16(feat_rs, off);
   };
   uint4 dr[DV];
   auto load_dout = [&](int tile) {
+    tile = tile < last_tile ? tile : last_tile;
     const int base = s0 + tile * STEP;
 #pragma unroll
     for (int j = 0; j < DV; ++j) {
       const int e = threadIdx.x + j * WG_THREADS;
-      if (DN % WG_THREADS != 0 && e >= DN) break;
-      const int r = e / DSEG, seg = e - r * DSEG;
+      const int ec = (DN % WG_THREADS != 0 && e >= DN) ? DN - 1 : e;
+      const int r = ec / DSEG, seg = ec - r * DSEG;
       const int site = base + r;
-      const uint32_t off = (uint32_t)site * (uint32_t)(COUT * ESZ) + (uint32_t)(seg * 16);
-      dr[j] = site < s1 ? *(const uint4 *)(dout + off) : make_uint4(0, 0, 0, 0);
+      const uint32_t off = site < s1 ? (uint32_t)site * (uint32_t)(COUT * ESZ) + (uint32_t)(seg * 16) : D3D_OOB_OFFSET;
+      dr[j] = d3d_buffer_load16(dout_rs, off);
     }
   };
   // LDS element offset of 16-byte segment `seg` of row r
@@ -122,29 +133,34 @@ __global__ void __launch_bounds__(WG_THREADS)
     else return r * rowlen + seg * 4;
   };
 
+  // pipeline registers: slot d holds the rows of the next stage with (stage % DEPTH) == d and the neighbour
+  // indices of the stage DEPTH after that one.  DEPTH divides KG, so inside the unrolled tile body the slot of
+  // offset kk is the compile-time constant kk % DEPTH.
+  static_assert(KG % DEPTH == 0, "prefetch depth must divide the offset group");
   uint4 fr[DEPTH];
   int ix[DEPTH];
-  if (nstages > 0) {
+  if (ntiles > 0) {
     load_dout(0);
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) ix[d] = d < nstages ? load_index(d) : -1;
+    for (int d = 0; d < DEPTH; ++d) ix[d] = load_index(d / KG, d % KG);
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-      fr[d] = load_feat(ix[d]);
-      ix[d] = d + DEPTH < nstages ? load_index(d + DEPTH) : -1;
+      fr[d] = load_feat(ix[d], d / KG);
+      ix[d] = load_index((d + DEPTH) / KG, (d + DEPTH) % KG);
     }
   }
 
-  for (int sb = 0; sb < nstages; sb += DEPTH) {
+  for (int tile = 0; tile < ntiles; ++tile) {
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      const int st = sb + d;
-      if (st >= nstages) break;
-      const int tile = st / KG, kk = st - tile * KG;
+    for (int kk = 0; kk < KG; ++kk) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int d = kk % DEPTH;                 // compile-time after unrolling
+      const int st = tile * KG + kk;
       unsigned char *bf = lds_f + (st & 1) * (FBUF * ESZ);
       unsigned char *bd = lds_d + (tile & 1) * (DBUF * ESZ);
-      // stage `st` -> LDS.  The buffer's previous readers (stage st-2) all passed the barrier of stage st-1
-      // after finishing their MFMAs, so one barrier per stage suffices
+      // stage `st` -> LDS.  The buffer's previous readers (stage st-2) finished their LDS reads before they
+      // arrived at the barrier of stage st-1, so one barrier per stage suffices
       *(uint4 *)(bf + lds_off(frow, fseg, CIT, FROW) * ESZ) = fr[d];
       if (kk == 0) {
 #pragma unroll
@@ -155,46 +171,42 @@ __global__ void __launch_bounds__(WG_THREADS)
           *(uint4 *)(bd + lds_off(r, seg, COT, DROW) * ESZ) = dr[j];
         }
       }
-      __syncthreads();
-      // refill the pipeline: rows of stage st+DEPTH (their indices arrived DEPTH stages ago), indices of
-      // stage st+2*DEPTH, and -- once per tile -- the next tile's dout rows
-      fr[d] = st + DEPTH < nstages ? load_feat(ix[d]) : make_uint4(0, 0, 0, 0);
-      ix[d] = st + 2 * DEPTH < nstages ? load_index(st + 2 * DEPTH) : -1;
-      if (kk == 0 && tile + 1 < ntiles) load_dout(tile + 1);
-#pragma unroll
-      for (int a = 0; a < KG; ++a) {
-        if (a != kk) continue;  // keeps acc[] statically indexed (uniform branch)
+      d3d_lds_barrier();
+      // refill: rows of stage st+DEPTH (their indices arrived DEPTH stages ago), indices of stage st+2*DEPTH,
+      // and -- once per tile -- the next tile's dout rows
+      fr[d] = load_feat(ix[d], tile + (kk + DEPTH) / KG);
+      ix[d] = load_index(tile + (kk + 2 * DEPTH) / KG, (kk + 2 * DEPTH) % KG);
+      if (kk == 0) load_dout(tile + 1);
 #pragma unroll 4
-        for (int q = 0; q < KSTEPS / CSPLIT; ++q) {
-          const int ks = q * CSPLIT + my_part;  // this wave's k-steps of the stage
+      for (int q = 0; q < KSTEPS / CSPLIT; ++q) {
+        const int ks = q * CSPLIT + my_part;  // this wave's k-steps of the stage
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) {
-            const int tl = my_tile + t * WG_WAVES;
-            const int cit = tl / COT, cot = tl - cit * COT;
-            if constexpr (BF16) {
-              // 32 sites = LDS chunks 2*ks and 2*ks+1.  Each lane passes the address of ITS 8 bytes in the
-              // row-major 4x16 block of sites [lg*4, lg*4+4); the hardware returns the transposed column lr.
-              // A and B use the same site order, so any consistent k labelling is a valid sum.
-              const uint16_t *f16 = (const uint16_t *)bf, *d16 = (const uint16_t *)bd;
-              wg_s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                  (__attribute__((address_space(3))) wg_s16x4_t *)(f16 + ((2 * ks) * CIT + cit) * 256 + lg * 64 + lr * 4));
-              wg_s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                  (__attribute__((address_space(3))) wg_s16x4_t *)(f16 + ((2 * ks + 1) * CIT + cit) * 256 + lg * 64 + lr * 4));
-              wg_s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                  (__attribute__((address_space(3))) wg_s16x4_t *)(d16 + ((2 * ks) * COT + cot) * 256 + lg * 64 + lr * 4));
-              wg_s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                  (__attribute__((address_space(3))) wg_s16x4_t *)(d16 + ((2 * ks + 1) * COT + cot) * 256 + lg * 64 + lr * 4));
-              wg_s16x8_t av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-              wg_s16x8_t bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-              acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wg_bf16x8_t, av),
-                                                                  __builtin_bit_cast(wg_bf16x8_t, bv), acc[a][t], 0, 0, 0);
-            } else {
-              // 4 sites: lane group lg supplies k = lg, lane lr the channel
-              const float *f32p = (const float *)bf, *d32p = (const float *)bd;
-              const float av = f32p[(ks * 4 + lg) * FROW + cit * 16 + lr];
-              const float bv = d32p[(ks * 4 + lg) * DROW + cot * 16 + lr];
-              acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[a][t], 0, 0, 0);
-            }
+        for (int t = 0; t < TPW; ++t) {
+          const int tl = my_tile + t * WG_WAVES;
+          const int cit = tl / COT, cot = tl - cit * COT;
+          if constexpr (BF16) {
+            // 32 sites = LDS chunks 2*ks and 2*ks+1.  Each lane passes the address of ITS 8 bytes in the
+            // row-major 4x16 block of sites [lg*4, lg*4+4); the hardware returns the transposed column lr.
+            // A and B use the same site order, so any consistent k labelling is a valid sum.
+            const uint16_t *f16 = (const uint16_t *)bf, *d16 = (const uint16_t *)bd;
+            wg_s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) wg_s16x4_t *)(f16 + ((2 * ks) * CIT + cit) * 256 + lg * 64 + lr * 4));
+            wg_s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) wg_s16x4_t *)(f16 + ((2 * ks + 1) * CIT + cit) * 256 + lg * 64 + lr * 4));
+            wg_s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) wg_s16x4_t *)(d16 + ((2 * ks) * COT + cot) * 256 + lg * 64 + lr * 4));
+            wg_s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) wg_s16x4_t *)(d16 + ((2 * ks + 1) * COT + cot) * 256 + lg * 64 + lr * 4));
+            wg_s16x8_t av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+            wg_s16x8_t bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wg_bf16x8_t, av),
+                                                                 __builtin_bit_cast(wg_bf16x8_t, bv), acc[kk][t], 0, 0, 0);
+          } else {
+            // 4 sites: lane group lg supplies k = lg, lane lr the channel
+            const float *f32p = (const float *)bf, *d32p = (const float *)bd;
+            const float av = f32p[(ks * 4 + lg) * FROW + cit * 16 + lr];
+            const float bv = d32p[(ks * 4 + lg) * DROW + cot * 16 + lr];
+            acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[kk][t], 0, 0, 0);
           }
         }
       }
@@ -313,11 +325,11 @@ static int wg_launch(const void *feat, const void *dout, const int32_t *nbr, int
     if (bf16) {                                                                                        \
       if (p.kg == KGMAIN) return wg_launch<CI, CO, KGMAIN, DMAIN, true>(WG_ARGS);                      \
       if (p.kg == 3) return wg_launch<CI, CO, 3, 3, true>(WG_ARGS);                                    \
-      if (p.kg == 1) return wg_launch<CI, CO, 1, 4, true>(WG_ARGS);                                    \
+      if (p.kg == 1) return wg_launch<CI, CO, 1, 1, true>(WG_ARGS);                                    \
     } else {                                                                                           \
-      if (p.kg == KGMAIN) return wg_launch<CI, CO, KGMAIN, (DMAIN > 4 ? 4 : DMAIN), false>(WG_ARGS);   \
+      if (p.kg == KGMAIN) return wg_launch<CI, CO, KGMAIN, 3, false>(WG_ARGS);                         \
       if (p.kg == 3) return wg_launch<CI, CO, 3, 3, false>(WG_ARGS);                                   \
-      if (p.kg == 1) return wg_launch<CI, CO, 1, 4, false>(WG_ARGS);                                   \
+      if (p.kg == 1) return wg_launch<CI, CO, 1, 1, false>(WG_ARGS);                                   \
     }                                                                                                  \
   }
 
@@ -325,12 +337,12 @@ static int wg_dispatch(const void *feat, const void *dout, const int32_t *nbr, i
                        int cin, int cout, bool bf16, const WgPlan &p, float *part, hipStream_t stream) {
   // prefetch depth: DEPTH stages x 16 KB of gathered rows in flight per CU, bounded by the 128 VGPRs a
   // 16-wave block leaves each lane (accumulators: 4 * KG * TPW)
-  WG_CASE(16, 16, 9, 8)
-  WG_CASE(16, 32, 9, 6)
-  WG_CASE(32, 32, 9, 8)
-  WG_CASE(32, 64, 9, 4)
-  WG_CASE(64, 64, 9, 8)
-  WG_CASE(64, 128, 9, 4)
+  WG_CASE(16, 16, 9, 3)
+  WG_CASE(16, 32, 9, 3)
+  WG_CASE(32, 32, 9, 3)
+  WG_CASE(32, 64, 9, 3)
+  WG_CASE(64, 64, 9, 9)
+  WG_CASE(64, 128, 9, 3)
   WG_CASE(128, 128, 3, 3)
   return d3d_set_error(D3D_EINVAL, "wgrad tile kernel: unsupported channels %d -> %d (kg %d)", cin, cout, p.kg);
 }
@@ -347,7 +359,7 @@ extern "C" int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const i
   // D3D_WGRAD_LEGACY=1: the round-1 kernels (one block per offset, float atomics) for A/B timing
   static const int legacy = getenv("D3D_WGRAD_LEGACY") ? atoi(getenv("D3D_WGRAD_LEGACY")) : 0;
   const bool tile_path = !legacy && wg_supported(cin, cout) && n_out > 0 &&
-                         (int64_t)cap * (cin > cout ? cin : cout) * 4 < ((int64_t)1 << 32);  // 32-bit row offsets
+                         (int64_t)cap * (cin > cout ? cin : cout) * 4 < (int64_t)D3D_RSRC_BYTES;  // 2 GB buffer descriptors
   if (!tile_path) return d3d_wgrad_legacy(feat, dout, nbr, cap, n_out, kvol, cin, cout, dtype, dw, stream);
   D3D_REQUIRE(feat && dout && nbr, "d3d_sparse_conv_wgrad: null pointer");
   const size_t need = d3d_sparse_conv_wgrad_workspace_bytes(n_out, kvol, cin, cout, dtype);

@@ -736,6 +736,16 @@ class SparseSequential(SparseModule):
                         input.features = bn_relu(module, input.features, relu)
                         i += 2 if relu else 1
                         continue
+                    if FUSE_BN_RELU and type(module).__name__ == "DistributedSyncBN":
+                        # cross-rank BN: the same sweeps split around its packed all-reduce, ReLU folded in
+                        from .syncbn import sync_bn_relu
+
+                        relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+                        y = sync_bn_relu(module, input.features, relu)
+                        if y is not None:
+                            input.features = y
+                            i += 2 if relu else 1
+                            continue
                     input.features = module(input.features)
             else:
                 link = None

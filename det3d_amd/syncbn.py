@@ -21,8 +21,11 @@ the summed affine gradients.  All three are kept.
 MI355X-first changes (results unchanged): the reference issues 2 small all-reduces forward and 4 backward per
 layer (~210 tiny RCCL collectives per iteration on the CBGS model); here each direction packs
 its per-channel vectors into ONE buffer -> 1 + 1 collectives per layer, which is what a latency-bound
-xGMI ring wants.  The element-wise parts are plain torch ops on the caller's stream, so the module also runs
-on CPU tensors over gloo (that is how tests/test_syncbn_cpu.py checks it with world_size 2).
+xGMI ring wants.  On the GPU the four element-wise kernels of the reference are the package's BN sweeps split at
+the collective (d3d_bn_stats | all-reduce | d3d_channel_affine, d3d_bn_bwd_reduce | all-reduce |
+d3d_channel_affine_bwd, ReLU fused when SparseSequential / the RPN block sees BN -> ReLU); the torch-op
+formulation below remains for CPU tensors over gloo (tests/test_syncbn_cpu.py, world_size 2) and layouts the
+sweeps do not take.
 """
 import torch
 import torch.distributed as dist
@@ -94,6 +97,126 @@ class _SyncBNFn(torch.autograd.Function):
         return dx.to(x.dtype), grad_gamma.to(gamma.dtype), grad_beta.to(gamma.dtype), None, None, None, None, None
 
 
+def _rows_view(x):
+    """[N, C] rows of a CUDA f32 / bf16 tensor the d3d_bn_* sweeps can walk, or None: sparse features as they
+    are, channels-last [B, C, H, W] maps through their [B*H*W, C] memory view."""
+    if not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16):
+        return None
+    c = x.shape[1]
+    epv = 8 if x.dtype == torch.bfloat16 else 4
+    if c % epv or c > 256 or 256 % (c // epv):
+        return None
+    if x.dim() == 2 and x.is_contiguous():
+        return x
+    if x.dim() == 4 and x.shape[1] > 1 and x.is_contiguous(memory_format=torch.channels_last):
+        return x.permute(0, 2, 3, 1).reshape(-1, c)
+    return None
+
+
+class _SyncBNReLUFusedFn(torch.autograd.Function):
+    """The same function as _SyncBNFn (+ optional ReLU) on the HIP sweeps: the reference's four kernels
+    (syncbn_cuda_kernel.cu collect_statistics :200-289, transform_input :166-198, collect_grad_statistics
+    :291-371, input_backward :595-640) are d3d_bn_stats | d3d_channel_affine and d3d_bn_bwd_reduce |
+    d3d_channel_affine_bwd, with ONE packed all-reduce between the halves of each direction.  The [C]-vector
+    algebra in between is a handful of tiny torch ops."""
+
+    @staticmethod
+    def forward(ctx, rows, gamma, beta, running_mean, running_var, momentum, eps, group, relu):
+        from . import _lib
+
+        L = _lib.lib()
+        n, c = rows.shape
+        dev = rows.device
+        dt = _lib.D3D_BF16 if rows.dtype == torch.bfloat16 else _lib.D3D_F32
+        st = _lib.stream_ptr(dev)
+        ws = torch.empty((_lib.D3D_BN_COPIES, 2 * c), dtype=torch.float32, device=dev)
+        _lib.check(L.d3d_bn_stats(rows.data_ptr(), n, c, dt, ws.data_ptr(), st), "d3d_bn_stats")
+        stats = ws.sum(0) / n  # local E[x] | E[x^2]
+        world = _world(group)
+        if world > 1:
+            dist.all_reduce(stats, group=group)
+            stats /= world
+        ex, exs = stats[:c], stats[c:]
+        cnt = n * world
+        if cnt <= 1:
+            raise ValueError("SyncBN needs more than one value per channel (got %d)" % cnt)
+        cf = cnt / (cnt - 1)
+        var = (exs - ex * ex) * cf
+        with torch.no_grad():
+            running_mean.mul_(1 - momentum).add_(momentum * ex.to(running_mean.dtype))
+            running_var.mul_(1 - momentum).add_(momentum * var.to(running_var.dtype))
+        std = (var + eps).sqrt()
+        g, b = gamma.float(), beta.float()
+        scale = (g / std).contiguous()
+        shift = (b - ex * scale).contiguous()
+        y = torch.empty_like(rows)
+        _lib.check(L.d3d_channel_affine(rows.data_ptr(), n, c, dt, scale.data_ptr(), shift.data_ptr(), int(relu),
+                                        y.data_ptr(), st), "d3d_channel_affine")
+        ctx.save_for_backward(rows, ex.contiguous(), std, gamma, beta, scale, shift)
+        ctx.cf, ctx.group, ctx.relu = cf, group, relu
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        from . import _lib
+
+        L = _lib.lib()
+        rows, ex, std, gamma, beta, scale, shift = ctx.saved_tensors
+        n, c = rows.shape
+        dev = rows.device
+        dt = _lib.D3D_BF16 if rows.dtype == torch.bfloat16 else _lib.D3D_F32
+        st = _lib.stream_ptr(dev)
+        dy = dy.contiguous().to(rows.dtype)
+        g, b = gamma.float().contiguous(), beta.float().contiguous()
+        invstd = (1.0 / std).contiguous()
+        partial = torch.empty((_lib.D3D_BN_COPIES, 2 * c), dtype=torch.float32, device=dev)
+        # sum dz * xhat | sum dz with xhat = (x - ex) / std and dz = dy masked by the ReLU
+        _lib.check(L.d3d_bn_bwd_reduce(rows.data_ptr(), dy.data_ptr(), n, c, dt, g.data_ptr(), b.data_ptr(),
+                                       ex.data_ptr(), invstd.data_ptr(), int(ctx.relu), partial.data_ptr(), st),
+                   "d3d_bn_bwd_reduce")
+        sums = partial.sum(0)
+        dot_p, dy_sum = sums[:c] * std, sums[c:]
+        inv3 = invstd * invstd * invstd
+        pack = torch.cat([-dy_sum * g * invstd + dot_p * g * inv3 * ex * ctx.cf,   # grad_ex
+                          dot_p * g * (-0.5) * inv3 * ctx.cf,                      # grad_exs
+                          dot_p * invstd,                                          # grad_gamma
+                          dy_sum])                                                 # grad_beta
+        world = _world(ctx.group)
+        if world > 1:
+            dist.all_reduce(pack, group=ctx.group)  # ONE collective for the four vectors
+            pack[: 2 * c] /= world
+        grad_ex, grad_exs, grad_gamma, grad_beta = pack[:c], pack[c:2 * c], pack[2 * c:3 * c], pack[3 * c:]
+        norm = 1.0 / n
+        ca = (invstd * g).contiguous()
+        cb = (grad_exs * (2.0 * norm)).contiguous()
+        cc = (grad_ex * norm).contiguous()
+        dx = torch.empty_like(rows)
+        _lib.check(L.d3d_channel_affine_bwd(rows.data_ptr(), dy.data_ptr(), n, c, dt, scale.data_ptr(),
+                                            shift.data_ptr(), int(ctx.relu), ca.data_ptr(), cb.data_ptr(),
+                                            cc.data_ptr(), dx.data_ptr(), st), "d3d_channel_affine_bwd")
+        return dx, grad_gamma.to(gamma.dtype), grad_beta.to(gamma.dtype), None, None, None, None, None, None
+
+
+def sync_bn_relu(bn, x, relu=False):
+    """DistributedSyncBN forward (+ fused ReLU) of module `bn` on `x` through the HIP sweeps when `x` is a CUDA
+    row matrix / channels-last map, otherwise None (the caller falls back to bn(x) and a separate ReLU)."""
+    distributed = dist.is_available() and dist.is_initialized()
+    if not (bn.training and bn.sync and distributed and bn.affine and bn.track_running_stats):
+        return None
+    if any(t.dtype != torch.float32 for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)):
+        return None
+    rows = _rows_view(x)
+    if rows is None or rows.shape[0] < 1:
+        return None
+    y = _SyncBNReLUFusedFn.apply(rows, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                 bn.process_group, bool(relu))
+    if x.dim() == 4:
+        b, c, h, w = x.shape
+        return y.view(b, h, w, c).permute(0, 3, 1, 2)
+    return y
+
+
 class DistributedSyncBN(_BatchNorm):
     """Same constructor as the reference (syncbn.py:121-139; note momentum defaults to 0.01 there).  Accepts
     [N, C] sparse features as well as [B, C, ...] dense maps.  `sync=False`, eval mode, or a
@@ -115,6 +238,9 @@ class DistributedSyncBN(_BatchNorm):
         self._check_input_dim(x)
         distributed = dist.is_available() and dist.is_initialized()
         if self.training and self.sync and distributed and self.affine and self.track_running_stats:
+            y = sync_bn_relu(self, x, relu=False)  # HIP sweeps for device rows / channels-last maps
+            if y is not None:
+                return y
             return _SyncBNFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var,
                                    self.momentum, self.eps, self.process_group)
         factor = 0.0

@@ -58,7 +58,14 @@ class TrainStep:
         self.grad_clip = grad_clip
         self.autocast_dtype = autocast_dtype
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self.bucket = d3d_dist.FlatGradBucket(self.params)
+        # one rank: a single concatenation after backward; several ranks: 3 buckets whose all-reduces start from
+        # autograd hooks and overlap the sparse backbone's backward (D3D_DP_BUCKETS overrides the count)
+        import os
+
+        nb = int(os.environ.get("D3D_DP_BUCKETS", "3"))
+        self.overlap = d3d_dist.world_size() > 1 and nb > 0
+        self.bucket = d3d_dist.OverlappedGradBuckets(self.params, nb) if self.overlap else \
+            d3d_dist.FlatGradBucket(self.params)
         kw = dict(lr=self.sched.low_lr, betas=(moms[0], 0.99), weight_decay=0.0)
         dev = self.params[0].device
         try:
@@ -92,9 +99,12 @@ class TrainStep:
             losses = self.model(example, return_loss=True)
         loss = sum(losses["loss"])
         loss.backward()
-        self.bucket.gather()  # one cat; p.grad become slices of the flat buffer
-        self.bucket.allreduce_mean()
-        gnorm = self.bucket.clip_norm_(self.grad_clip)
+        if self.overlap:
+            gnorm = self.bucket.finish(self.grad_clip)  # exchanges were started by the hooks during backward
+        else:
+            self.bucket.gather()  # one cat; p.grad become slices of the flat buffer
+            self.bucket.allreduce_mean()
+            gnorm = self.bucket.clip_norm_(self.grad_clip)
         with torch.no_grad():
             torch._foreach_mul_(self.params, 1.0 - self.wd * lr)  # true weight decay, bn_wd=True
         self.opt.step()

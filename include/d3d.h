@@ -329,6 +329,30 @@ int d3d_rotate_nms(const float *boxes, int n, float thresh, int max_keep, int32_
                    int32_t *n_keep, void *workspace, size_t workspace_bytes,
                    d3d_stream_t stream);
 
+/* All frames x one task group of MultiGroupHead.predict's front half on the device (mg_head.py:697-803, 805-1008;
+ * second_box_decode box_torch_ops.py:80-148): sigmoid + max over the group's classes, `>= score_threshold`,
+ * top-`pre_max_size` by score (descending; equal scores by ascending anchor index), decode of the survivors,
+ * class / direction argmax -- two launches instead of ~40 per frame.
+ *  box_preds dev [batch, A, code]  cls_preds dev [batch, A, nc]  dir_preds dev [batch, A, 2] or NULL  (dtype)
+ *  anchors dev [A, nd] (anchors_per_batch = 0) or [batch, A, nd] f32; nd = 7 | 9, code = nd (+1 with the angle vector)
+ *  out_boxes dev [batch, K, nd] f32, out_scores [batch, K] f32, out_labels / out_dir_labels [batch, K] i32
+ *  (out_dir_labels may be NULL), out_count dev [batch] i32; K = pre_max_size <= 1024; rows >= count are undefined */
+size_t d3d_decode_filter_topk_workspace_bytes(int batch, int anchors);
+int d3d_decode_filter_topk(const void *box_preds, const void *cls_preds, const void *dir_preds, int dtype,
+                           const float *anchors, int anchors_per_batch, int batch, int num_anchors, int code_size,
+                           int box_ndim, int num_classes, int encode_angle_vector, float score_threshold,
+                           int pre_max_size, float *out_boxes, float *out_scores, int32_t *out_labels,
+                           int32_t *out_dir_labels, int32_t *out_count, void *workspace, size_t workspace_bytes,
+                           d3d_stream_t stream);
+
+/* d3d_rotate_nms over `lists` independent, score-sorted box lists in one grid (frames x task groups):
+ *  boxes dev [lists, k, box_ndim] f32 with the BEV box in columns (0, 1, 3, 4, box_ndim-1) (mg_head.py:1008),
+ *  counts dev [lists] i32 valid rows per list; keep dev [lists, max_keep] i32 (-1 padded), n_keep dev [lists]. */
+size_t d3d_rotate_nms_batched_workspace_bytes(int lists, int k);
+int d3d_rotate_nms_batched(const float *boxes, int box_ndim, const int32_t *counts, int lists, int k, float thresh,
+                           int max_keep, int32_t *keep, int32_t *n_keep, void *workspace, size_t workspace_bytes,
+                           d3d_stream_t stream);
+
 /* pairwise rotated BEV IoU, iou[m,n]; boxes as above.  Covers the north-star
  * "rotated-IoU / iou3d" item (det3d/ops/iou3d/src/iou3d_kernel.cu:214-221,
  * dead code in the reference). */

@@ -1,0 +1,183 @@
+"""Two ranks on ONE GPU (the driver's multi-GPU runs are not ours to launch): the data-parallel step with
+overlapped gradient buckets and the fused cross-rank BatchNorm, both through `torch.distributed` with the gloo
+backend carrying CUDA tensors (D3D_DIST_BACKEND=gloo); RCCL itself refuses two ranks on one device
+("duplicate GPU"), which the nccl variant documents by skipping."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _small_kitti(seed=0):
+    from det3d_amd import Config, build_detector
+
+    cfg = Config.fromfile(os.path.join(ROOT, "det3d_amd", "configs", "kitti_car_second.py"))
+    torch.manual_seed(seed)
+    return cfg, build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg)
+
+
+def _dp_worker(rank, world, port, backend, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), D3D_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        from det3d_amd import dist as D
+        from det3d_amd import synthetic
+        from det3d_amd.trainer import TrainStep
+
+        D.init_dist()
+        dev = torch.device("cuda", 0)
+        cfg, model = _small_kitti()
+        model = model.to(dev).train()
+        D.broadcast_params(model)
+        step = TrainStep(model, total_steps=10, autocast_dtype=None)
+        assert step.overlap and len(step.bucket.buckets) >= 2
+        ds = synthetic.KittiCarSynthetic(n_points=6000, n_seeds=2)
+        ex = synthetic.make_example(ds.device_batch(rank, 1, dev), synthetic.KITTI_CAR)
+        step.bucket.zero()
+        loss = sum(model(ex, return_loss=True)["loss"])
+        loss.backward()
+        total = step.bucket.finish(max_norm=None)
+        torch.cuda.synchronize()
+        q.put((rank, [p.grad.float().cpu().numpy() for p in model.parameters()], float(total), float(loss)))
+        D.barrier()
+        torch.distributed.destroy_process_group()
+    except Exception:
+        import traceback
+
+        q.put((rank, "error", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_ranks_one_gpu_data_parallel_gradients_are_the_mean(backend):
+    """a15: each rank runs forward + backward of KITTI SECOND (fp32) on its own frame; the overlapped buckets must
+    leave every rank with the mean of the two per-frame gradients (computed here in one process)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        item = q.get(timeout=600)
+        if isinstance(item[1], str):
+            for p in procs:
+                p.join(30)
+            if backend == "nccl":
+                pytest.skip("RCCL with two ranks on one device: " + item[2].strip().splitlines()[-1][:200])
+            raise AssertionError(item[2])
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(120)
+    from det3d_amd import synthetic
+
+    dev = torch.device("cuda", 0)
+    cfg, model = _small_kitti()
+    model = model.to(dev).train()
+    ds = synthetic.KittiCarSynthetic(n_points=6000, n_seeds=2)
+    ref = None
+    for r in range(world):
+        model.zero_grad(set_to_none=True)
+        # same BN running statistics as the workers saw: fresh model each time would be cleaner, but train-mode BN
+        # normalises with batch statistics, so the running buffers do not enter the gradients
+        sum(model(synthetic.make_example(ds.device_batch(r, 1, dev), synthetic.KITTI_CAR), return_loss=True)["loss"]).backward()
+        g = [p.grad.float().cpu().numpy() / world for p in model.parameters()]
+        ref = g if ref is None else [a + b for a, b in zip(ref, g)]
+    for r in range(world):
+        grads, total, loss = res[r]
+        assert np.isfinite(total) and np.isfinite(loss)
+        for a, b in zip(grads, ref):
+            scale = np.abs(b).max() + 1e-9
+            assert np.abs(a - b).max() < 2e-3 * scale + 1e-6  # BN statistics are reduced with f32 atomics
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)  # both ranks hold bit-identical means
+
+
+def _syncbn_worker(rank, world, port, dtype_name, relu, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), D3D_DIST_BACKEND="gloo")
+    try:
+        from det3d_amd import dist as D
+        from det3d_amd import spconv
+        from det3d_amd.syncbn import DistributedSyncBN, _SyncBNFn
+
+        D.init_dist()
+        dev = torch.device("cuda", 0)
+        dtype = getattr(torch, dtype_name)
+        g = torch.Generator().manual_seed(100 + rank)
+        n = 3000 if rank == 0 else 4100  # different row counts per rank, like sparse tensors
+        x0 = (torch.randn((n, 64), generator=g) * 2 + 0.5)
+        bn = DistributedSyncBN(64, eps=1e-3, momentum=0.01).to(dev)
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 2.0, 64))
+            bn.bias.copy_(torch.linspace(-1.0, 1.0, 64))
+        seq = spconv.SparseSequential(bn, *( [torch.nn.ReLU()] if relu else [])).train()
+        w = torch.linspace(0.5, 1.5, 64, device=dev)
+        # fused sweeps (through SparseSequential, which folds the ReLU)
+        x = x0.to(dev).to(dtype).requires_grad_(True)
+        st = spconv.SparseConvTensor(x, torch.zeros((n, 4), dtype=torch.int32, device=dev), [1, 1, 1], 1)
+        y = seq(st).features
+        ((y.float() * w) ** 2).sum().backward()
+        fused = (y.detach().float().cpu().numpy(), x.grad.float().cpu().numpy(), bn.weight.grad.cpu().numpy(),
+                 bn.bias.grad.cpu().numpy(), bn.running_var.cpu().numpy().copy())
+        # torch-op formulation of the same function on the same data (pinned to the reference formulas on CPU)
+        bn2 = DistributedSyncBN(64, eps=1e-3, momentum=0.01).to(dev)
+        with torch.no_grad():
+            bn2.weight.copy_(bn.weight)
+            bn2.bias.copy_(bn.bias)
+        x2 = x0.to(dev).to(dtype).requires_grad_(True)
+        y2 = _SyncBNFn.apply(x2, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, bn2.momentum, bn2.eps, None)
+        if relu:
+            y2 = torch.relu(y2)
+        ((y2.float() * w) ** 2).sum().backward()
+        ref = (y2.detach().float().cpu().numpy(), x2.grad.float().cpu().numpy(), bn2.weight.grad.cpu().numpy(),
+               bn2.bias.grad.cpu().numpy(), bn2.running_var.cpu().numpy().copy())
+        torch.cuda.synchronize()
+        q.put((rank, fused, ref))
+        D.barrier()
+        torch.distributed.destroy_process_group()
+    except Exception:
+        import traceback
+
+        q.put((rank, "error", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("dtype_name", ["float32", "bfloat16"])
+@pytest.mark.parametrize("relu", [False, True])
+def test_two_ranks_one_gpu_fused_syncbn_equals_the_torch_formulation(dtype_name, relu):
+    """a16: DistributedSyncBN on the HIP sweeps (d3d_bn_stats | all-reduce | d3d_channel_affine and the backward
+    pair, ReLU folded by SparseSequential) against the torch-op formulation that tests/test_syncbn_cpu.py pins to
+    the reference's formulas; two ranks with different row counts."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, world, port, dtype_name, relu, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for _ in range(world):
+        item = q.get(timeout=600)
+        assert not isinstance(item[1], str), item[2]
+        rank, fused, ref = item
+        tol = 1e-4 if dtype_name == "float32" else 3e-2
+        for a, b in zip(fused, ref):
+            assert np.abs(a - b).max() < tol * (np.abs(b).max() + 1e-6), rank
+    for p in procs:
+        p.join(120)

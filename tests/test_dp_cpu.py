@@ -28,6 +28,59 @@ def _net():
                                torch.nn.Conv2d(8, 4, 1)).eval()
 
 
+def _worker_overlapped(rank, world, port, q, n_buckets):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from det3d_amd import dist as D
+
+    D.init_dist(backend="gloo")
+    net = _net()
+    D.broadcast_params(net)
+    x = torch.randn(2, 3, 6, 6, generator=torch.Generator().manual_seed(100 + rank))
+    bucket = D.OverlappedGradBuckets(net.parameters(), n_buckets)
+    out = []
+    for step in range(2):  # two steps: the hooks must re-arm cleanly
+        bucket.zero()
+        net(x * (1 + step)).pow(2).mean().backward()
+        total = bucket.finish(max_norm=1e9 if step == 0 else 0.05)
+        out.append(([p.grad.numpy().copy() for p in net.parameters()], float(total)))
+    D.barrier()
+    q.put((rank, out, [len(b) for b in bucket.buckets]))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_buckets", [1, 3])
+def test_overlapped_buckets_two_ranks_equal_single_process_mean(n_buckets):
+    """OverlappedGradBuckets (all-reduces started from autograd hooks during backward, a15 / 8e): the gradients
+    every rank ends with are the mean over ranks of the per-rank gradients, the norm is the global norm, the
+    clip scales all buckets by one coefficient, and a second step works on re-armed hooks."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_overlapped, args=(r, world, port, q, n_buckets)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sum(res[0][2]) == len(list(_net().parameters())) and 1 <= len(res[0][2]) <= n_buckets
+    assert n_buckets == 1 or len(res[0][2]) >= 2
+    xs = [torch.randn(2, 3, 6, 6, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    for step in range(2):
+        net = _net()
+        (sum(net(x * (1 + step)).pow(2).mean() for x in xs) / world).backward()
+        ref = [p.grad for p in net.parameters()]
+        norm = float(torch.sqrt(sum((r ** 2).sum() for r in ref)))
+        coef = 1.0 if step == 0 else min(1.0, 0.05 / (norm + 1e-6))
+        for rank, out, _ in res:
+            grads, total = out[step]
+            assert total == pytest.approx(norm, rel=1e-5)
+            for g, r in zip(grads, ref):
+                assert np.allclose(g, (r * coef).numpy(), atol=1e-6)
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),

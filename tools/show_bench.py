@@ -1,0 +1,17 @@
+"""compact view of a bench.py JSON line: tools/show_bench.py <file> [workloads]"""
+import json
+import sys
+
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+r = d.get("roofline", {})
+print("value %.1f %s  %.3f ms/step  roofline %s (%s us, %s GB/s)  sparse %s ms" % (
+    d["value"], d["unit"], d["ms_per_step"], r.get("frac"), r.get("avg_launch_us"), r.get("achieved"),
+    d.get("sparse_conv_ms_per_step")))
+for k, v in (d.get("kernels") or {}).items():
+    print("   %-34s x%-2d %7.2f us  %7.1f GB/s" % (k, v["launches_per_step"], v["avg_us"], v.get("achieved_GBs", 0)))
+for k in ("fp32", "predict", "rpn_mfma", "precision", "stages", "probe_error", "fp32_error"):
+    if k in d:
+        print("  ", k, json.dumps(d[k])[:400])
+if len(sys.argv) > 2 and "workloads" in d:
+    for k, v in d["workloads"].items():
+        print("  ", k, json.dumps(v)[:700])
