@@ -34,6 +34,7 @@ SIGNATURES = {
                                 vp, vp, vp, vp, sz, vp]),
     "d3d_pack_conv_weights": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "d3d_sparse_conv_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "d3d_set_tuning": (i32, [i32, i32]),
     "d3d_sparse_conv_fwd_ex": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "d3d_sparse_conv_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "d3d_sparse_conv_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),

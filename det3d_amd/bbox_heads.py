@@ -27,6 +27,9 @@ from .registry import HEADS
 # MultiGroupHead.loss through d3d_head_loss (one fused forward+gradient kernel per task group instead of
 # ~200 element-wise launches).  D3D_FUSE_LOSS=0 keeps the PyTorch-op formulation (also the CPU path).
 FUSE_LOSS = os.environ.get("D3D_FUSE_LOSS", "1") != "0"
+# MultiGroupHead.predict through d3d_decode_filter_topk + d3d_rotate_nms_batched (5 launches per task group for the
+# whole batch, one host sync per batch).  D3D_FUSE_PREDICT=0 keeps the per-frame PyTorch-op path.
+FUSE_PREDICT = os.environ.get("D3D_FUSE_PREDICT", "1") != "0"
 
 
 class _HeadLossFn(torch.autograd.Function):
@@ -335,7 +338,68 @@ class MultiGroupHead(nn.Module):
         return merged
 
     # ---------------------------------------------------------------- predict
+    def _fused_predict_ok(self, example, preds_dicts, test_cfg):
+        nms_cfg = test_cfg["nms"] if isinstance(test_cfg, dict) else test_cfg.nms
+        nget = (lambda k: nms_cfg[k]) if isinstance(nms_cfg, dict) else (lambda k: getattr(nms_cfg, k))
+        box = preds_dicts[0]["box_preds"]
+        return (FUSE_PREDICT and box.is_cuda and nget("use_rotate_nms") and not nget("use_multi_class_nms")
+                and self.encode_background_as_zeros and self.use_sigmoid_score and not self.bev_only
+                and "anchors_mask" not in example and 1 <= nget("nms_pre_max_size") <= 1024
+                and self.anchor_dim in (7, 9) and self.box_n_dim <= 10 and not self.box_coder.linear_dim)
+
+    def _predict_fused(self, example, preds_dicts, test_cfg):
+        """predict() on the device: per task group decode + score filter + top-k (2 launches) and one batched
+        rotated NMS (3 launches) for all frames, then a handful of [B, post] tensor ops for the direction flip
+        (mg_head.py:1042-1051), the centre-range mask (:1055-1063) and the label offsets (:787-801); the per-frame
+        result counts are read with ONE host sync per batch."""
+        nms_cfg = test_cfg["nms"] if isinstance(test_cfg, dict) else test_cfg.nms
+        tget = (lambda k: test_cfg[k]) if isinstance(test_cfg, dict) else (lambda k: getattr(test_cfg, k))
+        nget = (lambda k: nms_cfg[k]) if isinstance(nms_cfg, dict) else (lambda k: getattr(nms_cfg, k))
+        post, pre = int(nget("nms_post_max_size")), int(nget("nms_pre_max_size"))
+        rng = tget("post_center_limit_range")
+        batch = example["anchors"][0].shape[0]
+        dev = preds_dicts[0]["box_preds"].device
+        rng_t = torch.tensor(rng, dtype=torch.float32, device=dev) if len(rng) > 0 else None
+        ar = torch.arange(post, device=dev)[None]
+        all_boxes, all_scores, all_labels, all_valid = [], [], [], []
+        flag = 0
+        for task_id, preds in enumerate(preds_dicts):
+            nc = self.num_classes[task_id]
+            box = preds["box_preds"].reshape(batch, -1, self.box_n_dim)
+            cls = preds["cls_preds"].reshape(batch, -1, nc)
+            dirp = preds["dir_cls_preds"].reshape(batch, -1, 2) if self.use_direction_classifier else None
+            anchors = example["anchors"][task_id].reshape(batch, -1, self.anchor_dim)
+            cb, cs, cl, cd, cnt = box_ops.decode_filter_topk(box, cls, dirp, anchors, self.box_coder.vec_encode,
+                                                             tget("score_threshold"), pre)
+            keep, nkeep = box_ops.rotate_nms_batched(cb, cnt, nget("nms_iou_threshold"), post)
+            idx = keep.clamp(min=0).long()
+            sb = torch.gather(cb, 1, idx[..., None].expand(-1, -1, self.anchor_dim))
+            ss = torch.gather(cs, 1, idx)
+            sl = torch.gather(cl, 1, idx).long() + flag
+            valid = ar < nkeep[:, None]
+            if self.use_direction_classifier:
+                sd = torch.gather(cd, 1, idx).bool()
+                opp = ((sb[..., -1] - self.direction_offset) > 0) ^ sd
+                sb[..., -1] += torch.where(opp, torch.tensor(np.pi, dtype=sb.dtype, device=dev),
+                                           torch.tensor(0.0, dtype=sb.dtype, device=dev))
+            if rng_t is not None:
+                valid &= (sb[..., :3] >= rng_t[:3]).all(-1) & (sb[..., :3] <= rng_t[3:]).all(-1)
+            all_boxes.append(sb); all_scores.append(ss); all_labels.append(sl); all_valid.append(valid)
+            flag += nc
+        boxes, scores = torch.cat(all_boxes, 1), torch.cat(all_scores, 1)
+        labels, valid = torch.cat(all_labels, 1), torch.cat(all_valid, 1)
+        # valid entries first, original order kept (tasks in order, NMS order within a task)
+        order = torch.sort((~valid).to(torch.int8), dim=1, stable=True)[1]
+        boxes = torch.gather(boxes, 1, order[..., None].expand(-1, -1, self.anchor_dim))
+        scores, labels = torch.gather(scores, 1, order), torch.gather(labels, 1, order)
+        n_valid = valid.sum(1).cpu().tolist()  # the one host sync
+        meta = example["metadata"] if "metadata" in example and len(example["metadata"]) else [None] * batch
+        return [{"box3d_lidar": boxes[b, : n_valid[b]], "scores": scores[b, : n_valid[b]],
+                 "label_preds": labels[b, : n_valid[b]], "metadata": meta[b]} for b in range(batch)]
+
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
+        if self._fused_predict_ok(example, preds_dicts, test_cfg):
+            return self._predict_fused(example, preds_dicts, test_cfg)
         batch_anchors = example["anchors"]
         rets = []
         for task_id, preds_dict in enumerate(preds_dicts):

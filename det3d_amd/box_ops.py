@@ -142,6 +142,65 @@ def nms(bboxes, scores, pre_max_size=None, post_max_size=None, iou_threshold=0.5
     return _nms_entry("d3d_nms", bboxes, scores, pre_max_size, post_max_size, iou_threshold)
 
 
+def decode_filter_topk(box_preds, cls_preds, dir_preds, anchors, encode_angle_vector, score_threshold, pre_max_size):
+    """d3d_decode_filter_topk: the front half of MultiGroupHead.get_task_detections for ALL frames of one task group
+    (mg_head.py:984-1008 + second_box_decode) in two launches.  box_preds [B, A, code], cls_preds [B, A, nc],
+    dir_preds [B, A, 2] or None (float32 / bfloat16), anchors [A, nd] or [B, A, nd] -> (boxes [B, K, nd] f32 decoded,
+    scores [B, K] f32 descending, labels [B, K] i32, dir_labels [B, K] i32 or None, count [B] i32), K = pre_max_size;
+    rows past count[b] are undefined."""
+    if not box_preds.is_cuda:
+        raise _lib.D3dError("decode_filter_topk runs on the GPU only")
+    L = _lib.lib()
+    dt = box_preds.dtype
+    if dt not in (torch.float32, torch.bfloat16):
+        box_preds, dt = box_preds.float(), torch.float32
+    box_preds = box_preds.contiguous()
+    cls_preds = cls_preds.to(dt).contiguous()
+    dir_preds = dir_preds.to(dt).contiguous() if dir_preds is not None else None
+    anchors = anchors.float().contiguous()
+    b, a, code = box_preds.shape
+    nc = cls_preds.shape[-1]
+    nd = anchors.shape[-1]
+    k = int(pre_max_size)
+    dev = box_preds.device
+    boxes = torch.empty((b, k, nd), dtype=torch.float32, device=dev)
+    scores = torch.empty((b, k), dtype=torch.float32, device=dev)
+    labels = torch.empty((b, k), dtype=torch.int32, device=dev)
+    dirs = torch.empty((b, k), dtype=torch.int32, device=dev) if dir_preds is not None else None
+    count = torch.empty((b,), dtype=torch.int32, device=dev)
+    wsb = L.d3d_decode_filter_topk_workspace_bytes(b, a)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    rc = L.d3d_decode_filter_topk(box_preds.data_ptr(), cls_preds.data_ptr(), _lib.ptr(dir_preds),
+                                  _lib.D3D_BF16 if dt == torch.bfloat16 else _lib.D3D_F32, anchors.data_ptr(),
+                                  int(anchors.dim() == 3), b, a, code, nd, nc, int(bool(encode_angle_vector)),
+                                  float(score_threshold), k, boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(),
+                                  _lib.ptr(dirs), count.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
+    _lib.check(rc, "d3d_decode_filter_topk")
+    return boxes, scores, labels, dirs, count
+
+
+def rotate_nms_batched(boxes, counts, iou_threshold, post_max_size):
+    """d3d_rotate_nms_batched: boxes [S, K, nd] f32 (score-sorted lists, BEV box = columns 0, 1, 3, 4, -1), counts [S]
+    i32 -> keep [S, post_max_size] i32 (indices into each list, -1 padded), n_keep [S] i32; three launches for all
+    lists, no host sync."""
+    if not boxes.is_cuda:
+        raise _lib.D3dError("rotate_nms_batched runs on the GPU only")
+    L = _lib.lib()
+    boxes = boxes.float().contiguous()
+    counts = counts.int().contiguous()
+    s, k, nd = boxes.shape
+    dev = boxes.device
+    keep = torch.empty((s, int(post_max_size)), dtype=torch.int32, device=dev)
+    nkeep = torch.empty((s,), dtype=torch.int32, device=dev)
+    wsb = L.d3d_rotate_nms_batched_workspace_bytes(s, k)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    rc = L.d3d_rotate_nms_batched(boxes.data_ptr(), nd, counts.data_ptr(), s, k, float(iou_threshold),
+                                  int(post_max_size), keep.data_ptr(), nkeep.data_ptr(), ws.data_ptr(), wsb,
+                                  _lib.stream_ptr(dev))
+    _lib.check(rc, "d3d_rotate_nms_batched")
+    return keep, nkeep
+
+
 def rotate_iou(boxes_a, boxes_b):
     """pairwise rotated BEV IoU [M,N] of (x,y,w,l,r) boxes (d3d_rotate_iou)."""
     if not boxes_a.is_cuda:

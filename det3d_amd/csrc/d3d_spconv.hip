@@ -57,7 +57,7 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round to nearest 
 // A 16-wave block with ~100 VGPRs runs once per CU with DEPTH x WAVES x MT x 16 rows in flight (64->64,
 // DEPTH 5: 160 KB per CU, against 64 KB for the 8-waves-per-SIMD / depth-1 version).
 template <int CIN, int COUT, int MT, int WAVES, int DEPTH, bool BF16>
-__global__ void __launch_bounds__(WAVES * 64, 4)
+__global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
     spconv_fwd_mfma_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
                            const float *__restrict__ bias, const int32_t *__restrict__ nbr,
                            int cap, int n_out, int kvol, void *__restrict__ out_, D3dConvEpilogue ep) {
@@ -105,10 +105,14 @@ __global__ void __launch_bounds__(WAVES * 64, 4)
 #pragma unroll
     for (int m = 0; m < MT; ++m) ix[m] = nk[(uint32_t)(live[m] ? site[m] : n_out - 1)];
   };
-  auto gather = [&](const int (&ix)[MT], FragT (&f)[MT][KS]) {
+  // returns the wave's ballot of lanes with a real neighbour: a (tile group, offset) stage whose 16*MT sites all
+  // miss the neighbour skips its LDS reads and MFMAs (corner offsets of submanifold layers are mostly empty)
+  auto gather = [&](const int (&ix)[MT], FragT (&f)[MT][KS]) -> unsigned long long {
+    bool any = false;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const bool ok = live[m] && ix[m] >= 0;
+      any |= ok;
       const uint32_t base = ok ? (uint32_t)ix[m] * (uint32_t)(CIN * ESZ) + lane_off : D3D_OOB_OFFSET;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -117,6 +121,7 @@ __global__ void __launch_bounds__(WAVES * 64, 4)
         else f[m][ks] = d3d_buffer_load8(feat_rs, off);
       }
     }
+    return __ballot(any);
   };
   const unsigned char *wg = (const unsigned char *)wpack_;
   auto load_w = [&](int k, d3d_u32x4 (&w)[WPT]) {  // first-class vectors: arrays of HIP's uint4 struct stay in scratch
@@ -141,6 +146,7 @@ __global__ void __launch_bounds__(WAVES * 64, 4)
   FragT fr[DEPTH][MT][KS];
   int ix[DEPTH][MT];
   d3d_u32x4 wr[DEPTH][WPT];
+  unsigned long long okm[DEPTH];  // wave-uniform
   {
     d3d_u32x4 w0[WPT];
     load_w(0, w0);
@@ -150,7 +156,7 @@ __global__ void __launch_bounds__(WAVES * 64, 4)
     for (int d = 0; d < DEPTH; ++d) load_w(d + 1, wr[d]);
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-      gather(ix[d], fr[d]);
+      okm[d] = gather(ix[d], fr[d]);
       load_idx(d + DEPTH, ix[d]);
     }
     publish_w(0, w0);
@@ -162,7 +168,7 @@ __global__ void __launch_bounds__(WAVES * 64, 4)
     for (int d = 0; d < DEPTH; ++d) {
       const int k = kb + d;
       const unsigned char *wcur = wlds + (k & 1) * WBYTES;
-      if (k < kvol) {  // uniform; the tail stages of the last group only keep the pipeline's load counts fixed
+      if (k < kvol && okm[d] != 0ull) {  // uniform; tail stages of the last group only keep the load counts fixed
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int ch = ks * KW + lg * EPL;
@@ -197,7 +203,7 @@ __global__ void __launch_bounds__(WAVES * 64, 4)
       // three slots this stage freed; all loads unconditional, in consumption order
       publish_w((k + 1) & 1, wr[d]);
       load_w(k + 1 + DEPTH, wr[d]);
-      gather(ix[d], fr[d]);            // offset k + DEPTH (its indices arrived DEPTH stages ago)
+      okm[d] = gather(ix[d], fr[d]);   // offset k + DEPTH (its indices arrived DEPTH stages ago)
       load_idx(k + 2 * DEPTH, ix[d]);
       d3d_lds_barrier();
     }
@@ -357,6 +363,22 @@ static int launch_fwd(const void *feat, const void *wpack, const float *bias, co
                                                                      n_out, kvol, out, ep, stream); \
   }
 
+// tuning hook (tools/tune_fwd.py): alternative tilings of the dominant 64->64 bf16 layer, selectable per process
+// (D3D_FWD_VARIANT) or at run time (d3d_set_tuning)
+static int g_fwd_variant = -1;
+static int fwd_variant_env() {
+  static const int v = getenv("D3D_FWD_VARIANT") ? atoi(getenv("D3D_FWD_VARIANT")) : 0;
+  return v;
+}
+int g_d3d_wgrad_blocks = -1;  // d3d_wgrad.hip reads it
+extern "C" int d3d_set_tuning(int knob, int value) {
+  D3D_REQUIRE(knob == 0 || knob == 1, "d3d_set_tuning: unknown knob %d (0 = forward 64->64 tiling variant, "
+              "1 = target block count of the weight-gradient kernel)", knob);
+  if (knob == 0) g_fwd_variant = value;
+  else g_d3d_wgrad_blocks = value;
+  return D3D_OK;
+}
+
 extern "C" int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const float *bias,
                                    const int32_t *nbr, int cap, int n_out, int kvol, int cin,
                                    int cout, int dtype, void *out, d3d_stream_t stream_) {
@@ -383,18 +405,28 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
               cout);
   if (n_out == 0) return D3D_OK;
   D3D_REQUIRE(feat && wpack && nbr && out, "d3d_sparse_conv_fwd: null pointer");
-  D3D_REQUIRE((int64_t)cap * (int64_t)(cin > cout ? cin : cout) * 4 < (int64_t)D3D_RSRC_BYTES,
-              "d3d_sparse_conv_fwd: cap=%d rows x %d channels exceed the 2 GB the kernels' buffer descriptors address",
-              cap, cin > cout ? cin : cout);
+  // (the gathered matrix must stay below the 2 GB a buffer descriptor addresses; its row count is the caller's
+  // knowledge -- det3d_amd/spconv.py checks it -- the produced matrix is checked here)
+  D3D_REQUIRE((int64_t)n_out * cout * (dtype == D3D_BF16 ? 2 : 4) < (int64_t)D3D_RSRC_BYTES,
+              "d3d_sparse_conv_fwd: %d x %d outputs exceed 2 GB", n_out, cout);
   // (Cin, Cout) -> tiles per wave, waves per block, pipeline depth for bf16 / f32.  Depth x gathered bytes per
   // stage is what hides the L2 gather latency; it is bounded by the 128 VGPRs of a 4-waves-per-SIMD block.
   // D3D_FWD_VARIANT (tools/tune_fwd.py) selects alternative 64->64 tilings.
-  static const int fwd_variant = getenv("D3D_FWD_VARIANT") ? atoi(getenv("D3D_FWD_VARIANT")) : 0;
+  const int fwd_variant = g_fwd_variant >= 0 ? g_fwd_variant : fwd_variant_env();
   if (fwd_variant && cin == 64 && cout == 64 && dtype == D3D_BF16) {
-    if (fwd_variant == 1) return launch_fwd<64, 64, 1, 16, 3, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
-    if (fwd_variant == 2) return launch_fwd<64, 64, 1, 16, 7, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
-    if (fwd_variant == 3) return launch_fwd<64, 64, 2, 8, 3, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
-    if (fwd_variant == 4) return launch_fwd<64, 64, 1, 8, 5, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+#define FWD_VAR(V, MT, WV, DP) \
+    if (fwd_variant == V) return launch_fwd<64, 64, MT, WV, DP, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    FWD_VAR(1, 1, 16, 3)
+    FWD_VAR(2, 1, 16, 5)
+    FWD_VAR(3, 2, 8, 3)
+    FWD_VAR(4, 2, 8, 4)
+    FWD_VAR(5, 2, 16, 3)
+    FWD_VAR(6, 2, 4, 4)
+    FWD_VAR(7, 4, 4, 2)
+    FWD_VAR(8, 4, 8, 2)
+    FWD_VAR(9, 4, 4, 3)
+    FWD_VAR(10, 1, 8, 4)
+#undef FWD_VAR
   }
   FWD_CASE(16, 16, 2, 8, 5, 4)
   FWD_CASE(16, 32, 2, 8, 5, 4)
@@ -402,7 +434,7 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
   FWD_CASE(32, 32, 2, 8, 5, 3)
   FWD_CASE(32, 64, 2, 8, 4, 2)
   FWD_CASE(64, 32, 1, 16, 5, 2)
-  FWD_CASE(64, 64, 1, 16, 5, 2)
+  FWD_CASE(64, 64, 2, 8, 3, 1)
   FWD_CASE(64, 128, 1, 16, 3, 1)
   FWD_CASE(128, 64, 1, 16, 3, 1)
   FWD_CASE(128, 128, 1, 16, 2, 1)

@@ -6,3 +6,6 @@
 // small-channel fallbacks): used for dtypes and channel counts the tile kernel does not cover
 int d3d_wgrad_legacy(const void *feat, const void *dout, const int32_t *nbr, int cap, int n_out, int kvol,
                      int cin, int cout, int dtype, float *dw, hipStream_t stream);
+
+// d3d_set_tuning(1, blocks): run-time override of the weight-gradient kernel's target block count (-1 = default)
+extern int g_d3d_wgrad_blocks;

@@ -266,6 +266,7 @@ struct WgPlan {
 
 static int wg_target_blocks() {
   static const int v = getenv("D3D_WGRAD_BLOCKS") ? atoi(getenv("D3D_WGRAD_BLOCKS")) : 256;  // one per CU
+  if (g_d3d_wgrad_blocks > 0) return g_d3d_wgrad_blocks;
   return v < 1 ? 256 : v;
 }
 
@@ -359,7 +360,7 @@ extern "C" int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const i
   // D3D_WGRAD_LEGACY=1: the round-1 kernels (one block per offset, float atomics) for A/B timing
   static const int legacy = getenv("D3D_WGRAD_LEGACY") ? atoi(getenv("D3D_WGRAD_LEGACY")) : 0;
   const bool tile_path = !legacy && wg_supported(cin, cout) && n_out > 0 &&
-                         (int64_t)cap * (cin > cout ? cin : cout) * 4 < (int64_t)D3D_RSRC_BYTES;  // 2 GB buffer descriptors
+                         (int64_t)n_out * cout * (dtype == D3D_BF16 ? 2 : 4) < (int64_t)D3D_RSRC_BYTES;  // 2 GB descriptors
   if (!tile_path) return d3d_wgrad_legacy(feat, dout, nbr, cap, n_out, kvol, cin, cout, dtype, dw, stream);
   D3D_REQUIRE(feat && dout && nbr, "d3d_sparse_conv_wgrad: null pointer");
   const size_t need = d3d_sparse_conv_wgrad_workspace_bytes(n_out, kvol, cin, cout, dtype);

@@ -263,6 +263,8 @@ class _SparseConvFn(torch.autograd.Function):
         if feats.dtype not in _DT:
             raise _lib.D3dError("sparse conv supports float32 / bfloat16 features, got %s" % feats.dtype)
         feats = feats.contiguous()
+        if feats.numel() * feats.element_size() >= (1 << 31) - 16:
+            raise _lib.D3dError("sparse conv: the feature matrix must stay below 2 GB (buffer-descriptor gathers)")
         kvol, cin, cout = rb.kvol, weight.shape[-2], weight.shape[-1]
         assert feats.shape[0] == rb.n_in and feats.shape[1] == cin, (feats.shape, rb.n_in, cin)
         if weight.numel() != kvol * cin * cout:

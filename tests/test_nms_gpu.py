@@ -134,17 +134,20 @@ def test_axis_aligned_nms_vs_reference_nms_gpu_golden(case):
     assert keep.cpu().tolist() == ref.tolist()
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", ["kitti", "nusc", "lyft"])
-def test_head_predict_matches_reference_golden(name):
+def test_head_predict_matches_reference_golden(name, fused):
     """MultiGroupHead.predict on the GPU (decode, score filter, top-k, HIP rotated NMS, direction
     flip, range mask, multi-task merge) vs the detections the REFERENCE's predict() produced on the
     same predictions (tests/golden/head.pt; its NMS step used this repo's oracle, see make_golden.py)."""
     import logging
 
-    from det3d_amd import builder
+    from det3d_amd import bbox_heads, builder
     from det3d_amd.bbox_heads import MultiGroupHead
     from det3d_amd.config import ConfigDict
 
+    # fused = d3d_decode_filter_topk + d3d_rotate_nms_batched for the whole batch; unfused = per-frame torch ops
+    bbox_heads.FUSE_PREDICT = fused
     g = torch.load(os.path.join(GOLDEN, "head.pt"), weights_only=False)[name]
     coder = builder.GroundBox3dCoderTorch(g["coder"]["linear_dim"], g["coder"]["vec"], n_dim=g["coder"]["n_dim"])
     head = MultiGroupHead(
@@ -159,8 +162,13 @@ def test_head_predict_matches_reference_golden(name):
     head.load_state_dict(g["state"])
     head = head.cuda().eval()
     example = dict(anchors=[a.cuda() for a in g["anchors"]], metadata=[dict(token=i) for i in range(2)])
-    with torch.no_grad():
-        dets = head.predict(example, head(g["x"].cuda()), ConfigDict(g["test_cfg"]))
+    try:
+        with torch.no_grad():
+            preds = head(g["x"].cuda())
+            assert head._fused_predict_ok(example, preds, ConfigDict(g["test_cfg"])) == fused
+            dets = head.predict(example, preds, ConfigDict(g["test_cfg"]))
+    finally:
+        bbox_heads.FUSE_PREDICT = True
     assert len(dets) == len(g["dets"])
     for d, r in zip(dets, g["dets"]):
         assert d["box3d_lidar"].shape == r["box3d_lidar"].shape
@@ -168,3 +176,65 @@ def test_head_predict_matches_reference_golden(name):
         assert torch.allclose(d["scores"].cpu(), r["scores"], atol=1e-5)
         assert torch.equal(d["label_preds"].cpu(), r["label_preds"])
         assert d["metadata"] == r["metadata"]
+
+
+@pytest.mark.parametrize("nd,vec,use_dir,nc,dtype", [(7, False, True, 1, torch.float32), (9, True, False, 2, torch.bfloat16),
+                                                     (7, False, True, 2, torch.bfloat16), (9, True, False, 1, torch.float32)])
+def test_decode_filter_topk_vs_torch_formulation(nd, vec, use_dir, nc, dtype):
+    """d3d_decode_filter_topk against sigmoid -> max over classes -> threshold -> sort (score desc, anchor asc)
+    -> top-k -> second_box_decode in torch ops, incl. massive score ties (empty cells of a random-init head all
+    share one logit) and a frame with fewer candidates than K."""
+    from det3d_amd import box_ops
+
+    torch.manual_seed(nd + nc)
+    B, A, K = 3, 20000, 1000
+    code = nd + (1 if vec else 0)
+    dev = torch.device("cuda")
+    box = (torch.randn(B, A, code, device=dev) * 0.3).to(dtype)
+    cls = torch.randn(B, A, nc, device=dev) * 2 - 1.0
+    cls[0, 5000:, :] = 0.25          # 15000 anchors with identical scores above the threshold: ties at the cut
+    cls[2] = cls[2] - 6.0            # few candidates
+    cls = cls.to(dtype)
+    dirp = torch.randn(B, A, 2, device=dev).to(dtype) if use_dir else None
+    anchors = torch.zeros(A, nd, device=dev)
+    anchors[:, :2] = torch.rand(A, 2, device=dev) * 80 - 40
+    anchors[:, 2] = -1.0
+    anchors[:, 3:6] = torch.tensor([1.6, 3.9, 1.56], device=dev) * (1 + 0.2 * torch.rand(A, 3, device=dev))
+    anchors[:, -1] = torch.rand(A, device=dev) * 3.14
+    thr = 0.3
+    boxes, scores, labels, dirs, count = box_ops.decode_filter_topk(box, cls, dirp, anchors, vec, thr, K)
+    sc_all, lab_all = torch.sigmoid(cls.float()).max(-1)
+    for b in range(B):
+        cand = (sc_all[b] >= thr).nonzero()[:, 0]
+        s_sorted, order = torch.sort(sc_all[b][cand], descending=True, stable=True)  # ties keep ascending anchors
+        sel = cand[order][:K]
+        n = int(count[b])
+        assert n == min(len(cand), K)
+        assert torch.equal(scores[b, :n], s_sorted[:n])
+        assert torch.equal(labels[b, :n].long(), lab_all[b][sel])
+        ref = box_ops.second_box_decode(box[b, sel].float(), anchors[sel], vec, False)
+        assert torch.allclose(boxes[b, :n], ref, atol=1e-5, rtol=1e-5)
+        if use_dir:
+            assert torch.equal(dirs[b, :n].long(), dirp[b, sel].float().max(-1)[1])
+    assert int(count[2]) < K and int(count[0]) == K
+
+
+def test_rotate_nms_batched_equals_the_single_list_kernel():
+    from det3d_amd import box_ops
+
+    rng = np.random.default_rng(8)
+    S, K, nd = 5, 600, 9
+    counts = np.array([600, 0, 37, 129, 512], np.int32)
+    boxes = np.zeros((S, K, nd), np.float32)
+    boxes[..., :2] = rng.uniform(-30, 30, (S, K, 2))
+    boxes[..., 3:5] = rng.uniform(1, 6, (S, K, 2))
+    boxes[..., -1] = rng.uniform(-3.1, 3.1, (S, K))
+    bt = torch.from_numpy(boxes).cuda()
+    keep, nkeep = box_ops.rotate_nms_batched(bt, torch.from_numpy(counts).cuda(), 0.2, 83)
+    for s in range(S):
+        n = int(counts[s])
+        b5 = bt[s, :n][:, [0, 1, 3, 4, -1]]
+        sc = torch.arange(n, 0, -1, device="cuda").float()  # already sorted: descending scores
+        ref = box_ops.rotate_nms(b5, sc, 1000, 83, 0.2).cpu().tolist() if n else []
+        got = keep[s, : int(nkeep[s])].cpu().tolist()
+        assert got == ref and (keep[s, int(nkeep[s]):] == -1).all()
