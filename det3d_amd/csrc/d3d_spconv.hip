@@ -36,6 +36,25 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round to nearest 
   return (uint16_t)(u >> 16);
 }
 
+// tuning hook (tools/tune_fwd.py): alternative tilings of the dominant 64->64 bf16 layer, selectable per process
+// (D3D_FWD_VARIANT) or at run time (d3d_set_tuning)
+static int g_fwd_variant = -1;
+static int fwd_variant_env() {
+  static const int v = getenv("D3D_FWD_VARIANT") ? atoi(getenv("D3D_FWD_VARIANT")) : 0;
+  return v;
+}
+int g_d3d_wgrad_blocks = -1;  // d3d_wgrad.hip reads these two
+int g_xcd_remap = getenv("D3D_XCD_REMAP") ? atoi(getenv("D3D_XCD_REMAP")) : 1;
+extern "C" int d3d_set_tuning(int knob, int value) {
+  D3D_REQUIRE(knob >= 0 && knob <= 2, "d3d_set_tuning: unknown knob %d (0 = forward 64->64 tiling variant, "
+              "1 = target block count of the weight-gradient kernel, 2 = XCD-aware tile order on/off)", knob);
+  if (knob == 0) g_fwd_variant = value;
+  else if (knob == 1) g_d3d_wgrad_blocks = value;
+  else g_xcd_remap = value;
+  return D3D_OK;
+}
+
+
 // ===================================================================== forward
 // One wave = MT tiles of 16 output sites x all COUT columns; a block is WAVES waves that share W[k]: the
 // block stages W[k] (COUT x CIN) in LDS once per kernel offset (double buffered, +16 B row padding so
@@ -60,7 +79,8 @@ template <int CIN, int COUT, int MT, int WAVES, int DEPTH, bool BF16>
 __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
     spconv_fwd_mfma_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
                            const float *__restrict__ bias, const int32_t *__restrict__ nbr,
-                           int cap, int n_out, int kvol, void *__restrict__ out_, D3dConvEpilogue ep) {
+                           int cap, int n_out, int kvol, void *__restrict__ out_, D3dConvEpilogue ep,
+                           int xcd_remap) {
   constexpr int NT = COUT / 16;
   constexpr int ESZ = BF16 ? 2 : 4;
   constexpr int KW = BF16 ? ((CIN % 32 == 0) ? 32 : 16) : 16;  // channels per k-step
@@ -77,7 +97,14 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int row0 = (blockIdx.x * WAVES + wave) * (MT * 16);
+  // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, each with its
+  // own L2.  Output rows are sorted by cell index, so neighbouring tiles gather neighbouring rows; handing XCD x
+  // the x-th CONTIGUOUS eighth of the tiles keeps each L2's working set to ~1/8 of the feature matrix (+ halo)
+  // instead of all of it.  (Placement only affects speed: the mapping is a bijection on [0, gridDim.x).)
+  int tile_block = blockIdx.x;
+  if (xcd_remap) tile_block = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // gridDim.x % 8 == 0
+  const int row0 = (tile_block * WAVES + wave) * (MT * 16);
+  if (tile_block * WAVES * MT * 16 >= n_out) return;  // padding blocks of the rounded-up grid (whole block)
 
   f32x4_t acc[MT][NT];
 #pragma unroll
@@ -348,9 +375,11 @@ template <int CIN, int COUT, int MT, int WAVES, int DEPTH, bool BF16>
 static int launch_fwd(const void *feat, const void *wpack, const float *bias, const int32_t *nbr,
                       int cap, int n_out, int kvol, void *out, const D3dConvEpilogue &ep, hipStream_t stream) {
   const int rows_per_block = WAVES * MT * 16;
-  const int nb = (n_out + rows_per_block - 1) / rows_per_block;
+  int nb = (n_out + rows_per_block - 1) / rows_per_block;
+  const int remap = g_xcd_remap && nb >= 16;
+  if (remap) nb = (nb + 7) / 8 * 8;
   hipLaunchKernelGGL((spconv_fwd_mfma_kernel<CIN, COUT, MT, WAVES, DEPTH, BF16>), dim3(nb),
-                     dim3(WAVES * 64), 0, stream, feat, wpack, bias, nbr, cap, n_out, kvol, out, ep);
+                     dim3(WAVES * 64), 0, stream, feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, remap);
   D3D_LAUNCH_TRY("spconv_fwd_mfma_kernel");
   return D3D_OK;
 }
@@ -362,22 +391,6 @@ static int launch_fwd(const void *feat, const void *wpack, const float *bias, co
                              : launch_fwd<CI, CO, MT, WV, DF, false>(feat, wpack, bias, nbr, cap,   \
                                                                      n_out, kvol, out, ep, stream); \
   }
-
-// tuning hook (tools/tune_fwd.py): alternative tilings of the dominant 64->64 bf16 layer, selectable per process
-// (D3D_FWD_VARIANT) or at run time (d3d_set_tuning)
-static int g_fwd_variant = -1;
-static int fwd_variant_env() {
-  static const int v = getenv("D3D_FWD_VARIANT") ? atoi(getenv("D3D_FWD_VARIANT")) : 0;
-  return v;
-}
-int g_d3d_wgrad_blocks = -1;  // d3d_wgrad.hip reads it
-extern "C" int d3d_set_tuning(int knob, int value) {
-  D3D_REQUIRE(knob == 0 || knob == 1, "d3d_set_tuning: unknown knob %d (0 = forward 64->64 tiling variant, "
-              "1 = target block count of the weight-gradient kernel)", knob);
-  if (knob == 0) g_fwd_variant = value;
-  else g_d3d_wgrad_blocks = value;
-  return D3D_OK;
-}
 
 extern "C" int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const float *bias,
                                    const int32_t *nbr, int cap, int n_out, int kvol, int cin,
@@ -419,9 +432,7 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
     FWD_VAR(1, 1, 16, 3)
     FWD_VAR(2, 1, 16, 5)
     FWD_VAR(3, 2, 8, 3)
-    FWD_VAR(4, 2, 8, 4)
     FWD_VAR(5, 2, 16, 3)
-    FWD_VAR(6, 2, 4, 4)
     FWD_VAR(7, 4, 4, 2)
     FWD_VAR(8, 4, 8, 2)
     FWD_VAR(9, 4, 4, 3)

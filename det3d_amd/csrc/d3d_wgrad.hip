@@ -54,7 +54,7 @@ template <int CIN, int COUT, int KG, int DEPTH, bool BF16>
 __global__ void __launch_bounds__(WG_THREADS)
     spconv_wgrad_tile_kernel(const void *__restrict__ feat_, const void *__restrict__ dout_,
                              const int32_t *__restrict__ nbr, int cap, int n_out, int rows_per_split,
-                             int kvol, float *__restrict__ part) {
+                             int kvol, float *__restrict__ part, int xcd_remap) {
   using G = WgGeom<CIN, COUT, BF16>;
   constexpr int CIT = G::CIT, COT = G::COT, TILES = G::TILES, TPW = G::TPW, CSPLIT = G::CSPLIT;
   constexpr int FSEG = G::FSEG, DSEG = G::DSEG, STEP = G::STEP, EPV = G::EPV;
@@ -71,8 +71,18 @@ __global__ void __launch_bounds__(WG_THREADS)
   __shared__ __attribute__((aligned(16))) unsigned char lds_f[2 * FBUF * ESZ];
   __shared__ __attribute__((aligned(16))) unsigned char lds_d[2 * DBUF * ESZ];
 
-  const int k0 = blockIdx.x * KG;
-  const int s0 = blockIdx.y * rows_per_split;
+  // XCD-aware order (see spconv_fwd_mfma_kernel): workgroups are dealt round-robin to the 8 XCDs in linear
+  // (x fastest) order; give XCD x the x-th contiguous eighth of the (site split, offset group) pairs so that
+  // its L2 sees one slab of sites.  A bijection on the grid when the block count is a multiple of 8.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (xcd_remap) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y, total = gridDim.x * gridDim.y;
+    const int logical = (lin & 7) * (total >> 3) + (lin >> 3);
+    bx = logical % gridDim.x;
+    by = logical / gridDim.x;
+  }
+  const int k0 = bx * KG;
+  const int s0 = by * rows_per_split;
   int s1 = s0 + rows_per_split;
   if (s1 > n_out) s1 = n_out;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -214,7 +224,7 @@ __global__ void __launch_bounds__(WG_THREADS)
   }
 
   // partial dW of this (offset group, site split, wave share): plain stores, summed by wgrad_reduce_kernel
-  float *pbase = part + ((int64_t)blockIdx.y * CSPLIT + my_part) * kvol * (CIN * COUT);
+  float *pbase = part + ((int64_t)by * CSPLIT + my_part) * kvol * (CIN * COUT);
 #pragma unroll
   for (int a = 0; a < KG; ++a) {
 #pragma unroll
@@ -296,10 +306,12 @@ static WgPlan wg_plan(int n_out, int kvol, int cin, int cout, int dtype) {
   int max_splits = (tiles + 1) / 2;  // >= 2 tiles per block
   if (max_splits < 1) max_splits = 1;
   if (splits > max_splits) splits = max_splits;
+  if (splits >= 16) splits = splits / 8 * 8;  // XCD-aware order needs (offset groups x splits) % 8 == 0
   int tiles_per_split = (tiles + splits - 1) / splits;
   p.rows_per_split = tiles_per_split * p.step;
   p.splits = (n_out + p.rows_per_split - 1) / p.rows_per_split;
   if (p.splits < 1) p.splits = 1;
+  if (splits >= 16 && p.splits < splits) p.splits = splits;  // keep the multiple of 8: trailing splits are empty
   return p;
 }
 
@@ -312,8 +324,9 @@ extern "C" size_t d3d_sparse_conv_wgrad_workspace_bytes(int n_out, int kvol, int
 template <int CI, int CO, int KG, int DEPTH, bool BF16>
 static int wg_launch(const void *feat, const void *dout, const int32_t *nbr, int cap, int n_out, int kvol,
                      const WgPlan &p, float *part, hipStream_t stream) {
+  const int remap = g_xcd_remap && ((kvol / KG) * p.splits) % 8 == 0 && p.splits >= 8;
   hipLaunchKernelGGL((spconv_wgrad_tile_kernel<CI, CO, KG, DEPTH, BF16>), dim3(kvol / KG, p.splits),
-                     dim3(WG_THREADS), 0, stream, feat, dout, nbr, cap, n_out, p.rows_per_split, kvol, part);
+                     dim3(WG_THREADS), 0, stream, feat, dout, nbr, cap, n_out, p.rows_per_split, kvol, part, remap);
   D3D_LAUNCH_TRY("spconv_wgrad_tile_kernel");
   return D3D_OK;
 }
