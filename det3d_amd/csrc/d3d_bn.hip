@@ -55,15 +55,19 @@ template <bool BF16> struct BnVec {
 #define BN_MAXC 256
 
 // thread -> (row lane, 16-byte segment of the row); segs = c / EPV divides 256
-template <bool BF16>
-__global__ void __launch_bounds__(256)
+// NT = threads per block.  The two REDUCTION sweeps end with 2c global atomics per block, and same-address
+// float atomics retire at ~12 ns each on MI355X: on the RPN's [140800, 128] maps 2048 blocks x 256 atomics cost
+// more than the sweep itself.  Large inputs therefore run 1024-thread blocks, at most one per CU (64 KB of loads
+// in flight per CU, 65 k atomics per launch instead of 524 k).
+template <bool BF16, int NT>
+__global__ void __launch_bounds__(NT)
     bn_stats_kernel(const void *__restrict__ x, int n, int c, float *__restrict__ stats) {
   constexpr int EPV = BnVec<BF16>::EPV;
   __shared__ float red[2 * BN_MAXC];
-  for (int i = threadIdx.x; i < 2 * c; i += 256) red[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * c; i += NT) red[i] = 0.f;
   __syncthreads();
   const int segs = c / EPV;
-  const int seg = threadIdx.x % segs, rl = threadIdx.x / segs, rp = 256 / segs;
+  const int seg = threadIdx.x % segs, rl = threadIdx.x / segs, rp = NT / segs;
   float s[EPV], q[EPV];
 #pragma unroll
   for (int j = 0; j < EPV; ++j) s[j] = q[j] = 0.f;
@@ -97,7 +101,7 @@ __global__ void __launch_bounds__(256)
   }
   __syncthreads();
   float *dst = stats + (size_t)(blockIdx.x % D3D_BN_COPIES) * 2 * c;  // spread same-address atomics
-  for (int i = threadIdx.x; i < 2 * c; i += 256) atomicAdd(&dst[i], red[i]);
+  for (int i = threadIdx.x; i < 2 * c; i += NT) atomicAdd(&dst[i], red[i]);
 }
 
 template <bool BF16>
@@ -175,18 +179,18 @@ __global__ void __launch_bounds__(256)
 }
 
 // dz = dy * [z > 0] ; dbeta = sum dz ; dgamma = sum dz * xhat
-template <bool BF16>
-__global__ void __launch_bounds__(256)
+template <bool BF16, int NT>
+__global__ void __launch_bounds__(NT)
     bn_bwd_reduce_kernel(const void *__restrict__ x, const void *__restrict__ dy, int n, int c,
                          const float *__restrict__ gamma, const float *__restrict__ beta,
                          const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
                          float *__restrict__ partial) {
   constexpr int EPV = BnVec<BF16>::EPV;
   __shared__ float red[2 * BN_MAXC];
-  for (int i = threadIdx.x; i < 2 * c; i += 256) red[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * c; i += NT) red[i] = 0.f;
   __syncthreads();
   const int segs = c / EPV;
-  const int seg = threadIdx.x % segs, rl = threadIdx.x / segs, rp = 256 / segs;
+  const int seg = threadIdx.x % segs, rl = threadIdx.x / segs, rp = NT / segs;
   float mu[EPV], is[EPV], g[EPV], b[EPV], sg[EPV], sb[EPV];
 #pragma unroll
   for (int j = 0; j < EPV; ++j) {
@@ -235,7 +239,7 @@ __global__ void __launch_bounds__(256)
   }
   __syncthreads();
   float *dst = partial + (size_t)(blockIdx.x % D3D_BN_COPIES) * 2 * c;  // [copy][dgamma | dbeta]
-  for (int i = threadIdx.x; i < 2 * c; i += 256) atomicAdd(&dst[i], red[i]);
+  for (int i = threadIdx.x; i < 2 * c; i += NT) atomicAdd(&dst[i], red[i]);
 }
 
 // dx = gamma * invstd * (dz - dbeta/N - xhat * dgamma/N)
@@ -316,6 +320,28 @@ static int bn_check(int n, int c, int dtype, const char *who) {
   return D3D_OK;
 }
 
+// reduction sweeps (stats, bwd_reduce): block size and grid.  Small inputs keep 256-thread blocks (latency: many
+// blocks), large ones switch to 1024 threads x <= 256 blocks (see bn_stats_kernel).
+static bool bn_big(int n, int c) { return (int64_t)n * c >= ((int64_t)1 << 23); }
+static int bn_reduce_grid_big(int n, int c, int dtype) {
+  const int rp = 1024 / (c / (dtype == D3D_BF16 ? 8 : 4));
+  int nb = ((n + rp - 1) / rp + 3) / 4;
+  static const int cap = getenv("D3D_BN_BIG_BLOCKS") ? atoi(getenv("D3D_BN_BIG_BLOCKS")) : 256;
+  if (nb > cap) nb = cap;
+  return nb < 1 ? 1 : nb;
+}
+#define BN_LAUNCH_REDUCE(KERNEL, ...)                                                                       \
+  do {                                                                                                      \
+    if (bn_big(n, c)) {                                                                                     \
+      const int nbb = bn_reduce_grid_big(n, c, dtype);                                                      \
+      if (dtype == D3D_BF16) hipLaunchKernelGGL((KERNEL<true, 1024>), dim3(nbb), dim3(1024), 0, stream, __VA_ARGS__); \
+      else hipLaunchKernelGGL((KERNEL<false, 1024>), dim3(nbb), dim3(1024), 0, stream, __VA_ARGS__);        \
+    } else {                                                                                                \
+      if (dtype == D3D_BF16) hipLaunchKernelGGL((KERNEL<true, 256>), dim3(nb), dim3(256), 0, stream, __VA_ARGS__);   \
+      else hipLaunchKernelGGL((KERNEL<false, 256>), dim3(nb), dim3(256), 0, stream, __VA_ARGS__);           \
+    }                                                                                                       \
+  } while (0)
+
 static int bn_grid(int n, int c, int dtype) {
   const int rp = 256 / (c / (dtype == D3D_BF16 ? 8 : 4));
   int nb = (n + rp - 1) / rp;
@@ -344,10 +370,7 @@ extern "C" int d3d_bn_stats(const void *x, int n, int c, int dtype, float *stats
   D3D_REQUIRE(x && stats_ws, "d3d_bn_stats: null pointer");
   const int nb = bn_grid(n, c, dtype);
   D3D_HIP_TRY(d3d_fill_async(stream, stats_ws, 0, (size_t)D3D_BN_COPIES * 2 * c * sizeof(float)));
-  if (dtype == D3D_BF16)
-    hipLaunchKernelGGL(bn_stats_kernel<true>, dim3(nb), dim3(256), 0, stream, x, n, c, stats_ws);
-  else
-    hipLaunchKernelGGL(bn_stats_kernel<false>, dim3(nb), dim3(256), 0, stream, x, n, c, stats_ws);
+  BN_LAUNCH_REDUCE(bn_stats_kernel, x, n, c, stats_ws);
   D3D_LAUNCH_TRY("bn_stats_kernel");
   return D3D_OK;
 }
@@ -385,12 +408,7 @@ extern "C" int d3d_bn_bwd_reduce(const void *x, const void *dy, int n, int c, in
   D3D_REQUIRE(x && dy && save_mean && save_invstd && partial_ws, "d3d_bn_bwd_reduce: null pointer");
   const int nb = bn_grid(n, c, dtype);
   D3D_HIP_TRY(d3d_fill_async(stream, partial_ws, 0, (size_t)D3D_BN_COPIES * 2 * c * sizeof(float)));
-  if (dtype == D3D_BF16)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma, beta,
-                       save_mean, save_invstd, relu, partial_ws);
-  else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma, beta,
-                       save_mean, save_invstd, relu, partial_ws);
+  BN_LAUNCH_REDUCE(bn_bwd_reduce_kernel, x, dy, n, c, gamma, beta, save_mean, save_invstd, relu, partial_ws);
   D3D_LAUNCH_TRY("bn_bwd_reduce_kernel");
   return D3D_OK;
 }
@@ -510,10 +528,7 @@ extern "C" int d3d_bn_relu_fwd(const void *x, int n, int c, int dtype, const flo
   const int nb = bn_grid(n, c, dtype);
   if (training) {
     D3D_HIP_TRY(d3d_fill_async(stream, stats_ws, 0, (size_t)D3D_BN_COPIES * 2 * c * sizeof(float)));
-    if (dtype == D3D_BF16)
-      hipLaunchKernelGGL(bn_stats_kernel<true>, dim3(nb), dim3(256), 0, stream, x, n, c, stats_ws);
-    else
-      hipLaunchKernelGGL(bn_stats_kernel<false>, dim3(nb), dim3(256), 0, stream, x, n, c, stats_ws);
+    BN_LAUNCH_REDUCE(bn_stats_kernel, x, n, c, stats_ws);
     D3D_LAUNCH_TRY("bn_stats_kernel");
   }
   if (dtype == D3D_BF16)
@@ -540,17 +555,13 @@ extern "C" int d3d_bn_relu_bwd(const void *x, const void *dy, int n, int c, int 
               "d3d_bn_relu_bwd: null pointer");
   const int nb = bn_grid(n, c, dtype);
   D3D_HIP_TRY(d3d_fill_async(stream, partial_ws, 0, (size_t)D3D_BN_COPIES * 2 * c * sizeof(float)));
-  if (dtype == D3D_BF16) {
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nb), dim3(256), 0, stream, x, dy, n, c,
-                       gamma, beta, save_mean, save_invstd, relu, partial_ws);
+  BN_LAUNCH_REDUCE(bn_bwd_reduce_kernel, x, dy, n, c, gamma, beta, save_mean, save_invstd, relu, partial_ws);
+  if (dtype == D3D_BF16)
     hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma,
                        beta, save_mean, save_invstd, relu, partial_ws, copies, dgamma, dbeta, dx);
-  } else {
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nb), dim3(256), 0, stream, x, dy, n, c,
-                       gamma, beta, save_mean, save_invstd, relu, partial_ws);
+  else
     hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(nb), dim3(256), 0, stream, x, dy, n, c,
                        gamma, beta, save_mean, save_invstd, relu, partial_ws, copies, dgamma, dbeta, dx);
-  }
   D3D_LAUNCH_TRY("bn_bwd kernels");
   return D3D_OK;
 }

@@ -44,7 +44,9 @@ static int fwd_variant_env() {
   return v;
 }
 int g_d3d_wgrad_blocks = -1;  // d3d_wgrad.hip reads these two
-int g_xcd_remap = getenv("D3D_XCD_REMAP") ? atoi(getenv("D3D_XCD_REMAP")) : 1;
+// XCD-aware tile order: measured neutral-to-slightly-negative on MI355X for these gathers (profiles/round2_tune_fwd.txt:
+// 50.6 vs 50.6-54 us on the 126k-site 64->64 layer, 578 vs 566 frames/s end to end), so it is off by default
+int g_xcd_remap = getenv("D3D_XCD_REMAP") ? atoi(getenv("D3D_XCD_REMAP")) : 0;
 extern "C" int d3d_set_tuning(int knob, int value) {
   D3D_REQUIRE(knob >= 0 && knob <= 2, "d3d_set_tuning: unknown knob %d (0 = forward 64->64 tiling variant, "
               "1 = target block count of the weight-gradient kernel, 2 = XCD-aware tile order on/off)", knob);

@@ -9,5 +9,5 @@ int d3d_wgrad_legacy(const void *feat, const void *dout, const int32_t *nbr, int
 
 // d3d_set_tuning(1, blocks): run-time override of the weight-gradient kernel's target block count (-1 = default)
 extern int g_d3d_wgrad_blocks;
-// d3d_set_tuning(2, 0|1): XCD-aware block -> tile order of the gather kernels (default on)
+// d3d_set_tuning(2, 0|1): XCD-aware block -> tile order of the gather kernels (default off: measured neutral)
 extern int g_xcd_remap;

@@ -81,7 +81,7 @@ for remap in (1, 0):
                                                     64, 64, 1, o.data_ptr(), None, st))
         say("  first %d sites only: xcd_remap %d variant %2d %-12s: %6.1f us" % (n2, remap, v, names[v], us))
 L.d3d_set_tuning(0, -1)
-L.d3d_set_tuning(2, 1)
+L.d3d_set_tuning(2, 0)
 say("weight gradient (tile kernel + reduce), same rulebook")
 for ci, co in ((64, 64), (32, 32), (16, 16)):
     ff = torch.randn(n, ci, device=dev).bfloat16()
@@ -96,4 +96,4 @@ for ci, co in ((64, 64), (32, 32), (16, 16)):
                                                    1, dw.data_ptr(), ws.data_ptr(), wsb, st), 20)
         say("  %3dx%-3d blocks %4d xcd_remap %d: %6.1f us (both launches)" % (ci, co, blocks, remap, us))
 L.d3d_set_tuning(1, -1)
-L.d3d_set_tuning(2, 1)
+L.d3d_set_tuning(2, 0)
