@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--workload", default="c2-20k", choices=sorted(WORKLOADS) + ["all"],
                     help="headline workload; `all` also runs the other single-GPU configurations briefly")
+    ap.add_argument("--burn-in", type=float, default=1.5,
+                    help="seconds of untimed steps BEFORE the W warm-up steps: a fresh box needs them for MIOpen's "
+                         "find pass, the caching allocator's growth and the GPU clocks to settle (20 timed steps "
+                         "are 0.15 s); 0 disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-log", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip fp32 / precision / rpn / predict / stage probes")
@@ -278,7 +282,7 @@ class Workload:
             self.spec["config"].replace(".py", ""), self.batch, self.points, self.spec["note"])
 
 
-def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, freeze=True):
+def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, freeze=True, burn_in_s=0.0):
     """W untimed warm-up steps, then exactly `steps` steps bracketed by barrier + synchronize; returns
     (max-over-ranks elapsed seconds, launch records of the sampled steps, final loss)."""
     from det3d_amd import dist as D
@@ -297,6 +301,20 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
         drain()  # events of the previous step are complete: make_example just synced
         return wl.step_fn(ex)
 
+    burn = 0
+    if burn_in_s > 0:
+        t_b = time.perf_counter()
+        while True:
+            one(burn)
+            burn += 1
+            torch.cuda.synchronize()
+            flag = torch.tensor([1.0 if time.perf_counter() - t_b < burn_in_s else 0.0], device=dev)
+            if world > 1:  # every rank must leave the loop in the same iteration (the step has a collective)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            if float(flag.item()) == 0.0 or burn >= 2000:
+                break
+        note("%s %s burn-in: %d untimed steps" % (wl.name, wl.dtype, burn))
+    wl.burn_in_steps = burn
     for i in range(warmup):
         one(i)
         torch.cuda.synchronize()
@@ -655,7 +673,7 @@ def main():
     if head == "c3":
         dominant = None  # PointPillars has no sparse convolutions
     elapsed, records, loss = timed_region(wl, args.steps, args.warmup, rank, world, dev, note, dominant,
-                                          freeze=not args.no_gc_freeze)
+                                          freeze=not args.no_gc_freeze, burn_in_s=args.burn_in)
     frames = args.steps * wl.batch * world
     value = frames / elapsed
     out = {
@@ -667,7 +685,8 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": wl.describe(), "name": wl.name, "frames_per_gpu": wl.batch,
                    "points_per_frame": wl.points, "parallelism": "dp%d" % world,
-                   "final_loss": round(float(loss), 4), "timed_region_s": round(elapsed, 3)},
+                   "final_loss": round(float(loss), 4), "timed_region_s": round(elapsed, 3),
+                   "burn_in_steps": getattr(wl, "burn_in_steps", 0)},
     }
     if rank == 0 and records:
         roof = roofline_object(group_launches(records, esz), roof_key, args.dtype)

@@ -323,21 +323,31 @@ def test_fused_bn2d_relu_channels_last_vs_torch(shape, dtype):
     assert torch.allclose(y2.float(), ym.detach().float(), **tol)
 
 
-def test_fused_bn_large_row_count_matches_torch():
-    """140 800 x 128 rows (the KITTI RPN map): exercises the 2048-block grid, the 4x unrolled sweeps
-    and the replicated accumulators."""
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_bn_large_row_count_matches_torch(dtype):
+    """140 800 x 128 rows (the KITTI RPN map): the large-input reduction sweeps (1024-thread blocks, one per CU,
+    65 k instead of 524 k global atomics), the 4x unrolled sweeps and the replicated accumulators."""
     from det3d_amd import spconv
 
     torch.manual_seed(5)
     n, c = 140800, 128
-    x = (torch.randn(n, c, device="cuda") * 1.5 + 0.25)
-    g = torch.randn(n, c, device="cuda")
+    x = (torch.randn(n, c, device="cuda") * 1.5 + 0.25).to(dtype).float()
+    g = torch.randn(n, c, device="cuda").to(dtype).float()
     ref = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).cuda()
     mine = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).cuda()
     xr = x.clone().requires_grad_(True)
     xm = x.clone().requires_grad_(True)
     yr = torch.relu(ref(xr))
     (yr * g).sum().backward()
+    if dtype == torch.bfloat16:
+        xm = x.clone().to(dtype).requires_grad_(True)
+        ym = spconv.bn_relu(mine, xm, True)
+        (ym.float() * g).sum().backward()
+        assert torch.allclose(ym.float(), yr.detach(), atol=3e-2, rtol=2e-2)
+        assert torch.allclose(xm.grad.float(), xr.grad, atol=3e-2, rtol=3e-2)
+        assert torch.allclose(mine.weight.grad, ref.weight.grad, rtol=2e-2, atol=2e-2 * float(ref.weight.grad.abs().max()))
+        assert torch.allclose(mine.running_var, ref.running_var, rtol=1e-3)
+        return
     ym = spconv.bn_relu(mine, xm, True)
     (ym * g).sum().backward()
     assert torch.allclose(ym, yr.detach(), atol=1e-4, rtol=1e-4)

@@ -49,13 +49,26 @@ if wg:
     ww = pick(write, r"spconv_wgrad_tile_kernel<64, 64,")
     out["wgrad_64x64"] = dict(fetch_size_kib_per_launch=wg[1], write_size_kib_per_launch=ww[1] if ww else None, avg_us=wg[2])
 if mfma:
+    # SQ counters come as one row per instance (32 per dispatch on this part): instances = rows / dispatches, with the
+    # dispatch count of the same kernel from the FETCH_SIZE pass; busy fraction = sum over instances / (1024 SIMDs x cycles)
+    disp = {r[3]: r[0] for r in fetch}
+
+    def busy_frac(row):
+        inst = row[0] / disp[row[3]] if row[3] in disp and disp[row[3]] else 32.0
+        return row[1] * inst / (1024.0 * row[2] * 1e-6 * 2.4e9)
+
     conv = [r for r in mfma if re.search(r"igemm|grouped_conv|batched_gemm", r[3])]
-    busy = sum(r[0] * r[1] for r in conv)
-    cyc = sum(r[0] * r[2] * 1e-6 * 2.4e9 * 1024 for r in conv)  # 256 CUs x 4 SIMDs at 2.4 GHz
-    out["rpn_mfma_busy"] = dict(kernels=len(conv), busy_cycles=busy, frac_of_simd_cycles=round(busy / cyc, 4) if cyc else None,
-                                note="SQ_VALU_MFMA_BUSY_CYCLES summed over the MIOpen / CK conv kernels / (duration x 2.4 GHz x 1024 SIMDs)")
+    tot_t = sum(r[0] * r[2] for r in conv)
+    out["rpn_mfma_busy"] = dict(
+        kernels={r[3][:60]: round(busy_frac(r), 3) for r in conv[:8]},
+        time_weighted_frac=round(sum(busy_frac(r) * r[0] * r[2] for r in conv) / tot_t, 4) if tot_t else None,
+        note="SQ_VALU_MFMA_BUSY_CYCLES of the MIOpen / CK conv kernels, summed over the counter's instances, divided by "
+             "duration x 2.4 GHz x 1024 SIMDs: the share of SIMD cycles with the MFMA pipe busy")
     mine = pick(mfma, pat)
     if mine:
-        out["fwd_mfma_busy_frac"] = round(mine[1] / (mine[2] * 1e-6 * 2.4e9 * 1024), 4)
+        out["fwd_mfma_busy_frac"] = round(busy_frac(mine), 4)
+    wgm = pick(mfma, r"spconv_wgrad_tile_kernel<64, 64, 9")
+    if wgm:
+        out.setdefault("wgrad_64x64", {})["mfma_busy_frac"] = round(busy_frac(wgm), 4)
 json.dump(out, open(os.path.join(d, "round2_pmc_spconv.json"), "w"), indent=1)
 print("wrote", os.path.join(d, "round2_pmc_spconv.json"))
