@@ -303,11 +303,15 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
 
     burn = 0
     if burn_in_s > 0:
-        t_b = time.perf_counter()
+        t_b = None
         while True:
             one(burn)
             burn += 1
             torch.cuda.synchronize()
+            if t_b is None:
+                if burn < 3:  # the first steps compile / load kernels and capture the graphs: not burn-in time
+                    continue
+                t_b = time.perf_counter()
             flag = torch.tensor([1.0 if time.perf_counter() - t_b < burn_in_s else 0.0], device=dev)
             if world > 1:  # every rank must leave the loop in the same iteration (the step has a collective)
                 torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
@@ -686,7 +690,8 @@ def main():
         "config": {"workload": wl.describe(), "name": wl.name, "frames_per_gpu": wl.batch,
                    "points_per_frame": wl.points, "parallelism": "dp%d" % world,
                    "final_loss": round(float(loss), 4), "timed_region_s": round(elapsed, 3),
-                   "burn_in_steps": getattr(wl, "burn_in_steps", 0)},
+                   "burn_in_steps": getattr(wl, "burn_in_steps", 0),
+                   "graphed_tail": bool(wl.model.__dict__.get("_graph_tails"))},
     }
     if rank == 0 and records:
         roof = roofline_object(group_launches(records, esz), roof_key, args.dtype)

@@ -258,7 +258,9 @@ class MultiGroupHead(nn.Module):
             return False
         return self.box_n_dim <= 10
 
-    def _loss_fused(self, example, preds_dict, task_id, batch_size):
+    def loss_vector(self, example, preds_dict, task_id, batch_size):
+        """the [D3D_LOSS_SCALARS] result of d3d_head_loss for one task group (element 0 = the loss); tensor in,
+        tensor out, so that graph_tail.py can capture it"""
         num_class = self.num_classes[task_id]
         labels = example["labels"][task_id].contiguous()
         reg_targets = example["reg_targets"][task_id].float().contiguous()
@@ -274,13 +276,31 @@ class MultiGroupHead(nn.Module):
                    alpha=self.loss_cls._alpha, gamma=self.loss_cls._gamma or 0.0, sigma=self.loss_reg._sigma,
                    w_loc=self.loss_reg._loss_weight, w_cls=self.loss_cls._loss_weight,
                    w_dir=self.loss_aux._loss_weight if self.use_direction_classifier else 0.0)
-        s = _HeadLossFn.apply(box_preds, cls_preds, dir_preds, labels, reg_targets, anchors, cfg)
+        return _HeadLossFn.apply(box_preds, cls_preds, dir_preds, labels, reg_targets, anchors, cfg)
+
+    def _loss_dict(self, s):
         d = s.detach()
         return {"loss": s[0], "cls_pos_loss": d[4], "cls_neg_loss": d[5],
                 "dir_loss_reduced": d[3] if self.use_direction_classifier else torch.tensor(0),
                 "cls_loss_reduced": d[2], "loc_loss_reduced": d[1],
                 "loc_loss_elem": list(d[8: 8 + self.box_n_dim].unbind(0)),
                 "num_pos": d[6].long(), "num_neg": d[7].long()}
+
+    def _loss_fused(self, example, preds_dict, task_id, batch_size):
+        return self._loss_dict(self.loss_vector(example, preds_dict, task_id, batch_size))
+
+    def loss_vector_ok(self, feature_map, labels):
+        """every task group of this head goes through the fused loss for inputs like these"""
+        probe = {"box_preds": feature_map}
+        return all(self._fused_loss_ok(probe, lab) for lab in labels)
+
+    def loss_from_vectors(self, vecs):
+        """the dict `loss()` returns, from the per-task vectors of `loss_vector`"""
+        merged = defaultdict(list)
+        for s in vecs:
+            for k, v in self._loss_dict(s).items():
+                merged[k].append(v)
+        return merged
 
     def loss(self, example, preds_dicts, **kwargs):
         batch_anchors = example["anchors"]

@@ -360,25 +360,12 @@ __global__ void __launch_bounds__(64)
     nms_reduce_batched_kernel(const unsigned long long *__restrict__ mask_all, const int32_t *__restrict__ counts,
                               int K, int nblk_max, int max_keep, int32_t *__restrict__ keep_all,
                               int32_t *__restrict__ n_keep) {
-  __shared__ unsigned long long remv[NMS_MAX_BLK];
   const int s = blockIdx.x, lane = threadIdx.x;
   const int n = counts[s];
   const int nblk = (n + 63) / 64;
   const unsigned long long *mask = mask_all + (int64_t)s * K * nblk_max;
   int32_t *keep = keep_all + (int64_t)s * max_keep;
-  for (int w = lane; w < nblk; w += 64) remv[w] = 0ull;
-  __syncthreads();
-  int nk = 0;
-  for (int i = 0; i < n && nk < max_keep; ++i) {
-    const int blk = i >> 6;
-    const bool gone = (remv[blk] >> (i & 63)) & 1ull;
-    if (!gone) {
-      if (lane == 0) keep[nk] = i;
-      ++nk;
-      for (int w = blk + lane; w < nblk; w += 64) remv[w] |= mask[(int64_t)i * nblk_max + w];
-    }
-    __syncthreads();
-  }
+  const int nk = d3d_nms_reduce_list(mask, n, nblk, nblk_max, max_keep, keep);
   for (int i = nk + lane; i < max_keep; i += 64) keep[i] = -1;
   if (lane == 0) n_keep[s] = nk;
 }

@@ -7,7 +7,7 @@ padded [M, T, C] voxels, which then never have to be materialised.
 from torch import nn
 
 from . import backbones, bbox_heads, losses, necks, readers  # noqa: F401  (fill the registries)
-from . import builder
+from . import builder, graph_tail
 from .registry import DETECTORS
 
 
@@ -26,6 +26,14 @@ class SingleStageDetector(nn.Module):
     @property
     def with_neck(self):
         return hasattr(self, "neck") and self.neck is not None
+
+    def _train_tail(self, example, bev):
+        """training: the static-shape tail (neck, head, loss) replays as two hipGraphs (graph_tail.py); eagerly
+        when it cannot be captured"""
+        losses = graph_tail.run_tail(self, example, bev)
+        if losses is not None:
+            return losses
+        return self._finish(example, self.neck(bev) if self.with_neck else bev, True)
 
     def _finish(self, example, x, return_loss):
         preds = self.bbox_head(x)
@@ -47,6 +55,10 @@ class VoxelNet(SingleStageDetector):
         feats = example["voxel_mean"] if "voxel_mean" in example else example["voxels"]
         data = dict(features=feats, num_voxels=example["num_points"], coors=example["coordinates"],
                     batch_size=len(example["num_voxels"]), input_shape=example["shape"][0])
+        if return_loss and self.training and graph_tail.GRAPH_TAIL:
+            bev = self.backbone(self.reader(data["features"], data["num_voxels"]), data["coors"],
+                                data["batch_size"], data["input_shape"])
+            return self._train_tail(example, bev)
         return self._finish(example, self.extract_feat(data), return_loss)
 
 
@@ -63,4 +75,8 @@ class PointPillars(SingleStageDetector):
         data = dict(features=example["voxels"], num_voxels=example["num_points"],
                     coors=example["coordinates"], batch_size=len(example["num_voxels"]),
                     input_shape=example["shape"][0])
+        if return_loss and self.training and graph_tail.GRAPH_TAIL:
+            bev = self.backbone(self.reader(data["features"], data["num_voxels"], data["coors"]), data["coors"],
+                                data["batch_size"], data["input_shape"])
+            return self._train_tail(example, bev)
         return self._finish(example, self.extract_feat(data), return_loss)
