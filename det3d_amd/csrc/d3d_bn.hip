@@ -55,13 +55,55 @@ template <bool BF16> struct BnVec {
 #define BN_MAXC 256
 
 // thread -> (row lane, 16-byte segment of the row); segs = c / EPV divides 256
-// NT = threads per block.  The two REDUCTION sweeps end with 2c global atomics per block, and same-address
-// float atomics retire at ~12 ns each on MI355X: on the RPN's [140800, 128] maps 2048 blocks x 256 atomics cost
-// more than the sweep itself.  Large inputs therefore run 1024-thread blocks, at most one per CU (64 KB of loads
-// in flight per CU, 65 k atomics per launch instead of 524 k).
-template <bool BF16, int NT>
+// NT = threads per block, U = rows in flight per lane.  The two REDUCTION sweeps end with 2c global atomics per
+// block, and same-address float atomics retire at ~12-20 ns each on MI355X: on the RPN's [140800, 128] maps 2048
+// blocks x 256 atomics cost more than the sweep itself, so large inputs run fewer, larger blocks (the variant table
+// below; tools/bench_bn.py measures it).  Lanes of a wave that hold the same channels are folded with shuffles
+// before the LDS atomics.
+struct BnRaw { uint4 r; };
+template <bool BF16> __device__ __forceinline__ void bn_unpack(const uint4 &r, float *v) {
+  if (BF16) {
+    v[0] = bn_bf16_to_f32(r.x & 0xffffu); v[1] = bn_bf16_to_f32(r.x >> 16);
+    v[2] = bn_bf16_to_f32(r.y & 0xffffu); v[3] = bn_bf16_to_f32(r.y >> 16);
+    v[4] = bn_bf16_to_f32(r.z & 0xffffu); v[5] = bn_bf16_to_f32(r.z >> 16);
+    v[6] = bn_bf16_to_f32(r.w & 0xffffu); v[7] = bn_bf16_to_f32(r.w >> 16);
+  } else {
+    v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y);
+    v[2] = __uint_as_float(r.z); v[3] = __uint_as_float(r.w);
+  }
+}
+
+// fold the lanes of a wave that work on the same 16-byte segment (lane % segs), then one LDS atomic per channel
+// from the first `segs` lanes; finally the block's sums go to one of the replicated global accumulators
+template <int EPV, int NT>
+__device__ __forceinline__ void bn_block_reduce(float *a, float *b, int c, int segs, int seg, float *red,
+                                                float *__restrict__ dst_base, int skip_global) {
+  const int lane = threadIdx.x & 63;
+  if (segs < 64) {
+    for (int m = 32; m >= segs; m >>= 1) {
+#pragma unroll
+      for (int j = 0; j < EPV; ++j) {
+        a[j] += __shfl_xor(a[j], m, 64);
+        b[j] += __shfl_xor(b[j], m, 64);
+      }
+    }
+  }
+  if (segs >= 64 || lane < segs) {
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      atomicAdd(&red[seg * EPV + j], a[j]);
+      atomicAdd(&red[c + seg * EPV + j], b[j]);
+    }
+  }
+  __syncthreads();
+  if (skip_global) return;
+  float *dst = dst_base + (size_t)(blockIdx.x % D3D_BN_COPIES) * 2 * c;  // spread same-address atomics
+  for (int i = threadIdx.x; i < 2 * c; i += NT) atomicAdd(&dst[i], red[i]);
+}
+
+template <bool BF16, int NT, int U>
 __global__ void __launch_bounds__(NT)
-    bn_stats_kernel(const void *__restrict__ x, int n, int c, float *__restrict__ stats) {
+    bn_stats_kernel(const void *__restrict__ x, int n, int c, float *__restrict__ stats, int skip_global) {
   constexpr int EPV = BnVec<BF16>::EPV;
   __shared__ float red[2 * BN_MAXC];
   for (int i = threadIdx.x; i < 2 * c; i += NT) red[i] = 0.f;
@@ -73,35 +115,32 @@ __global__ void __launch_bounds__(NT)
   for (int j = 0; j < EPV; ++j) s[j] = q[j] = 0.f;
   const int64_t step = (int64_t)gridDim.x * rp;
   int64_t r = (int64_t)blockIdx.x * rp + rl;
-  for (; r + 3 * step < n; r += 4 * step) {  // four independent 16-byte loads in flight per lane
-    float v[4][EPV];
+  const uint4 *xv = (const uint4 *)x;
+  for (; r + (U - 1) * step < n; r += U * step) {  // U independent 16-byte loads in flight per lane
+    uint4 raw[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) BnVec<BF16>::load(x, (r + u * step) * segs + seg, v[u]);
+    for (int u = 0; u < U; ++u) raw[u] = xv[(r + u * step) * segs + seg];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < U; ++u) {
+      float v[EPV];
+      bn_unpack<BF16>(raw[u], v);
 #pragma unroll
       for (int j = 0; j < EPV; ++j) {
-        s[j] += v[u][j];
-        q[j] = fmaf(v[u][j], v[u][j], q[j]);
+        s[j] += v[j];
+        q[j] = fmaf(v[j], v[j], q[j]);
       }
+    }
   }
   for (; r < n; r += step) {
     float v[EPV];
-    BnVec<BF16>::load(x, r * segs + seg, v);
+    bn_unpack<BF16>(xv[r * segs + seg], v);
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
       s[j] += v[j];
       q[j] = fmaf(v[j], v[j], q[j]);
     }
   }
-#pragma unroll
-  for (int j = 0; j < EPV; ++j) {
-    atomicAdd(&red[seg * EPV + j], s[j]);
-    atomicAdd(&red[c + seg * EPV + j], q[j]);
-  }
-  __syncthreads();
-  float *dst = stats + (size_t)(blockIdx.x % D3D_BN_COPIES) * 2 * c;  // spread same-address atomics
-  for (int i = threadIdx.x; i < 2 * c; i += NT) atomicAdd(&dst[i], red[i]);
+  bn_block_reduce<EPV, NT>(s, q, c, segs, seg, red, stats, skip_global);
 }
 
 template <bool BF16>
@@ -179,71 +218,70 @@ __global__ void __launch_bounds__(256)
 }
 
 // dz = dy * [z > 0] ; dbeta = sum dz ; dgamma = sum dz * xhat
-template <bool BF16, int NT>
+template <bool BF16, int NT, int U>
 __global__ void __launch_bounds__(NT)
     bn_bwd_reduce_kernel(const void *__restrict__ x, const void *__restrict__ dy, int n, int c,
                          const float *__restrict__ gamma, const float *__restrict__ beta,
                          const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
-                         float *__restrict__ partial) {
+                         float *__restrict__ partial, int skip_global) {
   constexpr int EPV = BnVec<BF16>::EPV;
+  constexpr int UR = U / 2;  // rows in flight: each row is two loads (x, dy)
   __shared__ float red[2 * BN_MAXC];
   for (int i = threadIdx.x; i < 2 * c; i += NT) red[i] = 0.f;
   __syncthreads();
   const int segs = c / EPV;
   const int seg = threadIdx.x % segs, rl = threadIdx.x / segs, rp = NT / segs;
-  float mu[EPV], is[EPV], g[EPV], b[EPV], sg[EPV], sb[EPV];
+  // z = x * zs + zb (the ReLU mask), xhat = x * is - mu * is
+  float is[EPV], mi[EPV], zs[EPV], zb[EPV], sg[EPV], sb[EPV];
 #pragma unroll
   for (int j = 0; j < EPV; ++j) {
     int ch = seg * EPV + j;
-    mu[j] = mean[ch];
+    const float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
     is[j] = invstd[ch];
-    g[j] = gamma ? gamma[ch] : 1.f;
-    b[j] = beta ? beta[ch] : 0.f;
+    mi[j] = -mean[ch] * is[j];
+    zs[j] = g * is[j];
+    zb[j] = fmaf(mi[j], g, b);
     sg[j] = sb[j] = 0.f;
   }
   const int64_t step = (int64_t)gridDim.x * rp;
   int64_t r = (int64_t)blockIdx.x * rp + rl;
-  for (; r + step < n; r += 2 * step) {  // 2 rows x 2 tensors = four loads in flight per lane
-    float v[2][EPV], d[2][EPV];
+  const uint4 *xv = (const uint4 *)x, *dv = (const uint4 *)dy;
+  for (; r + (UR - 1) * step < n; r += UR * step) {
+    uint4 rx[UR], rd[UR];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      BnVec<BF16>::load(x, (r + u * step) * segs + seg, v[u]);
-      BnVec<BF16>::load(dy, (r + u * step) * segs + seg, d[u]);
+    for (int u = 0; u < UR; ++u) {
+      rx[u] = xv[(r + u * step) * segs + seg];
+      rd[u] = dv[(r + u * step) * segs + seg];
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < UR; ++u) {
+      float v[EPV], d[EPV];
+      bn_unpack<BF16>(rx[u], v);
+      bn_unpack<BF16>(rd[u], d);
 #pragma unroll
       for (int j = 0; j < EPV; ++j) {
-        float xh = (v[u][j] - mu[j]) * is[j];
-        float dz = (relu && fmaf(xh, g[j], b[j]) <= 0.f) ? 0.f : d[u][j];
+        float dz = (relu && fmaf(v[j], zs[j], zb[j]) <= 0.f) ? 0.f : d[j];
         sb[j] += dz;
-        sg[j] = fmaf(dz, xh, sg[j]);
+        sg[j] = fmaf(dz, fmaf(v[j], is[j], mi[j]), sg[j]);
       }
+    }
   }
   for (; r < n; r += step) {
     float v[EPV], d[EPV];
-    BnVec<BF16>::load(x, r * segs + seg, v);
-    BnVec<BF16>::load(dy, r * segs + seg, d);
+    bn_unpack<BF16>(xv[r * segs + seg], v);
+    bn_unpack<BF16>(dv[r * segs + seg], d);
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
-      float xh = (v[j] - mu[j]) * is[j];
-      float dz = (relu && fmaf(xh, g[j], b[j]) <= 0.f) ? 0.f : d[j];
+      float dz = (relu && fmaf(v[j], zs[j], zb[j]) <= 0.f) ? 0.f : d[j];
       sb[j] += dz;
-      sg[j] = fmaf(dz, xh, sg[j]);
+      sg[j] = fmaf(dz, fmaf(v[j], is[j], mi[j]), sg[j]);
     }
   }
-#pragma unroll
-  for (int j = 0; j < EPV; ++j) {
-    atomicAdd(&red[seg * EPV + j], sg[j]);
-    atomicAdd(&red[c + seg * EPV + j], sb[j]);
-  }
-  __syncthreads();
-  float *dst = partial + (size_t)(blockIdx.x % D3D_BN_COPIES) * 2 * c;  // [copy][dgamma | dbeta]
-  for (int i = threadIdx.x; i < 2 * c; i += NT) atomicAdd(&dst[i], red[i]);
+  bn_block_reduce<EPV, NT>(sg, sb, c, segs, seg, red, partial, skip_global);  // [copy][dgamma | dbeta]
 }
 
-// dx = gamma * invstd * (dz - dbeta/N - xhat * dgamma/N)
-template <bool BF16>
+// dx = gamma * invstd * (dz - dbeta/N - xhat * dgamma/N) = A dz + P x + Q per channel
+template <bool BF16, int UR>
 __global__ void __launch_bounds__(256)
     bn_bwd_dx_kernel(const void *__restrict__ x, const void *__restrict__ dy, int n, int c,
                      const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -264,47 +302,51 @@ __global__ void __launch_bounds__(256)
   __syncthreads();
   const int segs = c / EPV;
   const int seg = threadIdx.x % segs, rl = threadIdx.x / segs, rp = 256 / segs;
-  float mu[EPV], is[EPV], g[EPV], b[EPV], c1[EPV], c2[EPV];
+  float zs[EPV], zb[EPV], A[EPV], P[EPV], Q[EPV];
   const float inv_n = 1.f / (float)n;
 #pragma unroll
   for (int j = 0; j < EPV; ++j) {
     int ch = seg * EPV + j;
-    mu[j] = mean[ch];
-    is[j] = invstd[ch];
-    g[j] = gamma ? gamma[ch] : 1.f;
-    b[j] = beta ? beta[ch] : 0.f;
-    c1[j] = tot[c + ch] * inv_n;
-    c2[j] = tot[ch] * inv_n;
+    const float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
+    const float is = invstd[ch], mi = -mean[ch] * is;
+    const float c1 = tot[c + ch] * inv_n, c2 = tot[ch] * inv_n;
+    zs[j] = g * is;
+    zb[j] = fmaf(mi, g, b);
+    A[j] = g * is;
+    P[j] = -A[j] * c2 * is;
+    Q[j] = -A[j] * fmaf(c2, mi, c1);
   }
   const int64_t step = (int64_t)gridDim.x * rp;
   int64_t r = (int64_t)blockIdx.x * rp + rl;
-  for (; r + step < n; r += 2 * step) {
-    float v[2][EPV], d[2][EPV];
+  const uint4 *xv = (const uint4 *)x, *dv = (const uint4 *)dy;
+  for (; r + (UR - 1) * step < n; r += UR * step) {
+    uint4 rx[UR], rd[UR];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      BnVec<BF16>::load(x, (r + u * step) * segs + seg, v[u]);
-      BnVec<BF16>::load(dy, (r + u * step) * segs + seg, d[u]);
+    for (int u = 0; u < UR; ++u) {
+      rx[u] = xv[(r + u * step) * segs + seg];
+      rd[u] = dv[(r + u * step) * segs + seg];
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < UR; ++u) {
+      float v[EPV], d[EPV];
+      bn_unpack<BF16>(rx[u], v);
+      bn_unpack<BF16>(rd[u], d);
 #pragma unroll
       for (int j = 0; j < EPV; ++j) {
-        float xh = (v[u][j] - mu[j]) * is[j];
-        float dz = (relu && fmaf(xh, g[j], b[j]) <= 0.f) ? 0.f : d[u][j];
-        v[u][j] = g[j] * is[j] * (dz - c1[j] - xh * c2[j]);
+        float dz = (relu && fmaf(v[j], zs[j], zb[j]) <= 0.f) ? 0.f : d[j];
+        v[j] = fmaf(A[j], dz, fmaf(P[j], v[j], Q[j]));
       }
-      BnVec<BF16>::store(dx, (r + u * step) * segs + seg, v[u]);
+      BnVec<BF16>::store(dx, (r + u * step) * segs + seg, v);
     }
   }
   for (; r < n; r += step) {
     float v[EPV], d[EPV];
-    BnVec<BF16>::load(x, r * segs + seg, v);
-    BnVec<BF16>::load(dy, r * segs + seg, d);
+    bn_unpack<BF16>(xv[r * segs + seg], v);
+    bn_unpack<BF16>(dv[r * segs + seg], d);
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
-      float xh = (v[j] - mu[j]) * is[j];
-      float dz = (relu && fmaf(xh, g[j], b[j]) <= 0.f) ? 0.f : d[j];
-      v[j] = g[j] * is[j] * (dz - c1[j] - xh * c2[j]);
+      float dz = (relu && fmaf(v[j], zs[j], zb[j]) <= 0.f) ? 0.f : d[j];
+      v[j] = fmaf(A[j], dz, fmaf(P[j], v[j], Q[j]));
     }
     BnVec<BF16>::store(dx, r * segs + seg, v);
   }
@@ -320,26 +362,48 @@ static int bn_check(int n, int c, int dtype, const char *who) {
   return D3D_OK;
 }
 
-// reduction sweeps (stats, bwd_reduce): block size and grid.  Small inputs keep 256-thread blocks (latency: many
-// blocks), large ones switch to 1024 threads x <= 256 blocks (see bn_stats_kernel).
+// reduction sweeps (stats, bwd_reduce): block size, loads in flight and grid.  Small inputs keep 256-thread blocks
+// (latency: many blocks); inputs of >= 2^23 elements pick a row of this table (d3d_set_tuning knob 3, D3D_BN_VARIANT;
+// measured by tools/bench_bn.py on the RPN's [140800, 128] and [140800, 256] maps)
+struct BnVariant { int nt, u, cap; };
+static const BnVariant BN_VARIANTS[] = {
+    {1024, 4, 256}, {256, 4, 2048}, {256, 8, 1024}, {1024, 8, 256}, {512, 8, 512},
+    {256, 8, 2048}, {512, 4, 1024}, {1024, 8, 512}, {256, 4, 1024}, {512, 8, 256},
+};
+#define BN_NUM_VARIANTS ((int)(sizeof(BN_VARIANTS) / sizeof(BN_VARIANTS[0])))
+int g_bn_variant = getenv("D3D_BN_VARIANT") ? atoi(getenv("D3D_BN_VARIANT")) : 0;
+int g_bn_skip_global = 0;  // timing diagnosis only (knob 4): leave the global atomics out -> wrong sums
+int g_bn_dx_rows = getenv("D3D_BN_DX_ROWS") ? atoi(getenv("D3D_BN_DX_ROWS")) : 2;  // rows in flight in bwd_dx (knob 5)
+int g_bn_stream_blocks = 0;  // grid cap of the apply / bwd_dx sweeps (knob 6); 0 = D3D_BN_BLOCKS / 2048
 static bool bn_big(int n, int c) { return (int64_t)n * c >= ((int64_t)1 << 23); }
-static int bn_reduce_grid_big(int n, int c, int dtype) {
-  const int rp = 1024 / (c / (dtype == D3D_BF16 ? 8 : 4));
-  int nb = ((n + rp - 1) / rp + 3) / 4;
-  static const int cap = getenv("D3D_BN_BIG_BLOCKS") ? atoi(getenv("D3D_BN_BIG_BLOCKS")) : 256;
-  if (nb > cap) nb = cap;
+static BnVariant bn_variant_for(int n, int c) {
+  if (!bn_big(n, c)) return BnVariant{256, 4, 0};
+  int v = g_bn_variant;
+  if (v < 0 || v >= BN_NUM_VARIANTS) v = 0;
+  return BN_VARIANTS[v];
+}
+static int bn_reduce_grid(const BnVariant &v, int n, int c, int dtype, int small_grid) {
+  if (v.cap == 0) return small_grid;
+  const int rp = v.nt / (c / (dtype == D3D_BF16 ? 8 : 4));
+  int nb = ((n + rp - 1) / rp + v.u - 1) / v.u;
+  if (nb > v.cap) nb = v.cap;
   return nb < 1 ? 1 : nb;
 }
+#define BN_LAUNCH_NU(KERNEL, NT, U, ...)                                                                    \
+  do {                                                                                                      \
+    if (dtype == D3D_BF16) hipLaunchKernelGGL((KERNEL<true, NT, U>), dim3(nbr), dim3(NT), 0, stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<false, NT, U>), dim3(nbr), dim3(NT), 0, stream, __VA_ARGS__);           \
+  } while (0)
 #define BN_LAUNCH_REDUCE(KERNEL, ...)                                                                       \
   do {                                                                                                      \
-    if (bn_big(n, c)) {                                                                                     \
-      const int nbb = bn_reduce_grid_big(n, c, dtype);                                                      \
-      if (dtype == D3D_BF16) hipLaunchKernelGGL((KERNEL<true, 1024>), dim3(nbb), dim3(1024), 0, stream, __VA_ARGS__); \
-      else hipLaunchKernelGGL((KERNEL<false, 1024>), dim3(nbb), dim3(1024), 0, stream, __VA_ARGS__);        \
-    } else {                                                                                                \
-      if (dtype == D3D_BF16) hipLaunchKernelGGL((KERNEL<true, 256>), dim3(nb), dim3(256), 0, stream, __VA_ARGS__);   \
-      else hipLaunchKernelGGL((KERNEL<false, 256>), dim3(nb), dim3(256), 0, stream, __VA_ARGS__);           \
-    }                                                                                                       \
+    const BnVariant bv = bn_variant_for(n, c);                                                              \
+    const int nbr = bn_reduce_grid(bv, n, c, dtype, nb);                                                    \
+    if (bv.nt == 1024 && bv.u == 4) BN_LAUNCH_NU(KERNEL, 1024, 4, __VA_ARGS__);                             \
+    else if (bv.nt == 1024) BN_LAUNCH_NU(KERNEL, 1024, 8, __VA_ARGS__);                                     \
+    else if (bv.nt == 512 && bv.u == 4) BN_LAUNCH_NU(KERNEL, 512, 4, __VA_ARGS__);                          \
+    else if (bv.nt == 512) BN_LAUNCH_NU(KERNEL, 512, 8, __VA_ARGS__);                                       \
+    else if (bv.u == 4) BN_LAUNCH_NU(KERNEL, 256, 4, __VA_ARGS__);                                          \
+    else BN_LAUNCH_NU(KERNEL, 256, 8, __VA_ARGS__);                                                         \
   } while (0)
 
 static int bn_grid(int n, int c, int dtype) {
@@ -357,7 +421,8 @@ static int bn_grid(int n, int c, int dtype) {
     if (cap < 1) cap = 2048;
   }
   nb = (nb + 3) / 4;
-  if (nb > cap) nb = cap;
+  const int lim = g_bn_stream_blocks > 0 ? g_bn_stream_blocks : cap;
+  if (nb > lim) nb = lim;
   return nb < 1 ? 1 : nb;
 }
 
@@ -370,7 +435,7 @@ extern "C" int d3d_bn_stats(const void *x, int n, int c, int dtype, float *stats
   D3D_REQUIRE(x && stats_ws, "d3d_bn_stats: null pointer");
   const int nb = bn_grid(n, c, dtype);
   D3D_HIP_TRY(d3d_fill_async(stream, stats_ws, 0, (size_t)D3D_BN_COPIES * 2 * c * sizeof(float)));
-  BN_LAUNCH_REDUCE(bn_stats_kernel, x, n, c, stats_ws);
+  BN_LAUNCH_REDUCE(bn_stats_kernel, x, n, c, stats_ws, g_bn_skip_global);
   D3D_LAUNCH_TRY("bn_stats_kernel");
   return D3D_OK;
 }
@@ -408,7 +473,8 @@ extern "C" int d3d_bn_bwd_reduce(const void *x, const void *dy, int n, int c, in
   D3D_REQUIRE(x && dy && save_mean && save_invstd && partial_ws, "d3d_bn_bwd_reduce: null pointer");
   const int nb = bn_grid(n, c, dtype);
   D3D_HIP_TRY(d3d_fill_async(stream, partial_ws, 0, (size_t)D3D_BN_COPIES * 2 * c * sizeof(float)));
-  BN_LAUNCH_REDUCE(bn_bwd_reduce_kernel, x, dy, n, c, gamma, beta, save_mean, save_invstd, relu, partial_ws);
+  BN_LAUNCH_REDUCE(bn_bwd_reduce_kernel, x, dy, n, c, gamma, beta, save_mean, save_invstd, relu, partial_ws,
+                   g_bn_skip_global);
   D3D_LAUNCH_TRY("bn_bwd_reduce_kernel");
   return D3D_OK;
 }
@@ -424,12 +490,16 @@ extern "C" int d3d_bn_bwd_dx(const void *x, const void *dy, int n, int c, int dt
   D3D_REQUIRE(x && dy && dx && dgamma && dbeta && save_mean && save_invstd && partial_ws,
               "d3d_bn_bwd_dx: null pointer");
   const int nb = bn_grid(n, c, dtype);
-  if (dtype == D3D_BF16)
-    hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma, beta,
-                       save_mean, save_invstd, relu, partial_ws, copies, dgamma, dbeta, dx);
-  else
-    hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma, beta,
-                       save_mean, save_invstd, relu, partial_ws, copies, dgamma, dbeta, dx);
+#define BN_DX(BF, UR)                                                                                        \
+  hipLaunchKernelGGL((bn_bwd_dx_kernel<BF, UR>), dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma, beta,   \
+                     save_mean, save_invstd, relu, partial_ws, copies, dgamma, dbeta, dx)
+  const int ur = g_bn_dx_rows >= 4 ? 4 : (g_bn_dx_rows <= 1 ? 1 : 2);
+  if (dtype == D3D_BF16) {
+    if (ur == 4) BN_DX(true, 4); else if (ur == 2) BN_DX(true, 2); else BN_DX(true, 1);
+  } else {
+    if (ur == 4) BN_DX(false, 4); else if (ur == 2) BN_DX(false, 2); else BN_DX(false, 1);
+  }
+#undef BN_DX
   D3D_LAUNCH_TRY("bn_bwd_dx_kernel");
   return D3D_OK;
 }
@@ -518,50 +588,22 @@ extern "C" int d3d_bn_relu_fwd(const void *x, int n, int c, int dtype, const flo
                                float momentum, float eps, int training, int relu, void *y,
                                float *save_mean, float *save_invstd, float *stats_ws,
                                d3d_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  const int copies = D3D_BN_COPIES;
-  int rc = bn_check(n, c, dtype, "d3d_bn_relu_fwd");
-  if (rc) return rc;
-  D3D_REQUIRE(x && y, "d3d_bn_relu_fwd: null pointer");
   D3D_REQUIRE(training ? stats_ws != nullptr : (running_mean && running_var),
               "d3d_bn_relu_fwd: training needs stats_ws, eval needs running stats");
-  const int nb = bn_grid(n, c, dtype);
   if (training) {
-    D3D_HIP_TRY(d3d_fill_async(stream, stats_ws, 0, (size_t)D3D_BN_COPIES * 2 * c * sizeof(float)));
-    BN_LAUNCH_REDUCE(bn_stats_kernel, x, n, c, stats_ws);
-    D3D_LAUNCH_TRY("bn_stats_kernel");
+    int rc = d3d_bn_stats(x, n, c, dtype, stats_ws, stream_);
+    if (rc) return rc;
   }
-  if (dtype == D3D_BF16)
-    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(nb), dim3(256), 0, stream, x, n, c, gamma, beta,
-                       running_mean, running_var, momentum, eps, training, relu, stats_ws, copies, y,
-                       save_mean, save_invstd);
-  else
-    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(nb), dim3(256), 0, stream, x, n, c, gamma, beta,
-                       running_mean, running_var, momentum, eps, training, relu, stats_ws, copies, y,
-                       save_mean, save_invstd);
-  D3D_LAUNCH_TRY("bn_apply_kernel");
-  return D3D_OK;
+  return d3d_bn_apply(x, n, c, dtype, gamma, beta, running_mean, running_var, momentum, eps, training, relu,
+                      stats_ws, D3D_BN_COPIES, y, save_mean, save_invstd, stream_);
 }
 
 extern "C" int d3d_bn_relu_bwd(const void *x, const void *dy, int n, int c, int dtype,
                                const float *gamma, const float *beta, const float *save_mean,
                                const float *save_invstd, int relu, void *dx, float *dgamma,
                                float *dbeta, float *partial_ws, d3d_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  const int copies = D3D_BN_COPIES;
-  int rc = bn_check(n, c, dtype, "d3d_bn_relu_bwd");
+  int rc = d3d_bn_bwd_reduce(x, dy, n, c, dtype, gamma, beta, save_mean, save_invstd, relu, partial_ws, stream_);
   if (rc) return rc;
-  D3D_REQUIRE(x && dy && dx && dgamma && dbeta && save_mean && save_invstd && partial_ws,
-              "d3d_bn_relu_bwd: null pointer");
-  const int nb = bn_grid(n, c, dtype);
-  D3D_HIP_TRY(d3d_fill_async(stream, partial_ws, 0, (size_t)D3D_BN_COPIES * 2 * c * sizeof(float)));
-  BN_LAUNCH_REDUCE(bn_bwd_reduce_kernel, x, dy, n, c, gamma, beta, save_mean, save_invstd, relu, partial_ws);
-  if (dtype == D3D_BF16)
-    hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma,
-                       beta, save_mean, save_invstd, relu, partial_ws, copies, dgamma, dbeta, dx);
-  else
-    hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(nb), dim3(256), 0, stream, x, dy, n, c,
-                       gamma, beta, save_mean, save_invstd, relu, partial_ws, copies, dgamma, dbeta, dx);
-  D3D_LAUNCH_TRY("bn_bwd kernels");
-  return D3D_OK;
+  return d3d_bn_bwd_dx(x, dy, n, c, dtype, gamma, beta, save_mean, save_invstd, relu, partial_ws, D3D_BN_COPIES,
+                       dx, dgamma, dbeta, stream_);
 }

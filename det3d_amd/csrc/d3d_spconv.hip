@@ -47,12 +47,19 @@ int g_d3d_wgrad_blocks = -1;  // d3d_wgrad.hip reads these two
 // XCD-aware tile order: measured neutral-to-slightly-negative on MI355X for these gathers (profiles/round2_tune_fwd.txt:
 // 50.6 vs 50.6-54 us on the 126k-site 64->64 layer, 578 vs 566 frames/s end to end), so it is off by default
 int g_xcd_remap = getenv("D3D_XCD_REMAP") ? atoi(getenv("D3D_XCD_REMAP")) : 0;
+extern int g_bn_variant, g_bn_skip_global, g_bn_dx_rows, g_bn_stream_blocks;  // d3d_bn.hip
 extern "C" int d3d_set_tuning(int knob, int value) {
-  D3D_REQUIRE(knob >= 0 && knob <= 2, "d3d_set_tuning: unknown knob %d (0 = forward 64->64 tiling variant, "
-              "1 = target block count of the weight-gradient kernel, 2 = XCD-aware tile order on/off)", knob);
+  D3D_REQUIRE(knob >= 0 && knob <= 6, "d3d_set_tuning: unknown knob %d (0 = forward 64->64 tiling variant, "
+              "1 = target block count of the weight-gradient kernel, 2 = XCD-aware tile order on/off, 3 = BatchNorm "
+              "reduction variant for large inputs, 4 = skip the BatchNorm global atomics (timing diagnosis), 5 = rows "
+              "in flight in bn_bwd_dx, 6 = grid cap of the BatchNorm streaming sweeps)", knob);
   if (knob == 0) g_fwd_variant = value;
   else if (knob == 1) g_d3d_wgrad_blocks = value;
-  else g_xcd_remap = value;
+  else if (knob == 2) g_xcd_remap = value;
+  else if (knob == 3) g_bn_variant = value;
+  else if (knob == 4) g_bn_skip_global = value;
+  else if (knob == 5) g_bn_dx_rows = value;
+  else g_bn_stream_blocks = value;
   return D3D_OK;
 }
 

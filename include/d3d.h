@@ -156,8 +156,11 @@ typedef struct D3dConvEpilogue {
   float *bn_partial;
   int copies; /* replicas of the accumulator ([copies][2*cout]; 0 = D3D_BN_COPIES): block b adds to replica b % copies */
 } D3dConvEpilogue;
-/* tuning hook for tools/tune_fwd.py: knob 0 = tiling variant of the forward 64->64 bf16 kernel (0 = default),
- * knob 1 = target block count of the weight-gradient kernel (<= 0 = default, one block per CU) */
+/* tuning hook for tools/tune_fwd.py and tools/bench_bn.py: knob 0 = tiling variant of the forward 64->64 bf16
+ * kernel (0 = default), 1 = target block count of the weight-gradient kernel (<= 0 = default, one block per CU),
+ * 2 = XCD-aware tile order, 3 = BatchNorm reduction variant for inputs of >= 2^23 elements, 4 = leave the BatchNorm
+ * global atomics out (timing diagnosis: wrong sums), 5 = rows in flight in bn_bwd_dx (1, 2, 4), 6 = grid cap of the
+ * BatchNorm streaming sweeps (0 = default) */
 int d3d_set_tuning(int knob, int value);
 int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const float *bias,
                            const int32_t *nbr, int cap, int n_out, int kvol, int cin, int cout,
