@@ -81,6 +81,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip fp32 / precision / rpn / predict / stage probes")
     ap.add_argument("--cached-targets", action="store_true",
                     help="use the host-precomputed anchor targets instead of d3d_assign_targets in the step")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="build the geometry (voxelize, targets, rulebooks) inline at the start of each step instead of "
+                         "one batch ahead on a second stream")
     ap.add_argument("--no-gc-freeze", action="store_true",
                     help="do not gc.freeze() after warm-up (shows the cost of full CPython collections)")
     ap.add_argument("--no-channels-last", action="store_true",
@@ -282,24 +285,41 @@ class Workload:
             self.spec["config"].replace(".py", ""), self.batch, self.points, self.spec["note"])
 
 
-def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, freeze=True, burn_in_s=0.0):
+def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, freeze=True, burn_in_s=0.0,
+                 prefetch=True):
     """W untimed warm-up steps, then exactly `steps` steps bracketed by barrier + synchronize; returns
     (max-over-ranks elapsed seconds, launch records of the sampled steps, final loss)."""
     from det3d_amd import dist as D
     from det3d_amd import spconv, trainer
 
+    from det3d_amd.prefetch import GeometryPrefetcher
+
     records = []
+    # geometry of batch i+1 (voxelize, targets, rulebooks: both host syncs of a step) on a second stream while batch
+    # i trains; --no-prefetch builds it inline at the start of each step
+    pf = GeometryPrefetcher(wl.example, wl.model, dev, enabled=prefetch)
+    host = {"enqueue": 0.0, "geometry": 0.0}
 
     def drain():
         if spconv.LAUNCH_LOG:
             for kind, cin, cout, n_out, rb, e0, e1 in spconv.LAUNCH_LOG:
+                e1.synchronize()
                 records.append((kind, cin, cout, n_out, rb, e0.elapsed_time(e1)))
             spconv.LAUNCH_LOG.clear()
 
+    state = {"ex": pf.prepare(0)}
+
     def one(i):
-        ex = wl.example(i)
-        drain()  # events of the previous step are complete: make_example just synced
-        return wl.step_fn(ex)
+        """step i on the example prepared earlier, then the preparation of example i+1"""
+        drain()
+        t_a = time.perf_counter()
+        out = wl.step_fn(state["ex"])
+        t_b = time.perf_counter()
+        state["ex"] = pf.prepare(i + 1)
+        t_c = time.perf_counter()
+        host["enqueue"] += t_b - t_a
+        host["geometry"] += t_c - t_b
+        return out
 
     burn = 0
     if burn_in_s > 0:
@@ -320,7 +340,7 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
         note("%s %s burn-in: %d untimed steps" % (wl.name, wl.dtype, burn))
     wl.burn_in_steps = burn
     for i in range(warmup):
-        one(i)
+        one(burn + i)
         torch.cuda.synchronize()
         note("%s %s warmup step %d done" % (wl.name, wl.dtype, i))
     torch.cuda.synchronize()
@@ -334,12 +354,13 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
     spconv.LAUNCH_FILTER = launch_filter
     torch.cuda.synchronize()
     ms0 = torch.cuda.memory_stats(dev)
+    host["enqueue"] = host["geometry"] = 0.0
     t0 = time.perf_counter()
     loss = None
     for i in range(steps):
         if i == sample_from and launch_filter is not None:
             spconv.LAUNCH_LOG = []
-        loss = one(warmup + i)
+        loss = one(burn + warmup + i)  # K steps and K geometry builds (the last one for a step that is not run)
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
@@ -350,6 +371,7 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
     drain()
     spconv.LAUNCH_LOG = None
     spconv.LAUNCH_FILTER = None
+    wl.host_ms = {k: round(1e3 * v / max(steps, 1), 3) for k, v in host.items()}
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -677,7 +699,8 @@ def main():
     if head == "c3":
         dominant = None  # PointPillars has no sparse convolutions
     elapsed, records, loss = timed_region(wl, args.steps, args.warmup, rank, world, dev, note, dominant,
-                                          freeze=not args.no_gc_freeze, burn_in_s=args.burn_in)
+                                          freeze=not args.no_gc_freeze, burn_in_s=args.burn_in,
+                                          prefetch=not args.no_prefetch)
     frames = args.steps * wl.batch * world
     value = frames / elapsed
     out = {
@@ -691,7 +714,9 @@ def main():
                    "points_per_frame": wl.points, "parallelism": "dp%d" % world,
                    "final_loss": round(float(loss), 4), "timed_region_s": round(elapsed, 3),
                    "burn_in_steps": getattr(wl, "burn_in_steps", 0),
-                   "graphed_tail": bool(wl.model.__dict__.get("_graph_tails"))},
+                   "graphed_tail": bool(wl.model.__dict__.get("_graph_tails")),
+                   "geometry_prefetch": not args.no_prefetch,
+                   "host_ms_per_step": getattr(wl, "host_ms", None)},
     }
     if rank == 0 and records:
         roof = roofline_object(group_launches(records, esz), roof_key, args.dtype)

@@ -85,13 +85,26 @@ class SparseBasicBlock(spconv.SparseModule):
 class _SparseMiddle(nn.Module):
     """shared forward of the two sparse backbones (scn.py:184-197 / :357-370)."""
 
-    def _run(self, voxel_features, coors, batch_size, input_shape):
+    def plan_geometry(self, coors, batch_size, input_shape):
+        """Every rulebook of the sparse stack for these voxel coordinates (one host sync on the CURRENT stream),
+        as the dict `forward(..., plan=)` accepts: lets a caller build the geometry of the next batch on a second
+        stream while the current batch trains (prefetch.GeometryPrefetcher)."""
+        sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]
+        coors = coors.int()
+        probe = spconv.SparseConvTensor(coors.new_empty((coors.shape[0], 0), dtype=torch.float32), coors,
+                                        sparse_shape.tolist(), batch_size)
+        return dict(coors=coors, indice_dict=self.middle_conv.plan(probe))
+
+    def _run(self, voxel_features, coors, batch_size, input_shape, plan=None):
         sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]
         coors = coors.int()
         if torch.is_autocast_enabled():
             voxel_features = voxel_features.to(torch.get_autocast_dtype("cuda"))
         ret = spconv.SparseConvTensor(voxel_features, coors, sparse_shape.tolist(), batch_size)
-        self.middle_conv.plan(ret)  # every rulebook of the stack, one host sync
+        if plan is not None and plan["coors"].data_ptr() == coors.data_ptr() and plan["coors"].shape == coors.shape:
+            ret.indice_dict = plan["indice_dict"]  # built ahead of time for exactly these coordinates
+        else:
+            self.middle_conv.plan(ret)  # every rulebook of the stack, one host sync
         spconv.ARENA.reset(voxel_features.device)  # one launch zeroes every conv-epilogue accumulator of this pass
         ret = self.middle_conv(ret)
         self.last_indice_dict = ret.indice_dict
@@ -101,8 +114,8 @@ class _SparseMiddle(nn.Module):
     def init_weights(self, pretrained=None):
         pass
 
-    def forward(self, voxel_features, coors, batch_size, input_shape):
-        return self._run(voxel_features, coors, batch_size, input_shape)
+    def forward(self, voxel_features, coors, batch_size, input_shape, plan=None):
+        return self._run(voxel_features, coors, batch_size, input_shape, plan)
 
 
 @BACKBONES.register_module

@@ -371,10 +371,14 @@ static const BnVariant BN_VARIANTS[] = {
     {256, 8, 2048}, {512, 4, 1024}, {1024, 8, 512}, {256, 4, 1024}, {512, 8, 256},
 };
 #define BN_NUM_VARIANTS ((int)(sizeof(BN_VARIANTS) / sizeof(BN_VARIANTS[0])))
-int g_bn_variant = getenv("D3D_BN_VARIANT") ? atoi(getenv("D3D_BN_VARIANT")) : 0;
+// MI355X, [140800, 128] bf16 (profiles/round2_bench_bn.json): variant 9 = 13.5 / 28.8 us (stats / bwd_reduce incl. the
+// accumulator fill launch), variant 0 = 16.9 / 33.3, 2048 x 256-thread blocks (variant 1) = 22.3 / 39.5
+int g_bn_variant = getenv("D3D_BN_VARIANT") ? atoi(getenv("D3D_BN_VARIANT")) : 9;
 int g_bn_skip_global = 0;  // timing diagnosis only (knob 4): leave the global atomics out -> wrong sums
 int g_bn_dx_rows = getenv("D3D_BN_DX_ROWS") ? atoi(getenv("D3D_BN_DX_ROWS")) : 2;  // rows in flight in bwd_dx (knob 5)
-int g_bn_stream_blocks = 0;  // grid cap of the apply / bwd_dx sweeps (knob 6); 0 = D3D_BN_BLOCKS / 2048
+// grid cap of the apply / bwd_dx / affine sweeps (knob 6, D3D_BN_STREAM_BLOCKS): 512 blocks x 4 rows in flight is
+// 30.1 us for bwd_dx on the 36 MB map, 2048 blocks 40.6 us (same file); inputs under ~8 MB never reach the cap
+int g_bn_stream_blocks = getenv("D3D_BN_STREAM_BLOCKS") ? atoi(getenv("D3D_BN_STREAM_BLOCKS")) : 512;
 static bool bn_big(int n, int c) { return (int64_t)n * c >= ((int64_t)1 << 23); }
 static BnVariant bn_variant_for(int n, int c) {
   if (!bn_big(n, c)) return BnVariant{256, 4, 0};
@@ -421,9 +425,14 @@ static int bn_grid(int n, int c, int dtype) {
     if (cap < 1) cap = 2048;
   }
   nb = (nb + 3) / 4;
-  const int lim = g_bn_stream_blocks > 0 ? g_bn_stream_blocks : cap;
-  if (nb > lim) nb = lim;
+  if (nb > cap) nb = cap;
   return nb < 1 ? 1 : nb;
+}
+// grid of the non-reducing sweeps (apply, bwd_dx, channel affine)
+static int bn_stream_grid(int n, int c, int dtype) {
+  int nb = bn_grid(n, c, dtype);
+  if (g_bn_stream_blocks > 0 && nb > g_bn_stream_blocks) nb = g_bn_stream_blocks;
+  return nb;
 }
 
 // ---- the two halves of each direction as separate entry points: the conv epilogues (d3d_sparse_conv_fwd_ex)
@@ -451,7 +460,7 @@ extern "C" int d3d_bn_apply(const void *x, int n, int c, int dtype, const float 
   D3D_REQUIRE(x && y, "d3d_bn_apply: null pointer");
   D3D_REQUIRE(training ? stats_ws != nullptr : (running_mean && running_var),
               "d3d_bn_apply: training needs stats_ws, eval needs running stats");
-  const int nb = bn_grid(n, c, dtype);
+  const int nb = bn_stream_grid(n, c, dtype);
   if (dtype == D3D_BF16)
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(nb), dim3(256), 0, stream, x, n, c, gamma, beta,
                        running_mean, running_var, momentum, eps, training, relu, stats_ws, copies, y,
@@ -489,7 +498,7 @@ extern "C" int d3d_bn_bwd_dx(const void *x, const void *dy, int n, int c, int dt
   D3D_REQUIRE(copies >= 1 && copies <= 256, "d3d_bn_bwd_dx: copies=%d", copies);
   D3D_REQUIRE(x && dy && dx && dgamma && dbeta && save_mean && save_invstd && partial_ws,
               "d3d_bn_bwd_dx: null pointer");
-  const int nb = bn_grid(n, c, dtype);
+  const int nb = bn_stream_grid(n, c, dtype);
 #define BN_DX(BF, UR)                                                                                        \
   hipLaunchKernelGGL((bn_bwd_dx_kernel<BF, UR>), dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma, beta,   \
                      save_mean, save_invstd, relu, partial_ws, copies, dgamma, dbeta, dx)
@@ -554,7 +563,7 @@ extern "C" int d3d_channel_affine(const void *x, int n, int c, int dtype, const 
   int rc = bn_check(n, c, dtype, "d3d_channel_affine");
   if (rc) return rc;
   D3D_REQUIRE(x && y && scale && shift, "d3d_channel_affine: null pointer");
-  const int nb = bn_grid(n, c, dtype);
+  const int nb = bn_stream_grid(n, c, dtype);
   if (dtype == D3D_BF16)
     hipLaunchKernelGGL((bn_affine_kernel<true, false>), dim3(nb), dim3(256), 0, stream, x, nullptr, n, c, scale,
                        shift, relu, nullptr, nullptr, nullptr, y);
@@ -572,7 +581,7 @@ extern "C" int d3d_channel_affine_bwd(const void *x, const void *dy, int n, int 
   int rc = bn_check(n, c, dtype, "d3d_channel_affine_bwd");
   if (rc) return rc;
   D3D_REQUIRE(x && dy && dx && scale && shift && coef_dz && coef_x && coef_1, "d3d_channel_affine_bwd: null pointer");
-  const int nb = bn_grid(n, c, dtype);
+  const int nb = bn_stream_grid(n, c, dtype);
   if (dtype == D3D_BF16)
     hipLaunchKernelGGL((bn_affine_kernel<true, true>), dim3(nb), dim3(256), 0, stream, x, dy, n, c, scale, shift,
                        relu, coef_dz, coef_x, coef_1, dx);

@@ -44,9 +44,15 @@ class SingleStageDetector(nn.Module):
 
 @DETECTORS.register_module
 class VoxelNet(SingleStageDetector):
-    def extract_feat(self, data):
+    def _backbone(self, data):
         input_features = self.reader(data["features"], data["num_voxels"])
-        x = self.backbone(input_features, data["coors"], data["batch_size"], data["input_shape"])
+        if data.get("plan") is not None:  # rulebooks built ahead of time (prefetch.GeometryPrefetcher)
+            return self.backbone(input_features, data["coors"], data["batch_size"], data["input_shape"],
+                                 plan=data["plan"])
+        return self.backbone(input_features, data["coors"], data["batch_size"], data["input_shape"])
+
+    def extract_feat(self, data):
+        x = self._backbone(data)
         if self.with_neck:
             x = self.neck(x)
         return x
@@ -54,11 +60,10 @@ class VoxelNet(SingleStageDetector):
     def forward(self, example, return_loss=True, **kwargs):
         feats = example["voxel_mean"] if "voxel_mean" in example else example["voxels"]
         data = dict(features=feats, num_voxels=example["num_points"], coors=example["coordinates"],
-                    batch_size=len(example["num_voxels"]), input_shape=example["shape"][0])
+                    batch_size=len(example["num_voxels"]), input_shape=example["shape"][0],
+                    plan=example.get("sparse_plan"))
         if return_loss and self.training and graph_tail.GRAPH_TAIL:
-            bev = self.backbone(self.reader(data["features"], data["num_voxels"]), data["coors"],
-                                data["batch_size"], data["input_shape"])
-            return self._train_tail(example, bev)
+            return self._train_tail(example, self._backbone(data))
         return self._finish(example, self.extract_feat(data), return_loss)
 
 

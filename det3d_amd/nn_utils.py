@@ -42,11 +42,12 @@ def build_norm_layer(cfg, num_features, postfix=""):
     return name, layer
 
 
-# Optional: route the RPN's Conv2d -> BatchNorm2d -> ReLU triples (channels-last maps) through the fused
-# HIP BatchNorm+ReLU passes of the sparse layers.  OFF by default: on the 36 MB KITTI maps MIOpen's NHWC
-# batch norm + clamp is faster (438 vs 398 frames/s end to end, MI355X, round 1); the sparse-layer kernels
-# are tuned for 1-10 MB tensors.  D3D_FUSE_BN2D=1 turns it on.
-FUSE_BN2D_RELU = os.environ.get("D3D_FUSE_BN2D", "0") == "1"
+# The RPN's Conv2d -> BatchNorm2d -> ReLU triples (channels-last maps) go through the fused HIP BatchNorm+ReLU
+# sweeps of the sparse layers (d3d_bn.hip): 4 launches per layer and direction pair instead of MIOpen's 3 + 3
+# BatchNorm kernels plus the separate clamp / threshold-backward kernels.  Round 1 had this off (MIOpen was faster
+# on the 36 MB KITTI maps, 438 vs 398 frames/s); with the large-input variants of the reduction sweeps it is
+# 0.3 ms of GPU time per step ahead (profiles/round2_kernel_stats_v4.txt).  D3D_FUSE_BN2D=0 turns it off.
+FUSE_BN2D_RELU = os.environ.get("D3D_FUSE_BN2D", "1") == "1"
 
 
 class Sequential(nn.Module):

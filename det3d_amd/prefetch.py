@@ -1,0 +1,80 @@
+"""Input-side geometry of batch i+1 on a second HIP stream while batch i trains.
+
+The training step has two places where the host must read device-side counts: the voxel counts of the batch
+(point_cloud_ops.VoxelBatch.sync) and the output counts of the strided sparse convolutions
+(spconv.SparseSequential.plan).  Done inline, each of them drains the GPU at the start of a step, and the sparse
+forward that follows (short kernels, one Python autograd node each) is issued into an idle device.  Everything in
+that prologue depends only on the INPUT batch -- device voxelizer + fused mean VFE, anchor target assignment,
+every rulebook of the sparse backbone -- so it can run one batch ahead:
+
+    pf = GeometryPrefetcher(make_example, detector)
+    ex = pf.prepare(batch_0)
+    for i in range(steps):
+        loss = train_step(ex)            # enqueues forward + backward + optimiser of batch i (asynchronous)
+        ex = pf.prepare(batch_{i+1})     # side stream: its two host syncs wait for the side stream only
+
+The reference gets the same overlap from its DataLoader worker processes (voxelisation and target assignment on
+CPU cores, torchie/trainer/trainer.py:34-57 moves the finished example to the GPU); here the work is on the GPU,
+so the overlap is between two HIP streams of one process.
+
+Memory: tensors produced on the side stream are handed to the compute stream with `record_stream`, so the caching
+allocator does not recycle them while the compute stream still reads them.
+"""
+import torch
+
+
+def _tensors(obj, seen):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors(v, seen)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors(v, seen)
+    elif hasattr(obj, "__dict__") and not isinstance(obj, (type, torch.nn.Module)):
+        if id(obj) in seen:
+            return
+        seen.add(id(obj))
+        yield from _tensors(vars(obj), seen)
+
+
+class GeometryPrefetcher:
+    def __init__(self, make_example, detector=None, device=None, enabled=True):
+        """make_example(batch) -> example dict (runs the device voxelizer etc. on the CURRENT stream);
+        detector: if its backbone has `plan_geometry`, the rulebooks are built here too and travel in
+        example["sparse_plan"]."""
+        self.make_example = make_example
+        self.backbone = getattr(detector, "backbone", None) if detector is not None else None
+        if not hasattr(self.backbone, "plan_geometry"):
+            self.backbone = None
+        self.enabled = enabled and torch.cuda.is_available()
+        self.device = device
+        self.stream = None
+
+    def prepare(self, batch, ready_event=None):
+        """ready_event: recorded by whoever produced `batch` (e.g. the H2D copy); None = the tensors of `batch` are
+        already complete (resident inputs)."""
+        if not self.enabled:
+            return self._build(batch)
+        dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(dev, priority=-1)  # small kernels: let them cut in front of the step
+        main = torch.cuda.current_stream(dev)
+        if ready_event is not None:
+            self.stream.wait_event(ready_event)
+        with torch.cuda.stream(self.stream):
+            ex = self._build(batch)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        main.wait_event(done)
+        for t in _tensors(ex, set()):
+            if t.is_cuda:
+                t.record_stream(main)
+        return ex
+
+    def _build(self, batch):
+        ex = self.make_example(batch)
+        if self.backbone is not None and "coordinates" in ex and "sparse_plan" not in ex:
+            ex["sparse_plan"] = self.backbone.plan_geometry(ex["coordinates"], len(ex["num_voxels"]), ex["shape"][0])
+        return ex

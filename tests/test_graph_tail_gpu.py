@@ -30,6 +30,21 @@ def _kitti_examples(n, batch=2):
     return [synthetic.make_example(ds.device_batch(i, batch, dev), synthetic.KITTI_CAR) for i in range(n)]
 
 
+def _bias_before_bn(model):
+    """conv biases directly followed by a train-mode BatchNorm (SparseSequential order conv, bn): zero true gradient"""
+    from det3d_amd import spconv
+
+    out = set()
+    for name, m in model.named_modules():
+        if isinstance(m, spconv.SparseSequential):
+            mods = list(m._modules.items())
+            for (k0, a), (_, b) in zip(mods, mods[1:]):
+                if isinstance(a, spconv.SparseConvolution) and a.bias is not None and \
+                        isinstance(b, (torch.nn.BatchNorm1d,)):
+                    out.add("%s.%s.bias" % (name, k0))
+    return out
+
+
 def _run(model, examples, graphed, dtype):
     from det3d_amd import graph_tail
 
@@ -60,15 +75,24 @@ def test_graphed_tail_equals_the_eager_tail(dtype):
     assert "_graph_tails" in graphed.__dict__ and len(graphed.__dict__["_graph_tails"]) == 1, \
         "the tail was not captured: %s" % graphed.__dict__.get("_graph_tail_failed")
     assert "_graph_tails" not in eager.__dict__
-    # same kernels on the same data; MIOpen's split-K weight gradients and the BN atomics are order-dependent
+    # same kernels on the same data, but MIOpen's split-K weight gradients and the BatchNorm statistics are summed
+    # with atomics in a different order on every launch, and 14 train-mode BN layers amplify that (the 2-rank test
+    # in test_dist_gpu.py allows the same 1 % per element in f32)
     tol = 2e-4 if dtype is None else 2e-2
+    etol = 1e-2 if dtype is None else 1e-1
+    noise = _bias_before_bn(eager)
     for (la, lla, ga), (lb, llb, gb) in zip(a, b):
         assert lb == pytest.approx(la, rel=tol)
         assert llb == pytest.approx(lla, rel=tol)
         assert ga.keys() == gb.keys()
         for k in ga:
+            if k in noise:  # a bias in front of a train-mode BatchNorm: its exact gradient is 0, what is left is rounding
+                continue
             scale = float(ga[k].abs().max()) + 1e-12
-            assert float((ga[k] - gb[k]).abs().max()) <= tol * 5 * scale + 1e-7, k
+            assert float((ga[k] - gb[k]).abs().max()) <= etol * scale + 1e-7, k
+            if ga[k].numel() > 64:
+                cos = torch.nn.functional.cosine_similarity(ga[k].flatten(), gb[k].flatten(), dim=0)
+                assert float(cos) > (0.9995 if dtype is None else 0.99), k
     # BatchNorm running statistics advanced exactly as in the eager run (the capture warm-up is rolled back)
     sa, sb = eager.state_dict(), graphed.state_dict()
     for k in sa:
@@ -90,3 +114,45 @@ def test_graphed_tail_multi_task_head_and_train_step():
     losses = [float(step(ex)) for _ in range(6)]
     assert "_graph_tails" in model.__dict__, model.__dict__.get("_graph_tail_failed")
     assert all(torch.isfinite(torch.tensor(losses))) and min(losses[1:]) < losses[0]
+
+
+def test_prefetched_geometry_is_the_inline_geometry():
+    """prefetch.GeometryPrefetcher: example + rulebooks built on the side stream give the same step as the inline
+    path, and the backbone really consumes the prefetched plan (no second planning pass)."""
+    from det3d_amd import graph_tail, synthetic
+    from det3d_amd.prefetch import GeometryPrefetcher
+
+    cfg, model = _model("kitti_car_second.py")
+    ds = synthetic.KittiCarSynthetic(n_points=9000, n_seeds=4)
+    dev = torch.device("cuda", 0)
+    make = lambda i: synthetic.make_example(ds.device_batch(i, 2, dev), synthetic.KITTI_CAR)
+    pf = GeometryPrefetcher(make, model, dev)
+    graph_tail.GRAPH_TAIL = False
+    try:
+        for i in range(3):
+            ex_a = make(i)
+            model.zero_grad(set_to_none=True)
+            la = sum(model(ex_a, return_loss=True)["loss"])
+            la.backward()
+            ga = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+            ex_b = pf.prepare(i)
+            assert "sparse_plan" in ex_b and pf.stream is not None
+            calls = []
+            orig = model.backbone.middle_conv.plan
+            model.backbone.middle_conv.plan = lambda x: calls.append(1) or orig(x)
+            try:
+                model.zero_grad(set_to_none=True)
+                lb = sum(model(ex_b, return_loss=True)["loss"])
+                lb.backward()
+            finally:
+                del model.backbone.middle_conv.plan
+            assert not calls, "the backbone planned its rulebooks again"
+            assert float(lb) == pytest.approx(float(la), rel=1e-5)
+            noise = _bias_before_bn(model)
+            for k, g in ga.items():
+                if k in noise:
+                    continue
+                scale = float(g.abs().max()) + 1e-12
+                assert float((g - model.get_parameter(k).grad).abs().max()) <= 1e-2 * scale + 1e-7, k
+    finally:
+        graph_tail.GRAPH_TAIL = True

@@ -7,6 +7,9 @@ r = d.get("roofline", {})
 print("value %.1f %s  %.3f ms/step  roofline %s (%s us, %s GB/s)  sparse %s ms" % (
     d["value"], d["unit"], d["ms_per_step"], r.get("frac"), r.get("avg_launch_us"), r.get("achieved"),
     d.get("sparse_conv_ms_per_step")))
+c = d.get("config", {})
+print("   host ms/step %s  graphed_tail %s  prefetch %s  burn-in %s" % (
+    c.get("host_ms_per_step"), c.get("graphed_tail"), c.get("geometry_prefetch"), c.get("burn_in_steps")))
 for k, v in (d.get("kernels") or {}).items():
     print("   %-34s x%-2d %7.2f us  %7.1f GB/s" % (k, v["launches_per_step"], v["avg_us"], v.get("achieved_GBs", 0)))
 for k in ("fp32", "predict", "rpn_mfma", "precision", "stages", "probe_error", "fp32_error"):
