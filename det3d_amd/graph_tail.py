@@ -86,6 +86,12 @@ class GraphedTail:
         if not head.loss_vector_ok(bev, flat[: len(example["labels"])]):
             return None
         tail = _Tail(neck, head, with_anchors)
+        # the gradient accumulators of the parameters are created lazily, on whatever stream is current at their
+        # first use; make that the compute stream now -- inside make_graphed_callables it would be the capture
+        # stream, and every later backward would hop streams to accumulate (and run the gradient hooks there)
+        for p in tail.parameters():
+            if p.requires_grad:
+                p.view_as(p).grad_fn.next_functions[0][0]
         sample = (bev.detach().clone().requires_grad_(True),) + tuple(t.clone() for t in flat)
         ctx = torch.autocast(device_type="cuda", dtype=autocast_dtype, cache_enabled=False) \
             if autocast_dtype is not None else torch.autocast(device_type="cuda", enabled=False)

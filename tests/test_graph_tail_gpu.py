@@ -68,31 +68,32 @@ def _run(model, examples, graphed, dtype):
 @pytest.mark.parametrize("dtype", [None, torch.bfloat16])
 def test_graphed_tail_equals_the_eager_tail(dtype):
     cfg, eager = _model("kitti_car_second.py")
+    eager2 = copy.deepcopy(eager)
     graphed = copy.deepcopy(eager)
     examples = _kitti_examples(3)
     a = _run(eager, examples, False, dtype)
+    a2 = _run(eager2, examples, False, dtype)  # the run-to-run noise of the eager step itself
     b = _run(graphed, examples, True, dtype)
     assert "_graph_tails" in graphed.__dict__ and len(graphed.__dict__["_graph_tails"]) == 1, \
         "the tail was not captured: %s" % graphed.__dict__.get("_graph_tail_failed")
     assert "_graph_tails" not in eager.__dict__
-    # same kernels on the same data, but MIOpen's split-K weight gradients and the BatchNorm statistics are summed
-    # with atomics in a different order on every launch, and 14 train-mode BN layers amplify that (the 2-rank test
-    # in test_dist_gpu.py allows the same 1 % per element in f32)
+    # Same kernels on the same data -- but MIOpen's split-K weight gradients and the BatchNorm statistics are
+    # summed with atomics in a different order on every launch, and 14 train-mode BN + ReLU layers amplify that
+    # (in bf16 up to tens of percent on single elements of the stem's weight gradient).  So the yardstick is the
+    # eager step against ITSELF: the graphed step may deviate from eager run 1 by a few times what eager run 2 does.
     tol = 2e-4 if dtype is None else 2e-2
-    etol = 1e-2 if dtype is None else 1e-1
-    noise = _bias_before_bn(eager)
-    for (la, lla, ga), (lb, llb, gb) in zip(a, b):
-        assert lb == pytest.approx(la, rel=tol)
-        assert llb == pytest.approx(lla, rel=tol)
+    floor = 1e-3 if dtype is None else 1e-2
+    for (la, lla, ga), (la2, _, ga2), (lb, llb, gb) in zip(a, a2, b):
+        assert lb == pytest.approx(la, rel=tol + 4 * abs(la2 - la) / abs(la))
+        assert llb == pytest.approx(lla, rel=10 * tol)
         assert ga.keys() == gb.keys()
         for k in ga:
-            if k in noise:  # a bias in front of a train-mode BatchNorm: its exact gradient is 0, what is left is rounding
-                continue
             scale = float(ga[k].abs().max()) + 1e-12
-            assert float((ga[k] - gb[k]).abs().max()) <= etol * scale + 1e-7, k
+            noise = float((ga[k] - ga2[k]).abs().max())
+            assert float((ga[k] - gb[k]).abs().max()) <= 4 * noise + floor * scale + 1e-7, (k, noise / scale)
             if ga[k].numel() > 64:
-                cos = torch.nn.functional.cosine_similarity(ga[k].flatten(), gb[k].flatten(), dim=0)
-                assert float(cos) > (0.9995 if dtype is None else 0.99), k
+                cos = lambda x, y: float(torch.nn.functional.cosine_similarity(x.flatten(), y.flatten(), dim=0))
+                assert 1 - cos(ga[k], gb[k]) <= 4 * (1 - cos(ga[k], ga2[k])) + (5e-4 if dtype is None else 1e-2), k
     # BatchNorm running statistics advanced exactly as in the eager run (the capture warm-up is rolled back)
     sa, sb = eager.state_dict(), graphed.state_dict()
     for k in sa:
