@@ -64,6 +64,113 @@ extern "C" int d3d_set_tuning(int knob, int value) {
 }
 
 
+// epilogue shared by the forward kernels: lane holds couts [n*16 + lg*4, +4) of site[m].  Optional per-channel
+// reductions ride along (each saves one full sweep over the activations, see D3dConvEpilogue in include/d3d.h):
+//   ep.stats      forward : sum / sum of squares of the rows just produced (BatchNorm batch statistics)
+//   ep.bn_partial dgrad   : sum dz * xhat | sum dz of the BatchNorm(+ReLU) that produced this conv's input
+// `red`: LDS scratch [2 * COUT] no wave still reads for anything else.
+template <int COUT, int MT, bool BF16, int NTHREADS>
+__device__ __forceinline__ void spconv_fwd_epilogue(f32x4_t (&acc)[MT][COUT / 16], const int (&site)[MT],
+                                                    const bool (&live)[MT], const float *__restrict__ bias,
+                                                    void *__restrict__ out_, const D3dConvEpilogue &ep, float *red,
+                                                    int lr, int lg) {
+  constexpr int NT = COUT / 16;
+  const bool want_stats = ep.stats != nullptr, want_bnb = ep.bn_partial != nullptr;
+  if (want_stats || want_bnb) {
+    for (int i = threadIdx.x; i < 2 * COUT; i += NTHREADS) red[i] = 0.f;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int co = n * 16 + lg * 4;
+    float r0[4] = {0.f, 0.f, 0.f, 0.f}, r1[4] = {0.f, 0.f, 0.f, 0.f};
+    float bmu[4], bis[4], bga[4], bbe[4];
+    if (want_bnb) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bmu[j] = ep.bn_mean[co + j];
+        bis[j] = ep.bn_invstd[co + j];
+        bga[j] = ep.bn_gamma ? ep.bn_gamma[co + j] : 1.f;
+        bbe[j] = ep.bn_beta ? ep.bn_beta[co + j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (!live[m]) continue;
+      f32x4_t v = acc[m][n];
+      if (bias) {
+        v[0] += bias[co + 0];
+        v[1] += bias[co + 1];
+        v[2] += bias[co + 2];
+        v[3] += bias[co + 3];
+      }
+      float w[4];  // the values as stored (rounded to the feature dtype): what the next pass will read
+      if constexpr (BF16) {
+        uint16_t *o = (uint16_t *)out_ + (int64_t)site[m] * COUT + co;
+        const uint16_t h0 = f32_to_bf16(v[0]), h1 = f32_to_bf16(v[1]), h2 = f32_to_bf16(v[2]), h3 = f32_to_bf16(v[3]);
+        uint2 pk;
+        pk.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        pk.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
+        *(uint2 *)o = pk;
+        w[0] = bf16_to_f32(h0); w[1] = bf16_to_f32(h1); w[2] = bf16_to_f32(h2); w[3] = bf16_to_f32(h3);
+      } else {
+        float *o = (float *)out_ + (int64_t)site[m] * COUT + co;
+        *(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);
+        w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3];
+      }
+      if (want_stats) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          r0[j] += w[j];
+          r1[j] = fmaf(w[j], w[j], r1[j]);
+        }
+      }
+      if (want_bnb) {
+        float x[4];
+        if constexpr (BF16) {
+          const uint2 xr = *(const uint2 *)((const uint16_t *)ep.bn_x + (int64_t)site[m] * COUT + co);
+          x[0] = bf16_to_f32((uint16_t)(xr.x & 0xffffu)); x[1] = bf16_to_f32((uint16_t)(xr.x >> 16));
+          x[2] = bf16_to_f32((uint16_t)(xr.y & 0xffffu)); x[3] = bf16_to_f32((uint16_t)(xr.y >> 16));
+        } else {
+          const float4 xr = *(const float4 *)((const float *)ep.bn_x + (int64_t)site[m] * COUT + co);
+          x[0] = xr.x; x[1] = xr.y; x[2] = xr.z; x[3] = xr.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // same arithmetic as bn_bwd_reduce_kernel (d3d_bn.hip)
+          const float xh = (x[j] - bmu[j]) * bis[j];
+          const float dz = (ep.bn_relu && fmaf(xh, bga[j], bbe[j]) <= 0.f) ? 0.f : w[j];
+          r0[j] = fmaf(dz, xh, r0[j]);
+          r1[j] += dz;
+        }
+      }
+    }
+    if (want_stats || want_bnb) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a0 = r0[j], a1 = r1[j];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {  // the 16 sites of a tile sit in lanes lr = 0..15
+          a0 += __shfl_xor(a0, o, 64);
+          a1 += __shfl_xor(a1, o, 64);
+        }
+        if (lr == 0) {
+          atomicAdd(&red[co + j], a0);
+          atomicAdd(&red[COUT + co + j], a1);
+        }
+      }
+    }
+  }
+  if (want_stats || want_bnb) {
+    __syncthreads();
+    // [copy][2 * COUT]: (sum | sum sq) or (dgamma | dbeta), replicated to spread same-address atomics
+    // [copy][2 * COUT]: (sum | sum sq) or (dgamma | dbeta), replicated to spread same-address atomics.  (Agent-
+    // and workgroup-scope float adds lower to the same global_atomic_add_f32 on gfx950 and execute beyond the
+    // XCD's L2, so a per-XCD replica indexed by HW_REG_XCC_ID buys nothing over blockIdx % 8.)
+    float *dst = (want_stats ? ep.stats : ep.bn_partial) + (size_t)(blockIdx.x % (unsigned)ep.copies) * 2 * COUT;
+    for (int i = threadIdx.x; i < 2 * COUT; i += NTHREADS) atomicAdd(&dst[i], red[i]);
+  }
+}
+
 // ===================================================================== forward
 // One wave = MT tiles of 16 output sites x all COUT columns; a block is WAVES waves that share W[k]: the
 // block stages W[k] (COUT x CIN) in LDS once per kernel offset (double buffered, +16 B row padding so
@@ -245,105 +352,157 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
     }
   }
 
-  // epilogue: lane holds couts [n*16 + lg*4, +4) of site[m].  Optional per-channel reductions ride along
-  // (each saves one full sweep over the activations, see D3dConvEpilogue in include/d3d.h):
-  //   ep.stats      forward : sum / sum of squares of the rows just produced (BatchNorm batch statistics)
-  //   ep.bn_partial dgrad   : sum dz * xhat | sum dz of the BatchNorm(+ReLU) that produced this conv's input
-  const bool want_stats = ep.stats != nullptr, want_bnb = ep.bn_partial != nullptr;
-  float *red = (float *)wlds;  // [2 * COUT]; every wave is past the last barrier of the offset loop
-  if (want_stats || want_bnb) {
-    for (int i = threadIdx.x; i < 2 * COUT; i += NTHREADS) red[i] = 0.f;
-    __syncthreads();
+  // every wave is past the last barrier of the offset loop: the W buffers are free for the epilogue's sums
+  spconv_fwd_epilogue<COUT, MT, BF16, NTHREADS>(acc, site, live, bias, out_, ep, (float *)wlds, lr, lg);
+}
+
+// ---- chunk-resident weights (bf16, CIN % 32 == 0) ------------------------------------------------------------
+// The kernel above exchanges W[k] through LDS once per kernel offset, i.e. one workgroup barrier per offset: the
+// waves of a block run in lock step, so they all issue their gathers in the same cycles (SQ_VMEM_TA_CMD_FIFO_FULL
+// 20 % of the time), then all read LDS (29 % of the LDS cycles are bank conflicts on the padded rows), then all
+// queue for the MFMA pipe.  Counter passes on the 64->64 layer (profiles/round2_pmc_fwd.txt) show no unit above
+// 50 % (TA 44-50 %, LDS 28 %, MFMA 17-20 %, VALU 16 %): the time is the SUM of the phases, not their maximum.
+// Here W stays resident in LDS for KC offsets at a time (64->64: 9 offsets = 72 KB, unpadded rows with an XOR
+// swizzle of the 16-byte cells instead of padding, two blocks per CU), loaded with global_load_lds (no staging
+// registers, no ds_write) and fenced by ONE barrier pair per chunk: 3 instead of 27 rendezvous, and between them
+// every wave walks its offsets at its own pace, so gather issue, LDS reads and MFMAs of different waves overlap.
+//   LDS cell (16 B) c of a chunk holds weight cell c ^ ((c >> 4) & 15): global_load_lds writes lane-linear, so
+//   the (involutive) permutation is applied to the SOURCE address and again on the read side; the 16 lanes of an
+//   MFMA A-fragment read (rows r..r+15, same segment) then hit 16 distinct 16-byte bank groups.
+template <int CIN, int COUT, int MT, int WAVES, int DEPTH, int KC>
+__global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))  // second value: waves per SIMD
+    spconv_fwd_chunk_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
+                            const float *__restrict__ bias, const int32_t *__restrict__ nbr, int cap, int n_out,
+                            int kvol, void *__restrict__ out_, D3dConvEpilogue ep) {
+  constexpr int NT = COUT / 16;
+  constexpr int ESZ = 2, KW = 32, EPL = 8;
+  constexpr int KS = CIN / KW;
+  constexpr int SEGS = CIN * ESZ / 16;   // 16-byte cells per weight row
+  constexpr int WVEC = COUT * SEGS;      // cells per kernel offset
+  constexpr int CHUNK = KC * WVEC;       // cells per chunk
+  constexpr int NTHREADS = WAVES * 64;
+  constexpr int GPW = (CHUNK + NTHREADS - 1) / NTHREADS;  // global_load_lds instructions per wave and chunk
+  static_assert(CIN % 32 == 0 && COUT % 16 == 0, "bf16 x32 MFMA tiles");
+  static_assert(WVEC % 256 == 0, "the swizzle must not see the offset index");
+  static_assert(CHUNK % 64 == 0 && KC % DEPTH == 0, "chunk / pipeline shape");
+  __shared__ __attribute__((aligned(16))) unsigned char wlds[CHUNK * 16];
+  __shared__ float red[2 * COUT];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int row0 = (blockIdx.x * WAVES + wave) * (MT * 16);
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  int site[MT];
+  bool live[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    site[m] = row0 + m * 16 + lr;
+    live[m] = site[m] < n_out;
   }
+  const __amdgpu_buffer_rsrc_t feat_rs = d3d_make_rsrc(feat_);
+  const uint32_t lane_off = (uint32_t)(lg * EPL * ESZ);
+  const int kmax = kvol - 1;
+  auto load_idx = [&](int k, int (&ix)[MT]) {
+    k = k < kmax ? k : kmax;
+    const int32_t *nk = nbr + (int64_t)k * cap;
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int co = n * 16 + lg * 4;
-    float r0[4] = {0.f, 0.f, 0.f, 0.f}, r1[4] = {0.f, 0.f, 0.f, 0.f};
-    float bmu[4], bis[4], bga[4], bbe[4];
-    if (want_bnb) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        bmu[j] = ep.bn_mean[co + j];
-        bis[j] = ep.bn_invstd[co + j];
-        bga[j] = ep.bn_gamma ? ep.bn_gamma[co + j] : 1.f;
-        bbe[j] = ep.bn_beta ? ep.bn_beta[co + j] : 0.f;
-      }
-    }
+    for (int m = 0; m < MT; ++m) ix[m] = nk[(uint32_t)(live[m] ? site[m] : n_out - 1)];
+  };
+  auto gather = [&](const int (&ix)[MT], uint4 (&f)[MT][KS]) -> unsigned long long {
+    bool any = false;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      if (!live[m]) continue;
-      f32x4_t v = acc[m][n];
-      if (bias) {
-        v[0] += bias[co + 0];
-        v[1] += bias[co + 1];
-        v[2] += bias[co + 2];
-        v[3] += bias[co + 3];
-      }
-      float w[4];  // the values as stored (rounded to the feature dtype): what the next pass will read
-      if constexpr (BF16) {
-        uint16_t *o = (uint16_t *)out_ + (int64_t)site[m] * COUT + co;
-        const uint16_t h0 = f32_to_bf16(v[0]), h1 = f32_to_bf16(v[1]), h2 = f32_to_bf16(v[2]), h3 = f32_to_bf16(v[3]);
-        uint2 pk;
-        pk.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
-        pk.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
-        *(uint2 *)o = pk;
-        w[0] = bf16_to_f32(h0); w[1] = bf16_to_f32(h1); w[2] = bf16_to_f32(h2); w[3] = bf16_to_f32(h3);
-      } else {
-        float *o = (float *)out_ + (int64_t)site[m] * COUT + co;
-        *(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);
-        w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3];
-      }
-      if (want_stats) {
+      const bool ok = live[m] && ix[m] >= 0;
+      any |= ok;
+      const uint32_t base = ok ? (uint32_t)ix[m] * (uint32_t)(CIN * ESZ) + lane_off : D3D_OOB_OFFSET;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          r0[j] += w[j];
-          r1[j] = fmaf(w[j], w[j], r1[j]);
-        }
-      }
-      if (want_bnb) {
-        float x[4];
-        if constexpr (BF16) {
-          const uint2 xr = *(const uint2 *)((const uint16_t *)ep.bn_x + (int64_t)site[m] * COUT + co);
-          x[0] = bf16_to_f32((uint16_t)(xr.x & 0xffffu)); x[1] = bf16_to_f32((uint16_t)(xr.x >> 16));
-          x[2] = bf16_to_f32((uint16_t)(xr.y & 0xffffu)); x[3] = bf16_to_f32((uint16_t)(xr.y >> 16));
-        } else {
-          const float4 xr = *(const float4 *)((const float *)ep.bn_x + (int64_t)site[m] * COUT + co);
-          x[0] = xr.x; x[1] = xr.y; x[2] = xr.z; x[3] = xr.w;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {  // same arithmetic as bn_bwd_reduce_kernel (d3d_bn.hip)
-          const float xh = (x[j] - bmu[j]) * bis[j];
-          const float dz = (ep.bn_relu && fmaf(xh, bga[j], bbe[j]) <= 0.f) ? 0.f : w[j];
-          r0[j] = fmaf(dz, xh, r0[j]);
-          r1[j] += dz;
-        }
-      }
+      for (int ks = 0; ks < KS; ++ks)
+        f[m][ks] = d3d_buffer_load16(feat_rs, ok ? base + (uint32_t)(ks * KW * ESZ) : D3D_OOB_OFFSET);
     }
-    if (want_stats || want_bnb) {
+    return __ballot(any);
+  };
+  // this lane's A-fragment cells inside one offset (swizzled), bytes
+  uint32_t woff[NT][KS];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float a0 = r0[j], a1 = r1[j];
+  for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {  // the 16 sites of a tile sit in lanes lr = 0..15
-          a0 += __shfl_xor(a0, o, 64);
-          a1 += __shfl_xor(a1, o, 64);
+    for (int ks = 0; ks < KS; ++ks) {
+      uint32_t c = (uint32_t)((n * 16 + lr) * SEGS + ks * (KW * ESZ / 16) + lg);
+      c ^= (c >> 4) & 15u;
+      woff[n][ks] = c * 16u;
+    }
+  const unsigned char *wg = (const unsigned char *)wpack_;
+  const uint32_t wcells = (uint32_t)kvol * WVEC;
+  auto load_chunk = [&](int k0) {  // W[k0 .. k0+KC) -> LDS, lane-linear destination, permuted source
+#pragma unroll
+    for (int j = 0; j < GPW; ++j) {
+      if (CHUNK % NTHREADS != 0 && (j * WAVES + wave) * 64 >= CHUNK) break;  // wave-uniform
+      const uint32_t d = (uint32_t)((j * WAVES + wave) * 64 + lane);
+      uint32_t g = (uint32_t)k0 * WVEC + (d ^ ((d >> 4) & 15u));
+      g = g < wcells ? g : wcells - 1;  // offsets past the last one (kvol < KC): never read
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wg + (size_t)g * 16),
+                                       (__attribute__((address_space(3))) void *)(wlds + (j * WAVES + wave) * 1024),
+                                       16, 0, 0);
+    }
+  };
+
+  uint4 fr[DEPTH][MT][KS];
+  int ix[DEPTH][MT];
+  unsigned long long okm[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load_idx(d, ix[d]);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    okm[d] = gather(ix[d], fr[d]);
+    load_idx(d + DEPTH, ix[d]);
+  }
+
+  for (int k0 = 0; k0 < kvol; k0 += KC) {
+    if (k0) d3d_lds_barrier();  // every wave has finished reading the previous chunk
+    load_chunk(k0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // loads retire in order: the prefetched gathers landed too
+    d3d_lds_barrier();
+#pragma unroll 1
+    for (int kb = k0; kb < k0 + KC && kb < kvol; kb += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const int k = kb + d;
+        if (k < kvol && okm[d] != 0ull) {
+          const unsigned char *wk = wlds + (uint32_t)(k - k0) * (WVEC * 16);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              const uint4 wa = *(const uint4 *)(wk + woff[n][ks]);
+#pragma unroll
+              for (int m = 0; m < MT; ++m)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, fr[d][m][ks]), acc[m][n], 0, 0, 0);
+            }
         }
-        if (lr == 0) {
-          atomicAdd(&red[co + j], a0);
-          atomicAdd(&red[COUT + co + j], a1);
-        }
+        okm[d] = gather(ix[d], fr[d]);  // offset k + DEPTH
+        load_idx(k + 2 * DEPTH, ix[d]);
       }
     }
   }
-  if (want_stats || want_bnb) {
-    __syncthreads();
-    // [copy][2 * COUT]: (sum | sum sq) or (dgamma | dbeta), replicated to spread same-address atomics
-    // [copy][2 * COUT]: (sum | sum sq) or (dgamma | dbeta), replicated to spread same-address atomics.  (Agent-
-    // and workgroup-scope float adds lower to the same global_atomic_add_f32 on gfx950 and execute beyond the
-    // XCD's L2, so a per-XCD replica indexed by HW_REG_XCC_ID buys nothing over blockIdx % 8.)
-    float *dst = (want_stats ? ep.stats : ep.bn_partial) + (size_t)(blockIdx.x % (unsigned)ep.copies) * 2 * COUT;
-    for (int i = threadIdx.x; i < 2 * COUT; i += NTHREADS) atomicAdd(&dst[i], red[i]);
-  }
+  spconv_fwd_epilogue<COUT, MT, true, NTHREADS>(acc, site, live, bias, out_, ep, red, lr, lg);
+}
+
+template <int CIN, int COUT, int MT, int WAVES, int DEPTH, int KC>
+static int launch_fwd_chunk(const void *feat, const void *wpack, const float *bias, const int32_t *nbr, int cap,
+                            int n_out, int kvol, void *out, const D3dConvEpilogue &ep, hipStream_t stream) {
+  const int rows_per_block = WAVES * MT * 16;
+  const int nb = (n_out + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL((spconv_fwd_chunk_kernel<CIN, COUT, MT, WAVES, DEPTH, KC>), dim3(nb), dim3(WAVES * 64), 0,
+                     stream, feat, wpack, bias, nbr, cap, n_out, kvol, out, ep);
+  D3D_LAUNCH_TRY("spconv_fwd_chunk_kernel");
+  return D3D_OK;
 }
 
 // generic fallback (any cin/cout, e.g. the 4->16 / 5->16 stem): one thread per
@@ -447,6 +606,15 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
     FWD_VAR(9, 4, 4, 3)
     FWD_VAR(10, 1, 8, 4)
 #undef FWD_VAR
+#define FWD_CHUNK(V, MT, WV, DP, KC) \
+    if (fwd_variant == V) return launch_fwd_chunk<64, 64, MT, WV, DP, KC>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    FWD_CHUNK(20, 2, 8, 3, 9)
+    FWD_CHUNK(21, 1, 16, 3, 9)
+    FWD_CHUNK(22, 2, 4, 3, 9)
+    FWD_CHUNK(23, 2, 8, 1, 9)
+    FWD_CHUNK(24, 4, 4, 3, 9)
+    FWD_CHUNK(25, 1, 8, 3, 9)
+#undef FWD_CHUNK
   }
   FWD_CASE(16, 16, 2, 8, 5, 4)
   FWD_CASE(16, 32, 2, 8, 5, 4)

@@ -58,42 +58,38 @@ def timed(call, reps=30):
 
 
 say("forward 64->64 bf16, n=%d sites, %d pairs, B_alg %.1f MB" % (n, P, balg / 1e6))
-for remap in (1, 0):
-    L.d3d_set_tuning(2, remap)
-    for v in (0, 1, 2, 3, 5, 7, 8, 9, 10):
-        L.d3d_set_tuning(0, v)
-        res = []
-        for epi in (False, True):
-            ep = _lib.ConvEpilogue(stats=stats.data_ptr(), copies=8) if epi else None
-            res.append(timed(lambda: L.d3d_sparse_conv_fwd_ex(f.data_ptr(), w.data_ptr(), None, rb.nbr_out.data_ptr(), rb.cap_out,
-                                                              n, 27, 64, 64, 1, o.data_ptr(),
-                                                              ctypes.byref(ep) if ep else None, st)))
-        say("  xcd_remap %d variant %2d %-12s: plain %6.1f us (%.1f %% of 8 TB/s algorithmic), with BN-stats epilogue %6.1f us" % (
-            remap, v, names[v], res[0], balg / res[0] / 1e3 / 80, res[1]))
-L.d3d_set_tuning(0, -1)
-# a smaller level (the 64->64 layers of the deeper levels see 50-80 k sites): subsample the rulebook's rows
+names.update({20: "chunk MT2 x8w D3", 21: "chunk MT1 x16w D3", 22: "chunk MT2 x4w D3", 23: "chunk MT2 x8w D1",
+              24: "chunk MT4 x4w D3", 25: "chunk MT1 x8w D3"})
+variants = [int(v) for v in os.environ.get("D3D_TUNE_VARIANTS", "0,3,1,20,21,22,23,24,25").split(",")]
+
+
+def run(v, ep=None, rows=None):
+    L.d3d_set_tuning(0, v)
+    return L.d3d_sparse_conv_fwd_ex(f.data_ptr(), w.data_ptr(), None, rb.nbr_out.data_ptr(), rb.cap_out, rows or n, 27,
+                                    64, 64, 1, o.data_ptr(), ctypes.byref(ep) if ep else None, st)
+
+
+L.d3d_set_tuning(2, 0)
+run(0)
+ref = o.float().clone()
+stats.zero_()
+run(0, _lib.ConvEpilogue(stats=stats.data_ptr(), copies=8))
+ref_stats = stats.view(8, 128).sum(0).clone()
+for v in variants:
+    o.zero_()
+    _lib.check(run(v), "variant %d" % v)
+    err = float((o.float() - ref).abs().max())
+    stats.zero_()
+    run(v, _lib.ConvEpilogue(stats=stats.data_ptr(), copies=8))
+    serr = float(((stats.view(8, 128).sum(0) - ref_stats).abs() / (ref_stats.abs() + 1.0)).max())
+    res = []
+    for epi in (False, True):
+        ep = _lib.ConvEpilogue(stats=stats.data_ptr(), copies=8) if epi else None
+        res.append(timed(lambda: run(v, ep)))
+    say("  variant %2d %-18s: plain %6.1f us (%.1f %% of 8 TB/s algorithmic), with BN-stats epilogue %6.1f us; "
+        "max |out - variant 0| %.3g, stats rel err %.2g" % (v, names[v], res[0], balg / res[0] / 1e3 / 80, res[1], err, serr))
 n2 = n // 3
-for remap in (1, 0):
-    L.d3d_set_tuning(2, remap)
-    for v in (0, 1, 3, 5, 8, 10):
-        L.d3d_set_tuning(0, v)
-        us = timed(lambda: L.d3d_sparse_conv_fwd_ex(f.data_ptr(), w.data_ptr(), None, rb.nbr_out.data_ptr(), rb.cap_out, n2, 27,
-                                                    64, 64, 1, o.data_ptr(), None, st))
-        say("  first %d sites only: xcd_remap %d variant %2d %-12s: %6.1f us" % (n2, remap, v, names[v], us))
+for v in variants:
+    us = timed(lambda: run(v, None, n2))
+    say("  first %d sites only: variant %2d %-18s: %6.1f us" % (n2, v, names[v], us))
 L.d3d_set_tuning(0, -1)
-L.d3d_set_tuning(2, 0)
-say("weight gradient (tile kernel + reduce), same rulebook")
-for ci, co in ((64, 64), (32, 32), (16, 16)):
-    ff = torch.randn(n, ci, device=dev).bfloat16()
-    d = torch.randn(n, co, device=dev).bfloat16()
-    dw = torch.empty(27, ci, co, device=dev)
-    for blocks, remap in ((256, 1), (256, 0), (512, 1), (192, 1)):
-        L.d3d_set_tuning(1, blocks)
-        L.d3d_set_tuning(2, remap)
-        wsb = L.d3d_sparse_conv_wgrad_workspace_bytes(n, 27, ci, co, 1)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        us = timed(lambda: L.d3d_sparse_conv_wgrad(ff.data_ptr(), d.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, n, 27, ci, co,
-                                                   1, dw.data_ptr(), ws.data_ptr(), wsb, st), 20)
-        say("  %3dx%-3d blocks %4d xcd_remap %d: %6.1f us (both launches)" % (ci, co, blocks, remap, us))
-L.d3d_set_tuning(1, -1)
-L.d3d_set_tuning(2, 0)
