@@ -363,12 +363,11 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
 // queue for the MFMA pipe.  Counter passes on the 64->64 layer (profiles/round2_pmc_fwd.txt) show no unit above
 // 50 % (TA 44-50 %, LDS 28 %, MFMA 17-20 %, VALU 16 %): the time is the SUM of the phases, not their maximum.
 // Here W stays resident in LDS for KC offsets at a time (64->64: 9 offsets = 72 KB, unpadded rows with an XOR
-// swizzle of the 16-byte cells instead of padding, two blocks per CU), loaded with global_load_lds (no staging
-// registers, no ds_write) and fenced by ONE barrier pair per chunk: 3 instead of 27 rendezvous, and between them
-// every wave walks its offsets at its own pace, so gather issue, LDS reads and MFMAs of different waves overlap.
-//   LDS cell (16 B) c of a chunk holds weight cell c ^ ((c >> 4) & 15): global_load_lds writes lane-linear, so
-//   the (involutive) permutation is applied to the SOURCE address and again on the read side; the 16 lanes of an
-//   MFMA A-fragment read (rows r..r+15, same segment) then hit 16 distinct 16-byte bank groups.
+// swizzle of the 16-byte cells instead of padding, two blocks per CU) and is fenced by ONE barrier pair per chunk:
+// 3 instead of 27 rendezvous, and between them every wave walks its offsets at its own pace, so gather issue, LDS
+// reads and MFMAs of different waves overlap.
+//   weight cell (16 B) c of a chunk lives in LDS cell c ^ ((c >> 4) & 15): the 16 lanes of an MFMA A-fragment read
+//   (rows r..r+15, same segment) then hit 16 distinct 16-byte bank groups.
 template <int CIN, int COUT, int MT, int WAVES, int DEPTH, int KC>
 __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))  // second value: waves per SIMD
     spconv_fwd_chunk_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
@@ -427,10 +426,13 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4)) 
     }
     return __ballot(any);
   };
-  // this lane's A-fragment cells inside one offset (swizzled), bytes
-  uint32_t woff[NT][KS];
+  // this lane's A-fragment cell inside one offset (swizzled), bytes.  The swizzle term of row n*16 + lr only depends
+  // on n through the bits of (n*16*SEGS) >> 4 below 16, so a few registers cover all n (the rest is an immediate)
+  constexpr int NPER = (16 * SEGS / 16) >= 16 ? 1 : 16 / (16 * SEGS / 16);  // row tiles until the term repeats
+  constexpr int NW = NT < NPER ? NT : NPER;
+  uint32_t woff[NW][KS];
 #pragma unroll
-  for (int n = 0; n < NT; ++n)
+  for (int n = 0; n < NW; ++n)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       uint32_t c = (uint32_t)((n * 16 + lr) * SEGS + ks * (KW * ESZ / 16) + lg);
@@ -439,16 +441,27 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4)) 
     }
   const unsigned char *wg = (const unsigned char *)wpack_;
   const uint32_t wcells = (uint32_t)kvol * WVEC;
-  auto load_chunk = [&](int k0) {  // W[k0 .. k0+KC) -> LDS, lane-linear destination, permuted source
+  // W[k0 .. k0+KC) -> LDS through registers, SUB loads in flight per thread.  (global_load_lds would save the
+  // registers and the ds_write pass, but with an LDS-DMA possibly in flight hipcc waits vmcnt(0) before EVERY use
+  // of a gathered row -- measured: the offset pipeline collapses to depth 0.)
+  auto load_chunk = [&](int k0) {
+    constexpr int SUB = 3;
 #pragma unroll
-    for (int j = 0; j < GPW; ++j) {
-      if (CHUNK % NTHREADS != 0 && (j * WAVES + wave) * 64 >= CHUNK) break;  // wave-uniform
-      const uint32_t d = (uint32_t)((j * WAVES + wave) * 64 + lane);
-      uint32_t g = (uint32_t)k0 * WVEC + (d ^ ((d >> 4) & 15u));
-      g = g < wcells ? g : wcells - 1;  // offsets past the last one (kvol < KC): never read
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wg + (size_t)g * 16),
-                                       (__attribute__((address_space(3))) void *)(wlds + (j * WAVES + wave) * 1024),
-                                       16, 0, 0);
+    for (int j0 = 0; j0 < GPW; j0 += SUB) {
+      d3d_u32x4 w[SUB];
+#pragma unroll
+      for (int u = 0; u < SUB; ++u) {
+        if (j0 + u >= GPW) continue;
+        uint32_t g = (uint32_t)k0 * WVEC + (uint32_t)((j0 + u) * NTHREADS) + threadIdx.x;
+        g = g < wcells ? g : wcells - 1;  // offsets past the last one (kvol < KC): never read
+        w[u] = *(const d3d_u32x4 *)(wg + (size_t)g * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < SUB; ++u) {
+        if (j0 + u >= GPW) continue;
+        const uint32_t e = (uint32_t)((j0 + u) * NTHREADS) + threadIdx.x;
+        if (CHUNK % NTHREADS == 0 || e < (uint32_t)CHUNK) *(d3d_u32x4 *)(wlds + (e ^ ((e >> 4) & 15u)) * 16u) = w[u];
+      }
     }
   };
 
@@ -466,7 +479,6 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4)) 
   for (int k0 = 0; k0 < kvol; k0 += KC) {
     if (k0) d3d_lds_barrier();  // every wave has finished reading the previous chunk
     load_chunk(k0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // loads retire in order: the prefetched gathers landed too
     d3d_lds_barrier();
 #pragma unroll 1
     for (int kb = k0; kb < k0 + KC && kb < kvol; kb += DEPTH) {
@@ -479,7 +491,7 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4)) 
           for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-              const uint4 wa = *(const uint4 *)(wk + woff[n][ks]);
+              const uint4 wa = *(const uint4 *)(wk + woff[n % NW][ks] + (uint32_t)((n / NW) * NW * 16 * SEGS * 16));
 #pragma unroll
               for (int m = 0; m < MT; ++m)
                 acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
@@ -492,6 +504,159 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4)) 
     }
   }
   spconv_fwd_epilogue<COUT, MT, true, NTHREADS>(acc, site, live, bias, out_, ep, red, lr, lg);
+}
+
+// ---- grouped barriers: the pipelined kernel above with ONE rendezvous per DEPTH offsets -----------------------
+// LDS holds two groups of DEPTH weight matrices (unpadded rows, same cell swizzle as the chunk kernel).  During
+// group g every wave reads buffer g & 1 and writes W of group g+1 -- whose loads it issued a group earlier, riding the
+// same in-order vmcnt stream as the gathers -- into the other buffer; the barrier at the end of the group both
+// publishes those writes and retires the reads.  27 offsets = 9 barriers at DEPTH 3.
+template <int CIN, int COUT, int MT, int WAVES, int DEPTH>
+__global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
+    spconv_fwd_group_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
+                            const float *__restrict__ bias, const int32_t *__restrict__ nbr, int cap, int n_out,
+                            int kvol, void *__restrict__ out_, D3dConvEpilogue ep) {
+  constexpr int NT = COUT / 16;
+  constexpr int ESZ = 2, KW = 32, EPL = 8;
+  constexpr int KS = CIN / KW;
+  constexpr int SEGS = CIN * ESZ / 16;
+  constexpr int WVEC = COUT * SEGS;
+  constexpr int NTHREADS = WAVES * 64;
+  constexpr int WPT = (WVEC + NTHREADS - 1) / NTHREADS;
+  static_assert(CIN % 32 == 0 && COUT % 16 == 0 && WVEC % 256 == 0, "bf16 x32 MFMA tiles, swizzle period");
+  __shared__ __attribute__((aligned(16))) unsigned char wlds[2 * DEPTH * WVEC * 16];
+  __shared__ float red[2 * COUT];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int row0 = (blockIdx.x * WAVES + wave) * (MT * 16);
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  int site[MT];
+  bool live[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    site[m] = row0 + m * 16 + lr;
+    live[m] = site[m] < n_out;
+  }
+  const __amdgpu_buffer_rsrc_t feat_rs = d3d_make_rsrc(feat_);
+  const uint32_t lane_off = (uint32_t)(lg * EPL * ESZ);
+  const int kmax = kvol - 1;
+  auto load_idx = [&](int k, int (&ix)[MT]) {
+    k = k < kmax ? k : kmax;
+    const int32_t *nk = nbr + (int64_t)k * cap;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ix[m] = nk[(uint32_t)(live[m] ? site[m] : n_out - 1)];
+  };
+  auto gather = [&](const int (&ix)[MT], uint4 (&f)[MT][KS]) -> unsigned long long {
+    bool any = false;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const bool ok = live[m] && ix[m] >= 0;
+      any |= ok;
+      const uint32_t base = ok ? (uint32_t)ix[m] * (uint32_t)(CIN * ESZ) + lane_off : D3D_OOB_OFFSET;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        f[m][ks] = d3d_buffer_load16(feat_rs, ok ? base + (uint32_t)(ks * KW * ESZ) : D3D_OOB_OFFSET);
+    }
+    return __ballot(any);
+  };
+  constexpr int NPER = SEGS >= 16 ? 1 : 16 / SEGS;
+  constexpr int NW = NT < NPER ? NT : NPER;
+  uint32_t woff[NW][KS];
+#pragma unroll
+  for (int n = 0; n < NW; ++n)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint32_t c = (uint32_t)((n * 16 + lr) * SEGS + ks * (KW * ESZ / 16) + lg);
+      c ^= (c >> 4) & 15u;
+      woff[n][ks] = c * 16u;
+    }
+  const unsigned char *wg = (const unsigned char *)wpack_;
+  auto load_w = [&](int k, d3d_u32x4 (&w)[WPT]) {
+    k = k < kmax ? k : kmax;
+    const unsigned char *wk = wg + (size_t)k * (WVEC * 16);
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+      const int e = threadIdx.x + j * NTHREADS;
+      w[j] = *(const d3d_u32x4 *)(wk + (uint32_t)((e < WVEC ? e : WVEC - 1) * 16));
+    }
+  };
+  auto publish_w = [&](int buf, int slot, const d3d_u32x4 (&w)[WPT]) {
+    unsigned char *dst = wlds + (uint32_t)((buf * DEPTH + slot) * WVEC * 16);
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+      const uint32_t e = threadIdx.x + j * NTHREADS;
+      if (WVEC % NTHREADS == 0 || e < (uint32_t)WVEC) *(d3d_u32x4 *)(dst + (e ^ ((e >> 4) & 15u)) * 16u) = w[j];
+    }
+  };
+
+  // prologue: W(0..DEPTH) -> buffer 0; slots: fr[d] = gather(d), ix[d] = idx(d + DEPTH), wr[d] = W(d + DEPTH)
+  uint4 fr[DEPTH][MT][KS];
+  int ix[DEPTH][MT];
+  d3d_u32x4 wr[DEPTH][WPT];
+  unsigned long long okm[DEPTH];
+  {
+    d3d_u32x4 w0[DEPTH][WPT];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_w(d, w0[d]);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_idx(d, ix[d]);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_w(d + DEPTH, wr[d]);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      okm[d] = gather(ix[d], fr[d]);
+      load_idx(d + DEPTH, ix[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) publish_w(0, d, w0[d]);
+  }
+  d3d_lds_barrier();
+
+  int buf = 0;
+  for (int kb = 0; kb < kvol; kb += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int k = kb + d;
+      if (k < kvol && okm[d] != 0ull) {
+        const unsigned char *wk = wlds + (uint32_t)((buf * DEPTH + d) * WVEC * 16);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const uint4 wa = *(const uint4 *)(wk + woff[n % NW][ks] + (uint32_t)((n / NW) * NW * 16 * SEGS * 16));
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, fr[d][m][ks]), acc[m][n], 0, 0, 0);
+          }
+      }
+      publish_w(buf ^ 1, d, wr[d]);      // W(k + DEPTH): slot d of the next group
+      load_w(k + 2 * DEPTH, wr[d]);
+      okm[d] = gather(ix[d], fr[d]);     // offset k + DEPTH
+      load_idx(k + 2 * DEPTH, ix[d]);
+    }
+    d3d_lds_barrier();
+    buf ^= 1;
+  }
+  spconv_fwd_epilogue<COUT, MT, true, NTHREADS>(acc, site, live, bias, out_, ep, red, lr, lg);
+}
+
+template <int CIN, int COUT, int MT, int WAVES, int DEPTH>
+static int launch_fwd_group(const void *feat, const void *wpack, const float *bias, const int32_t *nbr, int cap,
+                            int n_out, int kvol, void *out, const D3dConvEpilogue &ep, hipStream_t stream) {
+  const int rows_per_block = WAVES * MT * 16;
+  const int nb = (n_out + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL((spconv_fwd_group_kernel<CIN, COUT, MT, WAVES, DEPTH>), dim3(nb), dim3(WAVES * 64), 0, stream,
+                     feat, wpack, bias, nbr, cap, n_out, kvol, out, ep);
+  D3D_LAUNCH_TRY("spconv_fwd_group_kernel");
+  return D3D_OK;
 }
 
 template <int CIN, int COUT, int MT, int WAVES, int DEPTH, int KC>
@@ -615,6 +780,15 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
     FWD_CHUNK(24, 4, 4, 3, 9)
     FWD_CHUNK(25, 1, 8, 3, 9)
 #undef FWD_CHUNK
+#define FWD_GROUP(V, MT, WV, DP) \
+    if (fwd_variant == V) return launch_fwd_group<64, 64, MT, WV, DP>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    FWD_GROUP(30, 2, 8, 3)
+    FWD_GROUP(31, 1, 16, 3)
+    FWD_GROUP(32, 2, 8, 2)
+    FWD_GROUP(33, 1, 8, 3)
+    FWD_GROUP(34, 2, 4, 3)
+    FWD_GROUP(35, 1, 8, 5)
+#undef FWD_GROUP
   }
   FWD_CASE(16, 16, 2, 8, 5, 4)
   FWD_CASE(16, 32, 2, 8, 5, 4)
