@@ -368,8 +368,8 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
 // reads and MFMAs of different waves overlap.
 //   weight cell (16 B) c of a chunk lives in LDS cell c ^ ((c >> 4) & 15): the 16 lanes of an MFMA A-fragment read
 //   (rows r..r+15, same segment) then hit 16 distinct 16-byte bank groups.
-template <int CIN, int COUT, int MT, int WAVES, int DEPTH, int KC>
-__global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))  // second value: waves per SIMD
+template <int CIN, int COUT, int MT, int WAVES, int DEPTH, int KC, int MINW>
+__global__ void __launch_bounds__(WAVES * 64, MINW)  // second value: waves per SIMD
     spconv_fwd_chunk_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
                             const float *__restrict__ bias, const int32_t *__restrict__ nbr, int cap, int n_out,
                             int kvol, void *__restrict__ out_, D3dConvEpilogue ep) {
@@ -487,16 +487,25 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4)) 
         const int k = kb + d;
         if (k < kvol && okm[d] != 0ull) {
           const unsigned char *wk = wlds + (uint32_t)(k - k0) * (WVEC * 16);
+          // all A fragments of this offset are requested before the first MFMA: one exposed LDS round trip per
+          // offset (the MFMAs then drain them with partial lgkmcnt waits) instead of one per fragment
+          uint4 wa[KS][NT];
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-              const uint4 wa = *(const uint4 *)(wk + woff[n % NW][ks] + (uint32_t)((n / NW) * NW * 16 * SEGS * 16));
+            for (int n = 0; n < NT; ++n)
+              wa[ks][n] = *(const uint4 *)(wk + woff[n % NW][ks] + (uint32_t)((n / NW) * NW * 16 * SEGS * 16));
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
               for (int m = 0; m < MT; ++m)
                 acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, fr[d][m][ks]), acc[m][n], 0, 0, 0);
-            }
+                    __builtin_bit_cast(bf16x8_t, wa[ks][n]), __builtin_bit_cast(bf16x8_t, fr[d][m][ks]), acc[m][n], 0, 0, 0);
+          // keep that order: left alone, the scheduler minimises registers and emits read / wait / 2 MFMAs eight times
+          __builtin_amdgcn_sched_group_barrier(0x100, KS * NT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, KS * NT * MT, 0);
         }
         okm[d] = gather(ix[d], fr[d]);  // offset k + DEPTH
         load_idx(k + 2 * DEPTH, ix[d]);
@@ -626,16 +635,22 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
       const int k = kb + d;
       if (k < kvol && okm[d] != 0ull) {
         const unsigned char *wk = wlds + (uint32_t)((buf * DEPTH + d) * WVEC * 16);
+        uint4 wa[KS][NT];  // requested together: one exposed LDS round trip per offset, not one per fragment
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            const uint4 wa = *(const uint4 *)(wk + woff[n % NW][ks] + (uint32_t)((n / NW) * NW * 16 * SEGS * 16));
+          for (int n = 0; n < NT; ++n)
+            wa[ks][n] = *(const uint4 *)(wk + woff[n % NW][ks] + (uint32_t)((n / NW) * NW * 16 * SEGS * 16));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
               acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                  __builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, fr[d][m][ks]), acc[m][n], 0, 0, 0);
-          }
+                  __builtin_bit_cast(bf16x8_t, wa[ks][n]), __builtin_bit_cast(bf16x8_t, fr[d][m][ks]), acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, KS * NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, KS * NT * MT, 0);
       }
       publish_w(buf ^ 1, d, wr[d]);      // W(k + DEPTH): slot d of the next group
       load_w(k + 2 * DEPTH, wr[d]);
@@ -659,12 +674,12 @@ static int launch_fwd_group(const void *feat, const void *wpack, const float *bi
   return D3D_OK;
 }
 
-template <int CIN, int COUT, int MT, int WAVES, int DEPTH, int KC>
+template <int CIN, int COUT, int MT, int WAVES, int DEPTH, int KC, int MINW = (MT * (COUT / 16) >= 16 ? 2 : 4)>
 static int launch_fwd_chunk(const void *feat, const void *wpack, const float *bias, const int32_t *nbr, int cap,
                             int n_out, int kvol, void *out, const D3dConvEpilogue &ep, hipStream_t stream) {
   const int rows_per_block = WAVES * MT * 16;
   const int nb = (n_out + rows_per_block - 1) / rows_per_block;
-  hipLaunchKernelGGL((spconv_fwd_chunk_kernel<CIN, COUT, MT, WAVES, DEPTH, KC>), dim3(nb), dim3(WAVES * 64), 0,
+  hipLaunchKernelGGL((spconv_fwd_chunk_kernel<CIN, COUT, MT, WAVES, DEPTH, KC, MINW>), dim3(nb), dim3(WAVES * 64), 0,
                      stream, feat, wpack, bias, nbr, cap, n_out, kvol, out, ep);
   D3D_LAUNCH_TRY("spconv_fwd_chunk_kernel");
   return D3D_OK;
@@ -762,6 +777,7 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
   if (fwd_variant && cin == 64 && cout == 64 && dtype == D3D_BF16) {
 #define FWD_VAR(V, MT, WV, DP) \
     if (fwd_variant == V) return launch_fwd<64, 64, MT, WV, DP, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    FWD_VAR(40, 2, 8, 3)  // the per-offset-barrier kernel that was the default before the grouped one
     FWD_VAR(1, 1, 16, 3)
     FWD_VAR(2, 1, 16, 5)
     FWD_VAR(3, 2, 8, 3)
@@ -779,7 +795,12 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
     FWD_CHUNK(23, 2, 8, 1, 9)
     FWD_CHUNK(24, 4, 4, 3, 9)
     FWD_CHUNK(25, 1, 8, 3, 9)
+    FWD_CHUNK(26, 2, 8, 2, 8)
 #undef FWD_CHUNK
+    // three blocks per CU: 6 offsets (48 KB) resident, <= 85 registers
+    if (fwd_variant == 27) return launch_fwd_chunk<64, 64, 1, 8, 1, 6, 6>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    if (fwd_variant == 28) return launch_fwd_chunk<64, 64, 1, 4, 1, 3, 6>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    if (fwd_variant == 29) return launch_fwd_chunk<64, 64, 1, 8, 1, 9, 4>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
 #define FWD_GROUP(V, MT, WV, DP) \
     if (fwd_variant == V) return launch_fwd_group<64, 64, MT, WV, DP>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
     FWD_GROUP(30, 2, 8, 3)
@@ -796,6 +817,9 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
   FWD_CASE(32, 32, 2, 8, 5, 3)
   FWD_CASE(32, 64, 2, 8, 4, 2)
   FWD_CASE(64, 32, 1, 16, 5, 2)
+  // 64 -> 64 bf16 (16 of the 39 launches of a KITTI step): grouped barriers, profiles/round2_tune_fwd.txt
+  if (cin == 64 && cout == 64 && dtype == D3D_BF16 && fwd_variant == 0)
+    return launch_fwd_group<64, 64, 2, 8, 2>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
   FWD_CASE(64, 64, 2, 8, 3, 1)
   FWD_CASE(64, 128, 1, 16, 3, 1)
   FWD_CASE(128, 64, 1, 16, 3, 1)

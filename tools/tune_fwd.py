@@ -59,9 +59,9 @@ def timed(call, reps=30):
 
 say("forward 64->64 bf16, n=%d sites, %d pairs, B_alg %.1f MB" % (n, P, balg / 1e6))
 names.update({20: "chunk MT2 x8w D3", 21: "chunk MT1 x16w D3", 22: "chunk MT2 x4w D3", 23: "chunk MT2 x8w D1",
-              24: "chunk MT4 x4w D3", 25: "chunk MT1 x8w D3", 30: "group MT2 x8w D3", 31: "group MT1 x16w D3",
+              24: "chunk MT4 x4w D3", 25: "chunk MT1 x8w D3", 26: "chunk8 MT2 x8w D2", 27: "chunk6 MT1 x8w D1 3blk", 28: "chunk3 MT1 x4w D1 6blk", 29: "chunk MT1 x8w D1", 30: "group MT2 x8w D3", 31: "group MT1 x16w D3",
               32: "group MT2 x8w D2", 33: "group MT1 x8w D3", 34: "group MT2 x4w D3", 35: "group MT1 x8w D5"})
-variants = [int(v) for v in os.environ.get("D3D_TUNE_VARIANTS", "0,3,20,21,22,23,24,25,30,31,32,33,34,35").split(",")]
+variants = [int(v) for v in os.environ.get("D3D_TUNE_VARIANTS", "0,23,25,27,28,29,32,33").split(",")]
 
 
 def run(v, ep=None, rows=None):
