@@ -1,0 +1,224 @@
+"""Runs of `SparseConvolution -> BatchNorm1d [-> ReLU]` layers as ONE autograd node.
+
+scn.py builds its backbones as long SparseSequentials of exactly these triples (SpMiddleFHD: 14 of them,
+det3d/models/backbones/scn.py:106-157).  Going through one `torch.autograd.Function` per conv and one per
+BatchNorm costs the host ~140 us per layer in the forward and ~100 us in the backward (Python wrappers, autograd
+graph nodes, SparseConvTensor objects) -- 2.0 + 1.5 ms of a 5.7 ms step, more than the GPU needs for those
+layers, i.e. the step was host-bound (profiles/round2_host_profile.txt).  Here the layer loop is a plain Python
+loop over C-ABI calls inside a single Function: the same kernels with the same arguments in the same order
+(conv forward with the BN-statistics epilogue, BN apply, and in the backward BN dx, conv dgrad with the
+BN-backward-sums epilogue for the layer in front, conv wgrad), no per-layer autograd bookkeeping.
+
+`run(seq, x)` is called by SparseSequential.forward; layers that do not fit the pattern (residual blocks,
+cross-rank BatchNorm, eval mode, empty tensors, VALU-fallback channel counts) keep the per-layer path.
+D3D_FUSE_STACK=0 disables it.
+"""
+import ctypes
+import os
+
+import torch
+from torch import nn
+
+from . import _lib
+
+FUSE_STACK = os.environ.get("D3D_FUSE_STACK", "1") != "0"
+
+
+class _Layer:
+    __slots__ = ("conv", "bn", "relu", "rb", "cin", "cout", "pad_cin")
+
+    def __init__(self, conv, bn, relu, rb):
+        self.conv, self.bn, self.relu, self.rb = conv, bn, relu, rb
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        self.pad_cin = 16 if (self.cin < 16 and self.cout % 16 == 0) else self.cin
+
+
+def _eligible(sp, conv, bn, feats_dtype, rb):
+    if conv.weight.dtype != torch.float32 or (conv.bias is not None and conv.bias.dtype != torch.float32):
+        return False
+    cin, cout = conv.in_channels, conv.out_channels
+    pad_cin = 16 if (cin < 16 and cout % 16 == 0) else cin
+    if not (pad_cin % 16 == 0 and cout % 16 == 0 and pad_cin <= 128 and cout <= 128):
+        return False  # VALU fallback kernels have no epilogues
+    if rb is None or rb.subm != conv.subm or rb.n_out <= 1 or rb.n_in <= 0:
+        return False
+    if type(bn) is not nn.BatchNorm1d or not bn.training or bn.momentum is None or not bn.track_running_stats:
+        return False
+    if bn.weight is None or bn.num_features != cout:
+        return False
+    if any(t is not None and t.dtype != torch.float32 for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)):
+        return False
+    epv = 8 if feats_dtype == torch.bfloat16 else 4
+    return cout % epv == 0 and 256 % (cout // epv) == 0
+
+
+def segment(sp, mods, start, x):
+    """the longest run of fusable (conv, bn[, relu]) triples beginning at mods[start]; returns (layers, next index)"""
+    layers = []
+    i = start
+    n_in = x.indices.shape[0]
+    while i + 1 < len(mods) and isinstance(mods[i], sp.SparseConvolution):
+        conv, bn = mods[i], mods[i + 1]
+        rb = x.indice_dict.get(conv._rulebook_key())
+        if rb is None or rb.n_in != n_in or not _eligible(sp, conv, bn, x.features.dtype, rb):
+            break
+        relu = i + 2 < len(mods) and type(mods[i + 2]) is nn.ReLU
+        layers.append(_Layer(conv, bn, relu, rb))
+        n_in = rb.n_out
+        i += 3 if relu else 2
+    return layers, i
+
+
+class _StackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, layers, sp, *params):
+        L = _lib.lib()
+        dev = feats.device
+        dtype = feats.dtype
+        dt = sp._DT[dtype]
+        st = _lib.stream_ptr(dev)
+        arena, copies = sp.ARENA, sp.EPI_COPIES
+        feats = feats.contiguous()
+        need_in_grad = ctx.needs_input_grad[0]
+        rec = []
+        x = feats
+        for li, ly in enumerate(layers):
+            rb, conv, bn = ly.rb, ly.conv, ly.bn
+            cin, cout, pad_cin = ly.cin, ly.cout, ly.pad_cin
+            if x.shape[0] != rb.n_in or x.shape[1] != cin:
+                raise _lib.D3dError("sparse stack: features %s do not match the rulebook (%d rows) / the conv "
+                                    "(%d channels)" % (tuple(x.shape), rb.n_in, cin))
+            if x.numel() * x.element_size() >= (1 << 31) - 16:
+                raise _lib.D3dError("sparse conv: the feature matrix must stay below 2 GB (buffer-descriptor gathers)")
+            if pad_cin != cin:
+                x = torch.nn.functional.pad(x, (0, pad_cin - cin))
+            wpack, wd = sp._packed_weights(conv.weight, rb.kvol, cin, cout, dtype, rb.subm,
+                                           li > 0 or need_in_grad, pad_cin)
+            out = torch.empty((rb.n_out, cout), dtype=dtype, device=dev)
+            stats = arena.take(dev, 2 * copies * cout)
+            ep = _lib.ConvEpilogue(stats=stats.data_ptr(), copies=copies)
+            b = conv.bias.detach() if conv.bias is not None else None
+            rc = sp._timed("fwd", pad_cin, cout, rb.n_out, rb, dev, lambda: L.d3d_sparse_conv_fwd_ex(
+                x.data_ptr(), wpack.data_ptr(), _lib.ptr(b), rb.nbr_out.data_ptr(), rb.cap_out, rb.n_out, rb.kvol,
+                pad_cin, cout, dt, out.data_ptr(), ctypes.byref(ep), st))
+            _lib.check(rc, "d3d_sparse_conv_fwd")
+            y = torch.empty_like(out)
+            save = torch.empty((2, cout), dtype=torch.float32, device=dev)
+            rc = L.d3d_bn_apply(out.data_ptr(), rb.n_out, cout, dt, bn.weight.data_ptr(), _lib.ptr(bn.bias),
+                                bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum),
+                                float(bn.eps), 1, int(ly.relu), stats.data_ptr(), copies, y.data_ptr(),
+                                save[0].data_ptr(), save[1].data_ptr(), st)
+            _lib.check(rc, "d3d_bn_apply")
+            # the conv behind this layer reduces this BatchNorm's backward sums in its dgrad epilogue
+            partial = arena.take(dev, 2 * copies * cout) if li + 1 < len(layers) else None
+            rec.append((x, out, save, wd, partial))
+            x = y
+        ctx.layers, ctx.rec, ctx.sp = layers, rec, sp
+        ctx.generation = arena.generation
+        ctx.dtype = dtype
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        sp, layers, rec = ctx.sp, ctx.layers, ctx.rec
+        dtype = ctx.dtype
+        dt = sp._DT[dtype]
+        dev = g.device
+        st = _lib.stream_ptr(dev)
+        copies = sp.EPI_COPIES
+        # arena slices are only ours until the next ARENA.reset(): a second forward in between -> separate sweeps
+        fused = sp.ARENA.generation == ctx.generation
+        grads = []  # per layer, in parameter order
+        reduced_next = False  # the previous iteration's dgrad filled rec[li][4]
+        for li in range(len(layers) - 1, -1, -1):
+            ly = layers[li]
+            rb, conv, bn = ly.rb, ly.conv, ly.bn
+            cin, cout, pad_cin = ly.cin, ly.cout, ly.pad_cin
+            x, out, save, wd, partial = rec[li]
+            dy = g.contiguous()
+            if dy.dtype != dtype:
+                dy = dy.to(dtype)
+            if reduced_next:
+                pcopies = copies
+            else:
+                pcopies = _lib.D3D_BN_COPIES
+                partial = torch.empty((2 * pcopies * cout,), dtype=torch.float32, device=dev)
+                rc = L.d3d_bn_bwd_reduce(out.data_ptr(), dy.data_ptr(), rb.n_out, cout, dt, bn.weight.data_ptr(),
+                                         _lib.ptr(bn.bias), save[0].data_ptr(), save[1].data_ptr(), int(ly.relu),
+                                         partial.data_ptr(), st)
+                _lib.check(rc, "d3d_bn_bwd_reduce")
+            gout = torch.empty_like(out)
+            gbn = torch.empty((2, cout), dtype=torch.float32, device=dev)
+            rc = L.d3d_bn_bwd_dx(out.data_ptr(), dy.data_ptr(), rb.n_out, cout, dt, bn.weight.data_ptr(),
+                                 _lib.ptr(bn.bias), save[0].data_ptr(), save[1].data_ptr(), int(ly.relu),
+                                 partial.data_ptr(), pcopies, gout.data_ptr(), gbn[0].data_ptr(), gbn[1].data_ptr(), st)
+            _lib.check(rc, "d3d_bn_bwd_dx")
+            # ---- conv backward
+            gin = None
+            reduced_next = False
+            if li > 0 or ctx.needs_input_grad[0]:
+                nbr, cap = (rb.nbr_out, rb.cap_out) if rb.subm else (rb.nbr_in, rb.cap_in)
+                gin = torch.empty((rb.n_in, pad_cin), dtype=dtype, device=dev)
+                ep = None
+                if li > 0 and fused and pad_cin == cin:
+                    pl = layers[li - 1]
+                    _, pout, psave, _, ppartial = rec[li - 1]
+                    ep = _lib.ConvEpilogue(bn_x=pout.data_ptr(), bn_mean=psave[0].data_ptr(),
+                                           bn_invstd=psave[1].data_ptr(), bn_gamma=pl.bn.weight.data_ptr(),
+                                           bn_beta=_lib.ptr(pl.bn.bias), bn_relu=int(pl.relu),
+                                           bn_partial=ppartial.data_ptr(), copies=copies)
+                    reduced_next = True
+                rc = sp._timed("dgrad", cout, pad_cin, rb.n_in, rb, dev, lambda: L.d3d_sparse_conv_fwd_ex(
+                    gout.data_ptr(), wd.data_ptr(), None, nbr.data_ptr(), cap, rb.n_in, rb.kvol, cout, pad_cin, dt,
+                    gin.data_ptr(), ctypes.byref(ep) if ep is not None else None, st))
+                _lib.check(rc, "d3d_sparse_conv_fwd(dgrad)")
+                if pad_cin != cin:
+                    gin = gin[:, :cin].contiguous()
+            gw = torch.empty((rb.kvol, pad_cin, cout), dtype=torch.float32, device=dev)
+            wsb = L.d3d_sparse_conv_wgrad_workspace_bytes(rb.n_out, rb.kvol, pad_cin, cout, dt)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+            rc = sp._timed("wgrad", pad_cin, cout, rb.n_out, rb, dev, lambda: L.d3d_sparse_conv_wgrad(
+                x.data_ptr(), gout.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, rb.n_out, rb.kvol, pad_cin, cout,
+                dt, gw.data_ptr(), ws.data_ptr(), wsb, st))
+            _lib.check(rc, "d3d_sparse_conv_wgrad")
+            if pad_cin != cin:
+                gw = gw[:, :cin]
+            lg = [gw.reshape(conv.weight.shape)]
+            if conv.bias is not None:
+                lg.append(gout.float().sum(0))
+            lg.append(gbn[0])
+            if bn.bias is not None:
+                lg.append(gbn[1])
+            grads.append(lg)
+            g = gin
+        flat = [t for lg in reversed(grads) for t in lg]
+        return (g, None, None) + tuple(flat)
+
+
+def params_of(layers):
+    out = []
+    for ly in layers:
+        out.append(ly.conv.weight)
+        if ly.conv.bias is not None:
+            out.append(ly.conv.bias)
+        out.append(ly.bn.weight)
+        if ly.bn.bias is not None:
+            out.append(ly.bn.bias)
+    return out
+
+
+def run(sp, layers, x):
+    """x: SparseConvTensor entering the first layer of `layers`; returns the SparseConvTensor after the last one."""
+    feats = _StackFn.apply(x.features, layers, sp, *params_of(layers))
+    last = layers[-1]
+    shape = x.spatial_shape
+    for ly in layers:
+        shape = ly.conv.out_spatial_shape(shape)
+    indices = x.indices
+    for ly in layers:
+        if not ly.conv.subm:
+            indices = ly.rb.out_indices
+    out = sp.SparseConvTensor(feats, indices, shape, x.batch_size, x.grid)
+    out.indice_dict = x.indice_dict
+    return out

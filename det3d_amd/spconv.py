@@ -19,13 +19,15 @@ There is no CPU implementation here: tensors must live on the GPU.
 import ctypes
 import math
 import os
+import sys
 
 import numpy as np
 import torch
 from torch import nn
 
-from . import _lib
+from . import _lib, sparse_stack
 
+_SELF = sys.modules[__name__]
 _DT = {torch.float32: _lib.D3D_F32, torch.bfloat16: _lib.D3D_BF16}
 
 # bench.py sets this to a list to time every d3d_sparse_conv_fwd launch with HIP events
@@ -710,8 +712,18 @@ class SparseSequential(SparseModule):
         mods = list(self._modules.values())
         i = 0
         link = None  # _BnLink of the fused BN whose output is `input.features` (if this stack produced it)
+        stack_ok = FUSE_BN_RELU and FUSE_BN_STATS and sparse_stack.FUSE_STACK and torch.is_grad_enabled()
         while i < len(mods):
             module = mods[i]
+            if stack_ok and isinstance(module, SparseConvolution) and isinstance(input, SparseConvTensor) and \
+                    input.features.is_cuda and input.features.dtype in _DT and input.indices.shape[0] > 1:
+                # a run of conv -> BatchNorm1d [-> ReLU] triples: one autograd node, a plain loop of C-ABI calls
+                layers, nxt = sparse_stack.segment(_SELF, mods, i, input)
+                if layers:
+                    input = sparse_stack.run(_SELF, layers, input)
+                    link = None
+                    i = nxt
+                    continue
             if isinstance(module, SparseConvolution) and FUSE_BN_RELU and i + 1 < len(mods) and \
                     isinstance(input, SparseConvTensor) and input.indices.shape[0] != 0 and \
                     _fusable_bn(mods[i + 1], input.features, channels=module.out_channels):

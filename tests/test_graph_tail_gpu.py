@@ -157,3 +157,43 @@ def test_prefetched_geometry_is_the_inline_geometry():
                 assert float((g - model.get_parameter(k).grad).abs().max()) <= 1e-2 * scale + 1e-7, k
     finally:
         graph_tail.GRAPH_TAIL = True
+
+
+@pytest.mark.parametrize("dtype", [None, torch.bfloat16])
+def test_fused_sparse_stack_equals_the_per_layer_path(dtype):
+    """sparse_stack.py: the whole SpMiddleFHD stack as one autograd node issues the same kernels as the per-layer
+    Functions -- same loss, same gradients (up to the run-to-run noise of the atomically summed BN statistics),
+    same running statistics."""
+    from det3d_amd import graph_tail, sparse_stack
+
+    cfg, a_model = _model("kitti_car_second.py")
+    a2_model = copy.deepcopy(a_model)
+    b_model = copy.deepcopy(a_model)
+    examples = _kitti_examples(2)
+    calls = []
+    orig = sparse_stack.run
+    try:
+        sparse_stack.FUSE_STACK = False
+        a = _run(a_model, examples, False, dtype)
+        a2 = _run(a2_model, examples, False, dtype)
+        sparse_stack.FUSE_STACK = True
+        sparse_stack.run = lambda sp, layers, x: calls.append(len(layers)) or orig(sp, layers, x)
+        b = _run(b_model, examples, False, dtype)
+    finally:
+        sparse_stack.FUSE_STACK = True
+        sparse_stack.run = orig
+        graph_tail.GRAPH_TAIL = True
+    assert calls == [14, 14], calls  # all 14 conv-BN-ReLU triples of SpMiddleFHD in one node, once per step
+    tol = 2e-4 if dtype is None else 2e-2
+    floor = 1e-3 if dtype is None else 1e-2
+    for (la, _, ga), (la2, _, ga2), (lb, _, gb) in zip(a, a2, b):
+        assert lb == pytest.approx(la, rel=tol + 4 * abs(la2 - la) / abs(la))
+        assert ga.keys() == gb.keys()
+        for k in ga:
+            scale = float(ga[k].abs().max()) + 1e-12
+            noise = float((ga[k] - ga2[k]).abs().max())
+            assert float((ga[k] - gb[k]).abs().max()) <= 4 * noise + floor * scale + 1e-7, (k, noise / scale)
+    sa, sb = a_model.state_dict(), b_model.state_dict()
+    for k in sa:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert torch.allclose(sa[k], sb[k], rtol=1e-3 if dtype is None else 2e-2, atol=1e-5), k
