@@ -14,7 +14,10 @@ buckets) fire as in the eager step.  Not captured: anything with a collective in
 world_size > 1) or a task group the fused loss does not cover -- `GraphedTail.build` returns None and the
 detector runs the tail eagerly.
 
-D3D_GRAPH_TAIL=0 disables it.
+D3D_GRAPH_TAIL=0 disables it.  With more than one rank it is OFF unless D3D_GRAPH_TAIL_DIST=1: capturing while a
+process group with a watchdog thread is alive has only been exercised with two gloo ranks on one GPU
+(tests/test_dist_gpu.py), not with RCCL across GPUs, and a failed capture is not something to discover in a
+multi-GPU job.
 """
 import os
 
@@ -22,6 +25,7 @@ import torch
 from torch import nn
 
 GRAPH_TAIL = os.environ.get("D3D_GRAPH_TAIL", "1") == "1"
+GRAPH_TAIL_DIST = os.environ.get("D3D_GRAPH_TAIL_DIST", "0") == "1"
 
 
 class _Tail(nn.Module):
@@ -89,9 +93,7 @@ class GraphedTail:
         # the gradient accumulators of the parameters are created lazily, on whatever stream is current at their
         # first use; make that the compute stream now -- inside make_graphed_callables it would be the capture
         # stream, and every later backward would hop streams to accumulate (and run the gradient hooks there)
-        for p in tail.parameters():
-            if p.requires_grad:
-                p.view_as(p).grad_fn.next_functions[0][0]
+        accumulators = [p.view_as(p).grad_fn.next_functions[0][0] for p in tail.parameters() if p.requires_grad]
         sample = (bev.detach().clone().requires_grad_(True),) + tuple(t.clone() for t in flat)
         ctx = torch.autocast(device_type="cuda", dtype=autocast_dtype, cache_enabled=False) \
             if autocast_dtype is not None else torch.autocast(device_type="cuda", enabled=False)
@@ -105,7 +107,9 @@ class GraphedTail:
             sd = tail.state_dict()
             for k, v in buffers.items():
                 sd[k].copy_(v)
-        return cls(graphed, cls.signature_of(bev, flat, autocast_dtype), len(example["labels"]), with_anchors)
+        gt = cls(graphed, cls.signature_of(bev, flat, autocast_dtype), len(example["labels"]), with_anchors)
+        gt.accumulators = accumulators  # the tensors only hold them weakly
+        return gt
 
     def __call__(self, bev, flat):
         return self.graphed(bev, *flat)
@@ -118,6 +122,11 @@ def run_tail(detector, example, bev):
         return None
     if getattr(detector, "_graph_tail_failed", False):
         return None
+    if not GRAPH_TAIL_DIST:
+        from . import dist as d3d_dist
+
+        if d3d_dist.world_size() > 1 and os.environ.get("D3D_DIST_BACKEND", "nccl") != "gloo":
+            return None
     autocast_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
     head = detector.bbox_head
     if not hasattr(head, "loss_vector"):
