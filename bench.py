@@ -396,6 +396,9 @@ def kernel_table(wl, step_index, rank, esz):
 _PAIRS = {}
 
 
+FWD64_BF16 = "spconv_fwd_group_kernel<64,64>"
+
+
 def group_launches(entries, esz):
     groups = {}
     for kind, cin, cout, n_out, rb, ms in entries:
@@ -408,6 +411,8 @@ def group_launches(entries, esz):
         else:
             mfma = cin % 16 == 0 and cout % 16 == 0
             key = ("spconv_fwd_mfma_kernel<%d,%d>" if mfma else "spconv_fwd_generic<%d,%d>") % (cin, cout)
+            if esz == 2 and cin == 64 and cout == 64:
+                key = FWD64_BF16  # the grouped-barrier kernel serves this shape in bf16 (d3d_sparse_conv_fwd_ex)
             byts = b_alg(kind, cin, cout, n_out, P, rb.kvol, esz)
         g = groups.setdefault(key, dict(ms=0.0, bytes=0.0, launches=0))
         g["ms"] += ms
@@ -695,7 +700,7 @@ def main():
                   batch=args.batch if custom else None, points=args.points if custom else None)
     esz = 2 if args.dtype == "bf16" else 4
     dominant = (lambda kind, cin, cout: kind != "wgrad" and cin == 64 and cout == 64) if not args.no_launch_log else None
-    roof_key = "spconv_fwd_mfma_kernel<64,64>"
+    roof_key = FWD64_BF16 if args.dtype == "bf16" else "spconv_fwd_mfma_kernel<64,64>"
     if head == "c3":
         dominant = None  # PointPillars has no sparse convolutions
     elapsed, records, loss = timed_region(wl, args.steps, args.warmup, rank, world, dev, note, dominant,

@@ -15,9 +15,8 @@ world_size > 1) or a task group the fused loss does not cover -- `GraphedTail.bu
 detector runs the tail eagerly.
 
 D3D_GRAPH_TAIL=0 disables it.  With more than one rank it is OFF unless D3D_GRAPH_TAIL_DIST=1: capturing while a
-process group with a watchdog thread is alive has only been exercised with two gloo ranks on one GPU
-(tests/test_dist_gpu.py), not with RCCL across GPUs, and a failed capture is not something to discover in a
-multi-GPU job.
+process group with a watchdog thread is alive, and gradient hooks that then run on the capture stream, have not been
+exercised with RCCL across GPUs, and a failed capture is not something to discover in a multi-GPU job.
 """
 import os
 
@@ -90,10 +89,10 @@ class GraphedTail:
         if not head.loss_vector_ok(bev, flat[: len(example["labels"])]):
             return None
         tail = _Tail(neck, head, with_anchors)
-        # the gradient accumulators of the parameters are created lazily, on whatever stream is current at their
-        # first use; make that the compute stream now -- inside make_graphed_callables it would be the capture
-        # stream, and every later backward would hop streams to accumulate (and run the gradient hooks there)
-        accumulators = [p.view_as(p).grad_fn.next_functions[0][0] for p in tail.parameters() if p.requires_grad]
+        # (The parameters' gradient accumulators are created inside make_graphed_callables, i.e. on its capture
+        # stream; autograd then reports a stream mismatch once and hops streams when it accumulates.  Creating and
+        # holding them on the compute stream beforehand is worse: the capture would have to synchronise with the
+        # default stream, which invalidates it -- measured: hipStreamEndCapture crashes.)
         sample = (bev.detach().clone().requires_grad_(True),) + tuple(t.clone() for t in flat)
         ctx = torch.autocast(device_type="cuda", dtype=autocast_dtype, cache_enabled=False) \
             if autocast_dtype is not None else torch.autocast(device_type="cuda", enabled=False)
@@ -107,9 +106,7 @@ class GraphedTail:
             sd = tail.state_dict()
             for k, v in buffers.items():
                 sd[k].copy_(v)
-        gt = cls(graphed, cls.signature_of(bev, flat, autocast_dtype), len(example["labels"]), with_anchors)
-        gt.accumulators = accumulators  # the tensors only hold them weakly
-        return gt
+        return cls(graphed, cls.signature_of(bev, flat, autocast_dtype), len(example["labels"]), with_anchors)
 
     def __call__(self, bev, flat):
         return self.graphed(bev, *flat)
@@ -125,7 +122,7 @@ def run_tail(detector, example, bev):
     if not GRAPH_TAIL_DIST:
         from . import dist as d3d_dist
 
-        if d3d_dist.world_size() > 1 and os.environ.get("D3D_DIST_BACKEND", "nccl") != "gloo":
+        if d3d_dist.world_size() > 1:
             return None
     autocast_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
     head = detector.bbox_head

@@ -34,11 +34,11 @@ def pick(rs, pat):
 
 
 fetch, write, mfma = rows("round2_pmc_fetch_size.txt"), rows("round2_pmc_write_size.txt"), rows("round2_pmc_sq_valu_mfma_busy_cycles.txt")
-pat = r"spconv_fwd_mfma_kernel<64, 64,"
+pat = r"spconv_fwd_(group|mfma)_kernel<64, 64, \d+, \d+, \d+(, true)?>"
 f, w = pick(fetch, pat), pick(write, pat)
 out = {"_comment": "separate rocprofv3 --kernel-trace --pmc passes over `bench.py --steps 3 --warmup 3` (tools/pmc_spconv.sh); "
                    "FETCH_SIZE / WRITE_SIZE in KiB per launch, read side x2 (MI355X_MICROARCH.md, gfx950), write side as is",
-       "kernel": "spconv_fwd_mfma_kernel<64,64>",
+       "kernel": (re.match(r"(?:void )?(spconv_fwd_\w+)<", f[3]).group(1) + "<64,64>") if f else "spconv_fwd_group_kernel<64,64>",
        "kernel_source_sha16": hashlib.sha256(open(os.path.join(ROOT, "det3d_amd", "csrc", "d3d_spconv.hip"), "rb").read()).hexdigest()[:16],
        "workload": {"name": "c2-20k", "frames_per_gpu": 4, "points_per_frame": 20000, "dtype": "bf16"}}
 if f and w:
