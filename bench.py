@@ -27,6 +27,7 @@ sparse conv fwd with the BN statistics in its epilogue) -> RPN / head (MIOpen vi
 import argparse
 import hashlib
 import json
+import math
 import os
 import statistics
 import sys
@@ -708,6 +709,11 @@ def main():
                                           prefetch=not args.no_prefetch)
     frames = args.steps * wl.batch * world
     value = frames / elapsed
+    gnorm = float(wl.step_fn.last["grad_norm"])
+    if not (math.isfinite(float(loss)) and math.isfinite(gnorm)):
+        # a step that produces inf / NaN is not the workload: refuse to report a throughput for it
+        raise SystemExit("bench.py: non-finite training state after the timed region (loss %r, gradient norm %r)"
+                         % (float(loss), gnorm))
     out = {
         "metric": "training frames/sec (%s, voxelize->sparse conv->RPN->head->loss->bwd->step)" % (
             "KITTI-car SECOND" if wl.spec["kind"] == "kitti" else wl.spec["config"].replace(".py", "")),
@@ -717,7 +723,8 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": wl.describe(), "name": wl.name, "frames_per_gpu": wl.batch,
                    "points_per_frame": wl.points, "parallelism": "dp%d" % world,
-                   "final_loss": round(float(loss), 4), "timed_region_s": round(elapsed, 3),
+                   "final_loss": round(float(loss), 4), "final_grad_norm": round(gnorm, 4),
+                   "timed_region_s": round(elapsed, 3),
                    "burn_in_steps": getattr(wl, "burn_in_steps", 0),
                    "graphed_tail": bool(wl.model.__dict__.get("_graph_tails")),
                    "geometry_prefetch": not args.no_prefetch,

@@ -100,7 +100,11 @@ class GraphedTail:
         # statistics (and counters) of the eager model unchanged by restoring them afterwards
         buffers = {k: v.clone() for k, v in tail.state_dict().items() if k.split(".")[-1] in
                    ("running_mean", "running_var", "num_batches_tracked")}
-        with ctx:
+        # MIOpen find mode (cudnn.benchmark) must be off while warming up and capturing: the solvers it picks for
+        # the weight gradients (split-K igemm with atomics) rely on zero-initialisation that is not part of the
+        # captured work, so every replay accumulated onto the previous one -- gradient norm inf after a few
+        # steps (tools/diag_nan.py).  Immediate-mode solvers replay correctly.
+        with ctx, torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=False):
             graphed = torch.cuda.make_graphed_callables(tail, sample, num_warmup_iters=3, allow_unused_input=True)
         with torch.no_grad():
             sd = tail.state_dict()

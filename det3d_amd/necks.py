@@ -94,4 +94,6 @@ class RPN(nn.Module):
             j = i - self._upsample_start_idx
             if j >= 0:
                 outs.append(self.deblocks[j](x))
+        if len(outs) == 1:
+            return outs[0]  # (the reference concatenates the single map with itself to no effect: a 72 MB copy)
         return torch.cat(outs, dim=1) if outs else x

@@ -50,6 +50,15 @@ def build_norm_layer(cfg, num_features, postfix=""):
 FUSE_BN2D_RELU = os.environ.get("D3D_FUSE_BN2D", "1") == "1"
 
 
+def _pad_folds_into(pad, conv):
+    """ZeroPad2d(p) followed by a zero-padded-by-nothing Conv2d == that Conv2d with padding p"""
+    if type(conv) is not nn.Conv2d or conv.padding_mode != "zeros":
+        return False
+    p = pad.padding
+    p = (p,) * 4 if isinstance(p, int) else tuple(p)
+    return len(set(p)) == 1 and p[0] >= 0 and tuple(conv.padding) == (0, 0)
+
+
 class Sequential(nn.Module):
     """nn.Sequential with `.add()`; children are named "0", "1", ... so state-dict keys
     match the reference (`neck.blocks.0.1.weight`, ...)."""
@@ -89,6 +98,15 @@ class Sequential(nn.Module):
         i = 0
         while i < len(mods):
             m = mods[i]
+            if type(m) is nn.ZeroPad2d and i + 1 < len(mods) and _pad_folds_into(m, mods[i + 1]) and \
+                    torch.is_tensor(input) and input.is_cuda:
+                # rpn.py:64-68 pads with a separate ZeroPad2d(1) and convolves without padding: the same sums as a
+                # padding=1 convolution, minus a 36 MB padded copy of the map (and its backward) per step
+                conv = mods[i + 1]
+                input = nn.functional.conv2d(input, conv.weight, conv.bias, conv.stride, (m.padding if isinstance(m.padding, int) else m.padding[0]), conv.dilation,
+                                             conv.groups)
+                i += 2
+                continue
             if FUSE_BN2D_RELU and type(m) is nn.BatchNorm2d and torch.is_tensor(input) and input.is_cuda:
                 from . import spconv  # the fused [N, C] BatchNorm(+ReLU) kernels (d3d_bn_relu_*)
 

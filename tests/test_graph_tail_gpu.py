@@ -114,10 +114,21 @@ def test_graphed_tail_multi_task_head_and_train_step():
     ds = synthetic.TaskGroupSynthetic(cfg, n_points=30000, n_seeds=2)
     dev = torch.device("cuda", 0)
     ex = ds.make_example(ds.device_batch(0, 2, dev))
-    step = TrainStep(model, total_steps=20, lr_max=1e-3, autocast_dtype=torch.bfloat16)
-    losses = [float(step(ex)) for _ in range(6)]
+    step = TrainStep(model, total_steps=40, lr_max=1e-3, autocast_dtype=torch.bfloat16)
+    # MIOpen find mode on, as in bench.py: the solvers it selects must not end up inside the graphs (their split-K
+    # weight gradients accumulated across replays -> gradient norm inf within 20 steps)
+    prev = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = True
+    try:
+        losses, norms = [], []
+        for _ in range(25):
+            losses.append(float(step(ex)))
+            norms.append(float(step.last["grad_norm"]))
+    finally:
+        torch.backends.cudnn.benchmark = prev
     assert "_graph_tails" in model.__dict__, model.__dict__.get("_graph_tail_failed")
-    assert all(torch.isfinite(torch.tensor(losses))) and min(losses[1:]) < losses[0]
+    assert all(torch.isfinite(torch.tensor(losses))) and all(torch.isfinite(torch.tensor(norms))), (losses, norms)
+    assert min(losses[1:]) < losses[0]
 
 
 def test_prefetched_geometry_is_the_inline_geometry():
