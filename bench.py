@@ -568,27 +568,37 @@ def rpn_mfma_probe(wl, dev, dtype):
 def predict_probe(wl, dev, dtype, iters=20):
     """inference frames/s (the reference's only speed probe is inference, tools/dist_test.py:178-193):
     voxelize -> backbone -> RPN -> head -> d3d_decode_filter_topk -> batched rotated NMS, eval mode; the decode and
-    NMS stages timed by HIP events in one extra batch.  Random-init heads score every anchor ~0.5, so with the
-    config's threshold each frame sends the full top-1000 into the NMS -- the worst case for those two stages."""
+    NMS stages timed by HIP events in one extra batch.  Measured twice: with the config's score threshold (a model
+    that has trained for a few hundred steps on the synthetic frames lets few or no anchors through) and SATURATED
+    (threshold 0: every frame sends its full top-`nms_pre_max_size` into the NMS -- the worst case for those stages)."""
     from det3d_amd import box_ops
 
     model = wl.model
     model.eval()
-    ev = {"decode": [], "nms": []}
     o_dec, o_nms = box_ops.decode_filter_topk, box_ops.rotate_nms_batched
+    tc = model.test_cfg
+    get_thr = (lambda: tc["score_threshold"]) if isinstance(tc, dict) else (lambda: tc.score_threshold)
 
-    def timed(kind, fn):
-        def wrap(*a, **k):
-            e0, e1 = _ev(), _ev()
-            e0.record()
-            r = fn(*a, **k)
-            e1.record()
-            ev[kind].append((e0, e1))
-            return r
-        return wrap
+    def set_thr(v):
+        if isinstance(tc, dict):
+            tc["score_threshold"] = v
+        else:
+            tc.score_threshold = v
 
-    try:
-        with torch.no_grad(), wl.step_fn._ctx():
+    def measure():
+        ev = {"decode": [], "nms": []}
+
+        def timed(kind, fn):
+            def wrap(*a, **k):
+                e0, e1 = _ev(), _ev()
+                e0.record()
+                r = fn(*a, **k)
+                e1.record()
+                ev[kind].append((e0, e1))
+                return r
+            return wrap
+
+        try:
             for i in range(3):
                 model(wl.example(i, targets=False), return_loss=False)
             torch.cuda.synchronize()
@@ -602,16 +612,28 @@ def predict_probe(wl, dev, dtype, iters=20):
             box_ops.decode_filter_topk, box_ops.rotate_nms_batched = timed("decode", o_dec), timed("nms", o_nms)
             model(wl.example(0, targets=False), return_loss=False)
             torch.cuda.synchronize()
+        finally:
+            box_ops.decode_filter_topk, box_ops.rotate_nms_batched = o_dec, o_nms
+        us = {k: [1e3 * a.elapsed_time(b) for a, b in v] for k, v in ev.items()}
+        return dict(frames_per_s=round(iters * wl.batch / dt, 1), ms_per_batch=round(1e3 * dt / iters, 3),
+                    detections_per_frame=round(n_det / (iters * wl.batch), 1), task_groups=len(us["nms"]),
+                    decode_filter_topk_us=round(sum(us["decode"]), 1), rotate_nms_batched_us=round(sum(us["nms"]), 1))
+
+    thr = get_thr()
+    try:
+        with torch.no_grad(), wl.step_fn._ctx():
+            configured = measure()
+            set_thr(0.0)
+            saturated = measure()
     finally:
-        box_ops.decode_filter_topk, box_ops.rotate_nms_batched = o_dec, o_nms
+        set_thr(thr)
         model.train()
-    us = {k: [1e3 * a.elapsed_time(b) for a, b in v] for k, v in ev.items()}
-    return dict(frames_per_s=round(iters * wl.batch / dt, 1), ms_per_batch=round(1e3 * dt / iters, 3),
-                detections_per_frame=round(n_det / (iters * wl.batch), 1), dtype=dtype,
-                task_groups=len(us["nms"]), decode_filter_topk_us=round(sum(us["decode"]), 1),
-                rotate_nms_batched_us=round(sum(us["nms"]), 1),
-                note="whole batch per call: d3d_decode_filter_topk (2 launches) + d3d_rotate_nms_batched (3 launches) "
-                     "per task group, one host sync per batch")
+    out = dict(saturated)
+    out.update(dtype=dtype, score_threshold="0 (saturated: full top-k into the NMS)",
+               as_configured=dict(configured, score_threshold=thr),
+               note="whole batch per call: d3d_decode_filter_topk (2 launches) + d3d_rotate_nms_batched (3 launches) "
+                    "per task group, one host sync per batch")
+    return out
 
 
 def precision_probe(dev):

@@ -14,7 +14,12 @@ buckets) fire as in the eager step.  Not captured: anything with a collective in
 world_size > 1) or a task group the fused loss does not cover -- `GraphedTail.build` returns None and the
 detector runs the tail eagerly.
 
-D3D_GRAPH_TAIL=0 disables it.  With more than one rank it is OFF unless D3D_GRAPH_TAIL_DIST=1: capturing while a
+OFF by default (D3D_GRAPH_TAIL=1 turns it on).  Measured on MI355X with the geometry prefetch in place
+(profiles/round2_bench_graph_ab.txt): the eager tail with MIOpen's find-mode solvers runs the KITTI step at 668
+frames/s, the graphed tail -- which has to be captured with find mode OFF, see build() -- at 643, and its private
+pool kept growing (24 GB reserved after 400 steps).  The graphs pay off only while the host is the bottleneck (662 ->
+697 frames/s before the step became GPU-bound; that 697 was measured with find-mode solvers inside the graph and is
+INVALID: their gradients were inf).  With more than one rank it stays off unless D3D_GRAPH_TAIL_DIST=1: capturing while a
 process group with a watchdog thread is alive, and gradient hooks that then run on the capture stream, have not been
 exercised with RCCL across GPUs, and a failed capture is not something to discover in a multi-GPU job.
 """
@@ -23,7 +28,7 @@ import os
 import torch
 from torch import nn
 
-GRAPH_TAIL = os.environ.get("D3D_GRAPH_TAIL", "1") == "1"
+GRAPH_TAIL = os.environ.get("D3D_GRAPH_TAIL", "0") == "1"
 GRAPH_TAIL_DIST = os.environ.get("D3D_GRAPH_TAIL_DIST", "0") == "1"
 
 

@@ -67,6 +67,7 @@ def _assert_same_up_to_run_to_run_noise(a, a2, b, dtype):
 def _run(model, examples, graphed, dtype):
     from det3d_amd import graph_tail
 
+    prev = graph_tail.GRAPH_TAIL
     graph_tail.GRAPH_TAIL = graphed
     out = []
     try:
@@ -80,7 +81,7 @@ def _run(model, examples, graphed, dtype):
             out.append((float(loss), [float(v) for v in losses["loc_loss_reduced"]],
                         {k: p.grad.float().clone() for k, p in model.named_parameters() if p.grad is not None}))
     finally:
-        graph_tail.GRAPH_TAIL = True
+        graph_tail.GRAPH_TAIL = prev
     return out
 
 
@@ -107,7 +108,7 @@ def test_graphed_tail_equals_the_eager_tail(dtype):
 def test_graphed_tail_multi_task_head_and_train_step():
     """CBGS head (several task groups, direction classifier) through the graphs inside TrainStep: the loss goes
     down on a repeated batch and the step leaves no gradient aliasing a graph-owned buffer behind."""
-    from det3d_amd import synthetic
+    from det3d_amd import graph_tail, synthetic
     from det3d_amd.trainer import TrainStep
 
     cfg, model = _model("nusc_cbgs.py")
@@ -117,8 +118,9 @@ def test_graphed_tail_multi_task_head_and_train_step():
     step = TrainStep(model, total_steps=40, lr_max=1e-3, autocast_dtype=torch.bfloat16)
     # MIOpen find mode on, as in bench.py: the solvers it selects must not end up inside the graphs (their split-K
     # weight gradients accumulated across replays -> gradient norm inf within 20 steps)
-    prev = torch.backends.cudnn.benchmark
+    prev, prev_g = torch.backends.cudnn.benchmark, graph_tail.GRAPH_TAIL
     torch.backends.cudnn.benchmark = True
+    graph_tail.GRAPH_TAIL = True
     try:
         losses, norms = [], []
         for _ in range(25):
@@ -126,6 +128,7 @@ def test_graphed_tail_multi_task_head_and_train_step():
             norms.append(float(step.last["grad_norm"]))
     finally:
         torch.backends.cudnn.benchmark = prev
+        graph_tail.GRAPH_TAIL = prev_g
     assert "_graph_tails" in model.__dict__, model.__dict__.get("_graph_tail_failed")
     assert all(torch.isfinite(torch.tensor(losses))) and all(torch.isfinite(torch.tensor(norms))), (losses, norms)
     assert min(losses[1:]) < losses[0]
@@ -142,6 +145,7 @@ def test_prefetched_geometry_is_the_inline_geometry():
     dev = torch.device("cuda", 0)
     make = lambda i: synthetic.make_example(ds.device_batch(i, 2, dev), synthetic.KITTI_CAR)
     pf = GeometryPrefetcher(make, model, dev)
+    prev_g = graph_tail.GRAPH_TAIL
     graph_tail.GRAPH_TAIL = False
     try:
         for i in range(3):
@@ -170,7 +174,7 @@ def test_prefetched_geometry_is_the_inline_geometry():
                 scale = float(g.abs().max()) + 1e-12
                 assert float((g - model.get_parameter(k).grad).abs().max()) <= 1e-2 * scale + 1e-7, k
     finally:
-        graph_tail.GRAPH_TAIL = True
+        graph_tail.GRAPH_TAIL = prev_g
 
 
 @pytest.mark.parametrize("dtype", [None, torch.bfloat16])
@@ -196,7 +200,6 @@ def test_fused_sparse_stack_equals_the_per_layer_path(dtype):
     finally:
         sparse_stack.FUSE_STACK = True
         sparse_stack.run = orig
-        graph_tail.GRAPH_TAIL = True
     assert calls == [14, 14], calls  # all 14 conv-BN-ReLU triples of SpMiddleFHD in one node, once per step
     _assert_same_up_to_run_to_run_noise(a, a2, b, dtype)
     sa, sb = a_model.state_dict(), b_model.state_dict()
