@@ -171,8 +171,9 @@ def test_prefetched_geometry_is_the_inline_geometry():
             for k, g in ga.items():
                 if k in noise:
                     continue
-                scale = float(g.abs().max()) + 1e-12
-                assert float((g - model.get_parameter(k).grad).abs().max()) <= 1e-2 * scale + 1e-7, k
+                # same kernels on the same geometry; what differs is the summation order of the BN statistics
+                # (run-to-run noise of the step itself, see _assert_same_up_to_run_to_run_noise): 2 % in relative L2
+                assert _rel_l2(g, model.get_parameter(k).grad) <= 2e-2, k
     finally:
         graph_tail.GRAPH_TAIL = prev_g
 
