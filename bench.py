@@ -709,9 +709,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the det3d_amd hot path has no CPU fallback")
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
-    # MIOpen find mode for the dense RPN convs (+3 % over immediate mode, < 20 s on a cold
-    # perf-db cache); D3D_MIOPEN_FIND=0 falls back to immediate mode
-    torch.backends.cudnn.benchmark = bool(int(os.environ.get("D3D_MIOPEN_FIND", "1")))
+    # MIOpen immediate mode for the dense RPN convs.  Find mode (D3D_MIOPEN_FIND=1, torch.backends.cudnn.benchmark)
+    # ranks its candidate solvers by ONE timing each, so what it settles on differs from run to run: 16 find-mode
+    # runs of this step landed between 558 and 749 frames/s (mean 657; the slow ones picked the assembly igemm
+    # solvers that need a 72 MB workspace zeroed by hipMemsetAsync, 12 x 169 us per step), immediate mode between
+    # 647 and 680 (profiles/round2_miopen_find_variance.txt).  A recorded user find-db does not pin the good picks:
+    # PyTorch's find call re-benchmarks and rewrites it.
+    torch.backends.cudnn.benchmark = bool(int(os.environ.get("D3D_MIOPEN_FIND", "0")))
 
     def note(msg):
         if rank == 0:

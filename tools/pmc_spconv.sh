@@ -9,7 +9,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$(realpath -m "${1:-gpurun_out/pmc}"); mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $REPO/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-launch-log --no-extras"
+CMD="python $REPO/bench.py --steps 3 --warmup 3 --burn-in 0 --no-cpu-baseline --no-launch-log --no-extras"  # fixed step count: the passes must see the same dispatches
 for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   rm -rf /tmp/d3d_pmc_$C
   timeout 600 rocprofv3 --kernel-trace --pmc $C -d /tmp/d3d_pmc_$C -- $CMD > /tmp/d3d_pmc_$C.out 2> /tmp/d3d_pmc_$C.err || { echo "pass $C failed"; tail -5 /tmp/d3d_pmc_$C.err; continue; }
