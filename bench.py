@@ -350,8 +350,9 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
         trainer.freeze_gc()
     D.barrier()
     # HIP-event timing of individual launches perturbs the stream (~0.4 ms per event pair on ROCm), so inside
-    # the timed region only the dominant kernel of the LAST TWO steps is timed
-    sample_from = max(steps - 2, 0)
+    # the timed region only the dominant kernel of the LAST step is timed (16 launches; with the driver's 20 steps
+    # two sampled steps cost 10 % of the window)
+    sample_from = max(steps - 1, 0)
     spconv.LAUNCH_FILTER = launch_filter
     torch.cuda.synchronize()
     ms0 = torch.cuda.memory_stats(dev)

@@ -33,8 +33,9 @@ def test_driver_flags_parse(monkeypatch):
     assert a.gpus == 1 and a.steps >= 10 and a.warmup >= 1 and not a.no_gc_freeze
 
 
-def test_recorded_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "round1_bench_v5.json")))
+@pytest.mark.parametrize("name", ["round1_bench_v5.json", "round2_bench_final.json"])
+def test_recorded_bench_line_has_the_contract_fields(name):
+    d = json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -46,6 +47,15 @@ def test_recorded_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["value"] - d["config"]["frames_per_gpu"] * d["n_gpus"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-2
+    if name.startswith("round2"):
+        import math
+
+        # round 2: a finite training state is part of the line, the precision question is answered next to it
+        assert math.isfinite(d["config"]["final_loss"]) and math.isfinite(d["config"]["final_grad_norm"])
+        assert d["fp32"]["dtype"] == "fp32" and d["fp32"]["value"] > 0
+        assert d["precision"]["fp32_within_tolerance"] is True
+        assert r["kernel"].startswith("spconv_fwd_") and r["traffic_measured_in_run"] is False
+        assert {"c2-60k", "c4"} <= set(d["workloads"]) and all(math.isfinite(w["final_loss"]) for w in d["workloads"].values())
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")

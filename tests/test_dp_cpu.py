@@ -202,3 +202,25 @@ def test_frame_partition_equals_reference_distributed_group_sampler():
                 assert len(mine) == len(s) and len(mine) % spg == 0
                 seen += mine
             assert set(seen) == set(range(len(flag)))  # every frame is visited each epoch
+
+
+def test_prefetcher_walks_nested_containers_and_is_transparent_without_a_gpu():
+    """prefetch.GeometryPrefetcher: on a machine without a GPU it degrades to calling make_example inline; the
+    tensor walker used for record_stream() reaches tensors inside dicts, lists and plain objects exactly once."""
+    import torch
+
+    from det3d_amd.prefetch import GeometryPrefetcher, _tensors
+
+    class Box:
+        def __init__(self):
+            self.t = torch.ones(2)
+            self.loop = self  # cycles must not hang the walk
+
+    ex = {"a": torch.zeros(3), "b": [torch.zeros(1), (torch.zeros(4), 5)], "c": {"d": Box()}, "e": "text"}
+    found = list(_tensors(ex, set()))
+    assert sorted(t.numel() for t in found) == [1, 2, 3, 4]
+    pf = GeometryPrefetcher(lambda i: {"i": i, "x": torch.full((2,), float(i))}, detector=None, enabled=True)
+    if not torch.cuda.is_available():
+        assert pf.enabled is False
+    out = pf.prepare(7)
+    assert out["i"] == 7 and out["x"].tolist() == [7.0, 7.0] and "sparse_plan" not in out
