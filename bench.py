@@ -434,7 +434,7 @@ def roofline_object(groups, key, dtype):
            "alg_bytes_per_launch": int(g["bytes"] / g["launches"]), "launches_timed": g["launches"],
            "limiter": "L2 gather latency / occupancy: measured HBM traffic is ~1/3 of the algorithmic bytes (each "
                       "row is gathered ~13x, served by L2 / Infinity Cache), see hbm_frac_true",
-           "note": "HIP events on the launch stream, fwd+dgrad launches of the last 2 timed steps; B_alg per "
+           "note": "HIP events on the launch stream, fwd+dgrad launches of the last timed step; B_alg per "
                    "SURVEY.md 8(d)"}
     return out
 

@@ -15,8 +15,8 @@ world_size > 1) or a task group the fused loss does not cover -- `GraphedTail.bu
 detector runs the tail eagerly.
 
 OFF by default (D3D_GRAPH_TAIL=1 turns it on).  Measured on MI355X with the geometry prefetch in place
-(profiles/round2_bench_graph_ab.txt): the eager tail with MIOpen's find-mode solvers runs the KITTI step at 668
-frames/s, the graphed tail -- which has to be captured with find mode OFF, see build() -- at 643, and its private
+(profiles/round2_bench_graph_ab.txt): the eager tail runs the KITTI step at 668 frames/s on that box, the
+graphed tail -- which has to be captured with find mode OFF, see build() -- at 643, and its private
 pool kept growing (24 GB reserved after 400 steps).  The graphs pay off only while the host is the bottleneck (662 ->
 697 frames/s before the step became GPU-bound; that 697 was measured with find-mode solvers inside the graph and is
 INVALID: their gradients were inf).  With more than one rank it stays off unless D3D_GRAPH_TAIL_DIST=1: capturing while a
