@@ -17,6 +17,7 @@
 // Input counts are read from device memory so voxelize -> rulebooks -> next level
 // chains on one stream with no host round trip.  All of it is integer, HBM/L2-bound.
 #include "d3d_scan.h"
+#include <stdlib.h>
 #include "d3d_fill.h"
 
 struct RbGeom {
@@ -230,6 +231,90 @@ struct RbEmitCoords {
   }
 };
 
+// The bitmap scan with 16-byte accesses: a thread owns 8 consecutive words (two uint4 loads, two int4 stores of
+// their prefixes), a block the same 2048-word tile as d3d_scan.h, so the spine kernel and the tile count are
+// shared.  The functor version above reads and writes one dword per lane at a 32-byte stride (every load
+// instruction touches 16 cache lines for 256 useful bytes) and was 50 us per launch at KITTI scale -- more than the
+// sparse convolution it prepares.  The word count is padded to a multiple of 8 (the arena aligns to 256 bytes and
+// the fill zeroes the padding).
+__device__ __forceinline__ void rb_load8(const uint32_t *bitmap, int64_t base, int64_t words8, uint32_t (&w)[8]) {
+  if (base < words8) {
+    const uint4 a = *(const uint4 *)(bitmap + base), b = *(const uint4 *)(bitmap + base + 4);
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+    w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = 0u;
+  }
+}
+
+__global__ void __launch_bounds__(D3D_SCAN_THREADS)
+    rb_scan_reduce_vec_kernel(const uint32_t *__restrict__ bitmap, int64_t words8, int *__restrict__ tile_sums) {
+  static_assert(D3D_SCAN_ITEMS == 8, "8 words per thread");
+  const int64_t base = (int64_t)blockIdx.x * D3D_SCAN_TILE + (int64_t)threadIdx.x * 8;
+  uint32_t w[8];
+  rb_load8(bitmap, base, words8, w);
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += __popc(w[j]);
+  int total;
+  d3d_block_excl_scan256(s, &total);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(D3D_SCAN_THREADS)
+    rb_scan_final_vec_kernel(const uint32_t *__restrict__ bitmap, int64_t words8, const int *__restrict__ tile_offsets,
+                             RbEmitCoords emit) {
+  const int64_t base = (int64_t)blockIdx.x * D3D_SCAN_TILE + (int64_t)threadIdx.x * 8;
+  uint32_t w[8];
+  rb_load8(bitmap, base, words8, w);
+  int v[8], s = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    v[j] = __popc(w[j]);
+    s += v[j];
+  }
+  int total;
+  int excl = d3d_block_excl_scan256(s, &total) + tile_offsets[blockIdx.x];
+  if (base >= words8) return;
+  int pre[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    pre[j] = excl;
+    excl += v[j];
+  }
+  *(int4 *)(emit.wordprefix + base) = make_int4(pre[0], pre[1], pre[2], pre[3]);
+  *(int4 *)(emit.wordprefix + base + 4) = make_int4(pre[4], pre[5], pre[6], pre[7]);
+  if (!s) return;
+  const uint32_t W = (uint32_t)emit.oshape[2], H = (uint32_t)emit.oshape[1], D = (uint32_t)emit.oshape[0];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    uint32_t bits = w[j];
+    if (!bits) continue;
+    // decode the word's first cell once (three integer divisions), then walk its 32 cells by carries: the functor
+    // version divides per emitted coordinate, which is what its 50 us per launch were spent on
+    const uint32_t key0 = (uint32_t)(base + j) << 5;
+    const uint32_t x0 = key0 % W;
+    uint32_t r = key0 / W;
+    const uint32_t y0 = r % H;
+    r /= H;
+    const uint32_t z0 = r % D, b0 = r / D;
+    int row = pre[j];
+    while (bits) {
+      const int bit = __ffs((int)bits) - 1;
+      bits &= bits - 1;
+      if (row < emit.cap_out) {
+        uint32_t x = x0 + (uint32_t)bit, y = y0, z = z0, b = b0;
+        while (x >= W) { x -= W; ++y; }
+        while (y >= H) { y -= H; ++z; }
+        while (z >= D) { z -= D; ++b; }
+        emit.coords_out[row] = make_int4((int)b, (int)z, (int)y, (int)x);
+      }
+      ++row;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256)
     rb_fill_neg1_kernel(int32_t *nbr, const int32_t *n_dev, int cap, int kvol) {
   int n = *n_dev;
@@ -271,7 +356,7 @@ __global__ void __launch_bounds__(256)
 
 static size_t rb_conv_words(int batch, const int32_t *out_shape) {
   double cells = (double)batch * out_shape[0] * out_shape[1] * out_shape[2];
-  return (size_t)((cells + 31) / 32);
+  return ((size_t)((cells + 31) / 32) + 7) / 8 * 8;  // padded to the 8 words a scan thread owns
 }
 
 extern "C" size_t d3d_conv_rulebook_workspace_bytes(int batch, const int32_t *out_shape) {
@@ -335,8 +420,21 @@ extern "C" int d3d_conv_rulebook(const int32_t *coords_in, const int32_t *n_in_d
   E.coords_out = (int4 *)coords_out;
   E.cap_out = cap_out;
   for (int j = 0; j < 3; ++j) E.oshape[j] = out_shape[j];
-  int rc = d3d_exclusive_scan(F, E, (int64_t)words, tiles, n_out_dev, stream);
-  if (rc) return rc;
+  static const bool scan_functor = getenv("D3D_RB_SCAN_FUNCTOR") && atoi(getenv("D3D_RB_SCAN_FUNCTOR"));
+  if (scan_functor) {
+    int rc = d3d_exclusive_scan(F, E, (int64_t)words, tiles, n_out_dev, stream);
+    if (rc) return rc;
+  } else {
+    const int ntiles = d3d_scan_num_tiles((int64_t)words);
+    hipLaunchKernelGGL(rb_scan_reduce_vec_kernel, dim3(ntiles), dim3(D3D_SCAN_THREADS), 0, stream, bitmap,
+                       (int64_t)words, tiles);
+    D3D_LAUNCH_TRY("rb_scan_reduce_vec_kernel");
+    hipLaunchKernelGGL(d3d_scan_spine_kernel, dim3(1), dim3(D3D_SCAN_THREADS), 0, stream, tiles, ntiles, n_out_dev);
+    D3D_LAUNCH_TRY("d3d_scan_spine_kernel");
+    hipLaunchKernelGGL(rb_scan_final_vec_kernel, dim3(ntiles), dim3(D3D_SCAN_THREADS), 0, stream, bitmap,
+                       (int64_t)words, tiles, E);
+    D3D_LAUNCH_TRY("rb_scan_final_vec_kernel");
+  }
   int64_t oitems = (int64_t)cap_out * G.kvol;
   int fb = (int)((oitems + 255) / 256);
   if (fb > 2048) fb = 2048;
