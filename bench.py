@@ -10,11 +10,15 @@ One step = one pass of the whole hot path over one batch of synthetic clouds tha
 HBM: device voxelizer + fused mean VFE -> anchor target assignment (HIP) -> sparse backbone (HIP rulebooks,
 sparse conv fwd with the BN statistics in its epilogue) -> RPN / head (MIOpen via PyTorch-ROCm) -> fused loss
 -> backward (HIP dgrad with the BN-backward sums in its epilogue / two-pass wgrad) -> gradient mean over ranks
-(RCCL) -> clip -> true-WD Adam.  Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      the hand-written sparse-conv gather kernel (spconv_fwd_mfma_kernel<64,64>), HIP events on the
-                launch stream inside the timed region; `frac` is the SURVEY.md 8(d) algorithmic-bytes figure
-                against the HBM peak, `hbm_frac_true` prices the measured HBM traffic (rocprofv3 PMC passes,
-                profiles/) the same way -- the kernel is bound by L2 gather latency, not by HBM bytes
+(RCCL) -> clip -> true-WD Adam.  The input-side geometry of step i+1 (voxelizer, targets, rulebooks) is built on a
+second HIP stream while step i runs (det3d_amd/prefetch.py; --no-prefetch builds it inline): K timed steps contain
+K geometry builds.  Rank 0 prints ONE JSON line and refuses to if the loss or the gradient norm after the timed
+region is not finite.  Besides the contract fields the line carries
+  roofline      the hand-written sparse-conv gather kernel (bf16: spconv_fwd_group_kernel<64,64>), HIP events on
+                the launch stream inside the timed region (last step); `frac` is the SURVEY.md 8(d)
+                algorithmic-bytes figure against the HBM peak, `hbm_frac_true` prices the measured HBM traffic
+                (rocprofv3 PMC passes, profiles/) the same way -- the kernel is bound by gather issue / latency in
+                front of L1/L2, not by HBM bytes
   fp32          the same workload without autocast: the precision that meets north_star's 1e-3 box tolerance
   precision     max |box regression - CPU oracle| of both dtypes on one frame with O(1)-scale outputs
   rpn_mfma      the dense RPN convolutions alone (MIOpen / CK): FLOPs per step / time / 2.5 PFLOP/s
@@ -432,8 +436,10 @@ def roofline_object(groups, key, dtype):
            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
            "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
            "alg_bytes_per_launch": int(g["bytes"] / g["launches"]), "launches_timed": g["launches"],
-           "limiter": "L2 gather latency / occupancy: measured HBM traffic is ~1/3 of the algorithmic bytes (each "
-                      "row is gathered ~13x, served by L2 / Infinity Cache), see hbm_frac_true",
+           "limiter": "gather issue / latency in front of L1/L2, not HBM bytes: measured HBM traffic is ~40 % of the "
+                      "algorithmic bytes (each row is gathered ~13x, served by L1 / L2 / Infinity Cache); counter "
+                      "passes (profiles/round2_pmc_fwd.txt): texture addresser 44-50 % busy, LDS 28 %, MFMA 17-20 %, "
+                      "no unit above 50 % -- see hbm_frac_true and DESIGN.md section 5",
            "note": "HIP events on the launch stream, fwd+dgrad launches of the last timed step; B_alg per "
                    "SURVEY.md 8(d)"}
     return out
