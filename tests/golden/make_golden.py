@@ -447,6 +447,58 @@ def augment_cases():
     print("augment:", sorted(out)[:4], "...")
 
 
+def object_noise_cases():
+    """noise_per_object_v3_ (core/sampler/preprocess.py:587-709) with the KITTI config's settings, seeded NumPy
+    stream, three frames with boxes close enough that candidates collide.  numba compiles `x is True` on a boolean
+    to a value comparison; run as plain Python the same text compares identities with a numpy.bool_ and is always
+    False, which would silently skip box_collision_test's containment branch -- so that one function is re-executed
+    with `is True/False` spelled `== True/False` (numba's semantics) before the reference code runs."""
+    import inspect
+    import re
+
+    prep = ref_loader.ref("det3d.core.sampler.preprocess")
+    src = inspect.getsource(prep.box_collision_test)
+    src = re.sub(r"^@numba\.njit\n", "", src)
+    src = src.replace(" is True", " == True").replace(" is False", " == False")
+    ns = prep.__dict__
+    exec(compile(src, "<box_collision_test with numba bool semantics>", "exec"), ns)
+    out = {}
+    for frame in range(3):
+        rng = np.random.default_rng(40 + frame)
+        n = 8
+        gt = np.zeros((n, 7), np.float32)
+        gx, gy = np.meshgrid(np.arange(4), np.arange(2))
+        gt[:, 0] = 10 + 4.2 * gx.ravel() + rng.uniform(-0.5, 0.5, n)
+        gt[:, 1] = -3 + 4.5 * gy.ravel() + rng.uniform(-0.5, 0.5, n)
+        gt[:, 2] = rng.uniform(-1.2, -0.8, n)
+        gt[:, 3:6] = np.array([1.7, 4.0, 1.6], np.float32) * rng.uniform(0.9, 1.1, (n, 3)).astype(np.float32)
+        gt[:, 6] = rng.uniform(-3.1, 3.1, n)
+        inside = []
+        for b in gt:  # points inside every box (they must move with it) + clutter around
+            loc = rng.uniform(-0.45, 0.45, (60, 3)) * b[3:6]
+            c, s_ = np.cos(b[6]), np.sin(b[6])
+            x = loc[:, 0] * c + loc[:, 1] * s_
+            y = -loc[:, 0] * s_ + loc[:, 1] * c
+            inside.append(np.stack([x + b[0], y + b[1], loc[:, 2] + b[2]], 1))
+        clutter = np.concatenate([rng.uniform(0, 30, (600, 1)), rng.uniform(-10, 10, (600, 1)),
+                                  rng.uniform(-2, 0.5, (600, 1))], 1)
+        pts = np.concatenate(inside + [clutter]).astype(np.float32)
+        pts = np.concatenate([pts, rng.uniform(0, 1, (len(pts), 1)).astype(np.float32)], 1)
+        valid = np.ones((n,), np.bool_)
+        valid[5] = False
+        out["f%d_gt_in" % frame], out["f%d_points_in" % frame], out["f%d_valid" % frame] = gt.copy(), pts.copy(), valid
+        np.random.seed(11 + frame)
+        state = np.random.get_state()
+        prep.noise_per_object_v3_(gt, pts, valid, rotation_perturb=[-0.78539816, 0.78539816],
+                                  center_noise_std=[1.0, 1.0, 0.5], global_random_rot_range=[0.0, 0.0],
+                                  group_ids=None, num_try=40)
+        out["f%d_gt_out" % frame], out["f%d_points_out" % frame] = gt, pts
+        del state
+    np.savez_compressed(os.path.join(HERE, "object_noise.npz"), **out)
+    moved = [int((out["f%d_gt_out" % f][:, :2] != out["f%d_gt_in" % f][:, :2]).any(1).sum()) for f in range(3)]
+    print("object_noise: boxes moved per frame", moved)
+
+
 def sampler_cases():
     """DistributedGroupSampler (datasets/loader/sampler.py:138-224): indices per rank and epoch."""
     sm = ref_loader.ref("det3d.datasets.loader.sampler")
@@ -720,13 +772,15 @@ def nms_gpu_cases():
 
 def main():
     ref_loader.install()
-    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "sampler", "collate", "pipeline", "rangefilter", "nmsgpu", "detectors"]
+    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "objnoise", "sampler", "collate", "pipeline", "rangefilter", "nmsgpu", "detectors"]
     if "anchors" in which:
         anchors_targets()
     if "tasks" in which:
         task_targets()
     if "augment" in which:
         augment_cases()
+    if "objnoise" in which:
+        object_noise_cases()
     if "sampler" in which:
         sampler_cases()
     if "collate" in which:

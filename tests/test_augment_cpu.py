@@ -55,3 +55,73 @@ def test_identity_parameters_leave_the_batch_unchanged():
     p = dict(flip_y=np.zeros(2, bool), flip_x=np.zeros(2, bool), rotation=np.zeros(2), scale=np.ones(2))
     a, b = augment.apply_global_augmentation(pts, off, gt, p)
     assert torch.allclose(a, pts) and torch.allclose(b, gt)
+
+
+def _object_noise_batch(z, frames, num_try=40):
+    """the golden's frames as one collated batch + the reference's draws re-made from the same seeds"""
+    pts = [z["f%d_points_in" % f] for f in frames]
+    off = torch.tensor(np.cumsum([0] + [len(p) for p in pts]), dtype=torch.int32)
+    gts = [z["f%d_gt_in" % f] for f in frames]
+    g = max(len(x) for x in gts) + 2                      # two padding slots: they must stay inert
+    gt = np.zeros((len(frames), g, 7), np.float32)
+    valid = np.zeros((len(frames), g), bool)
+    loc = np.zeros((len(frames), g, num_try, 3))
+    rot = np.zeros((len(frames), g, num_try))
+    for i, f in enumerate(frames):
+        n = len(gts[i])
+        gt[i, :n] = gts[i]
+        valid[i, :n] = z["f%d_valid" % f]
+        np.random.seed(11 + f)
+        p = augment.sample_object_noise_params(gts[i], num_try, [-0.78539816, 0.78539816], [1.0, 1.0, 0.5], [0.0, 0.0])
+        loc[i, :n], rot[i, :n] = p["loc_noises"], p["rot_noises"]
+    count = torch.tensor([len(x) for x in gts])
+    return torch.from_numpy(np.concatenate(pts)), off, torch.from_numpy(gt), count, \
+        dict(loc_noises=loc, rot_noises=rot), torch.from_numpy(valid)
+
+
+def test_per_object_noise_reproduces_the_reference_function():
+    """f2: noise_per_object_v3_ (core/sampler/preprocess.py:587-709) on a collated batch: the same candidate is
+    accepted for every box (collision tests incl. the boxes already moved), boxes and the points inside them land
+    where the reference's numba functions put them (tests/golden/object_noise.npz, made by running those functions)."""
+    z = np.load(os.path.join(GOLDEN, "object_noise.npz"))
+    frames = [0, 1, 2]
+    pts, off, gt, count, params, valid = _object_noise_batch(z, frames)
+    new_pts, new_gt, selected = augment.noise_per_object(pts, off, gt, count, params, valid_mask=valid)
+    for i, f in enumerate(frames):
+        n = int(count[i])
+        ref_gt, ref_pts = z["f%d_gt_out" % f], z["f%d_points_out" % f]
+        assert np.allclose(new_gt[i, :n].numpy(), ref_gt, atol=2e-5), f
+        assert torch.equal(new_gt[i, n:], gt[i, n:])          # padding untouched
+        a, b = int(off[i]), int(off[i + 1])
+        got = new_pts[a:b].numpy()
+        assert np.allclose(got, ref_pts, atol=5e-5), (f, np.abs(got - ref_pts).max())
+        moved = (z["f%d_gt_in" % f][:, :2] != ref_gt[:, :2]).any(1)
+        assert (selected[i, :n].numpy() >= 0).tolist() == moved.tolist()
+        assert not moved[5] and int(selected[i, 5]) == -1      # valid_mask False: an obstacle that stays put
+    assert (selected[:, -2:] == -1).all()
+
+
+def test_per_object_noise_never_leaves_boxes_colliding():
+    """property: after the walk no two real boxes overlap in the bird's-eye view unless they already did and found no
+    free candidate; points that were in no box do not move."""
+    rng = np.random.default_rng(5)
+    b, g, t = 3, 10, 30
+    gt = np.zeros((b, g, 7), np.float32)
+    gt[..., 0] = rng.uniform(0, 40, (b, g))
+    gt[..., 1] = rng.uniform(-20, 20, (b, g))
+    gt[..., 3:6] = rng.uniform(1.5, 4.5, (b, g, 3))
+    gt[..., 6] = rng.uniform(-3, 3, (b, g))
+    count = torch.tensor([10, 7, 0])
+    params = dict(loc_noises=rng.normal(scale=1.0, size=(b, g, t, 3)), rot_noises=rng.uniform(-0.78, 0.78, (b, g, t)))
+    pts = torch.from_numpy(rng.uniform(-60, -50, (300, 4)).astype(np.float32))   # far from every box
+    off = torch.tensor([0, 100, 200, 300], dtype=torch.int32)
+    new_pts, new_gt, sel = augment.noise_per_object(pts, off, torch.from_numpy(gt), count, params)
+    assert torch.equal(new_pts, pts)
+    assert (sel[2] == -1).all() and (sel[1, 7:] == -1).all()
+    for i in range(2):
+        n = int(count[i])
+        c = augment._bev_corners(new_gt[i, :n, 0:2], new_gt[i, :n, 3:5], new_gt[i, :n, 6])
+        coll = augment._box_collision(c[:, None], c[None, :])
+        coll.fill_diagonal_(False)
+        moved = sel[i, :n] >= 0
+        assert not coll[moved].any(), "a moved box collides with another box"
