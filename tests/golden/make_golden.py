@@ -499,6 +499,77 @@ def object_noise_cases():
     print("object_noise: boxes moved per frame", moved)
 
 
+def _numba_bool_semantics(prep):
+    """see object_noise_cases: box_collision_test with `is True/False` as numba compiles them"""
+    import inspect
+    import re
+
+    src = inspect.getsource(prep.box_collision_test)
+    src = re.sub(r"^@numba\.njit\n", "", src)
+    src = src.replace(" is True", " == True").replace(" is False", " == False")
+    exec(compile(src, "<box_collision_test with numba bool semantics>", "exec"), prep.__dict__)
+
+
+def gt_sampler_cases():
+    """DataBaseSamplerV2 (core/sampler/sample_ops.py:13-298) on a synthetic three-class database written to a temp
+    directory, KITTI-style groups and filters, four consecutive frames (the BatchSamplers are stateful) -- plus the
+    paste step of the train pipeline (pipelines/preprocess.py:163-181)."""
+    import logging
+    import tempfile
+
+    prep = ref_loader.ref("det3d.core.sampler.preprocess")
+    _numba_bool_semantics(prep)
+    sample_ops = ref_loader.ref("det3d.core.sampler.sample_ops")
+    box_np_ops = ref_loader.ref("det3d.core.bbox.box_np_ops")
+    rng = np.random.default_rng(77)
+    sizes = {"Car": (1.7, 4.0, 1.6), "Pedestrian": (0.6, 0.8, 1.75), "Cyclist": (0.6, 1.8, 1.7)}
+    out, db_infos = {}, {}
+    tmp = tempfile.mkdtemp()
+    for name, (w, l, h) in sizes.items():
+        infos = []
+        for k in range(40):
+            box = np.array([rng.uniform(2, 60), rng.uniform(-25, 25), rng.uniform(-1.5, -0.5), w * rng.uniform(0.9, 1.1),
+                            l * rng.uniform(0.9, 1.1), h * rng.uniform(0.9, 1.1), rng.uniform(-3.1, 3.1)], np.float32)
+            npts = int(rng.integers(2, 60))
+            pts = np.concatenate([rng.uniform(-0.5, 0.5, (npts, 3)) * box[3:6], rng.uniform(0, 1, (npts, 1))], 1).astype(np.float32)
+            path = "%s_%d.bin" % (name, k)
+            pts.tofile(os.path.join(tmp, path))
+            infos.append(dict(name=name, path=path, box3d_lidar=box, num_points_in_gt=npts,
+                              difficulty=int(rng.integers(-1, 3)), gt_idx=k, image_idx=k))
+            out["db_%s_%d_points" % (name, k)] = pts
+        db_infos[name] = infos
+        out["db_%s_boxes" % name] = np.stack([i["box3d_lidar"] for i in infos])
+        out["db_%s_npts" % name] = np.array([i["num_points_in_gt"] for i in infos])
+        out["db_%s_difficulty" % name] = np.array([i["difficulty"] for i in infos])
+    groups = [dict(Car=15), dict(Pedestrian=8), dict(Cyclist=8)]
+    prepor = prep.DataBasePreprocessor([
+        prep.DBFilterByMinNumPoint(dict(Car=5, Pedestrian=8, Cyclist=8), logger=logging.getLogger("g")),
+        prep.DBFilterByDifficulty([-1], logger=logging.getLogger("g"))])
+    np.random.seed(123)
+    sampler = sample_ops.DataBaseSamplerV2(db_infos, groups, prepor, 1.0, None, logger=logging.getLogger("g"))
+    for frame in range(4):
+        n = 3 + frame
+        gt = np.zeros((n, 7), np.float32)
+        gt[:, 0], gt[:, 1] = rng.uniform(5, 50, n), rng.uniform(-20, 20, n)
+        gt[:, 2] = -1.0
+        gt[:, 3:6] = sizes["Car"]
+        gt[:, 6] = rng.uniform(-3, 3, n)
+        names = np.array(["Car"] * (n - 1) + ["Pedestrian"])
+        pts = np.concatenate([rng.uniform(0, 65, (3000, 1)), rng.uniform(-30, 30, (3000, 1)), rng.uniform(-2, 0.5, (3000, 1)),
+                              rng.uniform(0, 1, (3000, 1))], 1).astype(np.float32)
+        out["f%d_gt" % frame], out["f%d_names" % frame], out["f%d_points" % frame] = gt, names, pts
+        s = sampler.sample_all(tmp, gt, names, 4, False, gt_group_ids=None, calib=None)
+        assert s is not None
+        for k in ("gt_names", "difficulty", "gt_boxes", "points", "gt_masks", "group_ids"):
+            out["f%d_s_%s" % (frame, k)] = s[k]
+        # the paste step, as Preprocess.__call__ does it
+        masks = box_np_ops.points_in_rbbox(pts, s["gt_boxes"])
+        kept = pts[np.logical_not(masks.any(-1))]
+        out["f%d_pasted_points" % frame] = np.concatenate([s["points"], kept], axis=0)
+    np.savez_compressed(os.path.join(HERE, "gt_sampler.npz"), **out)
+    print("gt_sampler: sampled per frame", [len(out["f%d_s_gt_names" % f]) for f in range(4)])
+
+
 def sampler_cases():
     """DistributedGroupSampler (datasets/loader/sampler.py:138-224): indices per rank and epoch."""
     sm = ref_loader.ref("det3d.datasets.loader.sampler")
@@ -772,7 +843,7 @@ def nms_gpu_cases():
 
 def main():
     ref_loader.install()
-    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "objnoise", "sampler", "collate", "pipeline", "rangefilter", "nmsgpu", "detectors"]
+    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "objnoise", "gtsampler", "sampler", "collate", "pipeline", "rangefilter", "nmsgpu", "detectors"]
     if "anchors" in which:
         anchors_targets()
     if "tasks" in which:
@@ -781,6 +852,8 @@ def main():
         augment_cases()
     if "objnoise" in which:
         object_noise_cases()
+    if "gtsampler" in which:
+        gt_sampler_cases()
     if "sampler" in which:
         sampler_cases()
     if "collate" in which:
