@@ -570,6 +570,69 @@ def gt_sampler_cases():
     print("gt_sampler: sampled per frame", [len(out["f%d_s_gt_names" % f]) for f in range(4)])
 
 
+def loading_cases():
+    """LoadPointCloudFromFile (datasets/pipelines/loading.py:66-163) on synthetic files: a nuScenes key frame with six
+    candidate sweeps (transform matrices, time lags, points near the sensor to be removed, one file with a partial
+    trailing row), KITTI with and without a `_reduced` twin, Lyft.  The files are not kept: the test rewrites them
+    from the arrays stored here."""
+    import tempfile
+
+    loading = ref_loader.ref("det3d.datasets.pipelines.loading")
+    rng = np.random.default_rng(5)
+    tmp = tempfile.mkdtemp()
+    out = {}
+
+    def cloud(n):
+        p = np.concatenate([rng.uniform(-40, 40, (n, 2)), rng.uniform(-3, 2, (n, 1)), rng.uniform(0, 255, (n, 1)),
+                            rng.uniform(0, 31, (n, 1))], 1).astype(np.float32)
+        p[: n // 10, :2] = rng.uniform(-0.9, 0.9, (n // 10, 2))  # inside the 1 m exclusion square
+        return p
+
+    key = cloud(700)
+    key.tofile(os.path.join(tmp, "key.bin"))
+    out["nusc_key"] = key
+    sweeps = []
+    for i in range(6):
+        p = cloud(300 + 40 * i)
+        raw = p.ravel()
+        if i == 2:
+            raw = np.concatenate([raw, np.array([1.0, 2.0, 3.0], np.float32)])  # partial row at the end
+        raw.tofile(os.path.join(tmp, "sweep%d.bin" % i))
+        ang = rng.uniform(-0.2, 0.2)
+        m = np.eye(4)
+        m[:2, :2] = [[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]]
+        m[:3, 3] = rng.uniform(-2, 2, 3)
+        sweeps.append(dict(lidar_path=os.path.join(tmp, "sweep%d.bin" % i), transform_matrix=m if i != 4 else None,
+                           time_lag=0.05 * (i + 1)))
+        out["nusc_sweep%d_raw" % i], out["nusc_sweep%d_matrix" % i] = raw, m
+        out["nusc_sweep%d_lag" % i] = np.float64(0.05 * (i + 1))
+    step = loading.LoadPointCloudFromFile(dataset="NuScenesDataset")
+    for nsweeps in (1, 4):
+        res = {"lidar": {"nsweeps": nsweeps}, "metadata": {}}
+        np.random.seed(9)
+        res, _ = step(res, dict(lidar_path=os.path.join(tmp, "key.bin"), sweeps=sweeps))
+        out["nusc_n%d_points" % nsweeps] = res["lidar"]["points"]
+        out["nusc_n%d_times" % nsweeps] = res["lidar"]["times"]
+        out["nusc_n%d_combined" % nsweeps] = res["lidar"]["combined"]
+    kitti = rng.uniform(-30, 30, (500, 4)).astype(np.float32)
+    os.makedirs(os.path.join(tmp, "training", "velodyne"))
+    kitti.tofile(os.path.join(tmp, "training", "velodyne", "000001.bin"))
+    out["kitti_raw"] = kitti
+    step = loading.LoadPointCloudFromFile(dataset="KittiDataset")
+    info = dict(point_cloud=dict(velodyne_path="training/velodyne/000001.bin"))
+    res, _ = step({"lidar": {}, "metadata": {"image_prefix": tmp, "num_point_features": 4}}, info)
+    out["kitti_points"] = res["lidar"]["points"]
+    os.makedirs(os.path.join(tmp, "training", "velodyne_reduced"))
+    kitti[:200].tofile(os.path.join(tmp, "training", "velodyne_reduced", "000001.bin"))
+    res, _ = step({"lidar": {}, "metadata": {"image_prefix": tmp, "num_point_features": 4}}, info)
+    out["kitti_reduced_points"] = res["lidar"]["points"]
+    step = loading.LoadPointCloudFromFile(dataset="LyftDataset")
+    res, _ = step({"lidar": {}, "metadata": {}}, dict(ref_info=dict(LIDAR_TOP=dict(lidar_path=os.path.join(tmp, "key.bin")))))
+    out["lyft_points"] = res["lidar"]["points"]
+    np.savez_compressed(os.path.join(HERE, "loading.npz"), **out)
+    print("loading:", {k: v.shape for k, v in out.items() if k.endswith("points")})
+
+
 def sampler_cases():
     """DistributedGroupSampler (datasets/loader/sampler.py:138-224): indices per rank and epoch."""
     sm = ref_loader.ref("det3d.datasets.loader.sampler")
@@ -843,7 +906,7 @@ def nms_gpu_cases():
 
 def main():
     ref_loader.install()
-    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "objnoise", "gtsampler", "sampler", "collate", "pipeline", "rangefilter", "nmsgpu", "detectors"]
+    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "objnoise", "gtsampler", "loading", "sampler", "collate", "pipeline", "rangefilter", "nmsgpu", "detectors"]
     if "anchors" in which:
         anchors_targets()
     if "tasks" in which:
@@ -854,6 +917,8 @@ def main():
         object_noise_cases()
     if "gtsampler" in which:
         gt_sampler_cases()
+    if "loading" in which:
+        loading_cases()
     if "sampler" in which:
         sampler_cases()
     if "collate" in which:
