@@ -1,7 +1,6 @@
 """TEST INFRASTRUCTURE.  Drives every entry point of the sanitizer build of the oracle (libd3d_oracle_asan.so) on
 ragged / empty / capped / adversarial inputs.  Run by tests/test_oracle_sanitizers_cpu.py in a child process with
 libasan preloaded; any AddressSanitizer / UBSan report aborts the process."""
-import ctypes
 import os
 import sys
 

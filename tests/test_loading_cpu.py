@@ -5,7 +5,6 @@ import os
 
 import numpy as np
 import pytest
-import torch
 
 from conftest import GOLDEN
 
