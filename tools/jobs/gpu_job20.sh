@@ -1,7 +1,7 @@
 #!/bin/bash
 # MIOpen's find pass picks its solvers from one timing each: runs land anywhere between 558 and 745 frames/s.
 # Record the user find-db of several find-mode runs, keep the best, and check that immediate mode with that db
-# reproduces it (tools/gpu_job20.sh -> det3d_amd/miopen_db/).
+# reproduces it (tools/jobs/gpu_job20.sh -> det3d_amd/miopen_db/).
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r2j20; mkdir -p $O
 export TMPDIR=/tmp
