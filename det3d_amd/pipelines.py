@@ -66,3 +66,114 @@ class Voxelization:
         res["lidar"]["voxels"] = dict(voxels=voxels, coordinates=coordinates, num_points=num_points,
                                       num_voxels=np.array([voxels.shape[0]], dtype=np.int64), shape=grid_size)
         return res, info
+
+
+def build_dbsampler(cfg, device="cuda", root_path=None, num_point_features=4):
+    """det3d/builder.py:378-396: the database infos pickle + groups + filters -> a sampler; here the one that keeps
+    the object clouds resident on the device (gt_sampler.DeviceGTSampler)."""
+    import pickle
+
+    from .gt_sampler import DeviceGTSampler
+
+    get = (lambda k, d=None: cfg.get(k, d)) if hasattr(cfg, "get") else (lambda k, d=None: getattr(cfg, k, d))
+    grot = list(get("global_random_rotation_range_per_object", []) or [])
+    if len(grot) == 2 and abs(grot[0] - grot[1]) >= 1e-3:
+        raise NotImplementedError("per-object global rotation of sampled boxes is not on the Det3D hot path")
+    with open(get("db_info_path"), "rb") as f:
+        db_infos = pickle.load(f)
+    return DeviceGTSampler(db_infos, [dict(g) for g in get("sample_groups")], [dict(s) for s in get("db_prep_steps")],
+                           rate=get("rate", 1.0), device=device, root_path=root_path,
+                           num_point_features=num_point_features)
+
+
+class Preprocess:
+    """The train / val preprocessing step (det3d/datasets/pipelines/preprocess.py:29-255) for ONE frame with the
+    points on the device: class filtering, GT-database sampling + pasting, per-object noise, global flip / rotation /
+    scaling, shuffle.  Every random draw is made with the reference's NumPy call at the reference's place in the
+    stream, so a seeded run yields the same boxes, the same points and the same point ORDER (the voxelizer is order
+    sensitive); the geometry runs on the device (augment.py, gt_sampler.py).  Branches of the reference that cannot
+    run there either (they use undefined names: remove_environment, min_points_in_gt) or need camera data
+    (add_rgb_to_points, reference_detections, remove_outside_points, random_crop) are rejected at construction."""
+
+    def __init__(self, cfg=None, device="cuda", root_path=None, **kwargs):
+        get = (lambda k, d=None: cfg.get(k, d)) if hasattr(cfg, "get") else (lambda k, d=None: getattr(cfg, k, d))
+        for flag in ("remove_environment", "add_rgb_to_points", "remove_outside_points", "random_crop", "random_select"):
+            if get(flag, False):
+                raise NotImplementedError("Preprocess(%s=True) is not on the Det3D hot path" % flag)
+        if get("reference_detections", None) is not None or get("min_points_in_gt", -1) > 0:
+            raise NotImplementedError("Preprocess: reference_detections / min_points_in_gt are not supported")
+        self.mode = get("mode")
+        self.device = device
+        self.shuffle_points = get("shuffle_points")
+        self.remove_unknown = get("remove_unknown_examples")
+        self.symmetry_intensity = get("symmetry_intensity", False)
+        if self.mode == "train":
+            self.gt_rotation_noise = get("gt_rot_noise")
+            self.gt_loc_noise_std = get("gt_loc_noise")
+            self.global_rotation_noise = get("global_rot_noise")
+            self.global_scaling_noise = get("global_scale_noise")
+            self.global_random_rot_range = get("global_rot_per_obj_range")
+            self.remove_points_after_sample = get("remove_points_after_sample")
+            self.class_names = list(get("class_names"))
+            db = get("db_sampler")
+            self.db_sampler = db if (db is None or hasattr(db, "sample_all")) else \
+                build_dbsampler(db, device=device, root_path=root_path)
+
+    def __call__(self, res, info):
+        import torch
+
+        from . import augment
+
+        res["mode"] = self.mode
+        points = res["lidar"]["combined"] if res["type"] == "NuScenesDataset" else res["lidar"]["points"]
+        if not torch.is_tensor(points):
+            points = torch.from_numpy(np.ascontiguousarray(points))
+        points = points.to(self.device)
+        if self.mode == "train":
+            anno = res["lidar"]["annotations"]
+            gt = {"gt_boxes": np.asarray(anno["boxes"]), "gt_names": np.array(anno["names"]).reshape(-1)}
+            gt["difficulty"] = np.asarray(anno["difficulty"]) if "difficulty" in anno else \
+                np.zeros([gt["gt_boxes"].shape[0]], dtype=np.int32)
+            keep = np.array([i for i, x in enumerate(gt["gt_names"]) if x not in ("DontCare", "ignore")], dtype=np.int64)
+            _dict_select(gt, keep)
+            if self.remove_unknown:
+                _dict_select(gt, np.logical_not(gt["difficulty"] == -1))
+            gt.pop("difficulty")
+            mask = np.array([n in self.class_names for n in gt["gt_names"]], dtype=np.bool_)
+            if self.db_sampler:
+                s = self.db_sampler.sample_all(gt["gt_boxes"], gt["gt_names"])
+                if s is not None:
+                    points, gt["gt_boxes"], gt["gt_names"], _ = self.db_sampler.paste(
+                        points, gt["gt_boxes"], gt["gt_names"], s, self.remove_points_after_sample)
+                    mask = np.concatenate([mask, s["gt_masks"]], axis=0)
+            boxes = np.asarray(gt["gt_boxes"])
+            n = boxes.shape[0]
+            # per-object noise: draws first (reference order), geometry on the device as a batch of one frame
+            p = augment.sample_object_noise_params(boxes, 100, self.gt_rotation_noise, self.gt_loc_noise_std,
+                                                   self.global_random_rot_range)
+            off = torch.tensor([0, points.shape[0]], dtype=torch.int32, device=points.device)
+            bt = torch.from_numpy(boxes.astype(np.float32))[None].to(points.device)
+            if n:
+                points, bt, _ = augment.noise_per_object(
+                    points, off, bt, torch.tensor([n], device=points.device),
+                    dict(loc_noises=p["loc_noises"][None], rot_noises=p["rot_noises"][None]),
+                    valid_mask=torch.from_numpy(mask)[None].to(points.device))
+            sel = torch.from_numpy(np.nonzero(mask)[0]).to(points.device)
+            bt = bt[:, sel]
+            gt["gt_names"] = gt["gt_names"][mask]
+            gt["gt_classes"] = np.array([self.class_names.index(x) + 1 for x in gt["gt_names"]], dtype=np.int32)
+            g = augment.sample_global_params(1, flip="both" if res["type"] == "NuScenesDataset" else "y",
+                                             rotation=self.global_rotation_noise, scaling=tuple(self.global_scaling_noise))
+            points, bt = augment.apply_global_augmentation(points, off, bt, g)
+            gt["gt_boxes"] = bt[0].cpu().numpy().astype(boxes.dtype if boxes.size else np.float32)
+        if self.shuffle_points:
+            order = np.arange(points.shape[0])
+            np.random.shuffle(order)  # the same permutation np.random.shuffle(points) applies to the rows
+            points = points[torch.from_numpy(order).to(points.device)]
+        if self.symmetry_intensity:
+            points = points.clone()
+            points[:, -1] -= 0.5
+        res["lidar"]["points"] = points
+        if self.mode == "train":
+            res["lidar"]["annotations"] = gt
+        return res, info

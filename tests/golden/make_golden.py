@@ -633,6 +633,98 @@ def loading_cases():
     print("loading:", {k: v.shape for k, v in out.items() if k.endswith("points")})
 
 
+def preprocess_cases():
+    """The reference's Preprocess step itself (datasets/pipelines/preprocess.py:29-255), train mode, KITTI settings
+    (GT-AUG sampler from a pickled synthetic database, per-object noise, flip, rotation, scaling, shuffle) and
+    nuScenes settings (double flip, 5-column `combined` cloud, no sampler hits), plus val mode.  The output cloud is
+    stored in full: its row ORDER is part of the contract (the voxelizer is order sensitive)."""
+    import pickle
+    import tempfile
+
+    from det3d_amd.config import ConfigDict
+
+    prep = ref_loader.ref("det3d.core.sampler.preprocess")
+    _numba_bool_semantics(prep)
+    pp = ref_loader.ref("det3d.datasets.pipelines.preprocess")
+    rng = np.random.default_rng(321)
+    tmp = tempfile.mkdtemp()
+    sizes = {"Car": (1.7, 4.0, 1.6), "Pedestrian": (0.6, 0.8, 1.75)}
+    db, out = {}, {}
+    for name, (w, l, h) in sizes.items():
+        infos = []
+        for k in range(30):
+            box = np.array([rng.uniform(5, 60), rng.uniform(-30, 30), -1.0, w, l, h, rng.uniform(-3, 3)], np.float32)
+            npts = int(rng.integers(6, 40))
+            pts = np.concatenate([rng.uniform(-0.5, 0.5, (npts, 3)) * box[3:6], rng.uniform(0, 1, (npts, 1))], 1).astype(np.float32)
+            pts.tofile(os.path.join(tmp, "%s_%d.bin" % (name, k)))
+            infos.append(dict(name=name, path="%s_%d.bin" % (name, k), box3d_lidar=box, num_points_in_gt=npts,
+                              difficulty=int(rng.integers(0, 3)), gt_idx=k, image_idx=k))
+            out["db_%s_%d_points" % (name, k)] = pts
+        db[name] = infos
+        out["db_%s_boxes" % name] = np.stack([i["box3d_lidar"] for i in infos])
+        out["db_%s_npts" % name] = np.array([i["num_points_in_gt"] for i in infos])
+        out["db_%s_difficulty" % name] = np.array([i["difficulty"] for i in infos])
+    with open(os.path.join(tmp, "dbinfos.pkl"), "wb") as f:
+        pickle.dump(db, f)
+    sampler_cfg = ConfigDict(type="GT-AUG", enable=True, db_info_path=os.path.join(tmp, "dbinfos.pkl"),
+                             sample_groups=[dict(Car=10), dict(Pedestrian=6)],
+                             db_prep_steps=[dict(filter_by_min_num_points=dict(Car=5, Pedestrian=5)),
+                                            dict(filter_by_difficulty=[-1])],
+                             global_random_rotation_range_per_object=[0, 0], rate=1.0)
+
+    def cfg(mode, names, **kw):
+        base = dict(mode=mode, shuffle_points=True, gt_loc_noise=[1.0, 1.0, 0.5], gt_rot_noise=[-0.785, 0.785],
+                    global_rot_noise=[-0.785, 0.785], global_scale_noise=[0.95, 1.05], global_rot_per_obj_range=[0, 0],
+                    global_trans_noise=[0.0, 0.0, 0.0], remove_points_after_sample=True, gt_drop_percentage=0.0,
+                    gt_drop_max_keep_points=15, remove_unknown_examples=False, remove_environment=False,
+                    db_sampler=sampler_cfg, class_names=names)
+        base.update(kw)
+        return ConfigDict(base)
+
+    def frame(nd, n_box, n_pts, names_pool):
+        gt = np.zeros((n_box, nd), np.float32)
+        gt[:, 0], gt[:, 1], gt[:, 2] = rng.uniform(5, 55, n_box), rng.uniform(-25, 25, n_box), -1.0
+        gt[:, 3:6] = [1.7, 4.0, 1.6]
+        gt[:, -1] = rng.uniform(-3, 3, n_box)
+        names = np.array([names_pool[i % len(names_pool)] for i in range(n_box)])
+        cols = 5 if nd == 9 else 4
+        pts = np.concatenate([rng.uniform(0, 65, (n_pts, 1)), rng.uniform(-35, 35, (n_pts, 1)), rng.uniform(-2.5, 0.5, (n_pts, 1)),
+                              rng.uniform(0, 1, (n_pts, cols - 3))], 1).astype(np.float32)
+        return gt, names, pts
+
+    # ---- KITTI-style: sampler active, two frames in a row (stateful sampler), DontCare dropped, Van kept out
+    np.random.seed(2024)
+    step = pp.Preprocess(cfg=cfg("train", ["Car", "Pedestrian"]))
+    for f in range(2):
+        gt, names, pts = frame(7, 5, 2500, ["Car", "DontCare", "Van", "Car", "Pedestrian"])
+        out["kitti%d_gt" % f], out["kitti%d_names" % f], out["kitti%d_points" % f] = gt.copy(), names.copy(), pts.copy()
+        res = dict(type="KittiDataset", metadata=dict(image_prefix=tmp, num_point_features=4),
+                   lidar=dict(points=pts, annotations=dict(boxes=gt, names=names)))
+        res, _ = step(res, {})
+        a = res["lidar"]["annotations"]
+        out["kitti%d_out_points" % f], out["kitti%d_out_boxes" % f] = res["lidar"]["points"], a["gt_boxes"]
+        out["kitti%d_out_names" % f], out["kitti%d_out_classes" % f] = a["gt_names"], a["gt_classes"]
+    # ---- nuScenes-style: 9-dim boxes, `combined` 5-column cloud, double flip, a sampler with nothing to add
+    np.random.seed(2025)
+    step = pp.Preprocess(cfg=cfg("train", ["Car", "Pedestrian"], gt_loc_noise=[0.0, 0.0, 0.0], gt_rot_noise=[0.0, 0.0],
+                                 db_sampler=ConfigDict(sampler_cfg, sample_groups=[dict(Car=1)])))
+    gt, names, pts = frame(9, 4, 1500, ["Car", "Pedestrian"])
+    gt[:, 6:8] = rng.normal(0, 2, (4, 2))
+    out["nusc_gt"], out["nusc_names"], out["nusc_points"] = gt.copy(), names.copy(), pts.copy()
+    res = dict(type="NuScenesDataset", metadata=dict(image_prefix=tmp, num_point_features=5),
+               lidar=dict(combined=pts, annotations=dict(boxes=gt, names=names)))
+    res, _ = step(res, {})
+    out["nusc_out_points"], out["nusc_out_boxes"] = res["lidar"]["points"], res["lidar"]["annotations"]["gt_boxes"]
+    out["nusc_out_names"] = res["lidar"]["annotations"]["gt_names"]
+    # ---- val mode: only the shuffle flag matters (off in the configs)
+    step = pp.Preprocess(cfg=ConfigDict(mode="val", shuffle_points=False, remove_environment=False,
+                                        remove_unknown_examples=False))
+    res, _ = step(dict(type="KittiDataset", metadata={}, lidar=dict(points=out["nusc_points"][:, :4].copy())), {})
+    out["val_out_points"] = res["lidar"]["points"]
+    np.savez_compressed(os.path.join(HERE, "preprocess.npz"), **out)
+    print("preprocess:", {k: v.shape for k, v in out.items() if "_out_" in k})
+
+
 def sampler_cases():
     """DistributedGroupSampler (datasets/loader/sampler.py:138-224): indices per rank and epoch."""
     sm = ref_loader.ref("det3d.datasets.loader.sampler")
@@ -906,7 +998,7 @@ def nms_gpu_cases():
 
 def main():
     ref_loader.install()
-    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "objnoise", "gtsampler", "loading", "sampler", "collate", "pipeline", "rangefilter", "nmsgpu", "detectors"]
+    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "objnoise", "gtsampler", "loading", "preprocess", "sampler", "collate", "pipeline", "rangefilter", "nmsgpu", "detectors"]
     if "anchors" in which:
         anchors_targets()
     if "tasks" in which:
@@ -919,6 +1011,8 @@ def main():
         gt_sampler_cases()
     if "loading" in which:
         loading_cases()
+    if "preprocess" in which:
+        preprocess_cases()
     if "sampler" in which:
         sampler_cases()
     if "collate" in which:

@@ -1,0 +1,97 @@
+"""f2: the Preprocess step (det3d_amd/pipelines.py) against the reference's own step run here on synthetic frames
+(tests/golden/preprocess.npz): GT-database sampling + pasting, per-object noise, flip(s), rotation, scaling, shuffle --
+same boxes, same names / class ids, same points IN THE SAME ORDER for the same NumPy seed."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+from det3d_amd import pipelines
+from det3d_amd.config import ConfigDict
+
+
+@pytest.fixture()
+def setup(tmp_path):
+    z = np.load(os.path.join(GOLDEN, "preprocess.npz"))
+    db = {}
+    for name in ("Car", "Pedestrian"):
+        boxes, npts, diff = z["db_%s_boxes" % name], z["db_%s_npts" % name], z["db_%s_difficulty" % name]
+        infos = []
+        for k in range(len(boxes)):
+            z["db_%s_%d_points" % (name, k)].tofile(tmp_path / ("%s_%d.bin" % (name, k)))
+            infos.append(dict(name=name, path="%s_%d.bin" % (name, k), box3d_lidar=boxes[k],
+                              num_points_in_gt=int(npts[k]), difficulty=int(diff[k])))
+        db[name] = infos
+    with open(tmp_path / "dbinfos.pkl", "wb") as f:
+        pickle.dump(db, f)
+    sampler = ConfigDict(type="GT-AUG", enable=True, db_info_path=str(tmp_path / "dbinfos.pkl"),
+                         sample_groups=[dict(Car=10), dict(Pedestrian=6)],
+                         db_prep_steps=[dict(filter_by_min_num_points=dict(Car=5, Pedestrian=5)),
+                                        dict(filter_by_difficulty=[-1])],
+                         global_random_rotation_range_per_object=[0, 0], rate=1.0)
+
+    def cfg(mode, **kw):
+        base = dict(mode=mode, shuffle_points=True, gt_loc_noise=[1.0, 1.0, 0.5], gt_rot_noise=[-0.785, 0.785],
+                    global_rot_noise=[-0.785, 0.785], global_scale_noise=[0.95, 1.05], global_rot_per_obj_range=[0, 0],
+                    global_trans_noise=[0.0, 0.0, 0.0], remove_points_after_sample=True, gt_drop_percentage=0.0,
+                    gt_drop_max_keep_points=15, remove_unknown_examples=False, remove_environment=False,
+                    db_sampler=sampler, class_names=["Car", "Pedestrian"])
+        base.update(kw)
+        return ConfigDict(base)
+
+    return z, tmp_path, cfg, sampler
+
+
+def test_kitti_train_step_matches_the_reference_step(setup):
+    z, tmp, cfg, _ = setup
+    np.random.seed(2024)
+    step = pipelines.Preprocess(cfg=cfg("train"), device="cpu", root_path=str(tmp))
+    for f in range(2):   # two frames in a row: the database samplers are stateful
+        res = dict(type="KittiDataset", metadata=dict(image_prefix=str(tmp), num_point_features=4),
+                   lidar=dict(points=z["kitti%d_points" % f].copy(),
+                              annotations=dict(boxes=z["kitti%d_gt" % f].copy(), names=z["kitti%d_names" % f].copy())))
+        res, _ = step(res, {})
+        a = res["lidar"]["annotations"]
+        assert res["mode"] == "train"
+        assert a["gt_names"].tolist() == z["kitti%d_out_names" % f].tolist(), f
+        assert np.array_equal(a["gt_classes"], z["kitti%d_out_classes" % f]) and a["gt_classes"].dtype == np.int32
+        assert np.allclose(a["gt_boxes"], z["kitti%d_out_boxes" % f], atol=3e-5), np.abs(a["gt_boxes"] - z["kitti%d_out_boxes" % f]).max()
+        got, ref = res["lidar"]["points"].numpy(), z["kitti%d_out_points" % f]
+        assert got.shape == ref.shape
+        assert np.allclose(got, ref, atol=1e-4), (f, np.abs(got - ref).max())   # row for row: same shuffle
+
+
+def test_nuscenes_train_step_and_val_mode(setup):
+    z, tmp, cfg, sampler = setup
+    np.random.seed(2025)
+    step = pipelines.Preprocess(cfg=cfg("train", gt_loc_noise=[0.0, 0.0, 0.0], gt_rot_noise=[0.0, 0.0],
+                                        db_sampler=ConfigDict(sampler, sample_groups=[dict(Car=1)])),
+                                device="cpu", root_path=str(tmp))
+    res = dict(type="NuScenesDataset", metadata=dict(image_prefix=str(tmp), num_point_features=5),
+               lidar=dict(combined=z["nusc_points"].copy(),
+                          annotations=dict(boxes=z["nusc_gt"].copy(), names=z["nusc_names"].copy())))
+    res, _ = step(res, {})
+    a = res["lidar"]["annotations"]
+    assert a["gt_names"].tolist() == z["nusc_out_names"].tolist()
+    assert np.allclose(a["gt_boxes"], z["nusc_out_boxes"], atol=3e-5)
+    assert np.allclose(res["lidar"]["points"].numpy(), z["nusc_out_points"], atol=1e-4)
+    val = pipelines.Preprocess(cfg=ConfigDict(mode="val", shuffle_points=False, remove_environment=False,
+                                              remove_unknown_examples=False), device="cpu")
+    res, _ = val(dict(type="KittiDataset", metadata={}, lidar=dict(points=z["nusc_points"][:, :4].copy())), {})
+    assert res["mode"] == "val" and np.array_equal(res["lidar"]["points"].numpy(), z["val_out_points"])
+    assert "annotations" not in res["lidar"]
+
+
+def test_unsupported_reference_branches_are_rejected_loudly(setup):
+    _, tmp, cfg, _ = setup
+    for flag in ("remove_environment", "add_rgb_to_points", "remove_outside_points", "random_crop"):
+        with pytest.raises(NotImplementedError):
+            pipelines.Preprocess(cfg=cfg("train", **{flag: True}), device="cpu", root_path=str(tmp))
+    with pytest.raises(NotImplementedError):
+        pipelines.build_dbsampler(ConfigDict(db_info_path=str(tmp / "dbinfos.pkl"), sample_groups=[dict(Car=1)],
+                                             db_prep_steps=[], global_random_rotation_range_per_object=[-0.5, 0.5],
+                                             rate=1.0), device="cpu", root_path=str(tmp))
