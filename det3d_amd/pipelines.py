@@ -11,8 +11,13 @@ AssignTarget.assign_batch); the per-frame classes exist so that an unmodified re
 """
 import numpy as np
 
+from .loading import LoadPointCloudFromFile
 from .point_cloud_ops import VoxelGenerator
-from .target_assigner import AssignTarget  # noqa: F401  (re-exported under the reference's name)
+from .registry import PIPELINES, build_from_cfg
+from .target_assigner import AssignTarget  # (re-exported under the reference's name)
+
+PIPELINES.register_module(LoadPointCloudFromFile)
+PIPELINES.register_module(AssignTarget)
 
 
 def box_bev_corners(gt_boxes):
@@ -43,6 +48,7 @@ def _dict_select(d, mask):
     return d
 
 
+@PIPELINES.register_module
 class Voxelization:
     def __init__(self, **kwargs):
         cfg = kwargs.get("cfg", None)
@@ -86,6 +92,7 @@ def build_dbsampler(cfg, device="cuda", root_path=None, num_point_features=4):
                            num_point_features=num_point_features)
 
 
+@PIPELINES.register_module
 class Preprocess:
     """The train / val preprocessing step (det3d/datasets/pipelines/preprocess.py:29-255) for ONE frame with the
     points on the device: class filtering, GT-database sampling + pasting, per-object noise, global flip / rotation /
@@ -176,4 +183,86 @@ class Preprocess:
         res["lidar"]["points"] = points
         if self.mode == "train":
             res["lidar"]["annotations"] = gt
+        return res, info
+
+
+@PIPELINES.register_module
+class LoadPointCloudAnnotations:
+    """datasets/pipelines/loading.py:166-222: the frame's ground truth as `res["lidar"]["annotations"]`.  nuScenes /
+    Lyft infos already hold lidar boxes; KITTI boxes come in camera coordinates with the origin at the bottom face:
+    DontCare rows dropped, (location, l h w, rotation_y) -> lidar (x y z, w l h, r) through the inverse of
+    R0_rect @ Tr_velo_to_cam, then moved to the box centre (box_np_ops.py:909-930, :1346-1349)."""
+
+    def __init__(self, with_bbox=True, **kwargs):
+        pass
+
+    def __call__(self, res, info):
+        if res["type"] in ("NuScenesDataset", "LyftDataset") and "gt_boxes" in info:
+            res["lidar"]["annotations"] = {"boxes": info["gt_boxes"].astype(np.float32), "names": info["gt_names"],
+                                           "tokens": info["gt_boxes_token"],
+                                           "velocities": info["gt_boxes_velocity"].astype(np.float32)}
+        elif res["type"] == "KittiDataset":
+            calib = info["calib"]
+            res["calib"] = {"rect": calib["R0_rect"], "Trv2c": calib["Tr_velo_to_cam"], "P2": calib["P2"]}
+            if "annos" in info:
+                annos = info["annos"]
+                keep = [i for i, x in enumerate(annos["name"]) if x != "DontCare"]
+                annos = {k: v[keep] for k, v in annos.items()}
+                cam = np.concatenate([annos["location"], annos["dimensions"], annos["rotation_y"][..., np.newaxis]],
+                                     axis=1).astype(np.float32)
+                xyz1 = np.concatenate([cam[:, 0:3], np.ones((cam.shape[0], 1))], axis=-1)
+                xyz = (xyz1 @ np.linalg.inv((calib["R0_rect"] @ calib["Tr_velo_to_cam"]).T))[:, :3]
+                boxes = np.concatenate([xyz, cam[:, 5:6], cam[:, 3:4], cam[:, 4:5], cam[:, 6:7]], axis=1)  # w, l, h
+                boxes[:, :3] += boxes[:, 3:6] * (np.array([0.5, 0.5, 0.5], boxes.dtype) - np.array([0.5, 0.5, 0], boxes.dtype))
+                res["lidar"]["annotations"] = {"boxes": boxes, "names": annos["name"]}
+                res["cam"]["annotations"] = {"boxes": annos["bbox"], "names": annos["name"]}
+        else:
+            raise NotImplementedError(res["type"])
+        return res, info
+
+
+@PIPELINES.register_module
+class Reformat:
+    """datasets/pipelines/formating.py:14-61: the per-frame `res` tree flattened into the example dict that
+    collate_kitti batches (collate.py)."""
+
+    def __init__(self, **kwargs):
+        pass
+
+    def __call__(self, res, info):
+        vox = res["lidar"]["voxels"]
+        out = dict(metadata=res["metadata"], points=res["lidar"]["points"], voxels=vox["voxels"], shape=vox["shape"],
+                   num_points=vox["num_points"], num_voxels=vox["num_voxels"], coordinates=vox["coordinates"],
+                   anchors=res["lidar"]["targets"]["anchors"])
+        if res.get("calib", None):
+            out["calib"] = res["calib"]
+        if res["mode"] != "test":
+            out["annos"] = res["lidar"]["annotations"]
+        if res["mode"] == "train":
+            if res["lidar"].get("ground_plane", None):
+                out["ground_plane"] = res["lidar"]["ground_plane"]
+            t = res["lidar"]["targets"]
+            out.update(labels=t["labels"], reg_targets=t["reg_targets"], reg_weights=t["reg_weights"])
+        return out, info
+
+
+@PIPELINES.register_module
+class Compose:
+    """datasets/pipelines/compose.py:7-27: the steps of a config's `train_pipeline` / `test_pipeline` list in order;
+    a step returning None drops the frame."""
+
+    def __init__(self, transforms):
+        self.transforms = []
+        for t in transforms:
+            if isinstance(t, dict):
+                t = build_from_cfg(t, PIPELINES)
+            elif not callable(t):
+                raise TypeError("transform must be callable or a dict")
+            self.transforms.append(t)
+
+    def __call__(self, res, info):
+        for t in self.transforms:
+            res, info = t(res, info)
+            if res is None:
+                return None
         return res, info

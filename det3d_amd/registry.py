@@ -56,3 +56,4 @@ def build_from_cfg(cfg, registry, default_args=None):
 
 READERS, BACKBONES, NECKS = Registry("reader"), Registry("backbone"), Registry("neck")
 HEADS, LOSSES, DETECTORS = Registry("head"), Registry("loss"), Registry("detector")
+PIPELINES = Registry("pipeline")  # det3d/datasets/registry.py:3-4

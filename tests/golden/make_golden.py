@@ -725,6 +725,37 @@ def preprocess_cases():
     print("preprocess:", {k: v.shape for k, v in out.items() if "_out_" in k})
 
 
+def annotation_cases():
+    """LoadPointCloudAnnotations (datasets/pipelines/loading.py:166-222) on a synthetic KITTI info (camera-frame boxes,
+    calibration matrices, a DontCare row) and a nuScenes info."""
+    loading = ref_loader.ref("det3d.datasets.pipelines.loading")
+    rng = np.random.default_rng(8)
+    n = 6
+    ang = 0.01
+    r0 = np.eye(4)
+    r0[:3, :3] = [[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]]
+    v2c = np.eye(4)
+    v2c[:3, :3] = [[0, -1, 0], [0, 0, -1], [1, 0, 0]]  # lidar x-forward -> camera z-forward
+    v2c[:3, 3] = [0.0, -0.08, -0.27]
+    p2 = np.array([[721.5, 0, 609.6, 44.9], [0, 721.5, 172.9, 0.2], [0, 0, 1, 0.003], [0, 0, 0, 1]])
+    annos = dict(name=np.array(["Car", "DontCare", "Pedestrian", "Car", "Van", "Cyclist"]),
+                 location=rng.uniform(-10, 30, (n, 3)), dimensions=rng.uniform(0.5, 4, (n, 3)),
+                 rotation_y=rng.uniform(-3, 3, n), bbox=rng.uniform(0, 300, (n, 4)), difficulty=rng.integers(0, 3, n))
+    info = dict(calib=dict(R0_rect=r0, Tr_velo_to_cam=v2c, P2=p2), annos={k: v.copy() for k, v in annos.items()})
+    res, _ = loading.LoadPointCloudAnnotations()(dict(type="KittiDataset", lidar={}, cam={}, metadata={}), info)
+    out = {"kitti_%s" % k: v for k, v in annos.items()}
+    out.update(kitti_r0=r0, kitti_v2c=v2c, kitti_p2=p2, kitti_out_boxes=res["lidar"]["annotations"]["boxes"],
+               kitti_out_names=res["lidar"]["annotations"]["names"], kitti_out_cam_boxes=res["cam"]["annotations"]["boxes"])
+    gt = rng.uniform(-40, 40, (5, 7))
+    info = dict(gt_boxes=gt, gt_names=np.array(["car", "bus", "car", "truck", "pedestrian"]),
+                gt_boxes_token=np.array(["a", "b", "c", "d", "e"]), gt_boxes_velocity=rng.normal(0, 2, (5, 3)))
+    res, _ = loading.LoadPointCloudAnnotations()(dict(type="NuScenesDataset", lidar={}, metadata={}), info)
+    out.update(nusc_gt=gt, nusc_vel=info["gt_boxes_velocity"], nusc_out_boxes=res["lidar"]["annotations"]["boxes"],
+               nusc_out_velocities=res["lidar"]["annotations"]["velocities"])
+    np.savez_compressed(os.path.join(HERE, "annotations.npz"), **out)
+    print("annotations:", out["kitti_out_boxes"].shape, out["kitti_out_boxes"].dtype)
+
+
 def sampler_cases():
     """DistributedGroupSampler (datasets/loader/sampler.py:138-224): indices per rank and epoch."""
     sm = ref_loader.ref("det3d.datasets.loader.sampler")
@@ -998,7 +1029,7 @@ def nms_gpu_cases():
 
 def main():
     ref_loader.install()
-    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "objnoise", "gtsampler", "loading", "preprocess", "sampler", "collate", "pipeline", "rangefilter", "nmsgpu", "detectors"]
+    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "objnoise", "gtsampler", "loading", "annotations", "preprocess", "sampler", "collate", "pipeline", "rangefilter", "nmsgpu", "detectors"]
     if "anchors" in which:
         anchors_targets()
     if "tasks" in which:
@@ -1011,6 +1042,8 @@ def main():
         gt_sampler_cases()
     if "loading" in which:
         loading_cases()
+    if "annotations" in which:
+        annotation_cases()
     if "preprocess" in which:
         preprocess_cases()
     if "sampler" in which:
