@@ -75,7 +75,16 @@ def install(force=False):
         _alias("det3d.ops.iou3d").__path__ = []
         _alias("det3d.ops.iou3d.iou3d_utils", **{k: getattr(iou3d_utils, k) for k in (
             "boxes_iou_bev", "boxes_overlap_bev", "boxes_iou3d_gpu", "nms_gpu", "nms_normal_gpu")})
+        from . import gt_sampler, loading, pipelines
+
         _alias("det3d.datasets").__path__ = []
+        _alias("det3d.datasets.registry", PIPELINES=registry.PIPELINES)
+        _alias("det3d.datasets.pipelines", Compose=pipelines.Compose, Preprocess=pipelines.Preprocess,
+               Voxelization=pipelines.Voxelization, AssignTarget=pipelines.AssignTarget, Reformat=pipelines.Reformat,
+               LoadPointCloudFromFile=loading.LoadPointCloudFromFile,
+               LoadPointCloudAnnotations=pipelines.LoadPointCloudAnnotations).__path__ = []
+        _alias("det3d.core.sampler").__path__ = []
+        _alias("det3d.core.sampler.sample_ops", DataBaseSamplerV2=gt_sampler.DeviceGTSampler)
         _alias("det3d.datasets.utils").__path__ = []
         _alias("det3d.datasets.utils.kitti_object_eval_python").__path__ = []
         _alias("det3d.datasets.utils.kitti_object_eval_python.rotate_iou",
