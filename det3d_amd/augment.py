@@ -187,8 +187,9 @@ def noise_per_object(points, frame_offsets, gt_boxes, gt_count, params, valid_ma
     corners = torch.where(real[..., None, None], corners, corners * 0 + far)
     selected = torch.full((b, g), -1, dtype=torch.int64, device=dev)
     others = torch.ones((g,), dtype=torch.bool, device=dev)
+    movable = valid.any(0).tolist()   # one host read for the whole walk
     for i in range(g):
-        if not bool(valid[:, i].any()):
+        if not movable[i]:
             continue
         cur = corners[:, i] - xy[:, i, None, :]                          # [B, 4, 2]
         cos, sin = torch.cos(rot[:, i])[:, :, None], torch.sin(rot[:, i])[:, :, None]   # [B, T, 1]
@@ -223,7 +224,6 @@ def noise_per_object(points, frame_offsets, gt_boxes, gt_count, params, valid_ma
         inside = (lx.abs() < half[..., 0]) & (ly.abs() < half[..., 1]) & (d[..., 2].abs() < half[..., 2]) & valid[fid]
         hit = inside.any(-1)
         j = inside.int().argmax(-1)                                      # first box, as points_transform_ breaks
-        rows = torch.arange(points.shape[0], device=dev)
         c_j = gt[fid, j][:, :3]
         a = rot_t[fid, j]
         ca, sa = torch.cos(a), torch.sin(a)
@@ -232,7 +232,6 @@ def noise_per_object(points, frame_offsets, gt_boxes, gt_count, params, valid_ma
         qy = -q[:, 0] * sa + q[:, 1] * ca
         new = torch.stack([qx, qy, q[:, 2]], -1) + c_j + loc_t[fid, j]
         pts[:, :3] = torch.where(hit[:, None], new.to(points.dtype), points[:, :3])
-        del rows
     # box3d_transform_ (:471-476)
     out = gt_boxes.clone().float()
     out[..., :3] = out[..., :3] + loc_t * valid[..., None]
