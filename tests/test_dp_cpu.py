@@ -224,3 +224,49 @@ def test_prefetcher_walks_nested_containers_and_is_transparent_without_a_gpu():
         assert pf.enabled is False
     out = pf.prepare(7)
     assert out["i"] == 7 and out["x"].tolist() == [7.0, 7.0] and "sparse_plan" not in out
+
+
+def test_sparse_stack_segments_only_cover_fusable_conv_bn_relu_runs():
+    """sparse_stack.segment: which layers of a SparseSequential go through the single-node path is decided from the
+    module list and the planned rulebooks alone -- checkable without a GPU with stand-in rulebooks."""
+    import types
+
+    import torch
+    from torch import nn
+
+    from det3d_amd import sparse_stack, spconv
+
+    def rb(n_in, n_out, subm):
+        return types.SimpleNamespace(n_in=n_in, n_out=n_out, subm=subm, kvol=27)
+
+    convs = [spconv.SubMConv3d(4, 16, 3, bias=False, indice_key="s0"), spconv.SubMConv3d(16, 16, 3, bias=False, indice_key="s0"),
+             spconv.SparseConv3d(16, 32, 3, 2, padding=1, bias=False), spconv.SubMConv3d(32, 32, 3, bias=False, indice_key="s1")]
+    mods = []
+    for c in convs:
+        mods += [c, nn.BatchNorm1d(c.out_channels), nn.ReLU()]
+    x = types.SimpleNamespace(indices=torch.zeros((100, 4), dtype=torch.int32), features=torch.zeros((100, 4), dtype=torch.bfloat16),
+                              indice_dict={"s0": rb(100, 100, True), convs[2]._rulebook_key(): rb(100, 40, False),
+                                           "s1": rb(40, 40, True)})
+    for m in mods:
+        m.train()
+    layers, nxt = sparse_stack.segment(spconv, mods, 0, x)
+    assert len(layers) == 4 and nxt == len(mods) and [ly.relu for ly in layers] == [True] * 4
+    assert [ly.pad_cin for ly in layers] == [16, 16, 16, 32]        # the 4-channel stem is padded to an MFMA tile
+    # a BatchNorm in eval mode ends the run in front of it
+    mods[4].eval()
+    layers, nxt = sparse_stack.segment(spconv, mods, 0, x)
+    assert len(layers) == 1 and nxt == 3
+    mods[4].train()
+    # a missing rulebook, a row-count mismatch, an unsupported width or a conv without a following BatchNorm: no run
+    x2 = types.SimpleNamespace(indices=x.indices, features=x.features, indice_dict={})
+    assert sparse_stack.segment(spconv, mods, 0, x2)[0] == []
+    x3 = types.SimpleNamespace(indices=torch.zeros((99, 4), dtype=torch.int32), features=x.features, indice_dict=x.indice_dict)
+    assert sparse_stack.segment(spconv, mods, 0, x3)[0] == []
+    wide = [spconv.SubMConv3d(16, 160, 3, bias=False, indice_key="s0"), nn.BatchNorm1d(160), nn.ReLU()]
+    wide[1].train()
+    assert sparse_stack.segment(spconv, wide, 0, x)[0] == []
+    assert sparse_stack.segment(spconv, [convs[1], nn.ReLU()], 0, x)[0] == []
+    # the parameter list handed to autograd follows the layer order: weight, [bias], gamma, beta
+    layers, _ = sparse_stack.segment(spconv, mods, 0, x)
+    ps = sparse_stack.params_of(layers)
+    assert len(ps) == 12 and ps[0] is convs[0].weight and ps[1] is mods[1].weight and ps[2] is mods[1].bias
