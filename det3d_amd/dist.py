@@ -101,6 +101,36 @@ class FlatGradBucket:
         return total
 
 
+class LocalGradClip:
+    """One rank: nothing to exchange, so nothing to concatenate either.  Global-norm clipping straight on the
+    per-parameter gradients with three multi-tensor launches (norms, norm of norms, scale) and one pass over the
+    parameter list on the host -- FlatGradBucket's cat + 84 re-pointed views cost the host ~0.4 ms per step for the
+    same arithmetic.  Same interface as FlatGradBucket as far as TrainStep uses it."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+
+    def zero(self):
+        for p in self.params:
+            p.grad = None
+
+    def gather(self):
+        for p in self.params:
+            if p.grad is None:  # FlatGradBucket substitutes zeros: Adam then still decays such a parameter's moments
+                p.grad = torch.zeros_like(p)
+        return None
+
+    def allreduce_mean(self):
+        return None
+
+    def clip_norm_(self, max_norm):
+        grads = [p.grad for p in self.params]
+        total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
+        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        torch._foreach_mul_(grads, coef)
+        return total
+
+
 class OverlappedGradBuckets:
     """Gradient mean over ranks, overlapped with the backward pass (replaces DDP's reducer,
     torchie/apis/train.py:282-289, and the reference's second flat all-reduce, dist_utils.py:31-57).

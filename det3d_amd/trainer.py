@@ -64,8 +64,12 @@ class TrainStep:
 
         nb = int(os.environ.get("D3D_DP_BUCKETS", "3"))
         self.overlap = d3d_dist.world_size() > 1 and nb > 0
-        self.bucket = d3d_dist.OverlappedGradBuckets(self.params, nb) if self.overlap else \
-            d3d_dist.FlatGradBucket(self.params)
+        if self.overlap:
+            self.bucket = d3d_dist.OverlappedGradBuckets(self.params, nb)
+        elif d3d_dist.world_size() > 1:
+            self.bucket = d3d_dist.FlatGradBucket(self.params)   # D3D_DP_BUCKETS=0: one flat all-reduce after backward
+        else:
+            self.bucket = d3d_dist.LocalGradClip(self.params)
         kw = dict(lr=self.sched.low_lr, betas=(moms[0], 0.99), weight_decay=0.0)
         dev = self.params[0].device
         try:

@@ -270,3 +270,34 @@ def test_sparse_stack_segments_only_cover_fusable_conv_bn_relu_runs():
     layers, _ = sparse_stack.segment(spconv, mods, 0, x)
     ps = sparse_stack.params_of(layers)
     assert len(ps) == 12 and ps[0] is convs[0].weight and ps[1] is mods[1].weight and ps[2] is mods[1].bias
+
+
+def test_single_rank_clip_equals_the_flat_bucket():
+    """LocalGradClip (one rank: no concatenation) clips to the same gradients and reports the same norm as
+    FlatGradBucket, including a parameter that received no gradient."""
+    import torch
+
+    from det3d_amd import dist as D
+
+    torch.manual_seed(0)
+    net_a = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    unused = torch.nn.Parameter(torch.ones(4))
+    net_b = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    net_b.load_state_dict(net_a.state_dict())
+    unused_b = torch.nn.Parameter(torch.ones(4))
+    x = torch.randn(5, 6)
+    outs = []
+    for net, extra, cls in ((net_a, unused, D.FlatGradBucket), (net_b, unused_b, D.LocalGradClip)):
+        params = list(net.parameters()) + [extra]
+        b = cls(params)
+        b.zero()
+        (net(x) ** 2).sum().backward()
+        b.gather()
+        b.allreduce_mean()
+        total = b.clip_norm_(0.5)
+        outs.append((float(total), [p.grad.clone() for p in params]))
+    assert outs[0][0] == pytest.approx(outs[1][0], rel=1e-6)
+    for ga, gb in zip(outs[0][1], outs[1][1]):
+        assert torch.allclose(ga, gb, rtol=1e-6, atol=1e-8)
+    assert float(torch.linalg.vector_norm(torch.cat([g.flatten() for g in outs[1][1]]))) == pytest.approx(0.5, rel=1e-4)
+    assert torch.equal(outs[1][1][-1], torch.zeros(4))
