@@ -20,6 +20,8 @@ so the overlap is between two HIP streams of one process (VERDICT 
 Memory: tensors produced on the side stream are handed to the compute stream with `record_stream`, so the caching
 allocator does not recycle them while the compute stream still reads them.
 """
+import os
+
 import torch
 
 
@@ -59,7 +61,8 @@ class GeometryPrefetcher:
             return self._build(batch)
         dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
         if self.stream is None:
-            self.stream = torch.cuda.Stream(dev, priority=-1)  # small kernels: let them cut in front of the step
+            # small kernels: by default they may cut in front of the step's (D3D_PREFETCH_PRIORITY=0: equal priority)
+            self.stream = torch.cuda.Stream(dev, priority=int(os.environ.get("D3D_PREFETCH_PRIORITY", "-1")))
         main = torch.cuda.current_stream(dev)
         if ready_event is not None:
             self.stream.wait_event(ready_event)
