@@ -213,7 +213,7 @@ def noise_per_object(points, frame_offsets, gt_boxes, gt_count, params, valid_ma
     rot_t = torch.gather(rot, 2, idx[..., None])[..., 0] * has
     # points inside the ORIGINAL boxes (centre origin, rotation about z) move with the first valid box that holds them
     pts = points.clone()
-    if points.shape[0]:
+    if points.shape[0] and g:
         fid = frame_index(frame_offsets.to(dev), points.shape[0])
         p = points[:, :3].float()
         d = p[:, None, :] - gt[fid][:, :, :3]                            # [P, G, 3]

@@ -125,3 +125,15 @@ def test_per_object_noise_never_leaves_boxes_colliding():
         coll.fill_diagonal_(False)
         moved = sel[i, :n] >= 0
         assert not coll[moved].any(), "a moved box collides with another box"
+
+
+def test_per_object_noise_handles_empty_frames_and_empty_clouds():
+    pts = torch.rand(10, 4)
+    off = torch.tensor([0, 10], dtype=torch.int32)
+    p, g, s = augment.noise_per_object(pts, off, torch.zeros((1, 0, 7)), torch.tensor([0]),
+                                       dict(loc_noises=np.zeros((1, 0, 5, 3)), rot_noises=np.zeros((1, 0, 5))))
+    assert torch.equal(p, pts) and g.shape == (1, 0, 7) and s.shape == (1, 0)
+    boxes = torch.tensor([[[0.0, 0, 0, 1, 2, 1, 0], [10, 0, 0, 1, 2, 1, 0]]])
+    p, g, s = augment.noise_per_object(torch.zeros((0, 4)), torch.tensor([0, 0], dtype=torch.int32), boxes,
+                                       torch.tensor([2]), dict(loc_noises=np.full((1, 2, 3, 3), 0.25), rot_noises=np.zeros((1, 2, 3))))
+    assert p.shape == (0, 4) and s.tolist() == [[0, 0]] and torch.allclose(g[0, :, :3], boxes[0, :, :3] + 0.25)
