@@ -35,6 +35,9 @@ SIGNATURES = {
     "d3d_pack_conv_weights": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "d3d_sparse_conv_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "d3d_set_tuning": (i32, [i32, i32]),
+    "d3d_sparse_conv_has_epilogue": (i32, [i32, i32, i32]),
+    "d3d_conv_epilogue_ws_floats": (sz, [i32, i32]),
+    "d3d_bn_reduce_ws_floats": (sz, [i32, i32, i32]),
     "d3d_sparse_conv_fwd_ex": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "d3d_sparse_conv_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "d3d_sparse_conv_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
@@ -73,10 +76,10 @@ SIGNATURES = {
     "d3d_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
 }
 
-ABI_VERSION = 3  # include/d3d.h D3D_ABI_VERSION
+ABI_VERSION = 4  # include/d3d.h D3D_ABI_VERSION
 D3D_F32 = 0
 D3D_BF16 = 1
-D3D_BN_COPIES = 8
+D3D_BN_COPIES = 1
 D3D_LOSS_SCALARS = 18
 D3D_IOU3D_OVERLAP, D3D_IOU3D_IOU_BEV, D3D_IOU3D_IOU_NORMAL = 0, 1, 2
 
@@ -88,7 +91,7 @@ class D3dError(RuntimeError):
 class ConvEpilogue(ctypes.Structure):
     """D3dConvEpilogue of include/d3d.h (device pointers as integers)"""
     _fields_ = [("stats", vp), ("bn_x", vp), ("bn_mean", vp), ("bn_invstd", vp), ("bn_gamma", vp),
-                ("bn_beta", vp), ("bn_relu", i32), ("bn_partial", vp), ("copies", i32)]
+                ("bn_beta", vp), ("bn_relu", i32), ("bn_partial", vp), ("ws_floats", i32)]
 
 
 def lib():

@@ -105,7 +105,7 @@ class _SparseMiddle(nn.Module):
             ret.indice_dict = plan["indice_dict"]  # built ahead of time for exactly these coordinates
         else:
             self.middle_conv.plan(ret)  # every rulebook of the stack, one host sync
-        spconv.ARENA.reset(voxel_features.device)  # one launch zeroes every conv-epilogue accumulator of this pass
+        spconv.ARENA.reset(voxel_features.device)  # rewind the fold workspaces of this pass's conv epilogues (no launch)
         ret = self.middle_conv(ret)
         self.last_indice_dict = ret.indice_dict
         # [B, C, D, H, W] -> [B, C*D, H, W]; optionally channels-last for MIOpen's NHWC kernels

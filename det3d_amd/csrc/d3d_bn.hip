@@ -9,10 +9,12 @@
 //          (block 0) and writes relu(x * scale + shift)
 //   bwd  = reduce pass (dbeta, dgamma; the ReLU mask is recomputed from x) + dx pass
 // Every pass is one coalesced 16 B/lane sweep over [N, C]: pure HBM streaming.
-// Statistics are accumulated with f32 atomics (LDS then global), so the last bits of
-// mean/var depend on arrival order -- the conv outputs themselves stay deterministic.
+// The reductions are DETERMINISTIC (round 3): lanes fold with shuffles, waves through per-wave LDS rows summed in
+// wave order, blocks through per-block slabs folded in block order by the last block to arrive (d3d_fold.h) --
+// no float atomics anywhere, two identical launches are bit-equal.
 #include "d3d_common.h"
 #include "d3d_fill.h"
+#include "d3d_fold.h"
 #include <stdlib.h>
 
 __device__ __forceinline__ float bn_bf16_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
@@ -73,12 +75,13 @@ template <bool BF16> __device__ __forceinline__ void bn_unpack(const uint4 &r, f
   }
 }
 
-// fold the lanes of a wave that work on the same 16-byte segment (lane % segs), then one LDS atomic per channel
-// from the first `segs` lanes; finally the block's sums go to one of the replicated global accumulators
+// fold the lanes of a wave that work on the same 16-byte segment (lane % segs) with shuffles, the waves of the block
+// through one LDS row per wave summed in wave order, the blocks through d3d_fold_block: a fixed summation tree
 template <int EPV, int NT>
-__device__ __forceinline__ void bn_block_reduce(float *a, float *b, int c, int segs, int seg, float *red,
-                                                float *__restrict__ dst_base, int skip_global) {
-  const int lane = threadIdx.x & 63;
+__device__ __forceinline__ void bn_block_reduce(float *a, float *b, int c, int segs, int seg,
+                                                float (*rows)[2 * BN_MAXC], float *tot, int *flag,
+                                                float *__restrict__ ws, unsigned *__restrict__ counters, int g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (segs < 64) {
     for (int m = 32; m >= segs; m >>= 1) {
 #pragma unroll
@@ -91,23 +94,29 @@ __device__ __forceinline__ void bn_block_reduce(float *a, float *b, int c, int s
   if (segs >= 64 || lane < segs) {
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
-      atomicAdd(&red[seg * EPV + j], a[j]);
-      atomicAdd(&red[c + seg * EPV + j], b[j]);
+      rows[wave][seg * EPV + j] = a[j];
+      rows[wave][c + seg * EPV + j] = b[j];
     }
   }
   __syncthreads();
-  if (skip_global) return;
-  float *dst = dst_base + (size_t)(blockIdx.x % D3D_BN_COPIES) * 2 * c;  // spread same-address atomics
-  for (int i = threadIdx.x; i < 2 * c; i += NT) atomicAdd(&dst[i], red[i]);
+  for (int i = threadIdx.x; i < 2 * c; i += NT) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) t += rows[w][i];
+    tot[i] = t;
+  }
+  __syncthreads();
+  d3d_fold_block<NT>(tot, 2 * c, ws, counters, g, flag);
 }
 
 template <bool BF16, int NT, int U>
 __global__ void __launch_bounds__(NT)
-    bn_stats_kernel(const void *__restrict__ x, int n, int c, float *__restrict__ stats, int skip_global) {
+    bn_stats_kernel(const void *__restrict__ x, int n, int c, float *__restrict__ stats,
+                    unsigned *__restrict__ counters, int fold_g) {
   constexpr int EPV = BnVec<BF16>::EPV;
-  __shared__ float red[2 * BN_MAXC];
-  for (int i = threadIdx.x; i < 2 * c; i += NT) red[i] = 0.f;
-  __syncthreads();
+  __shared__ float rows[NT / 64][2 * BN_MAXC];
+  __shared__ float tot[2 * BN_MAXC];
+  __shared__ int flag;
   const int segs = c / EPV;
   const int seg = threadIdx.x % segs, rl = threadIdx.x / segs, rp = NT / segs;
   float s[EPV], q[EPV];
@@ -140,7 +149,7 @@ __global__ void __launch_bounds__(NT)
       q[j] = fmaf(v[j], v[j], q[j]);
     }
   }
-  bn_block_reduce<EPV, NT>(s, q, c, segs, seg, red, stats, skip_global);
+  bn_block_reduce<EPV, NT>(s, q, c, segs, seg, rows, tot, &flag, stats, counters, fold_g);
 }
 
 template <bool BF16>
@@ -223,12 +232,12 @@ __global__ void __launch_bounds__(NT)
     bn_bwd_reduce_kernel(const void *__restrict__ x, const void *__restrict__ dy, int n, int c,
                          const float *__restrict__ gamma, const float *__restrict__ beta,
                          const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
-                         float *__restrict__ partial, int skip_global) {
+                         float *__restrict__ partial, unsigned *__restrict__ counters, int fold_g) {
   constexpr int EPV = BnVec<BF16>::EPV;
   constexpr int UR = U / 2;  // rows in flight: each row is two loads (x, dy)
-  __shared__ float red[2 * BN_MAXC];
-  for (int i = threadIdx.x; i < 2 * c; i += NT) red[i] = 0.f;
-  __syncthreads();
+  __shared__ float rows[NT / 64][2 * BN_MAXC];
+  __shared__ float tot[2 * BN_MAXC];
+  __shared__ int flag;
   const int segs = c / EPV;
   const int seg = threadIdx.x % segs, rl = threadIdx.x / segs, rp = NT / segs;
   // z = x * zs + zb (the ReLU mask), xhat = x * is - mu * is
@@ -277,7 +286,7 @@ __global__ void __launch_bounds__(NT)
       sg[j] = fmaf(dz, fmaf(v[j], is[j], mi[j]), sg[j]);
     }
   }
-  bn_block_reduce<EPV, NT>(sg, sb, c, segs, seg, red, partial, skip_global);  // [copy][dgamma | dbeta]
+  bn_block_reduce<EPV, NT>(sg, sb, c, segs, seg, rows, tot, &flag, partial, counters, fold_g);  // [dgamma | dbeta]
 }
 
 // dx = gamma * invstd * (dz - dbeta/N - xhat * dgamma/N) = A dz + P x + Q per channel
@@ -374,7 +383,7 @@ static const BnVariant BN_VARIANTS[] = {
 // MI355X, [140800, 128] bf16 (profiles/round2_bench_bn.json): variant 9 = 13.5 / 28.8 us (stats / bwd_reduce incl. the
 // accumulator fill launch), variant 0 = 16.9 / 33.3, 2048 x 256-thread blocks (variant 1) = 22.3 / 39.5
 int g_bn_variant = getenv("D3D_BN_VARIANT") ? atoi(getenv("D3D_BN_VARIANT")) : 9;
-int g_bn_skip_global = 0;  // timing diagnosis only (knob 4): leave the global atomics out -> wrong sums
+int g_bn_skip_global = 0;  // knob 4 of round 2 (skip the global atomics): there are no atomics left, ignored
 int g_bn_dx_rows = getenv("D3D_BN_DX_ROWS") ? atoi(getenv("D3D_BN_DX_ROWS")) : 2;  // rows in flight in bwd_dx (knob 5)
 // grid cap of the apply / bwd_dx / affine sweeps (knob 6, D3D_BN_STREAM_BLOCKS): 512 blocks x 4 rows in flight is
 // 30.1 us for bwd_dx on the 36 MB map, 2048 blocks 40.6 us (same file); inputs under ~8 MB never reach the cap
@@ -386,11 +395,13 @@ static BnVariant bn_variant_for(int n, int c) {
   if (v < 0 || v >= BN_NUM_VARIANTS) v = 0;
   return BN_VARIANTS[v];
 }
+#define BN_REDUCE_MAX_BLOCKS 512  // slabs the last block folds (d3d_fold.h): 32 groups of 16 at most
 static int bn_reduce_grid(const BnVariant &v, int n, int c, int dtype, int small_grid) {
-  if (v.cap == 0) return small_grid;
+  if (v.cap == 0) return small_grid > BN_REDUCE_MAX_BLOCKS ? BN_REDUCE_MAX_BLOCKS : small_grid;
   const int rp = v.nt / (c / (dtype == D3D_BF16 ? 8 : 4));
   int nb = ((n + rp - 1) / rp + v.u - 1) / v.u;
   if (nb > v.cap) nb = v.cap;
+  if (nb > BN_REDUCE_MAX_BLOCKS) nb = BN_REDUCE_MAX_BLOCKS;
   return nb < 1 ? 1 : nb;
 }
 #define BN_LAUNCH_NU(KERNEL, NT, U, ...)                                                                    \
@@ -402,6 +413,10 @@ static int bn_reduce_grid(const BnVariant &v, int n, int c, int dtype, int small
   do {                                                                                                      \
     const BnVariant bv = bn_variant_for(n, c);                                                              \
     const int nbr = bn_reduce_grid(bv, n, c, dtype, nb);                                                    \
+    const D3dFoldPlan fp = d3d_fold_plan(nbr, 2 * c);                                                       \
+    unsigned *counters = d3d_fold_counters(d3d_fold_counter_words(fp));                                     \
+    if (!counters) return D3D_EHIP;                                                                         \
+    const int fold_g = fp.g;                                                                                \
     if (bv.nt == 1024 && bv.u == 4) BN_LAUNCH_NU(KERNEL, 1024, 4, __VA_ARGS__);                             \
     else if (bv.nt == 1024) BN_LAUNCH_NU(KERNEL, 1024, 8, __VA_ARGS__);                                     \
     else if (bv.nt == 512 && bv.u == 4) BN_LAUNCH_NU(KERNEL, 512, 4, __VA_ARGS__);                          \
@@ -435,6 +450,16 @@ static int bn_stream_grid(int n, int c, int dtype) {
   return nb;
 }
 
+// floats of the workspace d3d_bn_stats / d3d_bn_bwd_reduce need: [2c] result | per-block slabs | group slabs
+extern "C" size_t d3d_bn_reduce_ws_floats(int n, int c, int dtype) {
+  if ((dtype != D3D_F32 && dtype != D3D_BF16) || n < 1 || c < 1) return 0;
+  const int epv = dtype == D3D_BF16 ? 8 : 4;
+  if (c % epv || c > BN_MAXC || 256 % (c / epv)) return 0;
+  const BnVariant bv = bn_variant_for(n, c);
+  const int nbr = bn_reduce_grid(bv, n, c, dtype, bn_grid(n, c, dtype));
+  return d3d_fold_ws_floats(nbr, 2 * c);
+}
+
 // ---- the two halves of each direction as separate entry points: the conv epilogues (d3d_sparse_conv_fwd_ex)
 // can produce the reductions, and cross-rank BatchNorm puts an all-reduce between the halves
 extern "C" int d3d_bn_stats(const void *x, int n, int c, int dtype, float *stats_ws, d3d_stream_t stream_) {
@@ -443,8 +468,7 @@ extern "C" int d3d_bn_stats(const void *x, int n, int c, int dtype, float *stats
   if (rc) return rc;
   D3D_REQUIRE(x && stats_ws, "d3d_bn_stats: null pointer");
   const int nb = bn_grid(n, c, dtype);
-  D3D_HIP_TRY(d3d_fill_async(stream, stats_ws, 0, (size_t)D3D_BN_COPIES * 2 * c * sizeof(float)));
-  BN_LAUNCH_REDUCE(bn_stats_kernel, x, n, c, stats_ws, g_bn_skip_global);
+  BN_LAUNCH_REDUCE(bn_stats_kernel, x, n, c, stats_ws, counters, fold_g);
   D3D_LAUNCH_TRY("bn_stats_kernel");
   return D3D_OK;
 }
@@ -481,9 +505,8 @@ extern "C" int d3d_bn_bwd_reduce(const void *x, const void *dy, int n, int c, in
   if (rc) return rc;
   D3D_REQUIRE(x && dy && save_mean && save_invstd && partial_ws, "d3d_bn_bwd_reduce: null pointer");
   const int nb = bn_grid(n, c, dtype);
-  D3D_HIP_TRY(d3d_fill_async(stream, partial_ws, 0, (size_t)D3D_BN_COPIES * 2 * c * sizeof(float)));
   BN_LAUNCH_REDUCE(bn_bwd_reduce_kernel, x, dy, n, c, gamma, beta, save_mean, save_invstd, relu, partial_ws,
-                   g_bn_skip_global);
+                   counters, fold_g);
   D3D_LAUNCH_TRY("bn_bwd_reduce_kernel");
   return D3D_OK;
 }
@@ -604,7 +627,7 @@ extern "C" int d3d_bn_relu_fwd(const void *x, int n, int c, int dtype, const flo
     if (rc) return rc;
   }
   return d3d_bn_apply(x, n, c, dtype, gamma, beta, running_mean, running_var, momentum, eps, training, relu,
-                      stats_ws, D3D_BN_COPIES, y, save_mean, save_invstd, stream_);
+                      stats_ws, 1, y, save_mean, save_invstd, stream_);
 }
 
 extern "C" int d3d_bn_relu_bwd(const void *x, const void *dy, int n, int c, int dtype,
@@ -613,6 +636,6 @@ extern "C" int d3d_bn_relu_bwd(const void *x, const void *dy, int n, int c, int 
                                float *dbeta, float *partial_ws, d3d_stream_t stream_) {
   int rc = d3d_bn_bwd_reduce(x, dy, n, c, dtype, gamma, beta, save_mean, save_invstd, relu, partial_ws, stream_);
   if (rc) return rc;
-  return d3d_bn_bwd_dx(x, dy, n, c, dtype, gamma, beta, save_mean, save_invstd, relu, partial_ws, D3D_BN_COPIES,
+  return d3d_bn_bwd_dx(x, dy, n, c, dtype, gamma, beta, save_mean, save_invstd, relu, partial_ws, 1,
                        dx, dgamma, dbeta, stream_);
 }

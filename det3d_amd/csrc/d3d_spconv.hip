@@ -22,6 +22,7 @@
 
 #include "d3d_common.h"
 #include "d3d_fill.h"
+#include "d3d_fold.h"
 #include "d3d_spconv_internal.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -64,22 +65,48 @@ extern "C" int d3d_set_tuning(int knob, int value) {
 }
 
 
+// the ABI's epilogue request + what the launcher adds for the deterministic cross-block fold (d3d_fold.h)
+struct ConvEpiDev : D3dConvEpilogue {
+  unsigned *counters;  // ticket words of this launch
+  int fold_g;          // blocks per fold group
+};
+
+// fold plan of a reducing launch: capacity check of the caller's buffer, ticket words from the library's ring
+static int epi_prepare(ConvEpiDev &ep, int nb, int cout) {
+  ep.counters = nullptr;
+  ep.fold_g = 16;
+  if (!ep.stats && !ep.bn_partial) return D3D_OK;
+  D3D_REQUIRE(nb <= D3D_FOLD_MAX_BLOCKS, "sparse conv epilogue reduction: %d blocks > %d", nb, D3D_FOLD_MAX_BLOCKS);
+  const D3dFoldPlan fp = d3d_fold_plan(nb, 2 * cout);
+  const size_t need = d3d_fold_ws_floats(nb, 2 * cout);
+  if ((size_t)ep.ws_floats < need)
+    return d3d_set_error(D3D_ECAPACITY, "sparse conv epilogue reduction: buffer of %d floats < %zu (use "
+                         "d3d_conv_epilogue_ws_floats)", ep.ws_floats, need);
+  ep.counters = d3d_fold_counters(d3d_fold_counter_words(fp));
+  if (!ep.counters) return D3D_EHIP;
+  ep.fold_g = fp.g;
+  return D3D_OK;
+}
+
 // epilogue shared by the forward kernels: lane holds couts [n*16 + lg*4, +4) of site[m].  Optional per-channel
 // reductions ride along (each saves one full sweep over the activations, see D3dConvEpilogue in include/d3d.h):
 //   ep.stats      forward : sum / sum of squares of the rows just produced (BatchNorm batch statistics)
 //   ep.bn_partial dgrad   : sum dz * xhat | sum dz of the BatchNorm(+ReLU) that produced this conv's input
-// `red`: LDS scratch [2 * COUT] no wave still reads for anything else.
+// The sums are deterministic: the MT tiles of a lane in order, the 16 sites of a tile by shuffles, the waves of a
+// block through one LDS row per wave summed in wave order, the blocks through d3d_fold_block.
+// `red`: LDS scratch of SPCONV_EPI_LDS_FLOATS(COUT, NTHREADS) floats; it may alias the weight buffers (the
+// reductions start behind a workgroup barrier, so no wave still reads W).
+#define SPCONV_EPI_LDS_FLOATS(COUT, NTHREADS) (((NTHREADS) / 64 + 1) * 2 * (COUT) + 4)
 template <int COUT, int MT, bool BF16, int NTHREADS>
 __device__ __forceinline__ void spconv_fwd_epilogue(f32x4_t (&acc)[MT][COUT / 16], const int (&site)[MT],
                                                     const bool (&live)[MT], const float *__restrict__ bias,
-                                                    void *__restrict__ out_, const D3dConvEpilogue &ep, float *red,
+                                                    void *__restrict__ out_, const ConvEpiDev &ep, float *red,
                                                     int lr, int lg) {
   constexpr int NT = COUT / 16;
+  constexpr int NW = NTHREADS / 64;
   const bool want_stats = ep.stats != nullptr, want_bnb = ep.bn_partial != nullptr;
-  if (want_stats || want_bnb) {
-    for (int i = threadIdx.x; i < 2 * COUT; i += NTHREADS) red[i] = 0.f;
-    __syncthreads();
-  }
+  const int wave = threadIdx.x >> 6;
+  if (want_stats || want_bnb) __syncthreads();  // `red` may alias LDS other waves were still reading
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int co = n * 16 + lg * 4;
@@ -153,21 +180,26 @@ __device__ __forceinline__ void spconv_fwd_epilogue(f32x4_t (&acc)[MT][COUT / 16
           a0 += __shfl_xor(a0, o, 64);
           a1 += __shfl_xor(a1, o, 64);
         }
-        if (lr == 0) {
-          atomicAdd(&red[co + j], a0);
-          atomicAdd(&red[COUT + co + j], a1);
+        if (lr == 0) {  // one lane per (wave, channel): plain stores
+          red[wave * 2 * COUT + co + j] = a0;
+          red[wave * 2 * COUT + COUT + co + j] = a1;
         }
       }
     }
   }
   if (want_stats || want_bnb) {
     __syncthreads();
-    // [copy][2 * COUT]: (sum | sum sq) or (dgamma | dbeta), replicated to spread same-address atomics
-    // [copy][2 * COUT]: (sum | sum sq) or (dgamma | dbeta), replicated to spread same-address atomics.  (Agent-
-    // and workgroup-scope float adds lower to the same global_atomic_add_f32 on gfx950 and execute beyond the
-    // XCD's L2, so a per-XCD replica indexed by HW_REG_XCC_ID buys nothing over blockIdx % 8.)
-    float *dst = (want_stats ? ep.stats : ep.bn_partial) + (size_t)(blockIdx.x % (unsigned)ep.copies) * 2 * COUT;
-    for (int i = threadIdx.x; i < 2 * COUT; i += NTHREADS) atomicAdd(&dst[i], red[i]);
+    float *tot = red + NW * 2 * COUT;
+    for (int i = threadIdx.x; i < 2 * COUT; i += NTHREADS) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[w * 2 * COUT + i];
+      tot[i] = t;
+    }
+    __syncthreads();
+    // (sum | sum sq) or (dgamma | dbeta): this block's slab, folded across blocks in a fixed order
+    d3d_fold_block<NTHREADS>(tot, 2 * COUT, want_stats ? ep.stats : ep.bn_partial, ep.counters, ep.fold_g,
+                             (int *)(tot + 2 * COUT));
   }
 }
 
@@ -195,7 +227,7 @@ template <int CIN, int COUT, int MT, int WAVES, int DEPTH, bool BF16>
 __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
     spconv_fwd_mfma_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
                            const float *__restrict__ bias, const int32_t *__restrict__ nbr,
-                           int cap, int n_out, int kvol, void *__restrict__ out_, D3dConvEpilogue ep,
+                           int cap, int n_out, int kvol, void *__restrict__ out_, ConvEpiDev ep,
                            int xcd_remap) {
   constexpr int NT = COUT / 16;
   constexpr int ESZ = BF16 ? 2 : 4;
@@ -208,6 +240,7 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
   constexpr int SEGS = CIN * ESZ / 16;    // 16-byte segments per weight row
   constexpr int WVEC = COUT * SEGS;       // 16-byte vectors in W[k]
   constexpr int WPT = (WVEC + NTHREADS - 1) / NTHREADS;
+  static_assert(2 * WBYTES >= 4 * SPCONV_EPI_LDS_FLOATS(COUT, NTHREADS), "epilogue scratch aliases the W buffers");
   __shared__ __attribute__((aligned(16))) unsigned char wlds[2 * WBYTES];
 
   const int lane = threadIdx.x & 63;
@@ -372,7 +405,7 @@ template <int CIN, int COUT, int MT, int WAVES, int DEPTH, int KC, int MINW>
 __global__ void __launch_bounds__(WAVES * 64, MINW)  // second value: waves per SIMD
     spconv_fwd_chunk_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
                             const float *__restrict__ bias, const int32_t *__restrict__ nbr, int cap, int n_out,
-                            int kvol, void *__restrict__ out_, D3dConvEpilogue ep) {
+                            int kvol, void *__restrict__ out_, ConvEpiDev ep) {
   constexpr int NT = COUT / 16;
   constexpr int ESZ = 2, KW = 32, EPL = 8;
   constexpr int KS = CIN / KW;
@@ -384,8 +417,9 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)  // second value: waves per 
   static_assert(CIN % 32 == 0 && COUT % 16 == 0, "bf16 x32 MFMA tiles");
   static_assert(WVEC % 256 == 0, "the swizzle must not see the offset index");
   static_assert(CHUNK % 64 == 0 && KC % DEPTH == 0, "chunk / pipeline shape");
+  static_assert(CHUNK * 16 >= 4 * SPCONV_EPI_LDS_FLOATS(COUT, NTHREADS), "epilogue scratch aliases the W buffers");
   __shared__ __attribute__((aligned(16))) unsigned char wlds[CHUNK * 16];
-  __shared__ float red[2 * COUT];
+  float *red = (float *)wlds;
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -524,7 +558,7 @@ template <int CIN, int COUT, int MT, int WAVES, int DEPTH>
 __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
     spconv_fwd_group_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
                             const float *__restrict__ bias, const int32_t *__restrict__ nbr, int cap, int n_out,
-                            int kvol, void *__restrict__ out_, D3dConvEpilogue ep) {
+                            int kvol, void *__restrict__ out_, ConvEpiDev ep) {
   constexpr int NT = COUT / 16;
   constexpr int ESZ = 2, KW = 32, EPL = 8;
   constexpr int KS = CIN / KW;
@@ -533,8 +567,9 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
   constexpr int NTHREADS = WAVES * 64;
   constexpr int WPT = (WVEC + NTHREADS - 1) / NTHREADS;
   static_assert(CIN % 32 == 0 && COUT % 16 == 0 && WVEC % 256 == 0, "bf16 x32 MFMA tiles, swizzle period");
+  static_assert(2 * DEPTH * WVEC * 16 >= 4 * SPCONV_EPI_LDS_FLOATS(COUT, NTHREADS), "epilogue scratch aliases the W buffers");
   __shared__ __attribute__((aligned(16))) unsigned char wlds[2 * DEPTH * WVEC * 16];
-  __shared__ float red[2 * COUT];
+  float *red = (float *)wlds;
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -665,9 +700,10 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
 
 template <int CIN, int COUT, int MT, int WAVES, int DEPTH>
 static int launch_fwd_group(const void *feat, const void *wpack, const float *bias, const int32_t *nbr, int cap,
-                            int n_out, int kvol, void *out, const D3dConvEpilogue &ep, hipStream_t stream) {
+                            int n_out, int kvol, void *out, ConvEpiDev ep, hipStream_t stream) {
   const int rows_per_block = WAVES * MT * 16;
   const int nb = (n_out + rows_per_block - 1) / rows_per_block;
+  if (int rc = epi_prepare(ep, nb, COUT)) return rc;
   hipLaunchKernelGGL((spconv_fwd_group_kernel<CIN, COUT, MT, WAVES, DEPTH>), dim3(nb), dim3(WAVES * 64), 0, stream,
                      feat, wpack, bias, nbr, cap, n_out, kvol, out, ep);
   D3D_LAUNCH_TRY("spconv_fwd_group_kernel");
@@ -676,9 +712,10 @@ static int launch_fwd_group(const void *feat, const void *wpack, const float *bi
 
 template <int CIN, int COUT, int MT, int WAVES, int DEPTH, int KC, int MINW = (MT * (COUT / 16) >= 16 ? 2 : 4)>
 static int launch_fwd_chunk(const void *feat, const void *wpack, const float *bias, const int32_t *nbr, int cap,
-                            int n_out, int kvol, void *out, const D3dConvEpilogue &ep, hipStream_t stream) {
+                            int n_out, int kvol, void *out, ConvEpiDev ep, hipStream_t stream) {
   const int rows_per_block = WAVES * MT * 16;
   const int nb = (n_out + rows_per_block - 1) / rows_per_block;
+  if (int rc = epi_prepare(ep, nb, COUT)) return rc;
   hipLaunchKernelGGL((spconv_fwd_chunk_kernel<CIN, COUT, MT, WAVES, DEPTH, KC, MINW>), dim3(nb), dim3(WAVES * 64), 0,
                      stream, feat, wpack, bias, nbr, cap, n_out, kvol, out, ep);
   D3D_LAUNCH_TRY("spconv_fwd_chunk_kernel");
@@ -721,11 +758,13 @@ __global__ void __launch_bounds__(256)
 
 template <int CIN, int COUT, int MT, int WAVES, int DEPTH, bool BF16>
 static int launch_fwd(const void *feat, const void *wpack, const float *bias, const int32_t *nbr,
-                      int cap, int n_out, int kvol, void *out, const D3dConvEpilogue &ep, hipStream_t stream) {
+                      int cap, int n_out, int kvol, void *out, ConvEpiDev ep, hipStream_t stream) {
   const int rows_per_block = WAVES * MT * 16;
   int nb = (n_out + rows_per_block - 1) / rows_per_block;
-  const int remap = g_xcd_remap && nb >= 16;
+  const bool reduces = ep.stats || ep.bn_partial;
+  const int remap = g_xcd_remap && nb >= 16 && !reduces;  // every block of a reducing launch takes a fold ticket
   if (remap) nb = (nb + 7) / 8 * 8;
+  if (int rc = epi_prepare(ep, nb, COUT)) return rc;
   hipLaunchKernelGGL((spconv_fwd_mfma_kernel<CIN, COUT, MT, WAVES, DEPTH, BF16>), dim3(nb),
                      dim3(WAVES * 64), 0, stream, feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, remap);
   D3D_LAUNCH_TRY("spconv_fwd_mfma_kernel");
@@ -740,6 +779,24 @@ static int launch_fwd(const void *feat, const void *wpack, const float *bias, co
                                                                      n_out, kvol, out, ep, stream); \
   }
 
+// channel pairs with an MFMA tiling below (FWD_CASE list): only these can carry the epilogue reductions
+extern "C" int d3d_sparse_conv_has_epilogue(int cin, int cout, int dtype) {
+  if (dtype != D3D_F32 && dtype != D3D_BF16) return 0;
+  static const int pairs[][2] = {{16, 16}, {16, 32}, {32, 16}, {32, 32}, {32, 64}, {64, 32},
+                                 {64, 64}, {64, 128}, {128, 64}, {128, 128}};
+  for (auto &pr : pairs)
+    if (pr[0] == cin && pr[1] == cout) return 1;
+  return 0;
+}
+// floats of the buffer D3dConvEpilogue.stats / .bn_partial point to for a launch producing n_out rows:
+// [2*cout] result | block slabs | group slabs, sized for the smallest tile any variant uses (64 rows per block)
+extern "C" size_t d3d_conv_epilogue_ws_floats(int n_out, int cout) {
+  if (n_out < 1 || cout < 1) return 0;
+  int nb = (n_out + 63) / 64 + 8;
+  if (nb > D3D_FOLD_MAX_BLOCKS) nb = D3D_FOLD_MAX_BLOCKS;
+  return d3d_fold_ws_floats(nb, 2 * cout);
+}
+
 extern "C" int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const float *bias,
                                    const int32_t *nbr, int cap, int n_out, int kvol, int cin,
                                    int cout, int dtype, void *out, d3d_stream_t stream_) {
@@ -751,15 +808,14 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
                                       int cout, int dtype, void *out, const D3dConvEpilogue *epilogue,
                                       d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  D3dConvEpilogue ep = {};
-  if (epilogue) ep = *epilogue;
+  ConvEpiDev ep = {};
+  if (epilogue) *(D3dConvEpilogue *)&ep = *epilogue;
   D3D_REQUIRE(!(ep.stats && ep.bn_partial), "d3d_sparse_conv_fwd_ex: one reduction per launch (stats or bn_partial)");
-  if (ep.copies <= 0) ep.copies = D3D_BN_COPIES;
-  D3D_REQUIRE(ep.copies <= 256, "d3d_sparse_conv_fwd_ex: copies=%d", ep.copies);
   D3D_REQUIRE(!ep.bn_partial || (ep.bn_x && ep.bn_mean && ep.bn_invstd),
               "d3d_sparse_conv_fwd_ex: bn_partial needs bn_x, bn_mean, bn_invstd");
-  D3D_REQUIRE(!(ep.stats || ep.bn_partial) || (cin % 16 == 0 && cout % 16 == 0 && cin <= 128 && cout <= 128),
-              "d3d_sparse_conv_fwd_ex: the fused reductions exist on the MFMA path only (channels %d -> %d)", cin, cout);
+  D3D_REQUIRE(!(ep.stats || ep.bn_partial) || d3d_sparse_conv_has_epilogue(cin, cout, dtype),
+              "d3d_sparse_conv_fwd_ex: the fused reductions exist on the MFMA tiles only, channels %d -> %d have "
+              "none (ask d3d_sparse_conv_has_epilogue)", cin, cout);
   D3D_REQUIRE(dtype == D3D_F32 || dtype == D3D_BF16, "d3d_sparse_conv_fwd: dtype %d", dtype);
   D3D_REQUIRE(n_out >= 0 && n_out <= cap && kvol >= 1 && cin >= 1 && cout >= 1,
               "d3d_sparse_conv_fwd: n_out=%d cap=%d kvol=%d cin=%d cout=%d", n_out, cap, kvol, cin,

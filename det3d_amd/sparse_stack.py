@@ -38,7 +38,7 @@ def _eligible(sp, conv, bn, feats_dtype, rb):
         return False
     cin, cout = conv.in_channels, conv.out_channels
     pad_cin = 16 if (cin < 16 and cout % 16 == 0) else cin
-    if not (pad_cin % 16 == 0 and cout % 16 == 0 and pad_cin <= 128 and cout <= 128):
+    if not sp.has_epilogue(pad_cin, cout, feats_dtype):
         return False  # VALU fallback kernels have no epilogues
     if rb is None or rb.subm != conv.subm or rb.n_out <= 1 or rb.n_in <= 0:
         return False
@@ -77,7 +77,7 @@ class _StackFn(torch.autograd.Function):
         dtype = feats.dtype
         dt = sp._DT[dtype]
         st = _lib.stream_ptr(dev)
-        arena, copies = sp.ARENA, sp.EPI_COPIES
+        arena = sp.ARENA
         feats = feats.contiguous()
         need_in_grad = ctx.needs_input_grad[0]
         rec = []
@@ -95,8 +95,8 @@ class _StackFn(torch.autograd.Function):
             wpack, wd = sp._packed_weights(conv.weight, rb.kvol, cin, cout, dtype, rb.subm,
                                            li > 0 or need_in_grad, pad_cin)
             out = torch.empty((rb.n_out, cout), dtype=dtype, device=dev)
-            stats = arena.take(dev, 2 * copies * cout)
-            ep = _lib.ConvEpilogue(stats=stats.data_ptr(), copies=copies)
+            stats = sp.epilogue_ws(dev, rb.n_out, cout)
+            ep = _lib.ConvEpilogue(stats=stats.data_ptr(), ws_floats=stats.numel())
             b = conv.bias.detach() if conv.bias is not None else None
             rc = sp._timed("fwd", pad_cin, cout, rb.n_out, rb, dev, lambda: L.d3d_sparse_conv_fwd_ex(
                 x.data_ptr(), wpack.data_ptr(), _lib.ptr(b), rb.nbr_out.data_ptr(), rb.cap_out, rb.n_out, rb.kvol,
@@ -106,11 +106,11 @@ class _StackFn(torch.autograd.Function):
             save = torch.empty((2, cout), dtype=torch.float32, device=dev)
             rc = L.d3d_bn_apply(out.data_ptr(), rb.n_out, cout, dt, bn.weight.data_ptr(), _lib.ptr(bn.bias),
                                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum),
-                                float(bn.eps), 1, int(ly.relu), stats.data_ptr(), copies, y.data_ptr(),
+                                float(bn.eps), 1, int(ly.relu), stats.data_ptr(), 1, y.data_ptr(),
                                 save[0].data_ptr(), save[1].data_ptr(), st)
             _lib.check(rc, "d3d_bn_apply")
             # the conv behind this layer reduces this BatchNorm's backward sums in its dgrad epilogue
-            partial = arena.take(dev, 2 * copies * cout) if li + 1 < len(layers) else None
+            partial = sp.epilogue_ws(dev, rb.n_out, cout) if li + 1 < len(layers) else None
             rec.append((x, out, save, wd, partial))
             x = y
         ctx.layers, ctx.rec, ctx.sp = layers, rec, sp
@@ -126,7 +126,6 @@ class _StackFn(torch.autograd.Function):
         dt = sp._DT[dtype]
         dev = g.device
         st = _lib.stream_ptr(dev)
-        copies = sp.EPI_COPIES
         # arena slices are only ours until the next ARENA.reset(): a second forward in between -> separate sweeps
         fused = sp.ARENA.generation == ctx.generation
         grads = []  # per layer, in parameter order
@@ -139,11 +138,8 @@ class _StackFn(torch.autograd.Function):
             dy = g.contiguous()
             if dy.dtype != dtype:
                 dy = dy.to(dtype)
-            if reduced_next:
-                pcopies = copies
-            else:
-                pcopies = _lib.D3D_BN_COPIES
-                partial = torch.empty((2 * pcopies * cout,), dtype=torch.float32, device=dev)
+            if not reduced_next:
+                partial = sp.reduce_ws(dev, rb.n_out, cout, dtype)
                 rc = L.d3d_bn_bwd_reduce(out.data_ptr(), dy.data_ptr(), rb.n_out, cout, dt, bn.weight.data_ptr(),
                                          _lib.ptr(bn.bias), save[0].data_ptr(), save[1].data_ptr(), int(ly.relu),
                                          partial.data_ptr(), st)
@@ -152,7 +148,7 @@ class _StackFn(torch.autograd.Function):
             gbn = torch.empty((2, cout), dtype=torch.float32, device=dev)
             rc = L.d3d_bn_bwd_dx(out.data_ptr(), dy.data_ptr(), rb.n_out, cout, dt, bn.weight.data_ptr(),
                                  _lib.ptr(bn.bias), save[0].data_ptr(), save[1].data_ptr(), int(ly.relu),
-                                 partial.data_ptr(), pcopies, gout.data_ptr(), gbn[0].data_ptr(), gbn[1].data_ptr(), st)
+                                 partial.data_ptr(), 1, gout.data_ptr(), gbn[0].data_ptr(), gbn[1].data_ptr(), st)
             _lib.check(rc, "d3d_bn_bwd_dx")
             # ---- conv backward
             gin = None
@@ -161,13 +157,13 @@ class _StackFn(torch.autograd.Function):
                 nbr, cap = (rb.nbr_out, rb.cap_out) if rb.subm else (rb.nbr_in, rb.cap_in)
                 gin = torch.empty((rb.n_in, pad_cin), dtype=dtype, device=dev)
                 ep = None
-                if li > 0 and fused and pad_cin == cin:
+                if li > 0 and fused and pad_cin == cin and sp.has_epilogue(cout, pad_cin, dtype):
                     pl = layers[li - 1]
                     _, pout, psave, _, ppartial = rec[li - 1]
                     ep = _lib.ConvEpilogue(bn_x=pout.data_ptr(), bn_mean=psave[0].data_ptr(),
                                            bn_invstd=psave[1].data_ptr(), bn_gamma=pl.bn.weight.data_ptr(),
                                            bn_beta=_lib.ptr(pl.bn.bias), bn_relu=int(pl.relu),
-                                           bn_partial=ppartial.data_ptr(), copies=copies)
+                                           bn_partial=ppartial.data_ptr(), ws_floats=ppartial.numel())
                     reduced_next = True
                 rc = sp._timed("dgrad", cout, pad_cin, rb.n_in, rb, dev, lambda: L.d3d_sparse_conv_fwd_ex(
                     gout.data_ptr(), wd.data_ptr(), None, nbr.data_ptr(), cap, rb.n_in, rb.kvol, cout, pad_cin, dt,

@@ -32,7 +32,6 @@ _DT = {torch.float32: _lib.D3D_F32, torch.bfloat16: _lib.D3D_BF16}
 
 # bench.py sets this to a list to time every d3d_sparse_conv_fwd launch with HIP events
 # recorded on the launch stream: entries are (kind, cin, cout, n_out, rulebook, ev0, ev1)
-EPI_COPIES = int(os.environ.get("D3D_EPI_COPIES", "8"))  # replicas of a conv-epilogue accumulator (same-address atomics)
 FUSE_BN_RELU = True  # SparseSequential / SparseBasicBlock route BatchNorm1d(+ReLU) to d3d_bn_relu_*
 LAUNCH_LOG = None
 LAUNCH_LOG_LIMIT = 256
@@ -58,12 +57,15 @@ FUSE_BN_STATS = os.environ.get("D3D_FUSE_BN_STATS", "1") != "0"  # BN batch stat
 #                       consuming conv's dgrad epilogue (d3d_sparse_conv_fwd_ex): 2 instead of 4 BN sweeps per layer
 
 
-class _ZeroArena:
-    """One flat f32 buffer per device handing out ZEROED per-channel accumulators (BN statistics / backward
-    partial sums written by conv epilogues).  `reset()` -- called by the backbones right before they run their
-    sparse stack, on the compute stream -- re-zeroes the whole buffer with ONE launch and bumps `generation`;
-    views handed out before a reset must not be accumulated into afterwards (the users compare generations).
-    Without resets (layers used on their own) the arena simply runs out and hands out private zeroed buffers."""
+class _ScratchArena:
+    """One flat f32 buffer per device handing out the fold workspaces of the conv-epilogue reductions (BN
+    statistics / BN-backward sums: [2C] result + per-block slabs, see csrc/d3d_fold.h).  Nothing needs zeroing
+    (round 2's atomically accumulated replicas did).  `reset()` -- called by the backbones right before they run
+    their sparse stack -- rewinds the buffer and bumps `generation`; views handed out before a reset must not be
+    written afterwards (the users compare generations).  Without resets (layers used on their own) the arena
+    simply runs out and hands out private buffers."""
+
+    WORDS = 1 << 24  # 64 MB
 
     def __init__(self):
         self.buf = {}
@@ -71,25 +73,38 @@ class _ZeroArena:
         self.generation = 0
 
     def reset(self, dev):
-        b = self.buf.get(dev)
-        if b is not None:
-            b.zero_()
         self.off[dev] = 0
         self.generation += 1
 
     def take(self, dev, n):
+        n = (int(n) + 63) // 64 * 64  # 256-byte aligned slices
         b = self.buf.get(dev)
         off = self.off.get(dev, 0)
-        if b is None or off + n > b.numel():
-            if b is None and off == 0:
-                b = self.buf[dev] = torch.zeros((1 << 20,), dtype=torch.float32, device=dev)  # 4 MB
-            else:  # arena exhausted (very deep stack): a private zeroed buffer, still correct
-                return torch.zeros((n,), dtype=torch.float32, device=dev)
+        if b is None:
+            b = self.buf[dev] = torch.empty((self.WORDS,), dtype=torch.float32, device=dev)
+        if off + n > b.numel():  # arena exhausted (very deep stack / huge clouds): a private buffer
+            return torch.empty((n,), dtype=torch.float32, device=dev)
         self.off[dev] = off + n
         return b[off: off + n]
 
 
-ARENA = _ZeroArena()
+def epilogue_ws(dev, n_out, cout):
+    """buffer for D3dConvEpilogue.stats / .bn_partial of a launch producing n_out rows of cout channels"""
+    return ARENA.take(dev, _lib.lib().d3d_conv_epilogue_ws_floats(int(n_out), int(cout)))
+
+
+def reduce_ws(dev, n, c, dtype):
+    """workspace of d3d_bn_stats / d3d_bn_bwd_reduce on an [n, c] matrix; the [2c] result sits at its start"""
+    return torch.empty((_lib.lib().d3d_bn_reduce_ws_floats(int(n), int(c), _DT[dtype]),), dtype=torch.float32,
+                       device=dev)
+
+
+def has_epilogue(cin, cout, dtype):
+    """channel pairs whose conv kernel can carry a BN reduction in its epilogue (the MFMA tilings)"""
+    return dtype in _DT and bool(_lib.lib().d3d_sparse_conv_has_epilogue(int(cin), int(cout), _DT[dtype]))
+
+
+ARENA = _ScratchArena()
 
 
 class _BnLink:
@@ -257,8 +272,8 @@ def finalize_conv_rulebook(rb, n_in, n_out):
 class _SparseConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, weight, bias, rb, stats, link):
-        """stats: zeroed f32 [D3D_BN_COPIES * 2 * cout] or None -- the launch adds sum / sum-of-squares of its
-        output rows (the batch statistics of the BatchNorm that follows).  link: _BnLink of the fused BN(+ReLU)
+        """stats: epilogue_ws() buffer or None -- the launch leaves sum / sum-of-squares of its output rows (the
+        batch statistics of the BatchNorm that follows) in stats[:2*cout].  link: _BnLink of the fused BN(+ReLU)
         that produced `feats`, or None -- the backward's dgrad launch then also reduces that BN's gradient sums."""
         _need_cuda(feats, "sparse conv")
         L = _lib.lib()
@@ -284,10 +299,10 @@ class _SparseConvFn(torch.autograd.Function):
         wpack, wd = _packed_weights(weight, kvol, cin, cout, feats.dtype, rb.subm, need_dgrad, pad_cin)
         out = torch.empty((rb.n_out, cout), dtype=feats.dtype, device=feats.device)
         b = bias.detach().float().contiguous() if bias is not None else None
-        mfma = pad_cin % 16 == 0 and cout % 16 == 0 and pad_cin <= 128 and cout <= 128
+        mfma = has_epilogue(pad_cin, cout, feats.dtype)
         ep = None
         if stats is not None and mfma and rb.n_out > 0:
-            ep = _lib.ConvEpilogue(stats=stats.data_ptr(), copies=EPI_COPIES)
+            ep = _lib.ConvEpilogue(stats=stats.data_ptr(), ws_floats=stats.numel())
         rc = _timed("fwd", pad_cin, cout, rb.n_out, rb, feats.device, lambda: L.d3d_sparse_conv_fwd_ex(
             feats.data_ptr(), wpack.data_ptr(), _lib.ptr(b), rb.nbr_out.data_ptr(), rb.cap_out,
             rb.n_out, kvol, pad_cin, cout, _DT[feats.dtype], out.data_ptr(),
@@ -324,13 +339,13 @@ class _SparseConvFn(torch.autograd.Function):
             gin = torch.empty((rb.n_in, pad_cin), dtype=feats.dtype, device=feats.device)
             ep = None
             link = ctx.link
-            if link is not None and ctx.mfma and pad_cin == cin and rb.n_in > 0 and \
-                    link.generation == ARENA.generation and not link.reduced:
+            if link is not None and has_epilogue(cout, pad_cin, feats.dtype) and pad_cin == cin and rb.n_in > 0 and \
+                    link.generation == ARENA.generation and not link.reduced and link.partial is not None:
                 # gin is dL/dy of the BN(+ReLU) that produced `feats`: reduce its gradient sums here
                 ep = _lib.ConvEpilogue(bn_x=link.x.data_ptr(), bn_mean=link.save[0].data_ptr(),
                                        bn_invstd=link.save[1].data_ptr(), bn_gamma=_lib.ptr(link.gamma),
                                        bn_beta=_lib.ptr(link.beta), bn_relu=int(link.relu),
-                                       bn_partial=link.partial.data_ptr(), copies=EPI_COPIES)
+                                       bn_partial=link.partial.data_ptr(), ws_floats=link.partial.numel())
             rc = _timed("dgrad", cout, pad_cin, rb.n_in, rb, feats.device, lambda: L.d3d_sparse_conv_fwd_ex(
                 gout.data_ptr(), wd.data_ptr(), None, nbr.data_ptr(), cap, rb.n_in, kvol, cout, pad_cin,
                 dt, gin.data_ptr(), ctypes.byref(ep) if ep is not None else None, stream))
@@ -369,10 +384,9 @@ class _BNReLUFn(torch.autograd.Function):
         y = torch.empty_like(x)
         save = torch.empty((2, c), dtype=torch.float32, device=dev)  # mean, invstd
         st = _lib.stream_ptr(dev)
-        copies = EPI_COPIES  # stats from a conv epilogue
+        copies = 1  # every producer (conv epilogue, d3d_bn_stats) folds its sums into one [2c] vector
         if training and stats is None:
-            copies = _lib.D3D_BN_COPIES
-            stats = torch.empty((2 * copies * c,), dtype=torch.float32, device=dev)
+            stats = reduce_ws(dev, n, c, x.dtype)
             _lib.check(L.d3d_bn_stats(x.data_ptr(), n, c, _DT[x.dtype], stats.data_ptr(), st), "d3d_bn_stats")
         rc = L.d3d_bn_apply(x.data_ptr(), n, c, _DT[x.dtype], _lib.ptr(weight), _lib.ptr(bias),
                             _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum), float(eps),
@@ -385,7 +399,7 @@ class _BNReLUFn(torch.autograd.Function):
         ctx.link = link
         if link is not None and training:
             link.x, link.save, link.gamma, link.beta, link.relu = x, save, weight, bias, bool(relu)
-            link.partial = ARENA.take(dev, 2 * EPI_COPIES * c)
+            link.partial = epilogue_ws(dev, n, c)
             link.generation = ARENA.generation
             link.reduced = False
         return y
@@ -402,11 +416,11 @@ class _BNReLUFn(torch.autograd.Function):
         g = torch.empty((2, c), dtype=torch.float32, device=x.device)
         st = _lib.stream_ptr(x.device)
         link = ctx.link
-        if link is not None and link.reduced and link.generation == ARENA.generation:
-            partial, copies = link.partial, EPI_COPIES  # reduced by the consuming conv's dgrad epilogue
+        copies = 1
+        if link is not None and link.reduced and link.generation == ARENA.generation and link.partial is not None:
+            partial = link.partial  # reduced by the consuming conv's dgrad epilogue
         else:
-            copies = _lib.D3D_BN_COPIES
-            partial = torch.empty((2 * copies * c,), dtype=torch.float32, device=x.device)
+            partial = reduce_ws(x.device, n, c, x.dtype)
             rc = L.d3d_bn_bwd_reduce(x.data_ptr(), dy.data_ptr(), n, c, _DT[x.dtype], _lib.ptr(weight),
                                      _lib.ptr(bias), save[0].data_ptr(), save[1].data_ptr(), int(ctx.relu),
                                      partial.data_ptr(), st)
@@ -417,6 +431,7 @@ class _BNReLUFn(torch.autograd.Function):
         _lib.check(rc, "d3d_bn_bwd_dx")
         if link is not None:
             link.x = link.save = link.partial = None  # drop the references held for the epilogue
+            link.reduced = False  # a second backward over the same graph runs its own reduction sweep
         gw = g[0].to(weight.dtype) if weight is not None else None
         gb = g[1].to(bias.dtype) if bias is not None else None
         return dx, gw, gb, None, None, None, None, None, None, None, None
@@ -456,10 +471,9 @@ def conv_bn_relu(conv, bn, relu, x, link_in=None, want_link=False):
     fuse = FUSE_BN_STATS and bn.training and x.features.is_cuda and x.features.shape[0] > 0
     stats = None
     if fuse:
-        stats = ARENA.take(x.features.device, 2 * EPI_COPIES * conv.out_channels)
+        stats = True  # the conv takes an epilogue_ws() slice once it knows its output row count
     out = conv(x, stats=stats, link=link_in if FUSE_BN_STATS else None)
-    if not getattr(out, "_stats_done", False):
-        stats = None
+    stats = getattr(out, "_stats", None)
     link = _BnLink() if (want_link and fuse) else None
     out.features = bn_relu(bn, out.features, relu, stats, link)
     return out, link
@@ -639,14 +653,16 @@ class SparseConvolution(SparseModule):
             raise _lib.D3dError("indice_key %r is shared between a submanifold and a strided convolution" % (self.indice_key,))
         cin = self.in_channels
         pad_cin = 16 if (cin < 16 and self.out_channels % 16 == 0) else cin
-        mfma = pad_cin % 16 == 0 and self.out_channels % 16 == 0 and pad_cin <= 128 and self.out_channels <= 128
-        if not mfma or rb.n_out == 0:
-            stats = None
+        if stats is not None:
+            if not has_epilogue(pad_cin, self.out_channels, x.features.dtype) or rb.n_out == 0:
+                stats = None  # no MFMA tiling for this channel pair: the BatchNorm runs its own statistics sweep
+            elif stats is True:
+                stats = epilogue_ws(x.features.device, rb.n_out, self.out_channels)
         out_feats = _SparseConvFn.apply(x.features, self.weight, self.bias, rb, stats, link)
         out = SparseConvTensor(out_feats, rb.out_indices if not self.subm else x.indices,
                                self.out_spatial_shape(x.spatial_shape), x.batch_size, x.grid)
         out.indice_dict = x.indice_dict
-        out._stats_done = stats is not None
+        out._stats = stats  # the epilogue's workspace: [2 * cout] sums first
         return out
 
 

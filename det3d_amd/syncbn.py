@@ -129,9 +129,9 @@ class _SyncBNReLUFusedFn(torch.autograd.Function):
         dev = rows.device
         dt = _lib.D3D_BF16 if rows.dtype == torch.bfloat16 else _lib.D3D_F32
         st = _lib.stream_ptr(dev)
-        ws = torch.empty((_lib.D3D_BN_COPIES, 2 * c), dtype=torch.float32, device=dev)
+        ws = torch.empty((L.d3d_bn_reduce_ws_floats(n, c, dt),), dtype=torch.float32, device=dev)
         _lib.check(L.d3d_bn_stats(rows.data_ptr(), n, c, dt, ws.data_ptr(), st), "d3d_bn_stats")
-        stats = ws.sum(0) / n  # local E[x] | E[x^2]
+        stats = ws[:2 * c] / n  # local E[x] | E[x^2] (deterministic fold: the sums sit at the start of the workspace)
         world = _world(group)
         if world > 1:
             dist.all_reduce(stats, group=group)
@@ -170,12 +170,12 @@ class _SyncBNReLUFusedFn(torch.autograd.Function):
         dy = dy.contiguous().to(rows.dtype)
         g, b = gamma.float().contiguous(), beta.float().contiguous()
         invstd = (1.0 / std).contiguous()
-        partial = torch.empty((_lib.D3D_BN_COPIES, 2 * c), dtype=torch.float32, device=dev)
+        partial = torch.empty((L.d3d_bn_reduce_ws_floats(n, c, dt),), dtype=torch.float32, device=dev)
         # sum dz * xhat | sum dz with xhat = (x - ex) / std and dz = dy masked by the ReLU
         _lib.check(L.d3d_bn_bwd_reduce(rows.data_ptr(), dy.data_ptr(), n, c, dt, g.data_ptr(), b.data_ptr(),
                                        ex.data_ptr(), invstd.data_ptr(), int(ctx.relu), partial.data_ptr(), st),
                    "d3d_bn_bwd_reduce")
-        sums = partial.sum(0)
+        sums = partial[:2 * c]
         dot_p, dy_sum = sums[:c] * std, sums[c:]
         inv3 = invstd * invstd * invstd
         pack = torch.cat([-dy_sum * g * invstd + dot_p * g * inv3 * ex * ctx.cf,   # grad_ex

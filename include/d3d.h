@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 3 /* 3: d3d_sparse_conv_wgrad takes a workspace (two-pass deterministic weight gradient); round-2 additions */
+#define D3D_ABI_VERSION 4 /* 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv */
 
 #define D3D_OK 0
 #define D3D_EINVAL -1    /* bad argument / unsupported shape           */
@@ -141,21 +141,26 @@ int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const float *bias,
  * the activations that the reference pays as a separate BatchNorm kernel (scn.py:106-157 applies
  * nn.BatchNorm1d + nn.ReLU modules to `.features` after every conv):
  *   forward: stats != NULL       -> sum / sum-of-squares of the produced rows (as stored, i.e. rounded to
- *            dtype) are ADDED to stats [D3D_BN_COPIES][2*cout] f32 = what d3d_bn_stats computes;
+ *            dtype) are written to stats[0 .. 2*cout) f32 = what d3d_bn_stats computes;
  *   dgrad  : bn_partial != NULL  -> the rows produced are dL/dy of the BatchNorm(+ReLU) whose output was this
  *            conv's input; with that layer's pre-BN activations bn_x [n_out, cout] (dtype), saved mean /
  *            invstd and gamma / beta (NULL = 1 / 0), sum dz*xhat | sum dz (dz = dy masked by the ReLU) are
- *            ADDED to bn_partial [D3D_BN_COPIES][2*cout] f32 = what d3d_bn_bwd_reduce computes.
- * The caller zeroes the accumulators.  Channel counts must be multiples of 16 (MFMA path).
- * Which of the D3D_BN_COPIES replicas a block adds to is the kernel's business (consumers fold all of them). */
+ *            written to bn_partial[0 .. 2*cout) f32 = what d3d_bn_bwd_reduce computes.
+ * The sums are DETERMINISTIC (ABI 4): blocks hand per-block partial vectors to a fixed-order fold, no float
+ * atomics; two identical launches give bit-equal sums.  The buffer behind stats / bn_partial therefore also
+ * holds the per-block slabs: `ws_floats` is its capacity in floats, d3d_conv_epilogue_ws_floats(n_out, cout)
+ * the amount needed; it need not be zeroed.  Only the channel pairs d3d_sparse_conv_has_epilogue() accepts
+ * (the MFMA tilings) can carry a reduction; others return D3D_EINVAL instead of silently skipping it. */
 typedef struct D3dConvEpilogue {
   float *stats;
   const void *bn_x;
   const float *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;
   int bn_relu;
   float *bn_partial;
-  int copies; /* replicas of the accumulator ([copies][2*cout]; 0 = D3D_BN_COPIES): block b adds to replica b % copies */
+  int ws_floats; /* capacity of the stats / bn_partial buffer in floats */
 } D3dConvEpilogue;
+int d3d_sparse_conv_has_epilogue(int cin, int cout, int dtype);
+size_t d3d_conv_epilogue_ws_floats(int n_out, int cout);
 /* tuning hook for tools/tune_fwd.py and tools/bench_bn.py: knob 0 = tiling variant of the forward 64->64 bf16
  * kernel (0 = default), 1 = target block count of the weight-gradient kernel (<= 0 = default, one block per CU),
  * 2 = XCD-aware tile order, 3 = BatchNorm reduction variant for inputs of >= 2^23 elements, 4 = leave the BatchNorm
@@ -182,16 +187,17 @@ int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const int32_t *nbr
  * (det3d/models/backbones/scn.py:106-157; residual blocks :76-87), F.batch_norm semantics
  * (biased variance to normalise, unbiased into running_var, eps, momentum).
  *  x, y, dy, dx dev [n,c] dtype; gamma/beta/running_* dev [c] f32 (gamma/beta may be NULL)
- *  training=1: batch statistics (stats_ws dev [D3D_BN_COPIES * 2c] f32 scratch: the per-channel
- *              sums are accumulated into D3D_BN_COPIES replicas to spread same-address atomics),
+ *  training=1: batch statistics (stats_ws dev f32 scratch of d3d_bn_reduce_ws_floats(n, c, dtype) floats:
+ *              [2c] sums | per-block slabs of the deterministic fold; need not be zeroed),
  *              running stats updated in place, save_mean/save_invstd dev [c] written for the backward
  *  training=0: running statistics, stats_ws unused
  *  relu=1 fuses max(0, .) into the apply pass (and its mask into the backward).
- *  bwd overwrites dgamma/dbeta dev [c] f32 and dx; partial_ws dev [D3D_BN_COPIES * 2c] f32 scratch.
+ *  bwd overwrites dgamma/dbeta dev [c] f32 and dx; partial_ws: scratch of d3d_bn_reduce_ws_floats floats.
  *  Works on any row-major [n,c] matrix, e.g. the [B*H*W, C] view of a channels-last feature map
  *  (the RPN's BatchNorm2d + ReLU pairs, det3d/models/necks/rpn.py:124-142).
  */
-#define D3D_BN_COPIES 8
+#define D3D_BN_COPIES 1 /* the reductions fold themselves: consumers read ONE [2c] vector */
+size_t d3d_bn_reduce_ws_floats(int n, int c, int dtype);
 int d3d_bn_relu_fwd(const void *x, int n, int c, int dtype, const float *gamma, const float *beta,
                     float *running_mean, float *running_var, float momentum, float eps,
                     int training, int relu, void *y, float *save_mean, float *save_invstd,
@@ -201,9 +207,10 @@ int d3d_bn_relu_bwd(const void *x, const void *dy, int n, int c, int dtype, cons
                     void *dx, float *dgamma, float *dbeta, float *partial_ws, d3d_stream_t stream);
 /* The halves of the two calls above as separate entry points (d3d_bn_relu_fwd = d3d_bn_stats + d3d_bn_apply,
  * d3d_bn_relu_bwd = d3d_bn_bwd_reduce + d3d_bn_bwd_dx; same buffers).  The reductions can then come from a
- * convolution epilogue (d3d_sparse_conv_fwd_ex) instead of their own sweep; d3d_bn_stats / d3d_bn_bwd_reduce
- * zero their accumulator first, the apply / dx halves only read it: [copies][2c] replicas (D3D_BN_COPIES from
- * d3d_bn_stats / d3d_bn_bwd_reduce; a conv epilogue may have used more to thin out same-address atomics). */
+ * convolution epilogue (d3d_sparse_conv_fwd_ex) instead of their own sweep.  Both reductions leave their [2c]
+ * result at the start of their workspace; the apply / dx halves read `copies` consecutive [2c] vectors and add
+ * them in order (copies = 1 for the producers of this library; > 1 lets a caller hand in several partial
+ * results, e.g. per-rank sums). */
 int d3d_bn_stats(const void *x, int n, int c, int dtype, float *stats_ws, d3d_stream_t stream);
 int d3d_bn_apply(const void *x, int n, int c, int dtype, const float *gamma, const float *beta,
                  float *running_mean, float *running_var, float momentum, float eps, int training, int relu,

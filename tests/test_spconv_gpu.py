@@ -495,17 +495,18 @@ def test_split_bn_entry_points_and_channel_affine_sweeps(dtype):
     rm2, rv2 = rm.clone(), rv.clone()
     y1, y2 = torch.empty_like(x), torch.empty_like(x)
     save1, save2 = torch.empty(2, c, device="cuda"), torch.empty(2, c, device="cuda")
-    ws1 = torch.empty(2 * _lib.D3D_BN_COPIES * c, device="cuda")
+    ws1 = torch.empty(L.d3d_bn_reduce_ws_floats(n, c, dt), device="cuda")
     ws2 = torch.empty_like(ws1)
     _lib.check(L.d3d_bn_relu_fwd(x.data_ptr(), n, c, dt, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
                                  0.01, 1e-3, 1, 1, y1.data_ptr(), save1[0].data_ptr(), save1[1].data_ptr(),
                                  ws1.data_ptr(), st), "fwd")
     _lib.check(L.d3d_bn_stats(x.data_ptr(), n, c, dt, ws2.data_ptr(), st), "stats")
     _lib.check(L.d3d_bn_apply(x.data_ptr(), n, c, dt, gamma.data_ptr(), beta.data_ptr(), rm2.data_ptr(), rv2.data_ptr(),
-                              0.01, 1e-3, 1, 1, ws2.data_ptr(), _lib.D3D_BN_COPIES, y2.data_ptr(), save2[0].data_ptr(),
+                              0.01, 1e-3, 1, 1, ws2.data_ptr(), 1, y2.data_ptr(), save2[0].data_ptr(),
                               save2[1].data_ptr(), st), "apply")
-    assert torch.allclose(y1.float(), y2.float(), atol=1e-2 if dtype == torch.bfloat16 else 1e-5)
-    assert torch.allclose(save1, save2, rtol=1e-4, atol=1e-6) and torch.allclose(rv, rv2, rtol=1e-5)
+    # deterministic reductions: the two routes are the same kernels on the same data -> bit-equal
+    assert torch.equal(ws1[:2 * c], ws2[:2 * c])
+    assert torch.equal(y1, y2) and torch.equal(save1, save2) and torch.equal(rv, rv2) and torch.equal(rm, rm2)
     # channel affine forward / backward
     scale, shift = gamma * save1[1], beta - save1[0] * gamma * save1[1]
     y3 = torch.empty_like(x)
