@@ -47,6 +47,11 @@ SIGNATURES = {
     "d3d_bn_apply": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, i32, vp, i32, vp, vp, vp, vp]),
     "d3d_bn_bwd_reduce": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]),
     "d3d_bn_bwd_dx": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]),
+    "d3d_conv2d_supported": (i32, [i32, i32, i32, i32]),
+    "d3d_conv2d_stats_ws_floats": (sz, [i32, i32, i32, i32]),
+    "d3d_conv2d_nhwc_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "d3d_conv2d_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
+    "d3d_conv2d_nhwc_wgrad": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "d3d_channel_affine": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp]),
     "d3d_channel_affine_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]),
     "d3d_pfn_fwd": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp, vp, vp, vp, f32, f32,
@@ -79,6 +84,7 @@ SIGNATURES = {
 ABI_VERSION = 4  # include/d3d.h D3D_ABI_VERSION
 D3D_F32 = 0
 D3D_BF16 = 1
+D3D_CONV_BF16, D3D_CONV_SPLIT = 0, 1
 D3D_BN_COPIES = 1
 D3D_LOSS_SCALARS = 18
 D3D_IOU3D_OVERLAP, D3D_IOU3D_IOU_BEV, D3D_IOU3D_IOU_NORMAL = 0, 1, 2

@@ -1,0 +1,589 @@
+// Dense 2D convolution on channels-last maps for the RPN (det3d/models/necks/rpn.py:70-159: 3x3 / stride 1-2 /
+// 128-256 channels; deblocks 1x1 and 2x2; the reference runs them on cuDNN), gfx950, as an implicit GEMM on MFMA:
+//
+//   out[p, co] = sum_{tap, ci} x[pix(p, tap), ci] * W[tap][co][ci]       p = (b, oy, ox) row-major
+//
+// Why not MIOpen (round 2): its assembly igemm ran the 128->128 3x3 layers at 12 % of the bf16 MFMA peak, wanted
+// 30 zero-fill launches and 30 cast kernels per step around it, summed its weight gradients with atomics
+// (run-to-run noise, not capturable in a hipGraph with find-mode solvers) and has no precision between bf16 and
+// the 16x slower f32 -- while north_star's 1e-3 box tolerance needs more than bf16.  Here:
+//   * block = 128 output pixels x 128 output channels, 4 waves of 64 x 64 (2 x 2 MFMA 32x32x16 tiles each), D^T
+//     form: A = W tile (rows = cout), B = x tile (cols = pixels), so a lane ends up with runs of 4 consecutive
+//     channels of ONE pixel -- 8 / 16-byte row stores, no transposes;
+//   * both operands are staged by LDS-DMA (buffer_load ... lds, 16 B per lane): rows of BK channels, XOR-swizzled
+//     through the SOURCE address (the LDS image of an LDS-DMA is lane-linear) so that ds_read_b128 of 32 different
+//     rows at one k-chunk is conflict-free; zero padding = out-of-range buffer offsets (the hardware writes zeros);
+//   * two LDS stages, one workgroup barrier per K step: the loads of step s+1 fly while step s multiplies;
+//   * SPLIT mode (the contract-compliant precision): activations and weights arrive as two bf16 planes
+//     (hi = bf16(v), lo = bf16(v - hi): 16 mantissa bits), three MFMAs per fragment pair (hi*hi + hi*lo + lo*hi),
+//     f32 accumulate, f32 output: |error| ~ 2^-16 of the products against 2^-8 for bf16, at 3 bf16 MFMAs = 1/5 of
+//     the time of the exact-f32 MFMA.
+//   * optional epilogue: per-channel sum / sum of squares of the produced rows (BatchNorm statistics), folded
+//     deterministically across blocks (d3d_fold.h).
+// The data gradient of a stride-1 layer is the same kernel on the output gradient with mirrored taps and
+// [tap][cin][cout] weights; the weight gradient is conv2d_wgrad_kernel below.
+#include "d3d_common.h"
+#include "d3d_fold.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 c2_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float c2_f32x16;
+typedef __attribute__((address_space(3))) void c2_lds_void;
+
+struct Conv2dGeom {
+  int batch, h, w, ho, wo;   // input / output map
+  int cout;                  // all output channels (grid.y tiles of 128)
+  int ksz, stride, pad;      // square kernel
+  int m;                     // batch * ho * wo output pixels
+  int x_bytes;               // num_records of the activation descriptor
+  int w_bytes;               // ... of the weight descriptor
+};
+
+struct Conv2dEpi {
+  float *stats;        // [2 * cout] result (sum | sum of squares), then one fold workspace per 128-channel tile; or nullptr
+  unsigned *counters;  // ticket words, `ctr_stride` per 128-channel tile
+  int fold_g, ws_stride, ctr_stride;
+};
+
+__device__ __forceinline__ uint16_t c2_f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// BK channels per K step; rows of RB = 2 * BK bytes = CPR 16-byte chunks.  Logical chunk c of row r lives in
+// physical chunk c ^ swz(r), swz(r) = (r / rows-per-256-B) % CPR: the 16 rows of a ds_read_b128 lane group then hit
+// 16 different 16-byte slots of the 256-byte bank row (lane groups: MI355X_MICROARCH.md, LDS table).
+template <int BK> struct C2Tile {
+  static constexpr int RB = BK * 2;
+  static constexpr int CPR = RB / 16;
+  static constexpr int RPB = 256 / RB;
+  static constexpr int PLANE = 128 * RB;            // bytes of one 128-row operand plane
+  static constexpr int INSTR = 2 * CPR / 4;         // LDS-DMA instructions per wave and plane (4 waves, 64 chunks each)
+  __device__ static __forceinline__ int swz(int row) { return (row / RPB) % CPR; }
+};
+
+template <int CIN, bool SPLIT, bool OUT_F32>
+__global__ void __launch_bounds__(256, 2)
+    conv2d_nhwc_kernel(const void *__restrict__ x_hi, const void *__restrict__ x_lo, const void *__restrict__ w_hi,
+                       const void *__restrict__ w_lo, void *__restrict__ y, Conv2dGeom G, Conv2dEpi ep) {
+  constexpr int BK = SPLIT ? 32 : 64;
+  using T = C2Tile<BK>;
+  constexpr int KC = CIN / BK;                 // K steps per tap
+  constexpr int NP = SPLIT ? 2 : 1;            // planes per operand
+  constexpr int STAGE = 2 * NP * T::PLANE;     // A planes then B planes
+  constexpr int KSUB = BK / 16;                // MFMA k-substeps per K step
+  static_assert(CIN % BK == 0, "channels per K step");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][STAGE]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wco = wave >> 1, wpx = wave & 1;  // 2 x 2 waves: cout half, pixel half
+  // XCD-aware order: consecutive workgroup ids are dealt round-robin to the 8 XCDs; give XCD i the i-th contiguous
+  // eighth of the pixel tiles so that the halo rows its tiles share stay in ITS L2 (bijective for any grid size)
+  int tile;
+  {
+    const int nb = (int)gridDim.x, q = nb >> 3, r = nb & 7, xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = tile * 128;
+  const int n0 = (int)blockIdx.y * 128;
+
+  // ---- per-thread staging slots: INSTR rows of the activation tile, INSTR rows of the weight tile
+  uint32_t a_off[T::INSTR];      // byte offset of tap (0,0) of the row's pixel + this lane's (swizzled) chunk
+  uint32_t a_vy[T::INSTR], a_vx[T::INSTR];  // bit k set: tap row / column k is inside the map
+  uint32_t b_off[T::INSTR];
+#pragma unroll
+  for (int j = 0; j < T::INSTR; ++j) {
+    const int idx = (wave * T::INSTR + j) * 64 + lane;
+    const int row = idx / T::CPR, cp = idx % T::CPR;
+    const int c = cp ^ T::swz(row);
+    const int m = m0 + row;
+    const int mm = m < G.m ? m : G.m - 1;
+    const int b = mm / (G.ho * G.wo), rem = mm - b * (G.ho * G.wo);
+    const int oy = rem / G.wo, ox = rem - oy * G.wo;
+    const int iy0 = oy * G.stride - G.pad, ix0 = ox * G.stride - G.pad;
+    uint32_t vy = 0, vx = 0;
+    for (int k = 0; k < G.ksz; ++k) {
+      vy |= (uint32_t)((iy0 + k >= 0 && iy0 + k < G.h) ? 1 : 0) << k;
+      vx |= (uint32_t)((ix0 + k >= 0 && ix0 + k < G.w) ? 1 : 0) << k;
+    }
+    if (m >= G.m) vy = vx = 0;
+    a_vy[j] = vy;
+    a_vx[j] = vx;
+    a_off[j] = (uint32_t)(((b * G.h + iy0) * G.w + ix0) * (CIN * 2) + c * 16);  // may wrap for invalid taps: masked
+    b_off[j] = (uint32_t)((n0 + row) * (CIN * 2) + c * 16);
+  }
+  const __amdgpu_buffer_rsrc_t xr_hi = __builtin_amdgcn_make_buffer_rsrc((void *)x_hi, 0, G.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr_hi = __builtin_amdgcn_make_buffer_rsrc((void *)w_hi, 0, G.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr_lo = __builtin_amdgcn_make_buffer_rsrc((void *)(SPLIT ? x_lo : x_hi), 0, G.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr_lo = __builtin_amdgcn_make_buffer_rsrc((void *)(SPLIT ? w_lo : w_hi), 0, G.w_bytes, 0x00020000);
+
+  const int nks = G.ksz * G.ksz * KC;
+  // stage K step `ks` (tap = ks / KC, channel block = ks % KC) into LDS stage `buf`
+  auto stage = [&](int ks, int buf) {
+    const int tap = ks / KC, kc = ks - tap * KC;
+    const int ky = tap / G.ksz, kx = tap - ky * G.ksz;
+    const uint32_t tap_off = (uint32_t)((ky * G.w + kx) * (CIN * 2) + kc * (BK * 2));
+    const uint32_t w_tap_off = (uint32_t)(tap * G.cout * (CIN * 2) + kc * (BK * 2));
+    unsigned char *sa = smem + buf * STAGE, *sb = sa + NP * T::PLANE;
+#pragma unroll
+    for (int j = 0; j < T::INSTR; ++j) {
+      const bool ok = ((a_vy[j] >> ky) & 1u) && ((a_vx[j] >> kx) & 1u);
+      const uint32_t off = ok ? a_off[j] + tap_off : D3D_OOB_OFFSET;
+      const int lds_off = (wave * T::INSTR + j) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr_hi, (c2_lds_void *)(sa + lds_off), 16, (int)off, 0, 0, 0);
+      if constexpr (SPLIT)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr_lo, (c2_lds_void *)(sa + T::PLANE + lds_off), 16, (int)off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < T::INSTR; ++j) {
+      const uint32_t off = b_off[j] + w_tap_off;
+      const int lds_off = (wave * T::INSTR + j) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr_hi, (c2_lds_void *)(sb + lds_off), 16, (int)off, 0, 0, 0);
+      if constexpr (SPLIT)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr_lo, (c2_lds_void *)(sb + T::PLANE + lds_off), 16, (int)off, 0, 0, 0);
+    }
+  };
+
+  c2_f32x16 acc[2][2];  // [cout tile][pixel tile]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses: lane reads row (lane & 31) of a 32-row tile, k-chunk (lane >> 5) of each 16-wide substep
+  const int frow = lane & 31, fk = lane >> 5;
+  int a_rd[2], b_rd[2];  // byte offsets of (row, chunk 0) + the row's swizzle, per tile
+  int a_sw[2], b_sw[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int wr = wco * 64 + t * 32 + frow;  // weight-tile row (cout)
+    const int xr = wpx * 64 + t * 32 + frow;  // activation-tile row (pixel)
+    a_rd[t] = wr * T::RB;
+    a_sw[t] = T::swz(wr);
+    b_rd[t] = xr * T::RB;
+    b_sw[t] = T::swz(xr);
+  }
+
+  stage(0, 0);
+  for (int ks = 0; ks < nks; ++ks) {
+    const int buf = ks & 1;
+    // my loads of step ks have landed; after the barrier everyone's have, and every wave has finished reading the
+    // other stage (step ks - 1), which the next loads overwrite
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ks + 1 < nks) stage(ks + 1, buf ^ 1);
+    const unsigned char *sa = smem + buf * STAGE, *sb = sa + NP * T::PLANE;
+#pragma unroll
+    for (int kk = 0; kk < KSUB; ++kk) {
+      const int chunk = kk * 2 + fk;
+      c2_bf16x8 wa[2][NP], xb[2][NP];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          wa[t][p] = *(const c2_bf16x8 *)(sb + p * T::PLANE + a_rd[t] + ((chunk ^ a_sw[t]) << 4));
+          xb[t][p] = *(const c2_bf16x8 *)(sa + p * T::PLANE + b_rd[t] + ((chunk ^ b_sw[t]) << 4));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][0], xb[j][0], acc[i][j], 0, 0, 0);
+          if constexpr (SPLIT) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][0], xb[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][1], xb[j][0], acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+  }
+
+  // ---- epilogue.  C/D of 32x32: col (pixel) = lane & 31, row (cout) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const bool want_stats = ep.stats != nullptr;
+  float s1[2][16], s2[2][16];  // per cout tile: this lane's channels, summed over its pixels
+  if (want_stats) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s1[i][r] = s2[i][r] = 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + wpx * 64 + j * 32 + (lane & 31);
+    const bool live = m < G.m;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int co_base = n0 + wco * 64 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = co_base + 8 * g;
+        float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if constexpr (OUT_F32) {
+          if (live) *(float4 *)((float *)y + (int64_t)m * G.cout + co) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          const uint16_t h0 = c2_f32_to_bf16(v[0]), h1 = c2_f32_to_bf16(v[1]), h2 = c2_f32_to_bf16(v[2]),
+                         h3 = c2_f32_to_bf16(v[3]);
+          if (live) {
+            uint2 pk;
+            pk.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            pk.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
+            *(uint2 *)((uint16_t *)y + (int64_t)m * G.cout + co) = pk;
+          }
+          v[0] = __uint_as_float((uint32_t)h0 << 16); v[1] = __uint_as_float((uint32_t)h1 << 16);
+          v[2] = __uint_as_float((uint32_t)h2 << 16); v[3] = __uint_as_float((uint32_t)h3 << 16);
+        }
+        if (want_stats && live) {  // statistics of the values as stored
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s1[i][4 * g + e] += v[e];
+            s2[i][4 * g + e] = fmaf(v[e], v[e], s2[i][4 * g + e]);
+          }
+        }
+      }
+    }
+  }
+  if (want_stats) {
+    // fold the 32 pixels of a lane half with shuffles, the two pixel-half waves of a cout half through LDS rows,
+    // the blocks through the fixed-order fold: deterministic
+    __syncthreads();  // every wave is done with the operand stages
+    float *red = (float *)smem;  // [2 pixel-half waves][2][128] then tot [2][128] then flag
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float a = s1[i][r], b = s2[i][r];
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+          a += __shfl_xor(a, o, 64);
+          b += __shfl_xor(b, o, 64);
+        }
+        if ((lane & 31) == 0) {
+          const int cl = wco * 64 + i * 32 + 4 * (lane >> 5) + 8 * (r >> 2) + (r & 3);  // channel within the block
+          red[wpx * 256 + cl] = a;
+          red[wpx * 256 + 128 + cl] = b;
+        }
+      }
+    __syncthreads();
+    float *tot = red + 512;
+    // the fold wants [sum over ALL cout | sumsq over ALL cout] per block row of grid.y: slab = 2 * 128 values of
+    // this block's channel tile; blocks of different grid.y tiles use different workspaces (see the launcher)
+    tot[threadIdx.x] = red[threadIdx.x] + red[256 + threadIdx.x];
+    __syncthreads();
+    float *ws = ep.stats + 2 * G.cout + (size_t)blockIdx.y * ep.ws_stride;
+    if (d3d_fold_block<256>(tot, 256, ws, ep.counters + blockIdx.y * ep.ctr_stride, ep.fold_g, (int *)(tot + 256))) {
+      // this block holds the channel tile's totals (thread i wrote ws[i]): place them in the [sum | sumsq] vector
+      const int i = threadIdx.x;
+      ep.stats[(i >> 7) * G.cout + n0 + (i & 127)] = ws[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- weight gradient
+//   dW[tap][co][ci] = sum_p g[p][co] * x[pix(p, tap)][ci]         (stride 1)
+// A GEMM whose K dimension is the pixel axis, which is NOT contiguous in either operand (channels are): tiles of
+// KP pixels x 128 channels are staged row-major by LDS-DMA and read as MFMA operands with the transposing LDS read
+// (ds_read_b64_tr_b16: four pixels of one channel per lane).  grid = (pixel splits, taps, cout tiles * cin tiles):
+// a block owns one tap, one 128 x 128 weight tile and a contiguous range of pixels; it writes ONE partial tile, the
+// partial tiles are summed in a fixed order by conv2d_wgrad_reduce_kernel: deterministic, no atomics.
+template <bool SPLIT>
+__global__ void __launch_bounds__(256, 2)
+    conv2d_wgrad_kernel(const void *__restrict__ g_hi, const void *__restrict__ g_lo, const void *__restrict__ x_hi,
+                        const void *__restrict__ x_lo, float *__restrict__ part, Conv2dGeom G, int cin,
+                        int pixels_per_split) {
+  constexpr int KP = SPLIT ? 32 : 64;          // pixels per K step
+  constexpr int NP = SPLIT ? 2 : 1;
+  constexpr int PLANE = KP * 256;              // KP rows of 128 channels (256 B)
+  constexpr int STAGE = 2 * NP * PLANE;        // g planes then x planes
+  constexpr int INSTR = PLANE / 1024 / 4;      // LDS-DMA instructions per wave and plane
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wco = wave >> 1, wci = wave & 1;
+  const int split = blockIdx.x, tap = blockIdx.y;
+  const int cin_tiles = cin / 128;
+  const int co0 = ((int)blockIdx.z / cin_tiles) * 128, ci0 = ((int)blockIdx.z % cin_tiles) * 128;
+  const int ky = tap / G.ksz, kx = tap - ky * G.ksz;
+  const int p_begin = split * pixels_per_split;
+  int p_end = p_begin + pixels_per_split;
+  if (p_end > G.m) p_end = G.m;
+  const int nks = (p_end - p_begin + KP - 1) / KP;
+
+  // staging: one LDS-DMA instruction = 4 pixel rows x 256 B; physical chunk cp of row r holds logical chunk
+  // cp ^ ((r & 3) << 2): the 4 pixel rows of a transposing read then sit in 4 different 64-byte quarters of the
+  // 256-byte bank row
+  const __amdgpu_buffer_rsrc_t gr_hi = __builtin_amdgcn_make_buffer_rsrc((void *)g_hi, 0, G.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t gr_lo = __builtin_amdgcn_make_buffer_rsrc((void *)(SPLIT ? g_lo : g_hi), 0, G.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr_hi = __builtin_amdgcn_make_buffer_rsrc((void *)x_hi, 0, G.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr_lo = __builtin_amdgcn_make_buffer_rsrc((void *)(SPLIT ? x_lo : x_hi), 0, G.x_bytes, 0x00020000);
+  auto stage = [&](int ks, int buf) {
+    unsigned char *sg = smem + buf * STAGE, *sx = sg + NP * PLANE;
+#pragma unroll
+    for (int j = 0; j < INSTR; ++j) {
+      const int inst = wave * INSTR + j;
+      const int row = inst * 4 + (lane >> 4), cp = lane & 15;
+      const int c = cp ^ ((row & 3) << 2);
+      const int p = p_begin + ks * KP + row;
+      const bool live = p < p_end;
+      const int pp = live ? p : p_begin;
+      const int b = pp / (G.ho * G.wo), rem = pp - b * (G.ho * G.wo);
+      const int oy = rem / G.wo, ox = rem - oy * G.wo;
+      const int iy = oy * G.stride - G.pad + ky, ix = ox * G.stride - G.pad + kx;
+      const bool inside = live && iy >= 0 && iy < G.h && ix >= 0 && ix < G.w;
+      const uint32_t goff = live ? (uint32_t)(pp * (G.cout * 2) + co0 * 2 + c * 16) : D3D_OOB_OFFSET;
+      const uint32_t xoff = inside ? (uint32_t)(((b * G.h + iy) * G.w + ix) * (cin * 2) + ci0 * 2 + c * 16) : D3D_OOB_OFFSET;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(gr_hi, (c2_lds_void *)(sg + inst * 1024), 16, (int)goff, 0, 0, 0);
+      if constexpr (SPLIT)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(gr_lo, (c2_lds_void *)(sg + PLANE + inst * 1024), 16, (int)goff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr_hi, (c2_lds_void *)(sx + inst * 1024), 16, (int)xoff, 0, 0, 0);
+      if constexpr (SPLIT)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr_lo, (c2_lds_void *)(sx + PLANE + inst * 1024), 16, (int)xoff, 0, 0, 0);
+    }
+  };
+
+  c2_f32x16 acc[2][2];  // [co tile][ci tile]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposing fragment read.  MFMA 32x32x16 operand: lane l holds row (l & 31), k = (l >> 5) * 8 .. + 8.  One
+  // ds_read_b64_tr_b16 serves a 16-lane group with a 4 (pixels) x 16 (channels) block: lane i of the group passes the
+  // address of pixel row i / 4, channels (i % 4) * 4 .. + 4 and receives channel i of the 4 pixels.
+  //   lanes  0-15: channels  0-15, pixels k0 + 0..3 (first read), +4..7 (second read)
+  //   lanes 16-31: channels 16-31           "
+  //   lanes 32-63: the same channels, pixels + 8
+  const int i16 = lane & 15;
+  const int prow = ((lane >> 5) << 3) + (i16 >> 2);                 // pixel row within a 16-pixel substep (first read)
+  const int chan = (((lane >> 4) & 1) << 4) + ((i16 & 3) << 2);     // channel within a 32-channel tile
+  auto frag = [&](const unsigned char *plane, int tile32, int kk) -> c2_bf16x8 {
+    typedef __attribute__((ext_vector_type(4))) short s4;
+    const int ch = tile32 * 32 + chan;  // channel within the 128-wide staged tile
+    s4 lo, hi;
+    {
+      const int r = kk * 16 + prow;
+      const int byte = r * 256 + ((((ch * 2) >> 4) ^ ((r & 3) << 2)) << 4) + ((ch * 2) & 15);
+      lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)(plane + byte));
+    }
+    {
+      const int r = kk * 16 + prow + 4;
+      const int byte = r * 256 + ((((ch * 2) >> 4) ^ ((r & 3) << 2)) << 4) + ((ch * 2) & 15);
+      hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)(plane + byte));
+    }
+    typedef __attribute__((ext_vector_type(8))) short s8;
+    s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(c2_bf16x8, v);
+  };
+
+  if (nks > 0) stage(0, 0);
+  for (int ks = 0; ks < nks; ++ks) {
+    const int buf = ks & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ks + 1 < nks) stage(ks + 1, buf ^ 1);
+    const unsigned char *sg = smem + buf * STAGE, *sx = sg + NP * PLANE;
+#pragma unroll
+    for (int kk = 0; kk < KP / 16; ++kk) {
+      c2_bf16x8 ga[2][NP], xb[2][NP];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          ga[t][p] = frag(sg + p * PLANE, wco * 2 + t, kk);
+          xb[t][p] = frag(sx + p * PLANE, wci * 2 + t, kk);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[i][0], xb[j][0], acc[i][j], 0, 0, 0);
+          if constexpr (SPLIT) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[i][0], xb[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[i][1], xb[j][0], acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+  }
+  // partial tile: part[split][tap][co][ci] (full cout x cin extent), D rows = co, cols = ci
+  float *dst = part + ((int64_t)split * (G.ksz * G.ksz) + tap) * ((int64_t)G.cout * cin);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ci = ci0 + wci * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wco * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        dst[(int64_t)co * cin + ci] = acc[i][j][r];
+      }
+    }
+}
+
+// dw[e] = sum over splits of part[s][e], ascending s
+__global__ void __launch_bounds__(256)
+    conv2d_wgrad_reduce_kernel(const float4 *__restrict__ part, int splits, int64_t n4, float4 *__restrict__ dw) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < splits; ++k) {
+      const float4 v = part[(int64_t)k * n4 + e];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    dw[e] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- host side
+static int c2_check(const char *who, int batch, int h, int w, int cin, int cout, int ksz, int stride, int pad,
+                    int mode) {
+  D3D_REQUIRE(mode == D3D_CONV_BF16 || mode == D3D_CONV_SPLIT, "%s: mode %d", who, mode);
+  D3D_REQUIRE(batch >= 1 && h >= 1 && w >= 1, "%s: map %d x %d x %d", who, batch, h, w);
+  D3D_REQUIRE(cin == 64 || cin == 128 || cin == 256, "%s: cin=%d (64, 128, 256)", who, cin);
+  D3D_REQUIRE(cout >= 128 && cout % 128 == 0, "%s: cout=%d (multiples of 128)", who, cout);
+  D3D_REQUIRE(ksz >= 1 && ksz <= 3 && stride >= 1 && stride <= 2 && pad >= 0 && pad < ksz,
+              "%s: kernel %d stride %d pad %d", who, ksz, stride, pad);
+  D3D_REQUIRE((int64_t)batch * h * w * cin * 2 < (int64_t)D3D_RSRC_BYTES, "%s: the input map exceeds 2 GB", who);
+  return D3D_OK;
+}
+
+extern "C" int d3d_conv2d_supported(int cin, int cout, int ksz, int stride) {
+  return (cin == 64 || cin == 128 || cin == 256) && cout >= 128 && cout % 128 == 0 && ksz >= 1 && ksz <= 3 &&
+         (stride == 1 || stride == 2);
+}
+
+extern "C" size_t d3d_conv2d_stats_ws_floats(int batch, int ho, int wo, int cout) {
+  const int64_t m = (int64_t)batch * ho * wo;
+  if (m < 1 || cout < 128 || cout % 128) return 0;
+  const int64_t nb = (m + 127) / 128;
+  if (nb > D3D_FOLD_MAX_BLOCKS) return 0;
+  return 2 * (size_t)cout + (size_t)(cout / 128) * d3d_fold_ws_floats((int)nb, 256);
+}
+
+static int c2_geom(const char *who, Conv2dGeom &G, int batch, int h, int w, int cin, int cout, int ksz, int stride,
+                   int pad) {
+  G.batch = batch; G.h = h; G.w = w;
+  G.ho = (h + 2 * pad - ksz) / stride + 1;
+  G.wo = (w + 2 * pad - ksz) / stride + 1;
+  D3D_REQUIRE(G.ho >= 1 && G.wo >= 1, "%s: empty output", who);
+  G.cout = cout; G.ksz = ksz; G.stride = stride; G.pad = pad;
+  const int64_t m = (int64_t)batch * G.ho * G.wo;
+  D3D_REQUIRE(m < ((int64_t)1 << 30) && m * cout * 2 < (int64_t)D3D_RSRC_BYTES, "%s: output too large", who);
+  G.m = (int)m;
+  G.x_bytes = (int)((int64_t)batch * h * w * cin * 2);
+  G.w_bytes = ksz * ksz * cout * cin * 2;
+  return D3D_OK;
+}
+
+extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo, void *y,
+                                   int batch, int h, int w, int cin, int cout, int ksz, int stride, int pad,
+                                   int mode, float *stats_ws, size_t stats_ws_floats, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = c2_check("d3d_conv2d_nhwc_fwd", batch, h, w, cin, cout, ksz, stride, pad, mode);
+  if (rc) return rc;
+  const bool split = mode == D3D_CONV_SPLIT;
+  D3D_REQUIRE(x_hi && w_hi && y && (!split || (x_lo && w_lo)), "d3d_conv2d_nhwc_fwd: null pointer");
+  Conv2dGeom G;
+  rc = c2_geom("d3d_conv2d_nhwc_fwd", G, batch, h, w, cin, cout, ksz, stride, pad);
+  if (rc) return rc;
+  const int nb = (G.m + 127) / 128;
+  Conv2dEpi ep = {nullptr, nullptr, 16, 0, 0};
+  if (stats_ws) {
+    D3D_REQUIRE(nb <= D3D_FOLD_MAX_BLOCKS, "d3d_conv2d_nhwc_fwd: %d pixel tiles > %d for the statistics fold", nb,
+                D3D_FOLD_MAX_BLOCKS);
+    const size_t need = d3d_conv2d_stats_ws_floats(batch, G.ho, G.wo, cout);
+    if (stats_ws_floats < need)
+      return d3d_set_error(D3D_ECAPACITY, "d3d_conv2d_nhwc_fwd: statistics workspace %zu floats < %zu", stats_ws_floats, need);
+    const D3dFoldPlan fp = d3d_fold_plan(nb, 256);
+    ep.stats = stats_ws;
+    ep.fold_g = fp.g;
+    ep.ws_stride = (int)d3d_fold_ws_floats(nb, 256);
+    ep.ctr_stride = d3d_fold_counter_words(fp);
+    ep.counters = d3d_fold_counters(ep.ctr_stride * (cout / 128));
+    if (!ep.counters) return D3D_EHIP;
+  }
+  const size_t lds = 2 * (size_t)(2 * (split ? 2 : 1) * 128 * (split ? 64 : 128));  // two stages of A + B planes
+#define C2_CASE(CIN)                                                                                            \
+  if (cin == CIN) {                                                                                             \
+    if (split) {                                                                                                \
+      D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_nhwc_kernel<CIN, true, true>,                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+      hipLaunchKernelGGL((conv2d_nhwc_kernel<CIN, true, true>), dim3(nb, cout / 128), dim3(256), lds, stream,   \
+                         x_hi, x_lo, w_hi, w_lo, y, G, ep);                                                     \
+    } else {                                                                                                    \
+      D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_nhwc_kernel<CIN, false, false>,                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+      hipLaunchKernelGGL((conv2d_nhwc_kernel<CIN, false, false>), dim3(nb, cout / 128), dim3(256), lds, stream, \
+                         x_hi, x_lo, w_hi, w_lo, y, G, ep);                                                     \
+    }                                                                                                           \
+  }
+  C2_CASE(64)
+  C2_CASE(128)
+  C2_CASE(256)
+#undef C2_CASE
+  D3D_LAUNCH_TRY("conv2d_nhwc_kernel");
+  return D3D_OK;
+}
+
+// weight gradient of the layer above (stride 1 or 2): g = dL/dy [batch, ho, wo, cout], x = the layer's input;
+// dw [ksz*ksz][cout][cin] f32 (the packed forward layout).  workspace: d3d_conv2d_wgrad_workspace_bytes.
+static int c2_wgrad_splits(int m) {
+  // ~2 blocks per CU over (splits x taps) at 9 taps and one weight tile; >= 8 K steps per block
+  int s = 56;
+  const int max_s = (m + 511) / 512;
+  if (s > max_s) s = max_s;
+  return s < 1 ? 1 : s;
+}
+extern "C" size_t d3d_conv2d_wgrad_workspace_bytes(int batch, int ho, int wo, int cin, int cout, int ksz) {
+  const int64_t m = (int64_t)batch * ho * wo;
+  if (m < 1) return 0;
+  return (size_t)c2_wgrad_splits((int)m) * ksz * ksz * cout * cin * sizeof(float);
+}
+
+extern "C" int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const void *x_hi, const void *x_lo,
+                                     float *dw, int batch, int h, int w, int cin, int cout, int ksz, int stride,
+                                     int pad, int mode, void *workspace, size_t workspace_bytes,
+                                     d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  D3D_REQUIRE(mode == D3D_CONV_BF16 || mode == D3D_CONV_SPLIT, "d3d_conv2d_nhwc_wgrad: mode %d", mode);
+  D3D_REQUIRE(cin % 128 == 0 && cout % 128 == 0 && cin >= 128 && cout >= 128 && cin <= 256 && cout <= 256,
+              "d3d_conv2d_nhwc_wgrad: channels %d -> %d (multiples of 128 up to 256)", cin, cout);
+  D3D_REQUIRE(ksz >= 1 && ksz <= 3 && stride >= 1 && stride <= 2 && pad >= 0 && pad < ksz,
+              "d3d_conv2d_nhwc_wgrad: kernel %d stride %d pad %d", ksz, stride, pad);
+  const bool split = mode == D3D_CONV_SPLIT;
+  D3D_REQUIRE(g_hi && x_hi && dw && (!split || (g_lo && x_lo)), "d3d_conv2d_nhwc_wgrad: null pointer");
+  Conv2dGeom G;
+  int rc = c2_geom("d3d_conv2d_nhwc_wgrad", G, batch, h, w, cin, cout, ksz, stride, pad);
+  if (rc) return rc;
+  D3D_REQUIRE((int64_t)batch * h * w * cin * 2 < (int64_t)D3D_RSRC_BYTES, "d3d_conv2d_nhwc_wgrad: the input map exceeds 2 GB");
+  G.w_bytes = (int)((int64_t)G.m * cout * 2);  // the descriptor of g
+  const int splits = c2_wgrad_splits(G.m);
+  const size_t need = d3d_conv2d_wgrad_workspace_bytes(batch, G.ho, G.wo, cin, cout, ksz);
+  if (!workspace || workspace_bytes < need)
+    return d3d_set_error(D3D_ECAPACITY, "d3d_conv2d_nhwc_wgrad: workspace %zu B < %zu B", workspace_bytes, need);
+  const int kp = split ? 32 : 64;
+  int pps = (G.m + splits - 1) / splits;
+  pps = (pps + kp - 1) / kp * kp;
+  const int nsplit = (G.m + pps - 1) / pps;
+  const size_t lds = 2 * (size_t)(2 * (split ? 2 : 1) * kp * 256);
+  const dim3 grid(nsplit, ksz * ksz, (cout / 128) * (cin / 128));
+  if (split) {
+    D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((conv2d_wgrad_kernel<true>), grid, dim3(256), lds, stream, g_hi, g_lo, x_hi, x_lo,
+                       (float *)workspace, G, cin, pps);
+  } else {
+    D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((conv2d_wgrad_kernel<false>), grid, dim3(256), lds, stream, g_hi, g_lo, x_hi, x_lo,
+                       (float *)workspace, G, cin, pps);
+  }
+  D3D_LAUNCH_TRY("conv2d_wgrad_kernel");
+  const int64_t n4 = (int64_t)ksz * ksz * cout * cin / 4;
+  int nbr = (int)((n4 + 255) / 256);
+  if (nbr > 1024) nbr = 1024;
+  hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3(nbr), dim3(256), 0, stream, (const float4 *)workspace, nsplit,
+                     n4, (float4 *)dw);
+  D3D_LAUNCH_TRY("conv2d_wgrad_reduce_kernel");
+  return D3D_OK;
+}

@@ -1,0 +1,113 @@
+"""Dense channels-last 2D convolution of the RPN on the library's own MFMA kernels (csrc/d3d_conv2d.hip) -- the
+host side: operand formats, weight packing, the autograd node.
+
+Reference: det3d/models/necks/rpn.py:70-159 builds nn.Conv2d(3x3) + BatchNorm2d + ReLU stacks and runs them on
+cuDNN.  Here a conv layer is `conv2d(x, weight, stride, pad, mode)` on a channels-last map:
+
+  mode "bf16"  : x bf16 [B,H,W,C], packed bf16 weights, bf16 output            (the fast mode)
+  mode "split" : x = (hi, lo) bf16 planes with hi + lo = the f32 value to 16 mantissa bits, weights likewise,
+                 f32 output: three bf16 MFMAs per product (hi*hi + hi*lo + lo*hi), relative error ~2^-16 -- the
+                 precision that meets north_star's 1e-3 box tolerance at bf16-MFMA speed.
+
+Weights keep nn.Conv2d's parameter layout [cout, cin, kh, kw] f32 (checkpoint compatible); the packed forms
+[tap][cout][cin] (forward) and [mirrored tap][cin][cout] (data gradient of stride-1 layers) are cached per
+parameter version like the sparse conv's.
+"""
+import weakref
+
+import torch
+
+from . import _lib
+
+_MODES = {"bf16": _lib.D3D_CONV_BF16, "split": _lib.D3D_CONV_SPLIT}
+
+
+def split_planes(t):
+    """f32 tensor -> (hi, lo) bf16 planes, hi = bf16(t), lo = bf16(t - hi)"""
+    t = t.float()
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+def join_planes(hi, lo):
+    return hi.float() + lo.float()
+
+
+_PACK = {}  # (id(weight), kind, mode) -> (weakref, version, data_ptr, tensors)
+
+
+def _packed(weight, kind, mode):
+    """kind 'fwd': [tap][cout][cin]; kind 'dgrad': [mirrored tap][cin][cout] (the forward layout of the transposed
+    problem).  Returns (hi, lo-or-None)."""
+    key = (id(weight), kind, mode)
+    hit = _PACK.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+        return hit[3]
+    w = weight.detach().float()
+    co, ci, kh, kw = w.shape
+    if kind == "fwd":
+        p = w.permute(2, 3, 0, 1).reshape(kh * kw, co, ci)
+    else:
+        p = w.flip(2, 3).permute(2, 3, 1, 0).reshape(kh * kw, ci, co)
+    p = p.contiguous()
+    out = split_planes(p) if mode == "split" else (p.to(torch.bfloat16), None)
+    out = tuple(t.contiguous() if t is not None else None for t in out)
+    if len(_PACK) > 256:
+        for k in [k for k, v in _PACK.items() if v[0]() is None]:
+            del _PACK[k]
+    _PACK[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), out)
+    return out
+
+
+def supported(cin, cout, ksz, stride):
+    return bool(_lib.lib().d3d_conv2d_supported(int(cin), int(cout), int(ksz), int(stride)))
+
+
+def _out_hw(h, w, ksz, stride, pad):
+    return (h + 2 * pad - ksz) // stride + 1, (w + 2 * pad - ksz) // stride + 1
+
+
+def conv2d_raw(x_hi, x_lo, w_hi, w_lo, ksz, stride, pad, mode, want_stats=False):
+    """x_hi (and x_lo in split mode): [B,H,W,Cin] bf16 contiguous; w_*: [ksz*ksz, Cout, Cin] bf16.
+    Returns (y [B,Ho,Wo,Cout] bf16 | f32, stats workspace or None: its first 2*Cout floats are sum | sum of squares)"""
+    L = _lib.lib()
+    b, h, w, cin = x_hi.shape
+    cout = w_hi.shape[1]
+    ho, wo = _out_hw(h, w, ksz, stride, pad)
+    dev = x_hi.device
+    y = torch.empty((b, ho, wo, cout), dtype=torch.float32 if mode == "split" else torch.bfloat16, device=dev)
+    ws = None
+    nws = 0
+    if want_stats:
+        nws = L.d3d_conv2d_stats_ws_floats(b, ho, wo, cout)
+        if nws == 0:
+            raise _lib.D3dError("conv2d statistics epilogue: unsupported shape")
+        ws = torch.empty((nws,), dtype=torch.float32, device=dev)
+    rc = L.d3d_conv2d_nhwc_fwd(x_hi.data_ptr(), _lib.ptr(x_lo), w_hi.data_ptr(), _lib.ptr(w_lo), y.data_ptr(), b, h, w,
+                               cin, cout, ksz, stride, pad, _MODES[mode], _lib.ptr(ws), nws, _lib.stream_ptr(dev))
+    _lib.check(rc, "d3d_conv2d_nhwc_fwd")
+    return y, ws
+
+
+def wgrad_raw(g_hi, g_lo, x_hi, x_lo, ksz, stride, pad, mode):
+    """dw [ksz*ksz, Cout, Cin] f32 from g = dL/dy [B,Ho,Wo,Cout] and the layer input x [B,H,W,Cin]"""
+    L = _lib.lib()
+    b, h, w, cin = x_hi.shape
+    cout = g_hi.shape[3]
+    ho, wo = _out_hw(h, w, ksz, stride, pad)
+    assert tuple(g_hi.shape[:3]) == (b, ho, wo)
+    dev = x_hi.device
+    dw = torch.empty((ksz * ksz, cout, cin), dtype=torch.float32, device=dev)
+    nb = L.d3d_conv2d_wgrad_workspace_bytes(b, ho, wo, cin, cout, ksz)
+    ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    rc = L.d3d_conv2d_nhwc_wgrad(g_hi.data_ptr(), _lib.ptr(g_lo), x_hi.data_ptr(), _lib.ptr(x_lo), dw.data_ptr(), b, h,
+                                 w, cin, cout, ksz, stride, pad, _MODES[mode], ws.data_ptr(), nb, _lib.stream_ptr(dev))
+    _lib.check(rc, "d3d_conv2d_nhwc_wgrad")
+    return dw
+
+
+def unpack_wgrad(dw, weight):
+    """[tap][cout][cin] -> nn.Conv2d's [cout, cin, kh, kw]"""
+    co, ci, kh, kw = weight.shape
+    return dw.view(kh, kw, co, ci).permute(2, 3, 0, 1)

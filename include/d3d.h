@@ -234,6 +234,36 @@ int d3d_channel_affine_bwd(const void *x, const void *dy, int n, int c, int dtyp
                            const float *coef_1, void *dx, d3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Dense 2D convolution on channels-last maps: the RPN's conv layers (det3d/models/necks/rpn.py:70-159, nn.Conv2d
+ * 3x3 stride 1/2 and the 1x1 / 2x2 deblock convs, bias-free; the reference runs them on cuDNN).  Implicit GEMM on
+ * MFMA, both operands through LDS-DMA, f32 accumulation.
+ *   x      dev [batch, h, w, cin]    bf16 (D3D_CONV_BF16) or two bf16 planes hi / lo (D3D_CONV_SPLIT: v = hi + lo,
+ *          hi = bf16(v), lo = bf16(v - hi) -- 16 mantissa bits; x_lo NULL in bf16 mode)
+ *   w      dev [ksz*ksz, cout, cin]  packed weights, W[tap][co][ci] = weight[co][ci][ky][kx] of nn.Conv2d, same planes
+ *   y      dev [batch, ho, wo, cout] bf16 (BF16 mode) or f32 (SPLIT mode); ho = (h + 2 pad - ksz) / stride + 1
+ *   stats_ws (optional): the per-channel sum | sum of squares of the produced rows (as stored) are left in
+ *          stats_ws[0 .. 2*cout) -- what d3d_bn_stats computes on y -- deterministically (fixed-order fold);
+ *          capacity d3d_conv2d_stats_ws_floats(batch, ho, wo, cout) floats, need not be zeroed.
+ *   cin in {64, 128, 256}, cout % 128 == 0, ksz 1..3, stride 1..2 (d3d_conv2d_supported).
+ * SPLIT mode multiplies hi*hi + hi*lo + lo*hi on the bf16 MFMA: relative error ~2^-16 of the products (bf16:
+ * 2^-8) at a fifth of the exact-f32 MFMA's time -- the precision mode that meets the 1e-3 box tolerance.
+ * The data gradient of a stride-1 layer is the same call on dL/dy with the taps mirrored and the weights packed
+ * as [tap'][cin][cout] (pad' = ksz - 1 - pad).
+ * d3d_conv2d_nhwc_wgrad: dw [ksz*ksz, cout, cin] f32 = sum over output pixels of g (x) x(tap), g = dL/dy
+ * [batch, ho, wo, cout] and x in the same element format; two-pass, bit-reproducible; cin, cout in {128, 256}. */
+#define D3D_CONV_BF16 0
+#define D3D_CONV_SPLIT 1
+int d3d_conv2d_supported(int cin, int cout, int ksz, int stride);
+size_t d3d_conv2d_stats_ws_floats(int batch, int ho, int wo, int cout);
+int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo, void *y, int batch,
+                        int h, int w, int cin, int cout, int ksz, int stride, int pad, int mode, float *stats_ws,
+                        size_t stats_ws_floats, d3d_stream_t stream);
+size_t d3d_conv2d_wgrad_workspace_bytes(int batch, int ho, int wo, int cin, int cout, int ksz);
+int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const void *x_hi, const void *x_lo, float *dw,
+                          int batch, int h, int w, int cin, int cout, int ksz, int stride, int pad, int mode,
+                          void *workspace, size_t workspace_bytes, d3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * PillarFeatureNet with one (last) PFNLayer: det3d/models/readers/pillar_encoder.py:115-155
  * (decorate + mask) and :42-57 (Linear(c+5 -> f, no bias), BatchNorm1d over all m*t rows, ReLU,
  * max over t), fused; nothing of size [m, t, *] is materialised.

@@ -1,0 +1,110 @@
+"""csrc/d3d_conv2d.hip: the RPN's dense channels-last convolutions (det3d/models/necks/rpn.py:70-159) as an implicit
+GEMM on MFMA, against torch's conv2d in float64 on the same (format-rounded) operands -- forward for every geometry the
+RPN configs use (3x3 stride 1 / 2 with padding, 1x1, 2x2 stride 2), the data gradient as the mirrored forward, the
+two-pass weight gradient, the fused BatchNorm statistics; bf16 and the split (hi + lo) precision mode."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GEOMS = [  # batch, h, w, cin, cout, ksz, stride, pad
+    (2, 20, 24, 128, 128, 3, 1, 1),      # SECOND rpn1 block conv (cropped map)
+    (1, 13, 11, 128, 128, 3, 1, 1),      # pixel count not a multiple of the 128-pixel tile, odd sizes
+    (2, 16, 16, 64, 128, 3, 2, 1),       # PointPillars down-sampling conv
+    (1, 18, 20, 256, 128, 3, 1, 1),      # CBGS first block: 256 input channels
+    (2, 12, 12, 128, 256, 3, 2, 1),      # CBGS second stage
+    (1, 10, 14, 256, 256, 3, 1, 1),
+    (2, 9, 9, 128, 128, 1, 1, 0),        # deblock 1x1
+    (1, 12, 16, 64, 128, 2, 2, 0),       # deblock Conv2d(k = s = 2)
+]
+
+
+def _ref_conv(x, w, stride, pad):
+    """x [B,H,W,C], w [Co,Ci,k,k] (both float64) -> [B,Ho,Wo,Co]"""
+    return torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, None, stride, pad).permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("mode", ["bf16", "split"])
+@pytest.mark.parametrize("geom", GEOMS)
+def test_forward_matches_conv2d(geom, mode):
+    from det3d_amd import dense_conv as dc
+
+    b, h, w, cin, cout, k, s, p = geom
+    g = torch.Generator(device="cuda").manual_seed(hash(geom) % 1000)
+    x = torch.randn((b, h, w, cin), device="cuda", generator=g)
+    wt = torch.randn((cout, cin, k, k), device="cuda", generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    wt[1, 2] += 0.5  # asymmetric: a transposed weight or swapped row / column map cannot pass
+    weight = torch.nn.Parameter(wt)
+    w_hi, w_lo = dc._packed(weight, "fwd", mode)
+    if mode == "bf16":
+        x_hi, x_lo = x.to(torch.bfloat16), None
+        xr, wr = x_hi.double(), wt.to(torch.bfloat16).double()
+    else:
+        x_hi, x_lo = dc.split_planes(x)
+        xr, wr = x.double(), wt.double()
+    y, ws = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, mode, want_stats=True)
+    ref = _ref_conv(xr, wr, s, p)
+    assert y.shape == ref.shape
+    err = float((y.double() - ref).abs().max())
+    scale = float(ref.abs().max())
+    # bf16: exact products of bf16 operands, f32 accumulation, one bf16 rounding of the result
+    # split: operands carry 16 mantissa bits, lo*lo dropped: ~2^-16 per product
+    tol = 2.0 ** -8 * scale if mode == "bf16" else 3e-5 * scale
+    assert err <= tol, (err, scale)
+    # the statistics epilogue = sums of the rows as stored
+    yd = y.double().reshape(-1, cout)
+    stats = ws[:2 * cout].double()
+    assert torch.allclose(stats[:cout], yd.sum(0), rtol=1e-4, atol=1e-3 * yd.shape[0] ** 0.5)
+    assert torch.allclose(stats[cout:], (yd * yd).sum(0), rtol=1e-4, atol=1e-3)
+    # ... bit-reproducible, and not needed for the output itself
+    y2, ws2 = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, mode, want_stats=True)
+    y3, _ = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, mode, want_stats=False)
+    assert torch.equal(y, y2) and torch.equal(y, y3) and torch.equal(ws[:2 * cout], ws2[:2 * cout])
+
+
+@pytest.mark.parametrize("mode", ["bf16", "split"])
+@pytest.mark.parametrize("geom", [g for g in GEOMS if g[6] == 1 and g[3] % 128 == 0])
+def test_data_gradient_is_the_mirrored_forward(geom, mode):
+    from det3d_amd import dense_conv as dc
+
+    b, h, w, cin, cout, k, s, p = geom
+    g = torch.Generator(device="cuda").manual_seed(7)
+    wt = torch.randn((cout, cin, k, k), device="cuda", generator=g) * (1.0 / (cout * k * k) ** 0.5)
+    weight = torch.nn.Parameter(wt)
+    gy = torch.randn((b, h, w, cout), device="cuda", generator=g)  # stride 1, "same" padding: ho = h
+    w_hi, w_lo = dc._packed(weight, "dgrad", mode)
+    if mode == "bf16":
+        g_hi, g_lo = gy.to(torch.bfloat16), None
+        gr, wr = g_hi.double(), wt.to(torch.bfloat16).double()
+    else:
+        g_hi, g_lo = dc.split_planes(gy)
+        gr, wr = gy.double(), wt.double()
+    dx, _ = dc.conv2d_raw(g_hi, g_lo, w_hi, w_lo, k, 1, k - 1 - p, mode)
+    ref = torch.nn.grad.conv2d_input((b, cin, h, w), wr, gr.permute(0, 3, 1, 2), 1, p).permute(0, 2, 3, 1)
+    err, scale = float((dx.double() - ref).abs().max()), float(ref.abs().max())
+    assert err <= (2.0 ** -8 if mode == "bf16" else 3e-5) * scale, (err, scale)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "split"])
+@pytest.mark.parametrize("geom", [g for g in GEOMS if g[3] % 128 == 0] + [(4, 40, 44, 128, 128, 3, 1, 1)])
+def test_weight_gradient(geom, mode):
+    from det3d_amd import dense_conv as dc
+
+    b, h, w, cin, cout, k, s, p = geom
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn((b, h, w, cin), device="cuda", generator=g)
+    ho, wo = dc._out_hw(h, w, k, s, p)
+    gy = torch.randn((b, ho, wo, cout), device="cuda", generator=g)
+    if mode == "bf16":
+        x_hi, x_lo, g_hi, g_lo = x.to(torch.bfloat16), None, gy.to(torch.bfloat16), None
+        xr, gr = x_hi.double(), g_hi.double()
+    else:
+        (x_hi, x_lo), (g_hi, g_lo) = dc.split_planes(x), dc.split_planes(gy)
+        xr, gr = x.double(), gy.double()
+    dw = dc.wgrad_raw(g_hi, g_lo, x_hi, x_lo, k, s, p, mode)
+    dw2 = dc.wgrad_raw(g_hi, g_lo, x_hi, x_lo, k, s, p, mode)
+    assert torch.equal(dw, dw2)  # two-pass, fixed-order
+    ref = torch.nn.grad.conv2d_weight(xr.permute(0, 3, 1, 2), (cout, cin, k, k), gr.permute(0, 3, 1, 2), s, p)
+    got = dc.unpack_wgrad(dw, ref)
+    err, scale = float((got.double() - ref).abs().max()), float(ref.abs().max())
+    assert err <= (1e-5 if mode == "bf16" else 3e-5) * scale + 1e-6, (err, scale)

@@ -54,7 +54,7 @@ def test_bn_reductions_are_bit_reproducible_and_right(dtype, n, c):
     xh = (x.float() - mean) * invstd
     dz = dy.float() * ((xh * gamma + beta) > 0)
     ref = torch.cat([(dz.double() * xh.double()).sum(0), dz.double().sum(0)])
-    assert torch.allclose(red[0].double(), ref, rtol=1e-4, atol=2e-2 * (n ** 0.5) * 1e-2 + 1e-3)
+    assert float((red[0].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-3  # f32 accumulation
 
 
 def _model(name="kitti_car_second.py"):
@@ -109,6 +109,7 @@ def test_conv_epilogue_reduction_refuses_a_channel_pair_without_mfma_tiles():
 
     L = _lib.lib()
     assert not spconv.has_epilogue(128, 16, torch.bfloat16) and not spconv.has_epilogue(48, 48, torch.float32)
+    assert not spconv.has_epilogue(64, 16, torch.float32)
     assert spconv.has_epilogue(64, 64, torch.bfloat16) and spconv.has_epilogue(16, 32, torch.float32)
     n, cin, cout = 500, 48, 48
     feats = torch.randn(n, cin, device="cuda")
@@ -122,12 +123,12 @@ def test_conv_epilogue_reduction_refuses_a_channel_pair_without_mfma_tiles():
     assert rc == -1 and b"d3d_sparse_conv_has_epilogue" in L.d3d_last_error()
     # ... and the module path falls back to the stand-alone statistics sweep with correct results
     torch.manual_seed(0)
-    conv = spconv.SubMConv3d(48, 48, 3, bias=False, indice_key="t").cuda()
-    bn = torch.nn.BatchNorm1d(48, eps=1e-3, momentum=0.01).cuda().train()
+    conv = spconv.SubMConv3d(64, 16, 3, bias=False, indice_key="t").cuda()  # SpMiddleFHD(num_input_features=64)
+    bn = torch.nn.BatchNorm1d(16, eps=1e-3, momentum=0.01).cuda().train()
     idx = torch.stack([torch.zeros(300, dtype=torch.int32), torch.randint(0, 8, (300,), dtype=torch.int32),
                        torch.randint(0, 16, (300,), dtype=torch.int32), torch.randint(0, 16, (300,), dtype=torch.int32)], 1)
     idx = torch.unique(idx, dim=0).cuda()
-    x = spconv.SparseConvTensor(torch.randn(idx.shape[0], 48, device="cuda"), idx, [8, 16, 16], 1)
+    x = spconv.SparseConvTensor(torch.randn(idx.shape[0], 64, device="cuda"), idx, [8, 16, 16], 1)
     y, _ = spconv.conv_bn_relu(conv, bn, True, x)
     ref = torch.relu(torch.nn.functional.batch_norm(conv(x).features, None, None, bn.weight, bn.bias, True, 0.0, 1e-3))
     assert torch.allclose(y.features, ref, atol=1e-4, rtol=1e-4)
