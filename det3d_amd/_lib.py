@@ -45,6 +45,8 @@ SIGNATURES = {
     "d3d_bn_relu_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]),
     "d3d_bn_stats": (i32, [vp, i32, i32, i32, vp, vp]),
     "d3d_bn_apply": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, i32, vp, i32, vp, vp, vp, vp]),
+    "d3d_bn_apply_split": (i32, [vp, i32, i32, vp, vp, vp, vp, f32, f32, i32, i32, vp, i32, vp, vp, vp, vp, vp]),
+    "d3d_bn_bwd_dx_split": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
     "d3d_bn_bwd_reduce": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]),
     "d3d_bn_bwd_dx": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]),
     "d3d_conv2d_supported": (i32, [i32, i32, i32, i32]),

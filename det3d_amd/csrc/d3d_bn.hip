@@ -56,6 +56,24 @@ template <bool BF16> struct BnVec {
 
 #define BN_MAXC 256
 
+// store of the streaming sweeps.  f32 data may instead be written as the two bf16 planes of the dense conv kernels'
+// split format (d3d_conv2d.hip): hi = bf16(v) -> `y`, lo = bf16(v - hi) -> `y_lo`, 8 bytes per plane and lane
+template <bool BF16>
+__device__ __forceinline__ void bn_store(void *y, void *y_lo, int64_t vec_index, const float *v) {
+  if (BF16 || y_lo == nullptr) {
+    BnVec<BF16>::store(y, vec_index, v);
+  } else {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h[j] = bn_f32_to_bf16(v[j]);
+      l[j] = bn_f32_to_bf16(v[j] - bn_bf16_to_f32(h[j]));
+    }
+    ((uint2 *)y)[vec_index] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    ((uint2 *)y_lo)[vec_index] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+  }
+}
+
 // thread -> (row lane, 16-byte segment of the row); segs = c / EPV divides 256
 // NT = threads per block, U = rows in flight per lane.  The two REDUCTION sweeps end with 2c global atomics per
 // block, and same-address float atomics retire at ~12-20 ns each on MI355X: on the RPN's [140800, 128] maps 2048
@@ -158,7 +176,7 @@ __global__ void __launch_bounds__(256)
                     const float *__restrict__ beta, float *running_mean, float *running_var,
                     float momentum, float eps, int training, int relu,
                     const float *__restrict__ stats, int copies, void *__restrict__ y, float *save_mean,
-                    float *save_invstd) {
+                    float *save_invstd, void *__restrict__ y_lo) {
   constexpr int EPV = BnVec<BF16>::EPV;
   __shared__ float scale[BN_MAXC], shift[BN_MAXC];
   for (int ch = threadIdx.x; ch < c; ch += 256) {
@@ -211,7 +229,7 @@ __global__ void __launch_bounds__(256)
         float z = fmaf(v[u][j], sc[j], sh[j]);
         v[u][j] = relu ? fmaxf(z, 0.f) : z;
       }
-      BnVec<BF16>::store(y, (r + u * step) * segs + seg, v[u]);
+      bn_store<BF16>(y, y_lo, (r + u * step) * segs + seg, v[u]);
     }
   }
   for (; r < n; r += step) {
@@ -222,7 +240,7 @@ __global__ void __launch_bounds__(256)
       float z = fmaf(v[j], sc[j], sh[j]);
       v[j] = relu ? fmaxf(z, 0.f) : z;
     }
-    BnVec<BF16>::store(y, r * segs + seg, v);
+    bn_store<BF16>(y, y_lo, r * segs + seg, v);
   }
 }
 
@@ -296,7 +314,7 @@ __global__ void __launch_bounds__(256)
                      const float *__restrict__ gamma, const float *__restrict__ beta,
                      const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
                      const float *__restrict__ partial, int copies, float *__restrict__ dgamma,
-                     float *__restrict__ dbeta, void *__restrict__ dx) {
+                     float *__restrict__ dbeta, void *__restrict__ dx, void *__restrict__ dx_lo) {
   constexpr int EPV = BnVec<BF16>::EPV;
   __shared__ float tot[2 * BN_MAXC];
   for (int i = threadIdx.x; i < 2 * c; i += 256) {  // fold the replicated partial sums
@@ -345,7 +363,7 @@ __global__ void __launch_bounds__(256)
         float dz = (relu && fmaf(v[j], zs[j], zb[j]) <= 0.f) ? 0.f : d[j];
         v[j] = fmaf(A[j], dz, fmaf(P[j], v[j], Q[j]));
       }
-      BnVec<BF16>::store(dx, (r + u * step) * segs + seg, v);
+      bn_store<BF16>(dx, dx_lo, (r + u * step) * segs + seg, v);
     }
   }
   for (; r < n; r += step) {
@@ -357,7 +375,7 @@ __global__ void __launch_bounds__(256)
       float dz = (relu && fmaf(v[j], zs[j], zb[j]) <= 0.f) ? 0.f : d[j];
       v[j] = fmaf(A[j], dz, fmaf(P[j], v[j], Q[j]));
     }
-    BnVec<BF16>::store(dx, r * segs + seg, v);
+    bn_store<BF16>(dx, dx_lo, r * segs + seg, v);
   }
 }
 
@@ -473,10 +491,30 @@ extern "C" int d3d_bn_stats(const void *x, int n, int c, int dtype, float *stats
   return D3D_OK;
 }
 
+static int bn_apply_impl(const void *x, int n, int c, int dtype, const float *gamma, const float *beta,
+                         float *running_mean, float *running_var, float momentum, float eps, int training,
+                         int relu, const float *stats_ws, int copies, void *y, void *y_lo, float *save_mean,
+                         float *save_invstd, d3d_stream_t stream_);
 extern "C" int d3d_bn_apply(const void *x, int n, int c, int dtype, const float *gamma, const float *beta,
                             float *running_mean, float *running_var, float momentum, float eps, int training,
                             int relu, const float *stats_ws, int copies, void *y, float *save_mean,
                             float *save_invstd, d3d_stream_t stream_) {
+  return bn_apply_impl(x, n, c, dtype, gamma, beta, running_mean, running_var, momentum, eps, training, relu, stats_ws,
+                       copies, y, nullptr, save_mean, save_invstd, stream_);
+}
+// f32 rows in, the split format of the dense conv kernels out (y_hi / y_lo: bf16 [n, c] planes)
+extern "C" int d3d_bn_apply_split(const float *x, int n, int c, const float *gamma, const float *beta,
+                                  float *running_mean, float *running_var, float momentum, float eps, int training,
+                                  int relu, const float *stats_ws, int copies, void *y_hi, void *y_lo,
+                                  float *save_mean, float *save_invstd, d3d_stream_t stream_) {
+  D3D_REQUIRE(y_lo, "d3d_bn_apply_split: null y_lo");
+  return bn_apply_impl(x, n, c, D3D_F32, gamma, beta, running_mean, running_var, momentum, eps, training, relu, stats_ws,
+                       copies, y_hi, y_lo, save_mean, save_invstd, stream_);
+}
+static int bn_apply_impl(const void *x, int n, int c, int dtype, const float *gamma, const float *beta,
+                         float *running_mean, float *running_var, float momentum, float eps, int training,
+                         int relu, const float *stats_ws, int copies, void *y, void *y_lo, float *save_mean,
+                         float *save_invstd, d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = bn_check(n, c, dtype, "d3d_bn_apply");
   if (rc) return rc;
@@ -488,11 +526,11 @@ extern "C" int d3d_bn_apply(const void *x, int n, int c, int dtype, const float 
   if (dtype == D3D_BF16)
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(nb), dim3(256), 0, stream, x, n, c, gamma, beta,
                        running_mean, running_var, momentum, eps, training, relu, stats_ws, copies, y,
-                       save_mean, save_invstd);
+                       save_mean, save_invstd, y_lo);
   else
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(nb), dim3(256), 0, stream, x, n, c, gamma, beta,
                        running_mean, running_var, momentum, eps, training, relu, stats_ws, copies, y,
-                       save_mean, save_invstd);
+                       save_mean, save_invstd, y_lo);
   D3D_LAUNCH_TRY("bn_apply_kernel");
   return D3D_OK;
 }
@@ -511,10 +549,30 @@ extern "C" int d3d_bn_bwd_reduce(const void *x, const void *dy, int n, int c, in
   return D3D_OK;
 }
 
+static int bn_bwd_dx_impl(const void *x, const void *dy, int n, int c, int dtype, const float *gamma,
+                          const float *beta, const float *save_mean, const float *save_invstd, int relu,
+                          const float *partial_ws, int copies, void *dx, void *dx_lo, float *dgamma, float *dbeta,
+                          d3d_stream_t stream_);
 extern "C" int d3d_bn_bwd_dx(const void *x, const void *dy, int n, int c, int dtype, const float *gamma,
                              const float *beta, const float *save_mean, const float *save_invstd, int relu,
                              const float *partial_ws, int copies, void *dx, float *dgamma, float *dbeta,
                              d3d_stream_t stream_) {
+  return bn_bwd_dx_impl(x, dy, n, c, dtype, gamma, beta, save_mean, save_invstd, relu, partial_ws, copies, dx, nullptr,
+                        dgamma, dbeta, stream_);
+}
+// f32 x / dy in, dx in the split format (bf16 planes) out
+extern "C" int d3d_bn_bwd_dx_split(const float *x, const float *dy, int n, int c, const float *gamma,
+                                   const float *beta, const float *save_mean, const float *save_invstd, int relu,
+                                   const float *partial_ws, int copies, void *dx_hi, void *dx_lo, float *dgamma,
+                                   float *dbeta, d3d_stream_t stream_) {
+  D3D_REQUIRE(dx_lo, "d3d_bn_bwd_dx_split: null dx_lo");
+  return bn_bwd_dx_impl(x, dy, n, c, D3D_F32, gamma, beta, save_mean, save_invstd, relu, partial_ws, copies, dx_hi,
+                        dx_lo, dgamma, dbeta, stream_);
+}
+static int bn_bwd_dx_impl(const void *x, const void *dy, int n, int c, int dtype, const float *gamma,
+                          const float *beta, const float *save_mean, const float *save_invstd, int relu,
+                          const float *partial_ws, int copies, void *dx, void *dx_lo, float *dgamma, float *dbeta,
+                          d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = bn_check(n, c, dtype, "d3d_bn_bwd_dx");
   if (rc) return rc;
@@ -524,7 +582,7 @@ extern "C" int d3d_bn_bwd_dx(const void *x, const void *dy, int n, int c, int dt
   const int nb = bn_stream_grid(n, c, dtype);
 #define BN_DX(BF, UR)                                                                                        \
   hipLaunchKernelGGL((bn_bwd_dx_kernel<BF, UR>), dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma, beta,   \
-                     save_mean, save_invstd, relu, partial_ws, copies, dgamma, dbeta, dx)
+                     save_mean, save_invstd, relu, partial_ws, copies, dgamma, dbeta, dx, dx_lo)
   const int ur = g_bn_dx_rows >= 4 ? 4 : (g_bn_dx_rows <= 1 ? 1 : 2);
   if (dtype == D3D_BF16) {
     if (ur == 4) BN_DX(true, 4); else if (ur == 2) BN_DX(true, 2); else BN_DX(true, 1);

@@ -222,6 +222,15 @@ int d3d_bn_bwd_reduce(const void *x, const void *dy, int n, int c, int dtype, co
 int d3d_bn_bwd_dx(const void *x, const void *dy, int n, int c, int dtype, const float *gamma, const float *beta,
                   const float *save_mean, const float *save_invstd, int relu, const float *partial_ws, int copies,
                   void *dx, float *dgamma, float *dbeta, d3d_stream_t stream);
+/* The same two sweeps on f32 rows with the result in the split format of the dense conv kernels (two bf16 planes
+ * hi = bf16(v), lo = bf16(v - hi); d3d_conv2d_nhwc_fwd, D3D_CONV_SPLIT): the BatchNorm2d + ReLU between two RPN
+ * convolutions writes the next convolution's operand directly (rpn.py:124-142). */
+int d3d_bn_apply_split(const float *x, int n, int c, const float *gamma, const float *beta, float *running_mean,
+                       float *running_var, float momentum, float eps, int training, int relu, const float *stats_ws,
+                       int copies, void *y_hi, void *y_lo, float *save_mean, float *save_invstd, d3d_stream_t stream);
+int d3d_bn_bwd_dx_split(const float *x, const float *dy, int n, int c, const float *gamma, const float *beta,
+                        const float *save_mean, const float *save_invstd, int relu, const float *partial_ws,
+                        int copies, void *dx_hi, void *dx_lo, float *dgamma, float *dbeta, d3d_stream_t stream);
 /* Per-channel affine sweeps for the reference's cross-rank BatchNorm (det3d/ops/syncbn/syncbn.py:15-118,
  * src/syncbn_cuda_kernel.cu:166-198 transform_input, :595-640 input_backward): the all-reduced statistics
  * arrive as [c] f32 vectors, so the passes take ready coefficients:
