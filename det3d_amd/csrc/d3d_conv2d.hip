@@ -246,26 +246,37 @@ __global__ void __launch_bounds__(256, 2)
     }
   }
   if (want_stats) {
-    // fold the 32 pixels of a lane half with shuffles, the two pixel-half waves of a cout half through LDS rows,
-    // the blocks through the fixed-order fold: deterministic
+    // The lane holds 64 partial sums (2 cout tiles x 16 channels x {sum, sumsq}) of ITS pixels; 32 lanes (pixels)
+    // share them.  Halving butterfly: at distance d = 16, 8, 4, 2, 1 a lane keeps one half of its values and hands
+    // the other half to its partner -- 32 + 16 + 8 + 4 + 2 = 62 cross-lane moves instead of 5 x 64, fixed order.
+    // Afterwards lane l holds the two totals with index v = ((l & 31) << 1) | k, k = 0, 1.
     __syncthreads();  // every wave is done with the operand stages
     float *red = (float *)smem;  // [2 pixel-half waves][2][128] then tot [2][128] then flag
+    float vals[64];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float a = s1[i][r], b = s2[i][r];
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) {
-          a += __shfl_xor(a, o, 64);
-          b += __shfl_xor(b, o, 64);
-        }
-        if ((lane & 31) == 0) {
-          const int cl = wco * 64 + i * 32 + 4 * (lane >> 5) + 8 * (r >> 2) + (r & 3);  // channel within the block
-          red[wpx * 256 + cl] = a;
-          red[wpx * 256 + 128 + cl] = b;
-        }
+        vals[i * 32 + r * 2 + 0] = s1[i][r];
+        vals[i * 32 + r * 2 + 1] = s2[i][r];
       }
+#pragma unroll
+    for (int d = 16, n = 64; d >= 1; d >>= 1, n >>= 1) {
+      const bool up = (lane & d) != 0;
+#pragma unroll
+      for (int k = 0; k < n / 2; ++k) {
+        const float send = up ? vals[k] : vals[k + n / 2];
+        const float keep = up ? vals[k + n / 2] : vals[k];
+        vals[k] = keep + __shfl_xor(send, d, 64);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int v = ((lane & 31) << 1) | k;         // = i * 32 + r * 2 + stat
+      const int i = v >> 5, r = (v >> 1) & 15, stat = v & 1;
+      const int cl = wco * 64 + i * 32 + 4 * (lane >> 5) + 8 * (r >> 2) + (r & 3);  // channel within the block
+      red[wpx * 256 + stat * 128 + cl] = vals[k];
+    }
     __syncthreads();
     float *tot = red + 512;
     // the fold wants [sum over ALL cout | sumsq over ALL cout] per block row of grid.y: slab = 2 * 128 values of
@@ -529,9 +540,9 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
 
 // weight gradient of the layer above (stride 1 or 2): g = dL/dy [batch, ho, wo, cout], x = the layer's input;
 // dw [ksz*ksz][cout][cin] f32 (the packed forward layout).  workspace: d3d_conv2d_wgrad_workspace_bytes.
-static int c2_wgrad_splits(int m) {
-  // ~2 blocks per CU over (splits x taps) at 9 taps and one weight tile; >= 8 K steps per block
-  int s = 56;
+static int c2_wgrad_splits(int m, int blocks_per_split) {
+  // ~2 blocks per CU over (splits x taps x weight tiles); >= 8 K steps per block
+  int s = (512 + blocks_per_split - 1) / blocks_per_split;
   const int max_s = (m + 511) / 512;
   if (s > max_s) s = max_s;
   return s < 1 ? 1 : s;
@@ -539,7 +550,7 @@ static int c2_wgrad_splits(int m) {
 extern "C" size_t d3d_conv2d_wgrad_workspace_bytes(int batch, int ho, int wo, int cin, int cout, int ksz) {
   const int64_t m = (int64_t)batch * ho * wo;
   if (m < 1) return 0;
-  return (size_t)c2_wgrad_splits((int)m) * ksz * ksz * cout * cin * sizeof(float);
+  return (size_t)c2_wgrad_splits((int)m, ksz * ksz * (cin / 128) * (cout / 128)) * ksz * ksz * cout * cin * sizeof(float);
 }
 
 extern "C" int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const void *x_hi, const void *x_lo,
@@ -559,7 +570,7 @@ extern "C" int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const v
   if (rc) return rc;
   D3D_REQUIRE((int64_t)batch * h * w * cin * 2 < (int64_t)D3D_RSRC_BYTES, "d3d_conv2d_nhwc_wgrad: the input map exceeds 2 GB");
   G.w_bytes = (int)((int64_t)G.m * cout * 2);  // the descriptor of g
-  const int splits = c2_wgrad_splits(G.m);
+  const int splits = c2_wgrad_splits(G.m, ksz * ksz * (cin / 128) * (cout / 128));
   const size_t need = d3d_conv2d_wgrad_workspace_bytes(batch, G.ho, G.wo, cin, cout, ksz);
   if (!workspace || workspace_bytes < need)
     return d3d_set_error(D3D_ECAPACITY, "d3d_conv2d_nhwc_wgrad: workspace %zu B < %zu B", workspace_bytes, need);

@@ -1,0 +1,225 @@
+"""Runs of `[ZeroPad2d] -> Conv2d -> BatchNorm2d [-> ReLU]` on a channels-last map as ONE autograd node on the
+library's own kernels (csrc/d3d_conv2d.hip + the BatchNorm sweeps of csrc/d3d_bn.hip).
+
+Reference: the RPN blocks and deblocks, det3d/models/necks/rpn.py:58-100 (`Sequential(ZeroPad2d(1), Conv2d(3x3),
+BN, ReLU, [Conv2d(3x3, padding=1), BN, ReLU] * n)`), cuDNN kernels behind nn.Conv2d / nn.BatchNorm2d.  Per layer:
+
+  forward   conv (BN statistics in its epilogue)  ->  bn_apply (+ReLU), written in the next conv's operand format
+  backward  bn_bwd_reduce -> bn_bwd_dx (written in the conv operand format) -> wgrad (two-pass) -> dgrad (= the
+            forward kernel on the mirrored taps)
+
+Two precisions, chosen by the dtype of the incoming map:
+  bfloat16 (the step runs under autocast)  : bf16 operands and activations, f32 accumulation
+  float32                                  : the SPLIT format -- every operand as two bf16 planes hi + lo, three bf16
+            MFMAs per product, f32 activations between the kernels: raw box regressions stay within north_star's
+            1e-3 of the f32 oracle (tests/test_e2e_gpu.py) at a fraction of the exact-f32 cost
+            (D3D_RPN_FP32=exact keeps such maps on MIOpen's f32 kernels).
+Everything is deterministic (fixed-order folds, two-pass weight gradients): two identical steps are bit-equal.
+"""
+import os
+
+import torch
+from torch import nn
+
+from . import _lib
+from . import dense_conv as dc
+
+ENABLED = os.environ.get("D3D_DENSE_CONV", "1") != "0"
+FP32_MODE = os.environ.get("D3D_RPN_FP32", "split")  # "split" | "exact" (MIOpen f32)
+
+
+class _Layer:
+    __slots__ = ("conv", "bn", "relu", "ksz", "pad", "cin", "cout")
+
+    def __init__(self, conv, bn, relu, pad):
+        self.conv, self.bn, self.relu = conv, bn, relu
+        self.ksz = conv.kernel_size[0]
+        self.pad = pad
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+
+
+def _conv_ok(conv, extra_pad):
+    if type(conv) is not nn.Conv2d or conv.bias is not None or conv.groups != 1 or conv.weight.dtype != torch.float32:
+        return None
+    k = conv.kernel_size
+    if k[0] != k[1] or conv.stride != (1, 1) or conv.dilation != (1, 1) or conv.padding_mode != "zeros":
+        return None
+    if not isinstance(conv.padding, tuple) or conv.padding[0] != conv.padding[1]:
+        return None
+    pad = conv.padding[0] + extra_pad
+    if pad >= k[0] or 2 * pad != k[0] - 1:  # "same" convolutions: the data gradient is the mirrored forward
+        return None
+    cin, cout = conv.in_channels, conv.out_channels
+    if cin not in (128, 256) or cout not in (128, 256) or not dc.supported(cin, cout, k[0], 1):
+        return None
+    return pad
+
+
+def _bn_ok(bn, c):
+    if type(bn) is not nn.BatchNorm2d or bn.momentum is None or not bn.track_running_stats or bn.weight is None:
+        return False
+    if any(t is not None and t.dtype != torch.float32 for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)):
+        return False
+    return bn.num_features == c and bn.bias is not None
+
+
+def collect(mods, i, x):
+    """longest run of eligible layers starting at mods[i]; returns (layers, index behind the run)"""
+    if not ENABLED or not torch.is_tensor(x) or not x.is_cuda or x.dim() != 4:
+        return [], i
+    if x.dtype == torch.float32:
+        if FP32_MODE != "split" or torch.is_autocast_enabled("cuda"):
+            return [], i
+    elif x.dtype != torch.bfloat16:
+        return [], i
+    if x.shape[1] == 1 or not x.is_contiguous(memory_format=torch.channels_last):
+        return [], i
+    if x.numel() * 2 >= (1 << 31) - 16:
+        return [], i
+    layers = []
+    c = x.shape[1]
+    training = None
+    while i < len(mods):
+        j, extra = i, 0
+        if type(mods[j]) is nn.ZeroPad2d:
+            p = mods[j].padding
+            p = (p, p, p, p) if isinstance(p, int) else tuple(p)
+            if len(set(p)) != 1 or j + 1 >= len(mods):
+                break
+            extra, j = p[0], j + 1
+        conv = mods[j]
+        pad = _conv_ok(conv, extra)
+        if pad is None or conv.in_channels != c or j + 1 >= len(mods) or not _bn_ok(mods[j + 1], conv.out_channels):
+            break
+        bn = mods[j + 1]
+        if training is None:
+            training = bn.training
+        if bn.training != training:
+            break
+        relu = j + 2 < len(mods) and type(mods[j + 2]) is nn.ReLU
+        layers.append(_Layer(conv, bn, relu, pad))
+        c = conv.out_channels
+        i = j + (3 if relu else 2)
+    return layers, i
+
+
+def _params(layers):
+    out = []
+    for ly in layers:
+        out += [ly.conv.weight, ly.bn.weight, ly.bn.bias]
+    return out
+
+
+class _DenseStackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, layers, *params):
+        L = _lib.lib()
+        dev = x.device
+        st = _lib.stream_ptr(dev)
+        split = x.dtype == torch.float32
+        mode = "split" if split else "bf16"
+        dt = _lib.D3D_F32 if split else _lib.D3D_BF16
+        b, _, h, w = x.shape
+        rows = x.permute(0, 2, 3, 1)  # [B,H,W,C] view of the channels-last memory
+        if not rows.is_contiguous():
+            rows = rows.contiguous()
+        a_hi, a_lo = dc.split_planes(rows) if split else (rows, None)
+        training = layers[0].bn.training
+        need_in_grad = ctx.needs_input_grad[0]
+        rec = []
+        out = None
+        for li, ly in enumerate(layers):
+            bn = ly.bn
+            w_hi, w_lo = dc._packed(ly.conv.weight, "fwd", mode)
+            y, ws = dc.conv2d_raw(a_hi, a_lo, w_hi, w_lo, ly.ksz, 1, ly.pad, mode, want_stats=training)
+            n = y.shape[0] * y.shape[1] * y.shape[2]
+            cout = ly.cout
+            save = torch.empty((2, cout), dtype=torch.float32, device=dev) if training else None
+            last = li + 1 == len(layers)
+            common = (n, cout)
+            tail = (bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                    float(bn.momentum), float(bn.eps), int(training), int(ly.relu), _lib.ptr(ws), 1)
+            if split and not last:
+                z_hi = torch.empty(y.shape, dtype=torch.bfloat16, device=dev)
+                z_lo = torch.empty_like(z_hi)
+                rc = L.d3d_bn_apply_split(y.data_ptr(), *common, *tail, z_hi.data_ptr(), z_lo.data_ptr(),
+                                          _lib.ptr(save[0]) if training else None,
+                                          _lib.ptr(save[1]) if training else None, st)
+                _lib.check(rc, "d3d_bn_apply_split")
+                nxt = (z_hi, z_lo)
+            else:
+                z = torch.empty_like(y)
+                rc = L.d3d_bn_apply(y.data_ptr(), *common, dt, *tail, z.data_ptr(),
+                                    _lib.ptr(save[0]) if training else None,
+                                    _lib.ptr(save[1]) if training else None, st)
+                _lib.check(rc, "d3d_bn_apply")
+                nxt = (z, None)
+                if last:
+                    out = z
+            rec.append((a_hi, a_lo, y, save))
+            a_hi, a_lo = nxt
+        ctx.layers, ctx.rec, ctx.mode, ctx.training = layers, rec, mode, training
+        ctx.in_dtype = x.dtype
+        ctx.need_in_grad = need_in_grad
+        return out.permute(0, 3, 1, 2)  # channels-last [B, C, H, W]
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.training:
+            raise _lib.D3dError("dense conv stack: backward is implemented for training-mode BatchNorm only")
+        L = _lib.lib()
+        layers, rec, mode = ctx.layers, ctx.rec, ctx.mode
+        split = mode == "split"
+        dt = _lib.D3D_F32 if split else _lib.D3D_BF16
+        tdt = torch.float32 if split else torch.bfloat16
+        dev = g.device
+        st = _lib.stream_ptr(dev)
+        dy = g.permute(0, 2, 3, 1)
+        if dy.dtype != tdt:
+            dy = dy.to(tdt)
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        grads = []
+        for li in range(len(layers) - 1, -1, -1):
+            ly = layers[li]
+            bn = ly.bn
+            a_hi, a_lo, y, save = rec[li]
+            n, cout = y.shape[0] * y.shape[1] * y.shape[2], ly.cout
+            partial = torch.empty((L.d3d_bn_reduce_ws_floats(n, cout, dt),), dtype=torch.float32, device=dev)
+            rc = L.d3d_bn_bwd_reduce(y.data_ptr(), dy.data_ptr(), n, cout, dt, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                     save[0].data_ptr(), save[1].data_ptr(), int(ly.relu), partial.data_ptr(), st)
+            _lib.check(rc, "d3d_bn_bwd_reduce")
+            gbn = torch.empty((2, cout), dtype=torch.float32, device=dev)
+            if split:
+                g_hi = torch.empty(y.shape, dtype=torch.bfloat16, device=dev)
+                g_lo = torch.empty_like(g_hi)
+                rc = L.d3d_bn_bwd_dx_split(y.data_ptr(), dy.data_ptr(), n, cout, bn.weight.data_ptr(),
+                                           bn.bias.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), int(ly.relu),
+                                           partial.data_ptr(), 1, g_hi.data_ptr(), g_lo.data_ptr(), gbn[0].data_ptr(),
+                                           gbn[1].data_ptr(), st)
+                _lib.check(rc, "d3d_bn_bwd_dx_split")
+            else:
+                g_hi, g_lo = torch.empty_like(y), None
+                rc = L.d3d_bn_bwd_dx(y.data_ptr(), dy.data_ptr(), n, cout, dt, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                     save[0].data_ptr(), save[1].data_ptr(), int(ly.relu), partial.data_ptr(), 1,
+                                     g_hi.data_ptr(), gbn[0].data_ptr(), gbn[1].data_ptr(), st)
+                _lib.check(rc, "d3d_bn_bwd_dx")
+            dw = dc.wgrad_raw(g_hi, g_lo, a_hi, a_lo, ly.ksz, 1, ly.pad, mode)
+            gw = dc.unpack_wgrad(dw, ly.conv.weight)
+            if li > 0 or ctx.need_in_grad:
+                wd_hi, wd_lo = dc._packed(ly.conv.weight, "dgrad", mode)
+                dy, _ = dc.conv2d_raw(g_hi, g_lo, wd_hi, wd_lo, ly.ksz, 1, ly.ksz - 1 - ly.pad, mode)
+            else:
+                dy = None
+            grads.append([gw, gbn[0], gbn[1]])
+        gin = None
+        if dy is not None:
+            gin = dy.permute(0, 3, 1, 2)
+            if gin.dtype != ctx.in_dtype:
+                gin = gin.to(ctx.in_dtype)
+        flat = [t for lg in reversed(grads) for t in lg]
+        return (gin, None) + tuple(flat)
+
+
+def run(layers, x):
+    return _DenseStackFn.apply(x, layers, *_params(layers))

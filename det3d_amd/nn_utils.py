@@ -98,6 +98,15 @@ class Sequential(nn.Module):
         i = 0
         while i < len(mods):
             m = mods[i]
+            if type(m) in (nn.ZeroPad2d, nn.Conv2d) and torch.is_tensor(input) and input.is_cuda:
+                # runs of [pad] conv -> BN [-> ReLU] on the library's own MFMA conv kernels, one autograd node
+                from . import dense_stack
+
+                layers, nxt = dense_stack.collect(mods, i, input)
+                if layers:
+                    input = dense_stack.run(layers, input)
+                    i = nxt
+                    continue
             if type(m) is nn.ZeroPad2d and i + 1 < len(mods) and _pad_folds_into(m, mods[i + 1]) and \
                     torch.is_tensor(input) and input.is_cuda:
                 # rpn.py:64-68 pads with a separate ZeroPad2d(1) and convolves without padding: the same sums as a

@@ -108,3 +108,79 @@ def test_weight_gradient(geom, mode):
     got = dc.unpack_wgrad(dw, ref)
     err, scale = float((got.double() - ref).abs().max()), float(ref.abs().max())
     assert err <= (1e-5 if mode == "bf16" else 3e-5) * scale + 1e-6, (err, scale)
+
+
+def _rpn_like(cin, widths):
+    from det3d_amd.nn_utils import Sequential
+    from torch import nn
+
+    seq = Sequential(nn.ZeroPad2d(1), nn.Conv2d(cin, widths[0], 3, bias=False), nn.BatchNorm2d(widths[0], eps=1e-3, momentum=0.01),
+                     nn.ReLU())
+    c = widths[0]
+    for wd in widths[1:]:
+        for layer in (nn.Conv2d(c, wd, 3, padding=1, bias=False), nn.BatchNorm2d(wd, eps=1e-3, momentum=0.01), nn.ReLU()):
+            seq.add(layer)
+        c = wd
+    return seq
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dense_stack_is_the_torch_module_stack(dtype):
+    """nn_utils.Sequential routes [pad] conv -> BN -> ReLU runs to dense_stack: same activations, gradients and running
+    statistics as the plain torch modules in float64 (split mode: 1e-4 relative; bf16: bf16-class tolerances)."""
+    import copy
+
+    from det3d_amd import dense_stack
+
+    torch.manual_seed(3)
+    seq = _rpn_like(256, [128, 128, 128]).cuda().train()
+    for m in seq.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            torch.nn.init.uniform_(m.weight, 0.5, 1.5)
+            torch.nn.init.normal_(m.bias, 0, 0.3)
+    ref = copy.deepcopy(seq).double()
+    x = torch.randn(2, 256, 20, 24, device="cuda").contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(2, 128, 20, 24, device="cuda").contiguous(memory_format=torch.channels_last)
+    xa = x.to(dtype).requires_grad_(True)
+    calls = []
+    orig = dense_stack.run
+    dense_stack.run = lambda layers, t: calls.append(len(layers)) or orig(layers, t)
+    try:
+        y = seq(xa)
+    finally:
+        dense_stack.run = orig
+    assert calls == [3], calls
+    assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(gy.to(dtype))
+    xr = x.double().requires_grad_(True)
+    prev = dense_stack.ENABLED
+    dense_stack.ENABLED = False
+    try:
+        yr = ref(xr)
+    finally:
+        dense_stack.ENABLED = prev
+    yr.backward(gy.double())
+    tol = 2e-4 if dtype == torch.float32 else 6e-2
+
+    def close(a, b, what, t=tol):
+        err, scale = float((a.double() - b).abs().max()), float(b.abs().max())
+        assert err <= t * scale, (what, err, scale)
+
+    close(y, yr, "output")
+    close(xa.grad, xr.grad, "input gradient", tol * 3)
+    for (k, p), (_, q) in zip(seq.named_parameters(), ref.named_parameters()):
+        close(p.grad, q.grad, k, tol * 3)
+    for (k, p), (_, q) in zip(seq.named_buffers(), ref.named_buffers()):
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert torch.allclose(p.double(), q, rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=1e-5), k
+    # eval mode: running statistics, no autograd bookkeeping
+    seq.eval()
+    ref.eval()
+    with torch.no_grad():
+        ye = seq(x.to(dtype))
+        dense_stack.ENABLED = False
+        try:
+            yer = ref(x.double())
+        finally:
+            dense_stack.ENABLED = prev
+    close(ye, yer, "eval output")

@@ -52,9 +52,13 @@ def test_bn_reductions_are_bit_reproducible_and_right(dtype, n, c):
         red.append(ws[:2 * c].clone())
     assert torch.equal(red[0], red[1]) and torch.equal(red[0], red[2])
     xh = (x.float() - mean) * invstd
-    dz = dy.float() * ((xh * gamma + beta) > 0)
+    z = xh.double() * gamma.double() + beta.double()
+    assert float((dy.float() * (z.abs() < 1e-4)).abs().sum()) < 50.0  # what a ReLU mask flipped by rounding may move
+    dz = dy.float() * (z > 0)
     ref = torch.cat([(dz.double() * xh.double()).sum(0), dz.double().sum(0)])
-    assert float((red[0].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-3  # f32 accumulation
+    # f32 accumulation + the handful of elements whose pre-activation is within rounding of the ReLU threshold
+    assert float((red[0].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-3 + \
+        float((dy.float() * xh * (z.abs() < 1e-5)).abs().sum())
 
 
 def _model(name="kitti_car_second.py"):
