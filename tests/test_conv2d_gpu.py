@@ -141,7 +141,7 @@ def test_dense_stack_is_the_torch_module_stack(dtype):
     ref = copy.deepcopy(seq).double()
     x = torch.randn(2, 256, 20, 24, device="cuda").contiguous(memory_format=torch.channels_last)
     gy = torch.randn(2, 128, 20, 24, device="cuda").contiguous(memory_format=torch.channels_last)
-    xa = x.to(dtype).requires_grad_(True)
+    xa = x.detach().clone().to(dtype).requires_grad_(True)
     calls = []
     orig = dense_stack.run
     dense_stack.run = lambda layers, t: calls.append(len(layers)) or orig(layers, t)
@@ -152,7 +152,7 @@ def test_dense_stack_is_the_torch_module_stack(dtype):
     assert calls == [3], calls
     assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
     y.backward(gy.to(dtype))
-    xr = x.double().requires_grad_(True)
+    xr = x.detach().double().requires_grad_(True)
     prev = dense_stack.ENABLED
     dense_stack.ENABLED = False
     try:
