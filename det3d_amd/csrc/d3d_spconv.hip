@@ -65,6 +65,27 @@ extern "C" int d3d_set_tuning(int knob, int value) {
 }
 
 
+// f32 -> (hi, lo) bf16 pairs, hi = bf16(v) and lo = bf16(v - hi), both round-to-nearest-even (v_cvt_pk_bf16_f32);
+// v - hi is exact in f32, so hi + lo carries 16 mantissa bits of v
+typedef __attribute__((ext_vector_type(2))) float sp_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 sp_bf16x2_t;
+__device__ __forceinline__ void spconv_split2(float a, float b, uint32_t &hi, uint32_t &lo) {
+  const sp_f32x2_t v = {a, b};
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, sp_bf16x2_t));
+  const sp_f32x2_t r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, sp_bf16x2_t));
+}
+__device__ __forceinline__ void spconv_split4(const uint4 &f, uint2 &hi, uint2 &lo) {
+  spconv_split2(__uint_as_float(f.x), __uint_as_float(f.y), hi.x, lo.x);
+  spconv_split2(__uint_as_float(f.z), __uint_as_float(f.w), hi.y, lo.y);
+}
+__device__ __forceinline__ void spconv_split8(const uint4 &f0, const uint4 &f1, uint4 &hi, uint4 &lo) {
+  spconv_split2(__uint_as_float(f0.x), __uint_as_float(f0.y), hi.x, lo.x);
+  spconv_split2(__uint_as_float(f0.z), __uint_as_float(f0.w), hi.y, lo.y);
+  spconv_split2(__uint_as_float(f1.x), __uint_as_float(f1.y), hi.z, lo.z);
+  spconv_split2(__uint_as_float(f1.z), __uint_as_float(f1.w), hi.w, lo.w);
+}
+
 // the ABI's epilogue request + what the launcher adds for the deterministic cross-block fold (d3d_fold.h)
 struct ConvEpiDev : D3dConvEpilogue {
   unsigned *counters;  // ticket words of this launch
@@ -229,16 +250,22 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
                            const float *__restrict__ bias, const int32_t *__restrict__ nbr,
                            int cap, int n_out, int kvol, void *__restrict__ out_, ConvEpiDev ep,
                            int xcd_remap) {
+  // f32 features (BF16 = false) are multiplied in SPLIT arithmetic (round 3): a gathered f32 fragment is split in
+  // registers into two bf16 vectors hi = bf16(v), lo = bf16(v - hi) (16 mantissa bits), the weights arrive
+  // pre-split as two bf16 planes, and each product is three bf16 MFMAs hi*hi + hi*lo + lo*hi with f32 accumulation:
+  // relative error ~2^-16 of the products instead of 2^-8 (bf16), at a fifth of the exact-f32 MFMA's time (round 2
+  // ran mfma_f32_16x16x4f32 here: 160 us for the 64->64 layer against 45 us in bf16).
   constexpr int NT = COUT / 16;
-  constexpr int ESZ = BF16 ? 2 : 4;
-  constexpr int KW = BF16 ? ((CIN % 32 == 0) ? 32 : 16) : 16;  // channels per k-step
+  constexpr int ESZ = BF16 ? 2 : 4;       // bytes per feature element in HBM
+  constexpr int NPL = BF16 ? 1 : 2;       // bf16 planes per weight matrix
+  constexpr int KW = (CIN % 32 == 0) ? 32 : 16;  // channels per k-step
   constexpr int KS = CIN / KW;
-  constexpr int EPL = KW / 4;             // elements per lane per step (8 | 4 bf16, 4 f32)
-  constexpr int ROWB = CIN * ESZ + 16;    // padded LDS row (bytes)
-  constexpr int WBYTES = COUT * ROWB;
+  constexpr int EPL = KW / 4;             // elements per lane per step (8 | 4)
+  constexpr int ROWB = CIN * 2 + 16;      // padded LDS row of one bf16 plane (bytes)
+  constexpr int WBYTES = NPL * COUT * ROWB;
   constexpr int NTHREADS = WAVES * 64;
-  constexpr int SEGS = CIN * ESZ / 16;    // 16-byte segments per weight row
-  constexpr int WVEC = COUT * SEGS;       // 16-byte vectors in W[k]
+  constexpr int SEGS = CIN * 2 / 16;      // 16-byte segments per weight row (one plane)
+  constexpr int WVEC = NPL * COUT * SEGS; // 16-byte vectors in W[k] (all planes)
   constexpr int WPT = (WVEC + NTHREADS - 1) / NTHREADS;
   static_assert(2 * WBYTES >= 4 * SPCONV_EPI_LDS_FLOATS(COUT, NTHREADS), "epilogue scratch aliases the W buffers");
   __shared__ __attribute__((aligned(16))) unsigned char wlds[2 * WBYTES];
@@ -268,8 +295,13 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
     site[m] = row0 + m * 16 + lr;
     live[m] = site[m] < n_out;
   }
-  // gathered-row fragment of one (tile, k-step): 16 B (8 bf16 | 4 f32) or 8 B (4 bf16, Cin = 16)
-  using FragT = typename std::conditional<(BF16 && KW == 16), uint2, uint4>::type;
+  // gathered-row fragment of one (tile, k-step): EPL elements = 16 B (8 bf16 | 4 f32), 8 B (4 bf16, Cin = 16) or
+  // 32 B (8 f32)
+  struct Frag32 { uint4 a, b; };
+  using FragT = typename std::conditional<BF16, typename std::conditional<KW == 16, uint2, uint4>::type,
+                                          typename std::conditional<KW == 16, uint4, Frag32>::type>::type;
+  // MFMA operand of one k-step: 8 bf16 (KW = 32) or 4 bf16 (KW = 16)
+  using OpT = typename std::conditional<KW == 16, uint2, uint4>::type;
   const __amdgpu_buffer_rsrc_t feat_rs = d3d_make_rsrc(feat_);
   const uint32_t lane_off = (uint32_t)(lg * EPL * ESZ);
   const int kmax = kvol - 1;
@@ -293,8 +325,14 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const uint32_t off = ok ? base + (uint32_t)(ks * KW * ESZ) : D3D_OOB_OFFSET;
-        if constexpr (sizeof(FragT) == 16) f[m][ks] = d3d_buffer_load16(feat_rs, off);
-        else f[m][ks] = d3d_buffer_load8(feat_rs, off);
+        if constexpr (sizeof(FragT) == 32) {
+          f[m][ks].a = d3d_buffer_load16(feat_rs, off);
+          f[m][ks].b = d3d_buffer_load16(feat_rs, ok ? off + 16u : D3D_OOB_OFFSET);
+        } else if constexpr (sizeof(FragT) == 16) {
+          f[m][ks] = d3d_buffer_load16(feat_rs, off);
+        } else {
+          f[m][ks] = d3d_buffer_load8(feat_rs, off);
+        }
       }
     }
     return __ballot(any);
@@ -314,7 +352,7 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
       const int e = threadIdx.x + j * NTHREADS;
-      if (WVEC % NTHREADS == 0 || e < WVEC) *(d3d_u32x4 *)(dst + (e / SEGS) * ROWB + (e % SEGS) * 16) = w[j];
+      if (WVEC % NTHREADS == 0 || e < WVEC) *(d3d_u32x4 *)(dst + (e / SEGS) * ROWB + (e % SEGS) * 16) = w[j];  // (planes follow each other row by row)
     }
   };
 
@@ -348,28 +386,43 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int ch = ks * KW + lg * EPL;
+          // B operands of this k-step: the gathered fragments as they are (bf16) or split into hi / lo (f32)
+          OpT xh[MT], xl[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            if constexpr (BF16) {
+              xh[m] = fr[d][m][ks];
+            } else if constexpr (KW == 32) {
+              spconv_split8(fr[d][m][ks].a, fr[d][m][ks].b, xh[m], xl[m]);
+            } else {
+              spconv_split4(fr[d][m][ks], xh[m], xl[m]);
+            }
+          }
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
-            const FragT wa = *(const FragT *)(wcur + (n * 16 + lr) * ROWB + ch * ESZ);
+            const OpT wa = *(const OpT *)(wcur + (n * 16 + lr) * ROWB + ch * 2);
+            OpT wl;
+            if constexpr (!BF16) wl = *(const OpT *)(wcur + (COUT + n * 16 + lr) * ROWB + ch * 2);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-              if constexpr (BF16 && KW == 32) {
+              if constexpr (KW == 32) {
                 acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, fr[d][m][ks]),
-                    acc[m][n], 0, 0, 0);
-              } else if constexpr (BF16) {
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
-                    __builtin_bit_cast(s16x4_t, wa), __builtin_bit_cast(s16x4_t, fr[d][m][ks]),
-                    acc[m][n], 0, 0, 0);
+                    __builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, xh[m]), acc[m][n], 0, 0, 0);
+                if constexpr (!BF16) {
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                      __builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, xl[m]), acc[m][n], 0, 0, 0);
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                      __builtin_bit_cast(bf16x8_t, wl), __builtin_bit_cast(bf16x8_t, xh[m]), acc[m][n], 0, 0, 0);
+                }
               } else {
-                // 16x16x4 f32 MFMA: lane group lg supplies k = lg; four of them walk the lane's 4
-                // consecutive channels (any consistent k labelling of A and B is a valid sum)
-                const float4 w4 = __builtin_bit_cast(float4, wa);
-                const float4 f4 = __builtin_bit_cast(float4, fr[d][m][ks]);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, f4.x, acc[m][n], 0, 0, 0);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, f4.y, acc[m][n], 0, 0, 0);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, f4.z, acc[m][n], 0, 0, 0);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, f4.w, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
+                    __builtin_bit_cast(s16x4_t, wa), __builtin_bit_cast(s16x4_t, xh[m]), acc[m][n], 0, 0, 0);
+                if constexpr (!BF16) {
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
+                      __builtin_bit_cast(s16x4_t, wa), __builtin_bit_cast(s16x4_t, xl[m]), acc[m][n], 0, 0, 0);
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
+                      __builtin_bit_cast(s16x4_t, wl), __builtin_bit_cast(s16x4_t, xh[m]), acc[m][n], 0, 0, 0);
+                }
               }
             }
           }
@@ -1220,25 +1273,35 @@ int d3d_wgrad_legacy(const void *feat, const void *dout, const int32_t *nbr, int
 //   dgrad    wpack_dgrad[kvol][cin][cout] = W[k] (k mirrored for submanifold layers)
 // One launch writes both (the PyTorch-op version was transpose-copy + cast + flip-copy + cast = 4
 // launches per layer and step).
-template <bool BF16>
+// mode 0: f32 copies (channel pairs without MFMA tiles: the generic kernels read f32), 1: bf16, 2: split = two bf16
+// planes per kernel offset, [k][plane][rows][cols] with plane 0 = bf16(w), plane 1 = bf16(w - plane 0)
 __global__ void __launch_bounds__(256)
-    spconv_pack_weights_kernel(const float *__restrict__ w, int kvol, int cin, int cout, int flip,
-                               void *__restrict__ fwd_, void *__restrict__ dgrad_) {
+    spconv_pack_weights_kernel(const float *__restrict__ w, int kvol, int cin, int cout, int flip, int mode_fwd,
+                               int mode_dgrad, void *__restrict__ fwd_, void *__restrict__ dgrad_) {
   const int per_k = cin * cout;
   const int total = kvol * per_k;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
     const int k = t / per_k, rem = t - k * per_k;
     const int ci = rem / cout, co = rem - ci * cout;
     const float v = w[t];
-    const int tf = (k * cout + co) * cin + ci;
-    const int td = ((flip ? kvol - 1 - k : k) * cin + ci) * cout + co;
-    if (BF16) {
-      const uint16_t h = f32_to_bf16(v);
-      if (fwd_) ((uint16_t *)fwd_)[tf] = h;
-      if (dgrad_) ((uint16_t *)dgrad_)[td] = h;
-    } else {
-      if (fwd_) ((float *)fwd_)[tf] = v;
-      if (dgrad_) ((float *)dgrad_)[td] = v;
+    const uint16_t h = f32_to_bf16(v);
+    const uint16_t l = f32_to_bf16(v - bf16_to_f32(h));
+    const int kd = flip ? kvol - 1 - k : k;
+    if (fwd_) {
+      if (mode_fwd == 0) ((float *)fwd_)[(k * cout + co) * cin + ci] = v;
+      else if (mode_fwd == 1) ((uint16_t *)fwd_)[(k * cout + co) * cin + ci] = h;
+      else {
+        ((uint16_t *)fwd_)[((k * 2 + 0) * cout + co) * cin + ci] = h;
+        ((uint16_t *)fwd_)[((k * 2 + 1) * cout + co) * cin + ci] = l;
+      }
+    }
+    if (dgrad_) {
+      if (mode_dgrad == 0) ((float *)dgrad_)[(kd * cin + ci) * cout + co] = v;
+      else if (mode_dgrad == 1) ((uint16_t *)dgrad_)[(kd * cin + ci) * cout + co] = h;
+      else {
+        ((uint16_t *)dgrad_)[((kd * 2 + 0) * cin + ci) * cout + co] = h;
+        ((uint16_t *)dgrad_)[((kd * 2 + 1) * cin + ci) * cout + co] = l;
+      }
     }
   }
 }
@@ -1253,12 +1316,11 @@ extern "C" int d3d_pack_conv_weights(const float *weight, int kvol, int cin, int
   const int total = kvol * cin * cout;
   int nb = (total + 255) / 256;
   if (nb > 1024) nb = 1024;
-  if (dtype == D3D_BF16)
-    hipLaunchKernelGGL(spconv_pack_weights_kernel<true>, dim3(nb), dim3(256), 0, stream, weight, kvol, cin,
-                       cout, flip_dgrad, wpack_fwd, wpack_dgrad);
-  else
-    hipLaunchKernelGGL(spconv_pack_weights_kernel<false>, dim3(nb), dim3(256), 0, stream, weight, kvol, cin,
-                       cout, flip_dgrad, wpack_fwd, wpack_dgrad);
+  // f32 features: the MFMA kernels multiply in split arithmetic and want bf16 hi / lo planes (same bytes as f32)
+  const int mode_fwd = dtype == D3D_BF16 ? 1 : (d3d_sparse_conv_has_epilogue(cin, cout, dtype) ? 2 : 0);
+  const int mode_dgrad = dtype == D3D_BF16 ? 1 : (d3d_sparse_conv_has_epilogue(cout, cin, dtype) ? 2 : 0);
+  hipLaunchKernelGGL(spconv_pack_weights_kernel, dim3(nb), dim3(256), 0, stream, weight, kvol, cin, cout, flip_dgrad,
+                     mode_fwd, mode_dgrad, wpack_fwd, wpack_dgrad);
   D3D_LAUNCH_TRY("spconv_pack_weights_kernel");
   return D3D_OK;
 }

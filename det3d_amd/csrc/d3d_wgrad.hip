@@ -31,6 +31,16 @@ typedef __attribute__((ext_vector_type(8))) short wg_s16x8_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 wg_bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float wg_f32x4_t;
 
+typedef __attribute__((ext_vector_type(2))) float wg_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 wg_bf16x2_t;
+// f32 pair -> hi = bf16(v), lo = bf16(v - hi) (round to nearest even; v - hi is exact)
+__device__ __forceinline__ void wg_split2(float a, float b, uint32_t &hi, uint32_t &lo) {
+  const wg_f32x2_t v = {a, b};
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, wg_bf16x2_t));
+  const wg_f32x2_t r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, wg_bf16x2_t));
+}
+
 #define WG_WAVES 16
 #define WG_THREADS (WG_WAVES * 64)
 
@@ -40,16 +50,28 @@ template <int CIN, int COUT, bool BF16> struct WgGeom {
   static constexpr int CIT = CIN / 16, COT = COUT / 16, TILES = CIT * COT;
   static constexpr int FSEG = CIN / EPV, DSEG = COUT / EPV;      // 16-byte segments per row
   static constexpr int STEP = WG_THREADS / FSEG;                 // sites per stage (1 vector / thread)
+  static constexpr int KSTEPS = STEP / 32;                       // MFMA k-steps (32 sites each) per stage
   static constexpr int TPW = TILES >= WG_WAVES ? TILES / WG_WAVES : 1;     // MFMA tiles per wave
-  static constexpr int CSPLIT = TILES >= WG_WAVES ? 1 : WG_WAVES / TILES;  // waves sharing one tile: they
-  //   split the sites of a stage and each keeps its own partial sum -> CSPLIT partial slabs per block
+  static constexpr int CSPLIT_ = TILES >= WG_WAVES ? 1 : WG_WAVES / TILES;
+  static constexpr int CSPLIT = CSPLIT_ < KSTEPS ? CSPLIT_ : KSTEPS;       // waves sharing one tile: they
+  //   split the sites of a stage and each keeps its own partial sum -> CSPLIT partial slabs per block (f32 rows of
+  //   16 channels give 8 k-steps per stage: 8 of the 16 waves multiply, all 16 load)
 };
+static int wg_csplit(int cin, int cout, int dtype) {
+  const int tiles = (cin / 16) * (cout / 16);
+  const int step = WG_THREADS / (cin / (dtype == D3D_BF16 ? 8 : 4));
+  int cs = tiles >= WG_WAVES ? 1 : WG_WAVES / tiles;
+  if (cs > step / 32) cs = step / 32;
+  return cs < 1 ? 1 : cs;
+}
 
 // One block = 16 waves, one group of KG kernel offsets, one contiguous range of output sites.
 //   bf16: LDS tiles [16 sites][16 ch], ds_read_b64_tr_b16 turns sites into the MFMA k dimension, two of them
 //         feed one mfma_f32_16x16x32_bf16 (32 sites per instruction)
-//   f32 : LDS rows [site][ch + 16 pad], one element per lane feeds mfma_f32_16x16x4f32 (4 sites per
-//         instruction, exact f32 products: the parity mode)
+//   f32 : SPLIT arithmetic (round 3; round 2 ran the exact mfma_f32_16x16x4f32 here at 216 us for 64x64 against
+//         64 us in bf16): the f32 rows are split where they are written to LDS -- hi = bf16(v), lo = bf16(v - hi)
+//         into two planes of the same [16 sites][16 ch] tiles -- and every product is three bf16 MFMAs
+//         (hi*hi + hi*lo + lo*hi), f32 accumulation: relative error ~2^-16 of the products
 template <int CIN, int COUT, int KG, int DEPTH, bool BF16>
 __global__ void __launch_bounds__(WG_THREADS)
     spconv_wgrad_tile_kernel(const void *__restrict__ feat_, const void *__restrict__ dout_,
@@ -60,16 +82,14 @@ __global__ void __launch_bounds__(WG_THREADS)
   constexpr int FSEG = G::FSEG, DSEG = G::DSEG, STEP = G::STEP, EPV = G::EPV;
   constexpr int DN = STEP * DSEG;
   constexpr int DV = (DN + WG_THREADS - 1) / WG_THREADS;  // dout vectors per thread and tile
-  // bf16: [chunk of 16 sites][ch tile][16 sites][16 ch]; f32: [site][ch + 16]  (elements)
-  constexpr int FROW = CIN + 16, DROW = COUT + 16;
-  constexpr int FBUF = BF16 ? STEP * CIN : STEP * FROW;
-  constexpr int DBUF = BF16 ? STEP * COUT : STEP * DROW;
-  constexpr int ESZ = BF16 ? 2 : 4;
-  // MFMA k-steps per stage and per wave: 32 sites (bf16) / 4 sites (f32) each, split over the CSPLIT waves
-  constexpr int KSTEPS = STEP / (BF16 ? 32 : 4);
-  static_assert(KSTEPS % CSPLIT == 0, "sites of a stage must split evenly over the waves sharing a tile");
-  __shared__ __attribute__((aligned(16))) unsigned char lds_f[2 * FBUF * ESZ];
-  __shared__ __attribute__((aligned(16))) unsigned char lds_d[2 * DBUF * ESZ];
+  // one plane: [chunk of 16 sites][ch tile][16 sites][16 ch] bf16; f32 inputs fill two planes (hi, lo)
+  constexpr int NPL = BF16 ? 1 : 2;
+  constexpr int FBUF = STEP * CIN, DBUF = STEP * COUT;  // elements per plane
+  constexpr int ESZ = BF16 ? 2 : 4;                      // bytes per element in HBM
+  constexpr int KSTEPS = G::KSTEPS;                      // 32 sites per MFMA k-step, split over the CSPLIT waves
+  static_assert(KSTEPS % CSPLIT == 0 && KSTEPS >= 1, "sites of a stage must split evenly over the waves sharing a tile");
+  __shared__ __attribute__((aligned(16))) unsigned char lds_f[2 * NPL * FBUF * 2];
+  __shared__ __attribute__((aligned(16))) unsigned char lds_d[2 * NPL * DBUF * 2];
 
   // XCD-aware order (see spconv_fwd_mfma_kernel): workgroups are dealt round-robin to the 8 XCDs in linear
   // (x fastest) order; give XCD x the x-th contiguous eighth of the (site split, offset group) pairs so that
@@ -137,10 +157,22 @@ __global__ void __launch_bounds__(WG_THREADS)
       dr[j] = d3d_buffer_load16(dout_rs, off);
     }
   };
-  // LDS element offset of 16-byte segment `seg` of row r
-  auto lds_off = [&](int r, int seg, int ctiles, int rowlen) -> int {
-    if constexpr (BF16) return ((r >> 4) * ctiles + (seg >> 1)) * 256 + (r & 15) * 16 + (seg & 1) * 8;
-    else return r * rowlen + seg * 4;
+  // LDS element offset (within a plane) of 16-byte HBM segment `seg` of row r: 8 bf16 or 4 f32 channels
+  auto lds_off = [&](int r, int seg, int ctiles) -> int {
+    const int c = seg * EPV;
+    return ((r >> 4) * ctiles + (c >> 4)) * 256 + (r & 15) * 16 + (c & 15);
+  };
+  // registers -> LDS; f32 rows are split into the hi / lo planes on the way
+  auto put = [&](unsigned char *buf, int plane_elems, int el, const uint4 &v) {
+    if constexpr (BF16) {
+      *(uint4 *)(buf + el * 2) = v;
+    } else {
+      uint32_t h0, l0, h1, l1;
+      wg_split2(__uint_as_float(v.x), __uint_as_float(v.y), h0, l0);
+      wg_split2(__uint_as_float(v.z), __uint_as_float(v.w), h1, l1);
+      *(uint2 *)(buf + el * 2) = make_uint2(h0, h1);
+      *(uint2 *)(buf + (plane_elems + el) * 2) = make_uint2(l0, l1);
+    }
   };
 
   // pipeline registers: slot d holds the rows of the next stage with (stage % DEPTH) == d and the neighbour
@@ -167,18 +199,18 @@ __global__ void __launch_bounds__(WG_THREADS)
       (void)dummy;
       const int d = kk % DEPTH;                 // compile-time after unrolling
       const int st = tile * KG + kk;
-      unsigned char *bf = lds_f + (st & 1) * (FBUF * ESZ);
-      unsigned char *bd = lds_d + (tile & 1) * (DBUF * ESZ);
+      unsigned char *bf = lds_f + (st & 1) * (NPL * FBUF * 2);
+      unsigned char *bd = lds_d + (tile & 1) * (NPL * DBUF * 2);
       // stage `st` -> LDS.  The buffer's previous readers (stage st-2) finished their LDS reads before they
       // arrived at the barrier of stage st-1, so one barrier per stage suffices
-      *(uint4 *)(bf + lds_off(frow, fseg, CIT, FROW) * ESZ) = fr[d];
+      put(bf, FBUF, lds_off(frow, fseg, CIT), fr[d]);
       if (kk == 0) {
 #pragma unroll
         for (int j = 0; j < DV; ++j) {
           const int e = threadIdx.x + j * WG_THREADS;
           if (DN % WG_THREADS != 0 && e >= DN) break;
           const int r = e / DSEG, seg = e - r * DSEG;
-          *(uint4 *)(bd + lds_off(r, seg, COT, DROW) * ESZ) = dr[j];
+          put(bd, DBUF, lds_off(r, seg, COT), dr[j]);
         }
       }
       d3d_lds_barrier();
@@ -188,35 +220,29 @@ __global__ void __launch_bounds__(WG_THREADS)
       ix[d] = load_index(tile + (kk + 2 * DEPTH) / KG, (kk + 2 * DEPTH) % KG);
       if (kk == 0) load_dout(tile + 1);
 #pragma unroll 4
-      for (int q = 0; q < KSTEPS / CSPLIT; ++q) {
+      for (int q = 0; q < (my_part < CSPLIT ? KSTEPS / CSPLIT : 0); ++q) {
         const int ks = q * CSPLIT + my_part;  // this wave's k-steps of the stage
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
           const int tl = my_tile + t * WG_WAVES;
           const int cit = tl / COT, cot = tl - cit * COT;
-          if constexpr (BF16) {
-            // 32 sites = LDS chunks 2*ks and 2*ks+1.  Each lane passes the address of ITS 8 bytes in the
-            // row-major 4x16 block of sites [lg*4, lg*4+4); the hardware returns the transposed column lr.
-            // A and B use the same site order, so any consistent k labelling is a valid sum.
-            const uint16_t *f16 = (const uint16_t *)bf, *d16 = (const uint16_t *)bd;
-            wg_s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) wg_s16x4_t *)(f16 + ((2 * ks) * CIT + cit) * 256 + lg * 64 + lr * 4));
-            wg_s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) wg_s16x4_t *)(f16 + ((2 * ks + 1) * CIT + cit) * 256 + lg * 64 + lr * 4));
-            wg_s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) wg_s16x4_t *)(d16 + ((2 * ks) * COT + cot) * 256 + lg * 64 + lr * 4));
-            wg_s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) wg_s16x4_t *)(d16 + ((2 * ks + 1) * COT + cot) * 256 + lg * 64 + lr * 4));
-            wg_s16x8_t av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-            wg_s16x8_t bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-            acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wg_bf16x8_t, av),
-                                                                 __builtin_bit_cast(wg_bf16x8_t, bv), acc[kk][t], 0, 0, 0);
-          } else {
-            // 4 sites: lane group lg supplies k = lg, lane lr the channel
-            const float *f32p = (const float *)bf, *d32p = (const float *)bd;
-            const float av = f32p[(ks * 4 + lg) * FROW + cit * 16 + lr];
-            const float bv = d32p[(ks * 4 + lg) * DROW + cot * 16 + lr];
-            acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[kk][t], 0, 0, 0);
+          // 32 sites = LDS chunks 2*ks and 2*ks+1.  Each lane passes the address of ITS 8 bytes in the
+          // row-major 4x16 block of sites [lg*4, lg*4+4); the hardware returns the transposed column lr.
+          // A and B use the same site order, so any consistent k labelling is a valid sum.
+          auto operand = [&](const unsigned char *plane, int ctiles, int ct) -> wg_bf16x8_t {
+            const uint16_t *p16 = (const uint16_t *)plane;
+            wg_s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) wg_s16x4_t *)(p16 + ((2 * ks) * ctiles + ct) * 256 + lg * 64 + lr * 4));
+            wg_s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) wg_s16x4_t *)(p16 + ((2 * ks + 1) * ctiles + ct) * 256 + lg * 64 + lr * 4));
+            return __builtin_bit_cast(wg_bf16x8_t, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+          };
+          const wg_bf16x8_t ah = operand(bf, CIT, cit), bh = operand(bd, COT, cot);
+          acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[kk][t], 0, 0, 0);
+          if constexpr (!BF16) {
+            const wg_bf16x8_t al = operand(bf + FBUF * 2, CIT, cit), bl = operand(bd + DBUF * 2, COT, cot);
+            acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[kk][t], 0, 0, 0);
+            acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[kk][t], 0, 0, 0);
           }
         }
       }
@@ -224,6 +250,7 @@ __global__ void __launch_bounds__(WG_THREADS)
   }
 
   // partial dW of this (offset group, site split, wave share): plain stores, summed by wgrad_reduce_kernel
+  if (my_part >= CSPLIT) return;  // (f32, 16 x 16: more waves than k-steps -- these only loaded)
   float *pbase = part + ((int64_t)by * CSPLIT + my_part) * kvol * (CIN * COUT);
 #pragma unroll
   for (int a = 0; a < KG; ++a) {
@@ -281,9 +308,10 @@ static int wg_target_blocks() {
 }
 
 // offsets per block: the accumulators of a wave are 4 * KG * TPW registers
-static int wg_kgroup(int kvol, int cin, int cout) {
+static int wg_kgroup(int kvol, int cin, int cout, int dtype) {
   const int tiles = (cin / 16) * (cout / 16);
-  const int kg = tiles <= 32 ? 9 : 3;
+  // (f32 = split arithmetic: two more operand sets live per MFMA group; 9 offsets x 2 tiles per wave spill)
+  const int kg = (tiles <= 16 || (tiles <= 32 && dtype == D3D_BF16)) ? 9 : 3;
   if (kvol % kg == 0 && kvol >= kg) return kg;
   return kvol % 3 == 0 ? 3 : 1;
 }
@@ -297,9 +325,9 @@ static WgPlan wg_plan(int n_out, int kvol, int cin, int cout, int dtype) {
   WgPlan p;
   const int epv = dtype == D3D_BF16 ? 8 : 4;
   const int tiles_mfma = (cin / 16) * (cout / 16);
-  p.kg = wg_kgroup(kvol, cin, cout);
+  p.kg = wg_kgroup(kvol, cin, cout, dtype);
   p.step = WG_THREADS / (cin / epv);
-  p.csplit = tiles_mfma >= WG_WAVES ? 1 : WG_WAVES / tiles_mfma;
+  p.csplit = wg_csplit(cin, cout, dtype);
   const int kgroups = kvol / p.kg;
   const int tiles = (n_out + p.step - 1) / p.step;
   int splits = (wg_target_blocks() + kgroups - 1) / kgroups;
