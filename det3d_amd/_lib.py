@@ -52,6 +52,8 @@ SIGNATURES = {
     "d3d_conv2d_supported": (i32, [i32, i32, i32, i32]),
     "d3d_conv2d_stats_ws_floats": (sz, [i32, i32, i32, i32]),
     "d3d_conv2d_nhwc_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "d3d_conv2d_pack_weights": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "d3d_split_planes": (i32, [vp, i64, vp, vp, vp]),
     "d3d_conv2d_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "d3d_conv2d_nhwc_wgrad": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "d3d_channel_affine": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp]),

@@ -22,6 +22,8 @@
 //     deterministically across blocks (d3d_fold.h).
 // The data gradient of a stride-1 layer is the same kernel on the output gradient with mirrored taps and
 // [tap][cin][cout] weights; the weight gradient is conv2d_wgrad_kernel below.
+#include <stdlib.h>
+
 #include "d3d_common.h"
 #include "d3d_fold.h"
 
@@ -63,21 +65,30 @@ template <int BK> struct C2Tile {
   __device__ static __forceinline__ int swz(int row) { return (row / RPB) % CPR; }
 };
 
-template <int CIN, bool SPLIT, bool OUT_F32>
-__global__ void __launch_bounds__(256, 2)
+// WPX: waves along the pixel axis (2 -> 128-pixel tiles, two blocks per CU; 4 -> 256-pixel tiles, one block per CU:
+//      the weight tile is shared by twice the pixels, 6 instead of 8 LDS-DMA instructions per wave and K step)
+// ILV: the LDS-DMA instructions of step s+1 are issued in KSUB portions between the MFMA groups of step s instead of
+//      all in front of them (an LDS-DMA costs the issuing wave 60-180 cycles: MI355X_MICROARCH.md; spread out they hide
+//      behind the wave's own MFMAs)
+template <int CIN, bool SPLIT, bool OUT_F32, int WPX, bool ILV>
+__global__ void __launch_bounds__(128 * WPX, (WPX == 2 ? 2 : 1))
     conv2d_nhwc_kernel(const void *__restrict__ x_hi, const void *__restrict__ x_lo, const void *__restrict__ w_hi,
                        const void *__restrict__ w_lo, void *__restrict__ y, Conv2dGeom G, Conv2dEpi ep) {
   constexpr int BK = SPLIT ? 32 : 64;
   using T = C2Tile<BK>;
+  constexpr int WAVES = 2 * WPX, NTH = WAVES * 64, BM = 64 * WPX;
   constexpr int KC = CIN / BK;                 // K steps per tap
   constexpr int NP = SPLIT ? 2 : 1;            // planes per operand
-  constexpr int STAGE = 2 * NP * T::PLANE;     // A planes then B planes
+  constexpr int APLANE = BM * T::RB, BPLANE = 128 * T::RB;
+  constexpr int STAGE = NP * (APLANE + BPLANE);  // A planes then B planes
   constexpr int KSUB = BK / 16;                // MFMA k-substeps per K step
-  static_assert(CIN % BK == 0, "channels per K step");
+  constexpr int AI = BM * T::CPR / 64 / WAVES;   // LDS-DMA instructions per wave: activation plane
+  constexpr int BI = 128 * T::CPR / 64 / WAVES;  // ... weight plane
+  static_assert(CIN % BK == 0 && AI >= 1 && BI >= 1, "tile shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][STAGE]
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wco = wave >> 1, wpx = wave & 1;  // 2 x 2 waves: cout half, pixel half
+  const int wco = wave / WPX, wpx = wave % WPX;  // 2 x WPX waves: cout half, pixel quarter / half
   // XCD-aware order: consecutive workgroup ids are dealt round-robin to the 8 XCDs; give XCD i the i-th contiguous
   // eighth of the pixel tiles so that the halo rows its tiles share stay in ITS L2 (bijective for any grid size)
   int tile;
@@ -85,16 +96,16 @@ __global__ void __launch_bounds__(256, 2)
     const int nb = (int)gridDim.x, q = nb >> 3, r = nb & 7, xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int m0 = tile * 128;
+  const int m0 = tile * BM;
   const int n0 = (int)blockIdx.y * 128;
 
-  // ---- per-thread staging slots: INSTR rows of the activation tile, INSTR rows of the weight tile
-  uint32_t a_off[T::INSTR];      // byte offset of tap (0,0) of the row's pixel + this lane's (swizzled) chunk
-  uint32_t a_vy[T::INSTR], a_vx[T::INSTR];  // bit k set: tap row / column k is inside the map
-  uint32_t b_off[T::INSTR];
+  // ---- per-thread staging slots: AI rows of the activation tile, BI rows of the weight tile
+  uint32_t a_off[AI];            // byte offset of tap (0,0) of the row's pixel + this lane's (swizzled) chunk
+  uint32_t a_vy[AI], a_vx[AI];   // bit k set: tap row / column k is inside the map
+  uint32_t b_off[BI];
 #pragma unroll
-  for (int j = 0; j < T::INSTR; ++j) {
-    const int idx = (wave * T::INSTR + j) * 64 + lane;
+  for (int j = 0; j < AI; ++j) {
+    const int idx = (wave * AI + j) * 64 + lane;
     const int row = idx / T::CPR, cp = idx % T::CPR;
     const int c = cp ^ T::swz(row);
     const int m = m0 + row;
@@ -103,15 +114,21 @@ __global__ void __launch_bounds__(256, 2)
     const int oy = rem / G.wo, ox = rem - oy * G.wo;
     const int iy0 = oy * G.stride - G.pad, ix0 = ox * G.stride - G.pad;
     uint32_t vy = 0, vx = 0;
-    for (int k = 0; k < G.ksz; ++k) {
-      vy |= (uint32_t)((iy0 + k >= 0 && iy0 + k < G.h) ? 1 : 0) << k;
-      vx |= (uint32_t)((ix0 + k >= 0 && ix0 + k < G.w) ? 1 : 0) << k;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      vy |= (uint32_t)((k < G.ksz && iy0 + k >= 0 && iy0 + k < G.h) ? 1 : 0) << k;
+      vx |= (uint32_t)((k < G.ksz && ix0 + k >= 0 && ix0 + k < G.w) ? 1 : 0) << k;
     }
     if (m >= G.m) vy = vx = 0;
     a_vy[j] = vy;
     a_vx[j] = vx;
     a_off[j] = (uint32_t)(((b * G.h + iy0) * G.w + ix0) * (CIN * 2) + c * 16);  // may wrap for invalid taps: masked
-    b_off[j] = (uint32_t)((n0 + row) * (CIN * 2) + c * 16);
+  }
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int idx = (wave * BI + j) * 64 + lane;
+    const int row = idx / T::CPR, cp = idx % T::CPR;
+    b_off[j] = (uint32_t)((n0 + row) * (CIN * 2) + (cp ^ T::swz(row)) * 16);
   }
   const __amdgpu_buffer_rsrc_t xr_hi = __builtin_amdgcn_make_buffer_rsrc((void *)x_hi, 0, G.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr_hi = __builtin_amdgcn_make_buffer_rsrc((void *)w_hi, 0, G.w_bytes, 0x00020000);
@@ -119,29 +136,32 @@ __global__ void __launch_bounds__(256, 2)
   const __amdgpu_buffer_rsrc_t wr_lo = __builtin_amdgcn_make_buffer_rsrc((void *)(SPLIT ? w_lo : w_hi), 0, G.w_bytes, 0x00020000);
 
   const int nks = G.ksz * G.ksz * KC;
-  // stage K step `ks` (tap = ks / KC, channel block = ks % KC) into LDS stage `buf`
-  auto stage = [&](int ks, int buf) {
+  // stage the slots with (slot % PARTS) == part of K step `ks` (tap = ks / KC, channel block = ks % KC) into LDS
+  // stage `buf`; slots 0 .. AI-1 are activation rows, AI .. AI+BI-1 weight rows
+  auto stage = [&](int ks, int buf, int part, int parts) {
     const int tap = ks / KC, kc = ks - tap * KC;
     const int ky = tap / G.ksz, kx = tap - ky * G.ksz;
     const uint32_t tap_off = (uint32_t)((ky * G.w + kx) * (CIN * 2) + kc * (BK * 2));
     const uint32_t w_tap_off = (uint32_t)(tap * G.cout * (CIN * 2) + kc * (BK * 2));
-    unsigned char *sa = smem + buf * STAGE, *sb = sa + NP * T::PLANE;
+    unsigned char *sa = smem + buf * STAGE, *sb = sa + NP * APLANE;
 #pragma unroll
-    for (int j = 0; j < T::INSTR; ++j) {
+    for (int j = 0; j < AI; ++j) {
+      if (j % parts != part) continue;
       const bool ok = ((a_vy[j] >> ky) & 1u) && ((a_vx[j] >> kx) & 1u);
       const uint32_t off = ok ? a_off[j] + tap_off : D3D_OOB_OFFSET;
-      const int lds_off = (wave * T::INSTR + j) * 1024;
+      const int lds_off = (wave * AI + j) * 1024;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xr_hi, (c2_lds_void *)(sa + lds_off), 16, (int)off, 0, 0, 0);
       if constexpr (SPLIT)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr_lo, (c2_lds_void *)(sa + T::PLANE + lds_off), 16, (int)off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr_lo, (c2_lds_void *)(sa + APLANE + lds_off), 16, (int)off, 0, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < T::INSTR; ++j) {
+    for (int j = 0; j < BI; ++j) {
+      if ((AI + j) % parts != part) continue;
       const uint32_t off = b_off[j] + w_tap_off;
-      const int lds_off = (wave * T::INSTR + j) * 1024;
+      const int lds_off = (wave * BI + j) * 1024;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wr_hi, (c2_lds_void *)(sb + lds_off), 16, (int)off, 0, 0, 0);
       if constexpr (SPLIT)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr_lo, (c2_lds_void *)(sb + T::PLANE + lds_off), 16, (int)off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr_lo, (c2_lds_void *)(sb + BPLANE + lds_off), 16, (int)off, 0, 0, 0);
     }
   };
 
@@ -167,15 +187,16 @@ __global__ void __launch_bounds__(256, 2)
     b_sw[t] = T::swz(xr);
   }
 
-  stage(0, 0);
+  stage(0, 0, 0, 1);
   for (int ks = 0; ks < nks; ++ks) {
     const int buf = ks & 1;
     // my loads of step ks have landed; after the barrier everyone's have, and every wave has finished reading the
     // other stage (step ks - 1), which the next loads overwrite
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (ks + 1 < nks) stage(ks + 1, buf ^ 1);
-    const unsigned char *sa = smem + buf * STAGE, *sb = sa + NP * T::PLANE;
+    const bool more = ks + 1 < nks;
+    if (!ILV && more) stage(ks + 1, buf ^ 1, 0, 1);
+    const unsigned char *sa = smem + buf * STAGE, *sb = sa + NP * APLANE;
 #pragma unroll
     for (int kk = 0; kk < KSUB; ++kk) {
       const int chunk = kk * 2 + fk;
@@ -184,10 +205,11 @@ __global__ void __launch_bounds__(256, 2)
       for (int t = 0; t < 2; ++t) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          wa[t][p] = *(const c2_bf16x8 *)(sb + p * T::PLANE + a_rd[t] + ((chunk ^ a_sw[t]) << 4));
-          xb[t][p] = *(const c2_bf16x8 *)(sa + p * T::PLANE + b_rd[t] + ((chunk ^ b_sw[t]) << 4));
+          wa[t][p] = *(const c2_bf16x8 *)(sb + p * BPLANE + a_rd[t] + ((chunk ^ a_sw[t]) << 4));
+          xb[t][p] = *(const c2_bf16x8 *)(sa + p * APLANE + b_rd[t] + ((chunk ^ b_sw[t]) << 4));
         }
       }
+      if (ILV && more) stage(ks + 1, buf ^ 1, kk, KSUB);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -198,6 +220,7 @@ __global__ void __launch_bounds__(256, 2)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][1], xb[j][0], acc[i][j], 0, 0, 0);
           }
         }
+      if (ILV) __builtin_amdgcn_sched_barrier(0);
     }
   }
 
@@ -251,7 +274,7 @@ __global__ void __launch_bounds__(256, 2)
     // the other half to its partner -- 32 + 16 + 8 + 4 + 2 = 62 cross-lane moves instead of 5 x 64, fixed order.
     // Afterwards lane l holds the two totals with index v = ((l & 31) << 1) | k, k = 0, 1.
     __syncthreads();  // every wave is done with the operand stages
-    float *red = (float *)smem;  // [2 pixel-half waves][2][128] then tot [2][128] then flag
+    float *red = (float *)smem;  // [WPX pixel waves][2][128] then tot [2][128] then flag
     float vals[64];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -278,16 +301,19 @@ __global__ void __launch_bounds__(256, 2)
       red[wpx * 256 + stat * 128 + cl] = vals[k];
     }
     __syncthreads();
-    float *tot = red + 512;
-    // the fold wants [sum over ALL cout | sumsq over ALL cout] per block row of grid.y: slab = 2 * 128 values of
-    // this block's channel tile; blocks of different grid.y tiles use different workspaces (see the launcher)
-    tot[threadIdx.x] = red[threadIdx.x] + red[256 + threadIdx.x];
+    float *tot = red + WPX * 256;
+    if (threadIdx.x < 256) {
+      float t = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < WPX; ++wv) t += red[wv * 256 + threadIdx.x];
+      tot[threadIdx.x] = t;
+    }
     __syncthreads();
     float *ws = ep.stats + 2 * G.cout + (size_t)blockIdx.y * ep.ws_stride;
-    if (d3d_fold_block<256>(tot, 256, ws, ep.counters + blockIdx.y * ep.ctr_stride, ep.fold_g, (int *)(tot + 256))) {
+    if (d3d_fold_block<NTH>(tot, 256, ws, ep.counters + blockIdx.y * ep.ctr_stride, ep.fold_g, (int *)(tot + 256))) {
       // this block holds the channel tile's totals (thread i wrote ws[i]): place them in the [sum | sumsq] vector
       const int i = threadIdx.x;
-      ep.stats[(i >> 7) * G.cout + n0 + (i & 127)] = ws[i];
+      if (i < 256) ep.stats[(i >> 7) * G.cout + n0 + (i & 127)] = ws[i];
     }
   }
 }
@@ -296,14 +322,14 @@ __global__ void __launch_bounds__(256, 2)
 //   dW[tap][co][ci] = sum_p g[p][co] * x[pix(p, tap)][ci]         (stride 1)
 // A GEMM whose K dimension is the pixel axis, which is NOT contiguous in either operand (channels are): tiles of
 // KP pixels x 128 channels are staged row-major by LDS-DMA and read as MFMA operands with the transposing LDS read
-// (ds_read_b64_tr_b16: four pixels of one channel per lane).  grid = (pixel splits, taps, cout tiles * cin tiles):
+// (ds_read_b64_tr_b16: four pixels of one channel per lane).  One block per (pixel split, tap, 128 x 128 weight tile):
 // a block owns one tap, one 128 x 128 weight tile and a contiguous range of pixels; it writes ONE partial tile, the
 // partial tiles are summed in a fixed order by conv2d_wgrad_reduce_kernel: deterministic, no atomics.
 template <bool SPLIT>
 __global__ void __launch_bounds__(256, 2)
     conv2d_wgrad_kernel(const void *__restrict__ g_hi, const void *__restrict__ g_lo, const void *__restrict__ x_hi,
                         const void *__restrict__ x_lo, float *__restrict__ part, Conv2dGeom G, int cin,
-                        int pixels_per_split) {
+                        int pixels_per_split, int nsplit) {
   constexpr int KP = SPLIT ? 32 : 64;          // pixels per K step
   constexpr int NP = SPLIT ? 2 : 1;
   constexpr int PLANE = KP * 256;              // KP rows of 128 channels (256 B)
@@ -313,9 +339,19 @@ __global__ void __launch_bounds__(256, 2)
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wco = wave >> 1, wci = wave & 1;
-  const int split = blockIdx.x, tap = blockIdx.y;
+  // 1-D grid; XCD-aware order with the tap fastest: the 9 taps of a pixel range read the same g rows and (shifted) x
+  // rows, and consecutive logical ids stay on one XCD, i.e. behind one L2
+  int logical;
+  {
+    const int nb = (int)gridDim.x, q = nb >> 3, r = nb & 7, xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int taps = G.ksz * G.ksz;
+  const int tap = logical % taps;
+  const int split = (logical / taps) % nsplit;
+  const int wtile = logical / (taps * nsplit);
   const int cin_tiles = cin / 128;
-  const int co0 = ((int)blockIdx.z / cin_tiles) * 128, ci0 = ((int)blockIdx.z % cin_tiles) * 128;
+  const int co0 = (wtile / cin_tiles) * 128, ci0 = (wtile % cin_tiles) * 128;
   const int ky = tap / G.ksz, kx = tap - ky * G.ksz;
   const int p_begin = split * pixels_per_split;
   int p_end = p_begin + pixels_per_split;
@@ -434,20 +470,81 @@ __global__ void __launch_bounds__(256, 2)
     }
 }
 
-// dw[e] = sum over splits of part[s][e], ascending s
+// dw = sum over splits of part[s], in a fixed order (8 slab groups walked in parallel, folded through LDS in group
+// order), written in nn.Conv2d's parameter layout [cout][cin][kh][kw]; part is [split][tap][cout][cin]
 __global__ void __launch_bounds__(256)
-    conv2d_wgrad_reduce_kernel(const float4 *__restrict__ part, int splits, int64_t n4, float4 *__restrict__ dw) {
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < splits; ++k) {
-      const float4 v = part[(int64_t)k * n4 + e];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    conv2d_wgrad_reduce_kernel(const float4 *__restrict__ part, int splits, int taps, int cout, int cin,
+                               float *__restrict__ dw) {
+  __shared__ float4 red[8][32];
+  const int64_t n4 = (int64_t)taps * cout * cin / 4;
+  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int64_t e = (int64_t)blockIdx.x * 32 + el;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < n4) {
+    for (int s0 = g; s0 < splits; s0 += 8) {
+      const float4 u = part[(int64_t)s0 * n4 + e];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
     }
-    dw[e] = s;
+  }
+  red[g][el] = a;
+  __syncthreads();
+  if (g == 0 && e < n4) {
+    float4 r = red[0][el];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      r.x += red[j][el].x; r.y += red[j][el].y; r.z += red[j][el].z; r.w += red[j][el].w;
+    }
+    const int64_t e1 = e * 4;  // (tap, co, ci .. ci + 3)
+    const int ci = (int)(e1 % cin), co = (int)((e1 / cin) % cout), tap = (int)(e1 / ((int64_t)cin * cout));
+    float *o = dw + ((int64_t)co * cin + ci) * taps + tap;
+    o[0] = r.x; o[taps] = r.y; o[2 * taps] = r.z; o[3 * taps] = r.w;
+  }
+}
+
+// nn.Conv2d weight [cout][cin][kh][kw] f32 -> the kernels' operands, one launch:
+//   fwd   [tap][cout][cin]            W[tap][co][ci] = w[co][ci][ky][kx]
+//   dgrad [mirrored tap][cin][cout]   (the forward operand of the transposed problem: stride-1 data gradient)
+// each as bf16 (hi only) or as hi / lo planes (split mode)
+__global__ void __launch_bounds__(256)
+    conv2d_pack_kernel(const float *__restrict__ w, int cout, int cin, int taps, uint16_t *__restrict__ f_hi,
+                       uint16_t *__restrict__ f_lo, uint16_t *__restrict__ d_hi, uint16_t *__restrict__ d_lo) {
+  const int total = cout * cin * taps;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+    const int tap = t % taps, ci = (t / taps) % cin, co = t / (taps * cin);
+    const float v = w[t];
+    const uint16_t h = c2_f32_to_bf16(v);
+    const uint16_t l = c2_f32_to_bf16(v - __uint_as_float((uint32_t)h << 16));
+    const int fi = (tap * cout + co) * cin + ci;
+    const int di = ((taps - 1 - tap) * cin + ci) * cout + co;
+    if (f_hi) f_hi[fi] = h;
+    if (f_lo) f_lo[fi] = l;
+    if (d_hi) d_hi[di] = h;
+    if (d_lo) d_lo[di] = l;
+  }
+}
+
+// f32 [n] -> hi = bf16(v), lo = bf16(v - hi) planes (n % 4 == 0)
+__global__ void __launch_bounds__(256)
+    conv2d_split_kernel(const float4 *__restrict__ x, int64_t n4, uint2 *__restrict__ hi, uint2 *__restrict__ lo) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = x[i];
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h[j] = c2_f32_to_bf16(f[j]);
+      l[j] = c2_f32_to_bf16(f[j] - __uint_as_float(h[j] << 16));
+    }
+    hi[i] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    lo[i] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
   }
 }
 
 // ---------------------------------------------------------------------------------------------------- host side
+// tiling variant of the forward kernel (d3d_set_tuning knob 7, D3D_CONV2D_VARIANT): bit 0 = interleaved LDS-DMA issue,
+// bit 1 = 256-pixel tiles (8 waves, one block per CU)
+int g_c2_variant = getenv("D3D_CONV2D_VARIANT") ? atoi(getenv("D3D_CONV2D_VARIANT")) : 0;
+
 static int c2_check(const char *who, int batch, int h, int w, int cin, int cout, int ksz, int stride, int pad,
                     int mode) {
   D3D_REQUIRE(mode == D3D_CONV_BF16 || mode == D3D_CONV_SPLIT, "%s: mode %d", who, mode);
@@ -499,7 +596,10 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
   Conv2dGeom G;
   rc = c2_geom("d3d_conv2d_nhwc_fwd", G, batch, h, w, cin, cout, ksz, stride, pad);
   if (rc) return rc;
-  const int nb = (G.m + 127) / 128;
+  const int variant = g_c2_variant;
+  const int wpx = (variant & 2) ? 4 : 2;
+  const int bm = 64 * wpx;
+  const int nb = (G.m + bm - 1) / bm;
   Conv2dEpi ep = {nullptr, nullptr, 16, 0, 0};
   if (stats_ws) {
     D3D_REQUIRE(nb <= D3D_FOLD_MAX_BLOCKS, "d3d_conv2d_nhwc_fwd: %d pixel tiles > %d for the statistics fold", nb,
@@ -515,31 +615,38 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
     ep.counters = d3d_fold_counters(ep.ctr_stride * (cout / 128));
     if (!ep.counters) return D3D_EHIP;
   }
-  const size_t lds = 2 * (size_t)(2 * (split ? 2 : 1) * 128 * (split ? 64 : 128));  // two stages of A + B planes
-#define C2_CASE(CIN)                                                                                            \
-  if (cin == CIN) {                                                                                             \
-    if (split) {                                                                                                \
-      D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_nhwc_kernel<CIN, true, true>,                        \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-      hipLaunchKernelGGL((conv2d_nhwc_kernel<CIN, true, true>), dim3(nb, cout / 128), dim3(256), lds, stream,   \
-                         x_hi, x_lo, w_hi, w_lo, y, G, ep);                                                     \
-    } else {                                                                                                    \
-      D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_nhwc_kernel<CIN, false, false>,                      \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-      hipLaunchKernelGGL((conv2d_nhwc_kernel<CIN, false, false>), dim3(nb, cout / 128), dim3(256), lds, stream, \
-                         x_hi, x_lo, w_hi, w_lo, y, G, ep);                                                     \
-    }                                                                                                           \
+  const size_t lds = 2 * (size_t)((split ? 2 : 1) * (bm + 128) * (split ? 64 : 128));  // two stages of A + B planes
+#define C2_LAUNCH(CIN, SPLIT, WPX, ILV)                                                                         \
+  do {                                                                                                          \
+    D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_nhwc_kernel<CIN, SPLIT, SPLIT, WPX, ILV>,              \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
+    hipLaunchKernelGGL((conv2d_nhwc_kernel<CIN, SPLIT, SPLIT, WPX, ILV>), dim3(nb, cout / 128), dim3(128 * WPX), \
+                       lds, stream, x_hi, x_lo, w_hi, w_lo, y, G, ep);                                          \
+  } while (0)
+#define C2_VARIANTS(CIN, SPLIT)                                         \
+  do {                                                                  \
+    if (variant == 1) C2_LAUNCH(CIN, SPLIT, 2, true);                   \
+    else if (variant == 2) C2_LAUNCH(CIN, SPLIT, 4, false);             \
+    else if (variant == 3) C2_LAUNCH(CIN, SPLIT, 4, true);              \
+    else C2_LAUNCH(CIN, SPLIT, 2, false);                               \
+  } while (0)
+#define C2_CASE(CIN)                             \
+  if (cin == CIN) {                              \
+    if (split) C2_VARIANTS(CIN, true);           \
+    else C2_VARIANTS(CIN, false);                \
   }
   C2_CASE(64)
   C2_CASE(128)
   C2_CASE(256)
 #undef C2_CASE
+#undef C2_VARIANTS
+#undef C2_LAUNCH
   D3D_LAUNCH_TRY("conv2d_nhwc_kernel");
   return D3D_OK;
 }
 
 // weight gradient of the layer above (stride 1 or 2): g = dL/dy [batch, ho, wo, cout], x = the layer's input;
-// dw [ksz*ksz][cout][cin] f32 (the packed forward layout).  workspace: d3d_conv2d_wgrad_workspace_bytes.
+// dw [cout][cin][ksz][ksz] f32 (nn.Conv2d's parameter layout).  workspace: d3d_conv2d_wgrad_workspace_bytes.
 static int c2_wgrad_splits(int m, int blocks_per_split) {
   // ~2 blocks per CU over (splits x taps x weight tiles); >= 8 K steps per block
   int s = (512 + blocks_per_split - 1) / blocks_per_split;
@@ -579,22 +686,46 @@ extern "C" int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const v
   pps = (pps + kp - 1) / kp * kp;
   const int nsplit = (G.m + pps - 1) / pps;
   const size_t lds = 2 * (size_t)(2 * (split ? 2 : 1) * kp * 256);
-  const dim3 grid(nsplit, ksz * ksz, (cout / 128) * (cin / 128));
+  const dim3 grid(nsplit * ksz * ksz * (cout / 128) * (cin / 128));
   if (split) {
     D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((conv2d_wgrad_kernel<true>), grid, dim3(256), lds, stream, g_hi, g_lo, x_hi, x_lo,
-                       (float *)workspace, G, cin, pps);
+                       (float *)workspace, G, cin, pps, nsplit);
   } else {
     D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((conv2d_wgrad_kernel<false>), grid, dim3(256), lds, stream, g_hi, g_lo, x_hi, x_lo,
-                       (float *)workspace, G, cin, pps);
+                       (float *)workspace, G, cin, pps, nsplit);
   }
   D3D_LAUNCH_TRY("conv2d_wgrad_kernel");
   const int64_t n4 = (int64_t)ksz * ksz * cout * cin / 4;
-  int nbr = (int)((n4 + 255) / 256);
-  if (nbr > 1024) nbr = 1024;
-  hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3(nbr), dim3(256), 0, stream, (const float4 *)workspace, nsplit,
-                     n4, (float4 *)dw);
+  hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, stream,
+                     (const float4 *)workspace, nsplit, ksz * ksz, cout, cin, dw);
   D3D_LAUNCH_TRY("conv2d_wgrad_reduce_kernel");
+  return D3D_OK;
+}
+
+extern "C" int d3d_conv2d_pack_weights(const float *weight, int cout, int cin, int ksz, void *fwd_hi, void *fwd_lo,
+                                       void *dgrad_hi, void *dgrad_lo, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  D3D_REQUIRE(weight && cout >= 1 && cin >= 1 && ksz >= 1 && ksz <= 7, "d3d_conv2d_pack_weights: arguments");
+  D3D_REQUIRE(fwd_hi || dgrad_hi, "d3d_conv2d_pack_weights: nothing to write");
+  const int total = cout * cin * ksz * ksz;
+  int nb = (total + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(conv2d_pack_kernel, dim3(nb), dim3(256), 0, stream, weight, cout, cin, ksz * ksz,
+                     (uint16_t *)fwd_hi, (uint16_t *)fwd_lo, (uint16_t *)dgrad_hi, (uint16_t *)dgrad_lo);
+  D3D_LAUNCH_TRY("conv2d_pack_kernel");
+  return D3D_OK;
+}
+
+extern "C" int d3d_split_planes(const float *x, int64_t n, void *hi, void *lo, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  D3D_REQUIRE(x && hi && lo && n >= 0 && n % 4 == 0, "d3d_split_planes: arguments (n %% 4 == 0)");
+  if (n == 0) return D3D_OK;
+  int64_t nb = (n / 4 + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(conv2d_split_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const float4 *)x, n / 4,
+                     (uint2 *)hi, (uint2 *)lo);
+  D3D_LAUNCH_TRY("conv2d_split_kernel");
   return D3D_OK;
 }

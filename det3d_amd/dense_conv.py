@@ -23,8 +23,14 @@ _MODES = {"bf16": _lib.D3D_CONV_BF16, "split": _lib.D3D_CONV_SPLIT}
 
 
 def split_planes(t):
-    """f32 tensor -> (hi, lo) bf16 planes, hi = bf16(t), lo = bf16(t - hi)"""
+    """f32 tensor -> (hi, lo) bf16 planes, hi = bf16(t), lo = bf16(t - hi); one launch on the GPU"""
     t = t.float()
+    if t.is_cuda and t.is_contiguous() and t.numel() % 4 == 0:
+        hi = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+        lo = torch.empty_like(hi)
+        _lib.check(_lib.lib().d3d_split_planes(t.data_ptr(), t.numel(), hi.data_ptr(), lo.data_ptr(),
+                                               _lib.stream_ptr(t.device)), "d3d_split_planes")
+        return hi, lo
     hi = t.to(torch.bfloat16)
     lo = (t - hi.float()).to(torch.bfloat16)
     return hi, lo
@@ -34,30 +40,35 @@ def join_planes(hi, lo):
     return hi.float() + lo.float()
 
 
-_PACK = {}  # (id(weight), kind, mode) -> (weakref, version, data_ptr, tensors)
+_PACK = {}  # (id(weight), mode) -> (weakref, version, data_ptr, {"fwd": (hi, lo), "dgrad": (hi, lo)})
 
 
 def _packed(weight, kind, mode):
     """kind 'fwd': [tap][cout][cin]; kind 'dgrad': [mirrored tap][cin][cout] (the forward layout of the transposed
-    problem).  Returns (hi, lo-or-None)."""
-    key = (id(weight), kind, mode)
+    problem).  Returns (hi, lo-or-None).  Both kinds are produced by ONE launch and cached until the parameter
+    changes (optimizer steps bump `_version`; writes through `.data` move no version, so the pointer is checked too)."""
+    key = (id(weight), mode)
     hit = _PACK.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
-        return hit[3]
-    w = weight.detach().float()
+        return hit[3][kind]
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
     co, ci, kh, kw = w.shape
-    if kind == "fwd":
-        p = w.permute(2, 3, 0, 1).reshape(kh * kw, co, ci)
-    else:
-        p = w.flip(2, 3).permute(2, 3, 1, 0).reshape(kh * kw, ci, co)
-    p = p.contiguous()
-    out = split_planes(p) if mode == "split" else (p.to(torch.bfloat16), None)
-    out = tuple(t.contiguous() if t is not None else None for t in out)
+    dev = w.device
+    f_hi = torch.empty((kh * kw, co, ci), dtype=torch.bfloat16, device=dev)
+    d_hi = torch.empty((kh * kw, ci, co), dtype=torch.bfloat16, device=dev)
+    f_lo = torch.empty_like(f_hi) if mode == "split" else None
+    d_lo = torch.empty_like(d_hi) if mode == "split" else None
+    rc = _lib.lib().d3d_conv2d_pack_weights(w.data_ptr(), co, ci, kh, f_hi.data_ptr(), _lib.ptr(f_lo), d_hi.data_ptr(),
+                                            _lib.ptr(d_lo), _lib.stream_ptr(dev))
+    _lib.check(rc, "d3d_conv2d_pack_weights")
+    out = {"fwd": (f_hi, f_lo), "dgrad": (d_hi, d_lo)}
     if len(_PACK) > 256:
         for k in [k for k, v in _PACK.items() if v[0]() is None]:
             del _PACK[k]
     _PACK[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), out)
-    return out
+    return out[kind]
 
 
 def supported(cin, cout, ksz, stride):
@@ -91,23 +102,17 @@ def conv2d_raw(x_hi, x_lo, w_hi, w_lo, ksz, stride, pad, mode, want_stats=False)
 
 
 def wgrad_raw(g_hi, g_lo, x_hi, x_lo, ksz, stride, pad, mode):
-    """dw [ksz*ksz, Cout, Cin] f32 from g = dL/dy [B,Ho,Wo,Cout] and the layer input x [B,H,W,Cin]"""
+    """dw [Cout, Cin, ksz, ksz] f32 (nn.Conv2d's layout) from g = dL/dy [B,Ho,Wo,Cout] and the layer input x"""
     L = _lib.lib()
     b, h, w, cin = x_hi.shape
     cout = g_hi.shape[3]
     ho, wo = _out_hw(h, w, ksz, stride, pad)
     assert tuple(g_hi.shape[:3]) == (b, ho, wo)
     dev = x_hi.device
-    dw = torch.empty((ksz * ksz, cout, cin), dtype=torch.float32, device=dev)
+    dw = torch.empty((cout, cin, ksz, ksz), dtype=torch.float32, device=dev)
     nb = L.d3d_conv2d_wgrad_workspace_bytes(b, ho, wo, cin, cout, ksz)
     ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
     rc = L.d3d_conv2d_nhwc_wgrad(g_hi.data_ptr(), _lib.ptr(g_lo), x_hi.data_ptr(), _lib.ptr(x_lo), dw.data_ptr(), b, h,
                                  w, cin, cout, ksz, stride, pad, _MODES[mode], ws.data_ptr(), nb, _lib.stream_ptr(dev))
     _lib.check(rc, "d3d_conv2d_nhwc_wgrad")
     return dw
-
-
-def unpack_wgrad(dw, weight):
-    """[tap][cout][cin] -> nn.Conv2d's [cout, cin, kh, kw]"""
-    co, ci, kh, kw = weight.shape
-    return dw.view(kh, kw, co, ci).permute(2, 3, 0, 1)

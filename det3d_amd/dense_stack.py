@@ -204,8 +204,7 @@ class _DenseStackFn(torch.autograd.Function):
                                      save[0].data_ptr(), save[1].data_ptr(), int(ly.relu), partial.data_ptr(), 1,
                                      g_hi.data_ptr(), gbn[0].data_ptr(), gbn[1].data_ptr(), st)
                 _lib.check(rc, "d3d_bn_bwd_dx")
-            dw = dc.wgrad_raw(g_hi, g_lo, a_hi, a_lo, ly.ksz, 1, ly.pad, mode)
-            gw = dc.unpack_wgrad(dw, ly.conv.weight)
+            gw = dc.wgrad_raw(g_hi, g_lo, a_hi, a_lo, ly.ksz, 1, ly.pad, mode)
             if li > 0 or ctx.need_in_grad:
                 wd_hi, wd_lo = dc._packed(ly.conv.weight, "dgrad", mode)
                 dy, _ = dc.conv2d_raw(g_hi, g_lo, wd_hi, wd_lo, ly.ksz, 1, ly.ksz - 1 - ly.pad, mode)

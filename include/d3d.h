@@ -258,8 +258,12 @@ int d3d_channel_affine_bwd(const void *x, const void *dy, int n, int c, int dtyp
  * 2^-8) at a fifth of the exact-f32 MFMA's time -- the precision mode that meets the 1e-3 box tolerance.
  * The data gradient of a stride-1 layer is the same call on dL/dy with the taps mirrored and the weights packed
  * as [tap'][cin][cout] (pad' = ksz - 1 - pad).
- * d3d_conv2d_nhwc_wgrad: dw [ksz*ksz, cout, cin] f32 = sum over output pixels of g (x) x(tap), g = dL/dy
- * [batch, ho, wo, cout] and x in the same element format; two-pass, bit-reproducible; cin, cout in {128, 256}. */
+ * d3d_conv2d_nhwc_wgrad: dw [cout, cin, ksz, ksz] f32 (nn.Conv2d's layout) = sum over output pixels of
+ * g (x) x(tap), g = dL/dy [batch, ho, wo, cout] and x in the same element format; two-pass, bit-reproducible;
+ * cin, cout in {128, 256}.
+ * d3d_conv2d_pack_weights: nn.Conv2d weight [cout, cin, ksz, ksz] f32 -> the forward operand [tap][cout][cin] and
+ * the data-gradient operand [mirrored tap][cin][cout], each as a bf16 hi plane and (optional, split mode) lo plane.
+ * d3d_split_planes: f32 [n] -> the hi / lo planes of the split format. */
 #define D3D_CONV_BF16 0
 #define D3D_CONV_SPLIT 1
 int d3d_conv2d_supported(int cin, int cout, int ksz, int stride);
@@ -267,6 +271,9 @@ size_t d3d_conv2d_stats_ws_floats(int batch, int ho, int wo, int cout);
 int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo, void *y, int batch,
                         int h, int w, int cin, int cout, int ksz, int stride, int pad, int mode, float *stats_ws,
                         size_t stats_ws_floats, d3d_stream_t stream);
+int d3d_conv2d_pack_weights(const float *weight, int cout, int cin, int ksz, void *fwd_hi, void *fwd_lo,
+                            void *dgrad_hi, void *dgrad_lo, d3d_stream_t stream);
+int d3d_split_planes(const float *x, int64_t n, void *hi, void *lo, d3d_stream_t stream);
 size_t d3d_conv2d_wgrad_workspace_bytes(int batch, int ho, int wo, int cin, int cout, int ksz);
 int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const void *x_hi, const void *x_lo, float *dw,
                           int batch, int h, int w, int cin, int cout, int ksz, int stride, int pad, int mode,

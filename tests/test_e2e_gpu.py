@@ -472,16 +472,19 @@ def test_resnet_fhd_backbone_vs_oracle_on_a_larger_cloud(name):
     out.backward(gout.cuda())
     scale = float(out_ref.abs().max())
     assert float((out.cpu() - out_ref).abs().max()) < 1e-3 * max(scale, 1.0)
-    gi = float((f_gpu.grad.cpu() - f_ref.grad).abs().max()) / float(f_ref.grad.abs().max())
-    assert gi < 2e-2, gi
+    # Gradients are compared in relative L2 and direction, not element-wise: the f32 path multiplies in split
+    # arithmetic (2^-16 relative per product, not 2^-24), so a pre-activation within ~1e-5 of zero can land on the
+    # other side of a ReLU than in the oracle.  The forward effect is nil (checked to 1e-3 above); the backward mask is
+    # discontinuous there, so single sites differ by O(1) while the tensors agree to a fraction of a percent.
+    l2 = lambda a, b: float((a - b).norm()) / (float(b.norm()) + 1e-30)
+    gi = l2(f_gpu.grad.cpu(), f_ref.grad)
+    assert gi < 1e-2, gi
     worst, worst_cos = 0.0, 0.0
     for (k, p), (_, q) in zip(prod.named_parameters(), ref.named_parameters()):
         if float(q.grad.abs().max()) < 1e-5 or _bias_before_bn(k):
             continue
-        worst = max(worst, float((p.grad.cpu() - q.grad).abs().max()) / float(q.grad.abs().max()))
+        worst = max(worst, l2(p.grad.cpu(), q.grad))
         worst_cos = max(worst_cos, 1.0 - float(torch.nn.functional.cosine_similarity(p.grad.cpu().flatten(), q.grad.flatten(), dim=0)))
-    print("%s ResNetFHD %d voxels: input-grad rel err %.2e, worst param-grad rel err %.2e, worst 1-cos %.2e" % (
+    print("%s ResNetFHD %d voxels: input-grad rel L2 %.2e, worst param-grad rel L2 %.2e, worst 1-cos %.2e" % (
         name, len(feats), gi, worst, worst_cos))
-    # two f32 implementations through 27 train-mode BN + ReLU layers (see test_forward_loss_and_grads_fp32):
-    # element-wise 5 % of each tensor's max, direction 1e-3
-    assert worst < 5e-2 and worst_cos < 1e-3
+    assert worst < 2e-2 and worst_cos < 1e-3

@@ -466,13 +466,17 @@ def test_conv_epilogue_bn_fusions_match_the_separate_sweeps(dtype, cin0):
     (ya, ga, pa, ba), (yb, gb, pb, bb) = res
     tol = 1e-4 if dtype == torch.float32 else 2e-2
     rel = lambda a, b: float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+    # gradients in relative L2: the two routes sum the statistics in different orders, the activations differ in
+    # their last bits, and a pre-activation that close to zero takes the other side of a ReLU in one of them -- the
+    # backward mask is discontinuous there (single sites differ by O(1)), the tensors agree
+    l2 = lambda a, b: float((a - b).norm()) / (float(b.norm()) + 1e-30)
     assert rel(ya, yb) < tol
-    assert rel(ga, gb) < 5 * tol
+    assert l2(ga, gb) < 5 * tol
     names = [n for n, _ in net.named_parameters()]
     for name, a, b in zip(names, pa, pb):
         if name == "9.bias":  # conv bias in front of a train-mode BN: zero true gradient, rounding noise only
             continue
-        assert rel(a, b) < 5 * tol, name
+        assert l2(a, b) < 5 * tol, name
     for a, b in zip(ba, bb):
         if a.is_floating_point():
             assert torch.allclose(a, b, rtol=1e-3, atol=1e-5)

@@ -37,17 +37,23 @@ def main():
         gy = torch.randn((b, ho, wo, cout), device="cuda")
         flop = 2.0 * b * ho * wo * cout * cin * k * k
         row = {"shape": [b, h, w, cin, cout, k, s, p], "gflop": flop / 1e9}
+        from det3d_amd import _lib
+        variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
         for mode in ("bf16", "split"):
             w_hi, w_lo = dc._packed(wt, "fwd", mode)
             if mode == "bf16":
                 x_hi, x_lo, g_hi, g_lo = x.to(torch.bfloat16), None, gy.to(torch.bfloat16), None
             else:
                 (x_hi, x_lo), (g_hi, g_lo) = dc.split_planes(x), dc.split_planes(gy)
-            t = timeit(lambda: dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, mode))
-            ts = timeit(lambda: dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, mode, want_stats=True))
-            row[mode + "_fwd_us"] = round(t, 1)
-            row[mode + "_fwd_stats_us"] = round(ts, 1)
-            row[mode + "_fwd_TF"] = round(flop / t / 1e6, 1)
+            for v in variants:
+                _lib.lib().d3d_set_tuning(7, v)
+                t = timeit(lambda: dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, mode))
+                ts = timeit(lambda: dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, mode, want_stats=True))
+                tag = mode + ("_v%d" % v if v else "")
+                row[tag + "_fwd_us"] = round(t, 1)
+                row[tag + "_fwd_stats_us"] = round(ts, 1)
+                row[tag + "_fwd_TF"] = round(flop / t / 1e6, 1)
+            _lib.lib().d3d_set_tuning(7, variants[0])
             if cin % 128 == 0:
                 tw = timeit(lambda: dc.wgrad_raw(g_hi, g_lo, x_hi, x_lo, k, s, p, mode))
                 row[mode + "_wgrad_us"] = round(tw, 1)
