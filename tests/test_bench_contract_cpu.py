@@ -27,7 +27,7 @@ def test_driver_flags_parse(monkeypatch):
 
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "7", "--warmup", "3"])
     a = bench.parse()
-    assert (a.gpus, a.steps, a.warmup, a.batch, a.points, a.dtype) == (8, 7, 3, 4, 20000, "bf16")
+    assert (a.gpus, a.steps, a.warmup, a.batch, a.points, a.dtype) == (8, 7, 3, 4, 20000, "fp32")
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
     assert a.gpus == 1 and a.steps >= 10 and a.warmup >= 1 and not a.no_gc_freeze

@@ -471,12 +471,13 @@ def test_conv_epilogue_bn_fusions_match_the_separate_sweeps(dtype, cin0):
     # backward mask is discontinuous there (single sites differ by O(1)), the tensors agree
     l2 = lambda a, b: float((a - b).norm()) / (float(b.norm()) + 1e-30)
     assert rel(ya, yb) < tol
-    assert l2(ga, gb) < 5 * tol
+    gtol = 2e-3 if dtype == torch.float32 else 5 * tol
+    assert l2(ga, gb) < gtol
     names = [n for n, _ in net.named_parameters()]
     for name, a, b in zip(names, pa, pb):
         if name == "9.bias":  # conv bias in front of a train-mode BN: zero true gradient, rounding noise only
             continue
-        assert l2(a, b) < 5 * tol, name
+        assert l2(a, b) < gtol, name
     for a, b in zip(ba, bb):
         if a.is_floating_point():
             assert torch.allclose(a, b, rtol=1e-3, atol=1e-5)

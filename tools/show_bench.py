@@ -12,7 +12,7 @@ print("   host ms/step %s  graphed_tail %s  prefetch %s  burn-in %s" % (
     c.get("host_ms_per_step"), c.get("graphed_tail"), c.get("geometry_prefetch"), c.get("burn_in_steps")))
 for k, v in (d.get("kernels") or {}).items():
     print("   %-34s x%-2d %7.2f us  %7.1f GB/s" % (k, v["launches_per_step"], v["avg_us"], v.get("achieved_GBs", 0)))
-for k in ("fp32", "predict", "rpn_mfma", "precision", "stages", "probe_error", "fp32_error"):
+for k in ("fp32", "bf16", "predict", "rpn_mfma", "precision", "stages", "probe_error", "other_dtype_error"):
     if k in d:
         print("  ", k, json.dumps(d[k])[:400])
 if len(sys.argv) > 2 and "workloads" in d:
