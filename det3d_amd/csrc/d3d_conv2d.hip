@@ -365,28 +365,50 @@ __global__ void __launch_bounds__(256, 2)
   const __amdgpu_buffer_rsrc_t gr_lo = __builtin_amdgcn_make_buffer_rsrc((void *)(SPLIT ? g_lo : g_hi), 0, G.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t xr_hi = __builtin_amdgcn_make_buffer_rsrc((void *)x_hi, 0, G.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t xr_lo = __builtin_amdgcn_make_buffer_rsrc((void *)(SPLIT ? x_lo : x_hi), 0, G.x_bytes, 0x00020000);
-  auto stage = [&](int ks, int buf) {
+  // per staging slot: the pixel this lane loads in the NEXT stage() call, as (image, row, column); stage() is called
+  // for ks = 0, 1, 2, ... in order and advances the slot by KP pixels (no divisions in the loop)
+  int sp[INSTR], sb_[INSTR], sy[INSTR], sx_[INSTR];
+  uint32_t schunk[INSTR];
+#pragma unroll
+  for (int j = 0; j < INSTR; ++j) {
+    const int inst = wave * INSTR + j;
+    const int row = inst * 4 + (lane >> 4), cp = lane & 15;
+    schunk[j] = (uint32_t)((cp ^ ((row & 3) << 2)) * 16);
+    const int p = p_begin + row;
+    sp[j] = p;
+    const int pc = p < G.m ? p : G.m - 1;
+    sb_[j] = pc / (G.ho * G.wo);
+    const int rem = pc - sb_[j] * (G.ho * G.wo);
+    sy[j] = rem / G.wo;
+    sx_[j] = rem - sy[j] * G.wo;
+  }
+  auto stage = [&](int buf) {
     unsigned char *sg = smem + buf * STAGE, *sx = sg + NP * PLANE;
 #pragma unroll
     for (int j = 0; j < INSTR; ++j) {
       const int inst = wave * INSTR + j;
-      const int row = inst * 4 + (lane >> 4), cp = lane & 15;
-      const int c = cp ^ ((row & 3) << 2);
-      const int p = p_begin + ks * KP + row;
-      const bool live = p < p_end;
-      const int pp = live ? p : p_begin;
-      const int b = pp / (G.ho * G.wo), rem = pp - b * (G.ho * G.wo);
-      const int oy = rem / G.wo, ox = rem - oy * G.wo;
-      const int iy = oy * G.stride - G.pad + ky, ix = ox * G.stride - G.pad + kx;
+      const bool live = sp[j] < p_end;
+      const int iy = sy[j] * G.stride - G.pad + ky, ix = sx_[j] * G.stride - G.pad + kx;
       const bool inside = live && iy >= 0 && iy < G.h && ix >= 0 && ix < G.w;
-      const uint32_t goff = live ? (uint32_t)(pp * (G.cout * 2) + co0 * 2 + c * 16) : D3D_OOB_OFFSET;
-      const uint32_t xoff = inside ? (uint32_t)(((b * G.h + iy) * G.w + ix) * (cin * 2) + ci0 * 2 + c * 16) : D3D_OOB_OFFSET;
+      const uint32_t goff = live ? (uint32_t)(sp[j] * (G.cout * 2) + co0 * 2) + schunk[j] : D3D_OOB_OFFSET;
+      const uint32_t xoff = inside ? (uint32_t)(((sb_[j] * G.h + iy) * G.w + ix) * (cin * 2) + ci0 * 2) + schunk[j]
+                                   : D3D_OOB_OFFSET;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(gr_hi, (c2_lds_void *)(sg + inst * 1024), 16, (int)goff, 0, 0, 0);
       if constexpr (SPLIT)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(gr_lo, (c2_lds_void *)(sg + PLANE + inst * 1024), 16, (int)goff, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xr_hi, (c2_lds_void *)(sx + inst * 1024), 16, (int)xoff, 0, 0, 0);
       if constexpr (SPLIT)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr_lo, (c2_lds_void *)(sx + PLANE + inst * 1024), 16, (int)xoff, 0, 0, 0);
+      // advance by KP pixels
+      sp[j] += KP;
+      sx_[j] += KP;
+      while (sx_[j] >= G.wo) {
+        sx_[j] -= G.wo;
+        if (++sy[j] >= G.ho) {
+          sy[j] = 0;
+          ++sb_[j];
+        }
+      }
     }
   };
 
@@ -426,12 +448,12 @@ __global__ void __launch_bounds__(256, 2)
     return __builtin_bit_cast(c2_bf16x8, v);
   };
 
-  if (nks > 0) stage(0, 0);
+  if (nks > 0) stage(0);
   for (int ks = 0; ks < nks; ++ks) {
     const int buf = ks & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (ks + 1 < nks) stage(ks + 1, buf ^ 1);
+    if (ks + 1 < nks) stage(buf ^ 1);
     const unsigned char *sg = smem + buf * STAGE, *sx = sg + NP * PLANE;
 #pragma unroll
     for (int kk = 0; kk < KP / 16; ++kk) {
