@@ -546,14 +546,44 @@ def rpn_mfma_probe(wl, dev, dtype):
 
     convs = [m for m in list(wl.model.neck.modules()) + list(wl.model.bbox_head.modules())
              if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))]
+    # shapes: the fused stacks call kernels, not the conv modules, so module hooks never fire for them -- take the
+    # neck's input shape from a hook on the neck and walk its Sequentials
+    neck_in = {}
     shapes = {}
-    hooks = [m.register_forward_hook(lambda mod, inp, out: shapes.__setitem__(mod, (tuple(inp[0].shape), tuple(out.shape))))
-             for m in convs]
+    hooks = [wl.model.neck.register_forward_hook(lambda mod, inp, out: neck_in.__setitem__("s", tuple(inp[0].shape)))]
+    hooks += [m.register_forward_hook(lambda mod, inp, out: shapes.__setitem__(mod, (tuple(inp[0].shape), tuple(out.shape))))
+              for m in wl.model.bbox_head.modules() if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))]
     ex = wl.example(0)
     with torch.no_grad(), wl.step_fn._ctx():
         wl.model(ex, return_loss=True)
     for h in hooks:
         h.remove()
+
+    def walk(seq, shape):
+        b, c, h, w = shape
+        for m in seq:
+            if isinstance(m, nn.ZeroPad2d):
+                p = m.padding if isinstance(m.padding, int) else m.padding[0]
+                h, w = h + 2 * p, w + 2 * p
+            elif isinstance(m, nn.Conv2d):
+                ho = (h + 2 * m.padding[0] - m.kernel_size[0]) // m.stride[0] + 1
+                wo = (w + 2 * m.padding[1] - m.kernel_size[1]) // m.stride[1] + 1
+                shapes[m] = ((b, c, h, w), (b, m.out_channels, ho, wo))
+                c, h, w = m.out_channels, ho, wo
+            elif isinstance(m, nn.ConvTranspose2d):
+                ho, wo = h * m.stride[0], w * m.stride[1]
+                shapes[m] = ((b, c, h, w), (b, m.out_channels, ho, wo))
+                c, h, w = m.out_channels, ho, wo
+        return (b, c, h, w)
+
+    neck = wl.model.neck
+    if "s" in neck_in and hasattr(neck, "blocks"):
+        cur = neck_in["s"]
+        for i, stage in enumerate(neck.blocks):
+            cur = walk(stage, cur)
+            j = i - neck._upsample_start_idx
+            if j >= 0:
+                walk(neck.deblocks[j], cur)
     mode = "bf16" if dtype == "bf16" else "split"
 
     def ev_time(fn, reps=5):
@@ -581,7 +611,9 @@ def rpn_mfma_probe(wl, dev, dtype):
             flops = 2.0 * oshape[0] * oshape[1] * ishape[1] * kk * oshape[2] * oshape[3]
         pad = dense_stack._conv_ok(m, 0) if isinstance(m, nn.Conv2d) else None
         if pad is None and isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.padding == (0, 0):
-            pad = dense_stack._conv_ok(m, 1)  # the stage's first conv sits behind a ZeroPad2d(1)
+            pad = dense_stack._conv_ok(m, 1)  # the stage's first conv sits behind a ZeroPad2d(1): folded into padding
+            if pad is not None:
+                ishape = (ishape[0], ishape[1], ishape[2] - 2, ishape[3] - 2)
         if pad is None:
             other_flops += 3 * flops
             continue

@@ -18,7 +18,7 @@ def init_dist(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or SINGLE_RANK_COLLECTIVES) and not dist.is_initialized():
         if backend is None:
             # D3D_DIST_BACKEND=gloo lets several ranks share one GPU (flow test without RCCL)
             backend = os.environ.get("D3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -33,13 +33,27 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+# D3D_DIST_SINGLE=1: initialise the process group even for ONE rank and issue every collective of the step (gradient
+# buckets, SyncBN statistics, barriers) on it.  A 1-rank RCCL communicator moves no data, but the whole code path --
+# backend "nccl" init, asynchronous all-reduce handles on the communication stream, the packed SyncBN exchange --
+# executes on the one GPU a test box has (tests/test_dist_gpu.py::test_single_rank_rccl_smoke).
+SINGLE_RANK_COLLECTIVES = os.environ.get("D3D_DIST_SINGLE", "0") == "1"
+
+
+def exchanging():
+    """True when the step has to issue its collectives: several ranks, or one rank with D3D_DIST_SINGLE=1"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or SINGLE_RANK_COLLECTIVES
+
+
 def get_rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
 def broadcast_params(module, src=0):
     """same starting point on every rank (DDP does this at wrap time)."""
-    if world_size() == 1:
+    if not exchanging():
         return
     tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
     # every rank must issue the broadcasts in the SAME order: iterate dtypes sorted by name (a set
@@ -48,8 +62,14 @@ def broadcast_params(module, src=0):
         group = [t for t in tensors if t.dtype == dtype]
         flat = torch._utils._flatten_dense_tensors(group)
         dist.broadcast(flat, src)
-        for t, f in zip(group, torch._utils._unflatten_dense_tensors(flat, group)):
-            t.copy_(f)
+        with torch.no_grad():
+            for t, f in zip(group, torch._utils._unflatten_dense_tensors(flat, group)):
+                t.copy_(f)
+    # the packed-weight caches key on (parameter, version, pointer): in-place copies through .data move neither
+    from . import dense_conv, spconv
+
+    spconv._PACK_CACHE.clear()
+    dense_conv._PACK.clear()
 
 
 class FlatGradBucket:
@@ -86,11 +106,10 @@ class FlatGradBucket:
         """mean over ranks (= allreduce_grads + div_(world_size), dist_utils.py:23-28)"""
         if self.flat is None:
             self.gather()
-        w = world_size()
-        if w == 1:
+        if not exchanging():
             return
         dist.all_reduce(self.flat)
-        self.flat.div_(w)
+        self.flat.div_(world_size())
 
     def clip_norm_(self, max_norm):
         if self.flat is None:
@@ -195,7 +214,7 @@ class OverlappedGradBuckets:
                 grads.append((torch.zeros_like(p) if g is None else g).reshape(-1))
             flat = torch.cat(grads)
             self.flats[b] = flat
-            if world_size() > 1:
+            if exchanging():
                 self.handles[b] = dist.all_reduce(flat, async_op=True)
             self.next_launch += 1
 
@@ -233,5 +252,5 @@ def all_gather_objects(obj):
 
 
 def barrier():
-    if world_size() > 1:
+    if exchanging():
         dist.barrier()

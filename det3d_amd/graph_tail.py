@@ -55,7 +55,7 @@ def _has_collective(module):
     from .syncbn import DistributedSyncBN
     from . import dist as d3d_dist
 
-    return d3d_dist.world_size() > 1 and any(isinstance(m, DistributedSyncBN) for m in module.modules())
+    return d3d_dist.exchanging() and any(isinstance(m, DistributedSyncBN) for m in module.modules())
 
 
 class GraphedTail:
@@ -131,7 +131,7 @@ def run_tail(detector, example, bev):
     if not GRAPH_TAIL_DIST:
         from . import dist as d3d_dist
 
-        if d3d_dist.world_size() > 1:
+        if d3d_dist.exchanging():
             return None
     autocast_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
     head = detector.bbox_head

@@ -88,10 +88,9 @@ class _StackFn(torch.autograd.Function):
             if x.shape[0] != rb.n_in or x.shape[1] != cin:
                 raise _lib.D3dError("sparse stack: features %s do not match the rulebook (%d rows) / the conv "
                                     "(%d channels)" % (tuple(x.shape), rb.n_in, cin))
-            if x.numel() * x.element_size() >= (1 << 31) - 16:
-                raise _lib.D3dError("sparse conv: the feature matrix must stay below 2 GB (buffer-descriptor gathers)")
             if pad_cin != cin:
                 x = torch.nn.functional.pad(x, (0, pad_cin - cin))
+            sp.check_gather_source(x, "the feature matrix")
             wpack, wd = sp._packed_weights(conv.weight, rb.kvol, cin, cout, dtype, rb.subm,
                                            li > 0 or need_in_grad, pad_cin)
             out = torch.empty((rb.n_out, cout), dtype=dtype, device=dev)
@@ -145,6 +144,7 @@ class _StackFn(torch.autograd.Function):
                                          partial.data_ptr(), st)
                 _lib.check(rc, "d3d_bn_bwd_reduce")
             gout = torch.empty_like(out)
+            sp.check_gather_source(gout, "the output gradient")
             gbn = torch.empty((2, cout), dtype=torch.float32, device=dev)
             rc = L.d3d_bn_bwd_dx(out.data_ptr(), dy.data_ptr(), rb.n_out, cout, dt, bn.weight.data_ptr(),
                                  _lib.ptr(bn.bias), save[0].data_ptr(), save[1].data_ptr(), int(ly.relu),

@@ -88,6 +88,14 @@ class _ScratchArena:
         return b[off: off + n]
 
 
+def check_gather_source(t, what):
+    """every matrix a conv kernel GATHERS rows from is addressed through a 2 GB buffer descriptor (rows beyond it
+    would read as zeros): features in the forward, the output gradient in the data gradient, the padded features
+    in the weight gradient"""
+    if t.numel() * t.element_size() >= (1 << 31) - 16:
+        raise _lib.D3dError("sparse conv: %s %s must stay below 2 GB (buffer-descriptor gathers)" % (what, tuple(t.shape)))
+
+
 def epilogue_ws(dev, n_out, cout):
     """buffer for D3dConvEpilogue.stats / .bn_partial of a launch producing n_out rows of cout channels"""
     return ARENA.take(dev, _lib.lib().d3d_conv_epilogue_ws_floats(int(n_out), int(cout)))
@@ -120,7 +128,7 @@ class _BnLink:
         self.reduced = False
 
 
-_PACK_CACHE = {}  # id(weight) -> (weakref, version, dtype, flip, pad, wpack, wdgrad)
+_PACK_CACHE = {}  # id(weight) -> (weakref, version, dtype, flip, pad, wpack, wdgrad, (data_ptr, device))
 
 
 def _packed_weights(weight, kvol, cin, cout, dtype, subm, need_dgrad, pad_cin):
@@ -131,8 +139,12 @@ def _packed_weights(weight, kvol, cin, cout, dtype, subm, need_dgrad, pad_cin):
 
     key = id(weight)
     hit = _PACK_CACHE.get(key)
+    # (`_version` does not move for writes through `.data` -- parameter broadcasts, EMA copies, `.to()` re-pointing
+    # `.data` -- so the storage pointer and device are part of the identity as well; dist.broadcast_params also
+    # clears the cache)
     if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == dtype and \
-            hit[3] == subm and hit[4] == pad_cin and (hit[6] is not None or not need_dgrad):
+            hit[3] == subm and hit[4] == pad_cin and (hit[6] is not None or not need_dgrad) and \
+            hit[7] == (weight.data_ptr(), weight.device):
         return hit[5], hit[6]
     L = _lib.lib()
     w32 = weight.detach().float().reshape(kvol, cin, cout)
@@ -147,7 +159,8 @@ def _packed_weights(weight, kvol, cin, cout, dtype, subm, need_dgrad, pad_cin):
     if len(_PACK_CACHE) > 512:
         for k in [k for k, v in _PACK_CACHE.items() if v[0]() is None]:
             del _PACK_CACHE[k]
-    _PACK_CACHE[key] = (weakref.ref(weight), weight._version, dtype, subm, pad_cin, wpack, wd)
+    _PACK_CACHE[key] = (weakref.ref(weight), weight._version, dtype, subm, pad_cin, wpack, wd,
+                        (weight.data_ptr(), weight.device))
     return wpack, wd
 
 
@@ -280,8 +293,6 @@ class _SparseConvFn(torch.autograd.Function):
         if feats.dtype not in _DT:
             raise _lib.D3dError("sparse conv supports float32 / bfloat16 features, got %s" % feats.dtype)
         feats = feats.contiguous()
-        if feats.numel() * feats.element_size() >= (1 << 31) - 16:
-            raise _lib.D3dError("sparse conv: the feature matrix must stay below 2 GB (buffer-descriptor gathers)")
         kvol, cin, cout = rb.kvol, weight.shape[-2], weight.shape[-1]
         assert feats.shape[0] == rb.n_in and feats.shape[1] == cin, (feats.shape, rb.n_in, cin)
         if weight.numel() != kvol * cin * cout:
@@ -295,6 +306,7 @@ class _SparseConvFn(torch.autograd.Function):
         pad_cin = 16 if (cin < 16 and cout % 16 == 0) else cin
         if pad_cin != cin:
             feats = torch.nn.functional.pad(feats, (0, pad_cin - cin))
+        check_gather_source(feats, "the feature matrix")
         need_dgrad = ctx.needs_input_grad[0]
         wpack, wd = _packed_weights(weight, kvol, cin, cout, feats.dtype, rb.subm, need_dgrad, pad_cin)
         out = torch.empty((rb.n_out, cout), dtype=feats.dtype, device=feats.device)
@@ -326,6 +338,7 @@ class _SparseConvFn(torch.autograd.Function):
         kvol, cout = rb.kvol, weight.shape[-1]
         cin, pad_cin = ctx.pad
         gout = gout.contiguous().to(feats.dtype)
+        check_gather_source(gout, "the output gradient")
         dt = _DT[feats.dtype]
         stream = _lib.stream_ptr(feats.device)
         gin = gw = gb = None

@@ -38,6 +38,13 @@ def _world(group):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def _exchange(group):
+    """issue the collectives: several ranks, or one rank under D3D_DIST_SINGLE=1 (dist.exchanging)"""
+    from . import dist as d3d_dist
+
+    return _world(group) > 1 or d3d_dist.exchanging()
+
+
 def _per_channel(v, x):
     shape = [1] * x.dim()
     shape[1] = -1
@@ -53,7 +60,7 @@ class _SyncBNFn(torch.autograd.Function):
         world = _world(group)
         xf = x.float()
         stats = torch.cat([xf.mean(dims), (xf * xf).mean(dims)])  # local E[x], E[x^2] -> one [2C] buffer
-        if world > 1:
+        if _exchange(group):
             dist.all_reduce(stats, group=group)
             stats /= world
         ex, exs = stats[:c], stats[c:]
@@ -87,7 +94,7 @@ class _SyncBNFn(torch.autograd.Function):
                           dot_p * invstd,                                          # grad_gamma
                           dy_sum])                                                 # grad_beta
         world = _world(ctx.group)
-        if world > 1:
+        if _exchange(ctx.group):
             dist.all_reduce(pack, group=ctx.group)  # ONE collective for the four vectors
             pack[: 2 * c] /= world
         grad_ex, grad_exs, grad_gamma, grad_beta = pack[:c], pack[c:2 * c], pack[2 * c:3 * c], pack[3 * c:]
@@ -133,7 +140,7 @@ class _SyncBNReLUFusedFn(torch.autograd.Function):
         _lib.check(L.d3d_bn_stats(rows.data_ptr(), n, c, dt, ws.data_ptr(), st), "d3d_bn_stats")
         stats = ws[:2 * c] / n  # local E[x] | E[x^2] (deterministic fold: the sums sit at the start of the workspace)
         world = _world(group)
-        if world > 1:
+        if _exchange(group):
             dist.all_reduce(stats, group=group)
             stats /= world
         ex, exs = stats[:c], stats[c:]
@@ -183,7 +190,7 @@ class _SyncBNReLUFusedFn(torch.autograd.Function):
                           dot_p * invstd,                                          # grad_gamma
                           dy_sum])                                                 # grad_beta
         world = _world(ctx.group)
-        if world > 1:
+        if _exchange(ctx.group):
             dist.all_reduce(pack, group=ctx.group)  # ONE collective for the four vectors
             pack[: 2 * c] /= world
         grad_ex, grad_exs, grad_gamma, grad_beta = pack[:c], pack[c:2 * c], pack[2 * c:3 * c], pack[3 * c:]

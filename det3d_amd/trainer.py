@@ -63,10 +63,10 @@ class TrainStep:
         import os
 
         nb = int(os.environ.get("D3D_DP_BUCKETS", "3"))
-        self.overlap = d3d_dist.world_size() > 1 and nb > 0
+        self.overlap = d3d_dist.exchanging() and nb > 0
         if self.overlap:
             self.bucket = d3d_dist.OverlappedGradBuckets(self.params, nb)
-        elif d3d_dist.world_size() > 1:
+        elif d3d_dist.exchanging():
             self.bucket = d3d_dist.FlatGradBucket(self.params)   # D3D_DP_BUCKETS=0: one flat all-reduce after backward
         else:
             self.bucket = d3d_dist.LocalGradClip(self.params)
