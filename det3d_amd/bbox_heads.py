@@ -418,140 +418,83 @@ class MultiGroupHead(nn.Module):
                  "label_preds": labels[b, : n_valid[b]], "metadata": meta[b]} for b in range(batch)]
 
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
+        """detections per frame: [{"box3d_lidar" [n, box_dim], "scores" [n], "label_preds" [n], "metadata"}] -- the
+        contract of MultiGroupHead.predict (mg_head.py:697-803).  On the GPU with the shipped settings the whole batch
+        goes through `_predict_fused`; everything else (CPU tensors, anchor masks, axis-aligned NMS, softmax scores)
+        is decided frame by frame in `_frame_detections`."""
         if self._fused_predict_ok(example, preds_dicts, test_cfg):
             return self._predict_fused(example, preds_dicts, test_cfg)
-        batch_anchors = example["anchors"]
-        rets = []
-        for task_id, preds_dict in enumerate(preds_dicts):
-            batch_size = batch_anchors[task_id].shape[0]
-            if "metadata" not in example or len(example["metadata"]) == 0:
-                meta_list = [None] * batch_size
-            else:
-                meta_list = example["metadata"]
-            batch_task_anchors = example["anchors"][task_id].view(batch_size, -1, self.anchor_dim)
-            if "anchors_mask" not in example:
-                batch_anchors_mask = [None] * batch_size
-            else:
-                batch_anchors_mask = example["anchors_mask"][task_id].view(batch_size, -1)
-            box_ndim = self.box_n_dim - 2 if self.bev_only else self.box_n_dim
-            batch_box_preds = preds_dict["box_preds"].float().view(batch_size, -1, box_ndim)
-            ncls = self.num_classes[task_id] + (0 if self.encode_background_as_zeros else 1)
-            batch_cls_preds = preds_dict["cls_preds"].float().view(batch_size, -1, ncls)
-            batch_reg_preds = self.box_coder.decode_torch(batch_box_preds[:, :, : self.box_coder.code_size],
-                                                          batch_task_anchors)
-            if self.use_direction_classifier:
-                batch_dir_preds = preds_dict["dir_cls_preds"].float().view(batch_size, -1, 2)
-            else:
-                batch_dir_preds = [None] * batch_size
-            rets.append(self.get_task_detections(task_id, ncls, test_cfg, batch_cls_preds, batch_reg_preds,
-                                                 batch_dir_preds, batch_anchors_mask, meta_list))
-        num_samples = len(rets[0])
-        ret_list = []
-        for i in range(num_samples):
-            ret = {}
-            for k in rets[0][i].keys():
-                if k in ("box3d_lidar", "scores"):
-                    ret[k] = torch.cat([r[i][k] for r in rets])
-                elif k == "label_preds":
-                    flag = 0
-                    for j, num_class in enumerate(self.num_classes):
-                        rets[j][i][k] += flag
-                        flag += num_class
-                    ret[k] = torch.cat([r[i][k] for r in rets])
-                elif k == "metadata":
-                    ret[k] = rets[0][i][k]
-            ret_list.append(ret)
-        return ret_list
+        batch = example["anchors"][0].shape[0]
+        meta = example["metadata"] if len(example.get("metadata", [])) else [None] * batch
+        frames = [dict(box3d_lidar=[], scores=[], label_preds=[], metadata=meta[b]) for b in range(batch)]
+        first_label = 0  # labels of task t are offset by the class counts of tasks 0 .. t-1 (mg_head.py:787-801)
+        for task_id, preds in enumerate(preds_dicts):
+            n_cls = self.num_classes[task_id]
+            n_logit = n_cls if self.encode_background_as_zeros else n_cls + 1
+            code = self.box_n_dim - 2 if self.bev_only else self.box_n_dim
+            anchors = example["anchors"][task_id].view(batch, -1, self.anchor_dim)
+            raw = preds["box_preds"].float().view(batch, -1, code)
+            boxes = self.box_coder.decode_torch(raw[:, :, : self.box_coder.code_size], anchors)
+            logits = preds["cls_preds"].float().view(batch, -1, n_logit)
+            dirs = preds["dir_cls_preds"].float().view(batch, -1, 2) if self.use_direction_classifier else None
+            masks = example["anchors_mask"][task_id].view(batch, -1) if "anchors_mask" in example else None
+            for b in range(batch):
+                sel = slice(None) if masks is None else masks[b]
+                det = self._frame_detections(test_cfg, boxes[b][sel], logits[b][sel],
+                                             None if dirs is None else dirs[b][sel])
+                frames[b]["box3d_lidar"].append(det[0])
+                frames[b]["scores"].append(det[1])
+                frames[b]["label_preds"].append(det[2] + first_label)
+            first_label += n_cls
+        for f in frames:
+            for k in ("box3d_lidar", "scores", "label_preds"):
+                f[k] = torch.cat(f[k])
+        return frames
 
-    def get_task_detections(self, task_id, num_class_with_bg, test_cfg, batch_cls_preds, batch_reg_preds,
-                            batch_dir_preds=None, batch_anchors_mask=None, meta_list=None):
+    def _class_scores(self, logits):
+        """[A, classes] foreground scores from the classification logits"""
+        if self.encode_background_as_zeros:
+            if not self.use_sigmoid_score:
+                raise AssertionError("encode_background_as_zeros needs use_sigmoid_score")
+            return torch.sigmoid(logits)
+        probs = torch.sigmoid(logits) if self.use_sigmoid_score else torch.softmax(logits, dim=-1)
+        return probs[..., 1:]  # column 0 is the background
+
+    def _frame_detections(self, test_cfg, boxes, logits, dir_logits):
+        """(boxes [n, box_dim], scores [n], labels [n] int64) of one frame and one task group:
+        score threshold -> NMS in the BEV plane -> direction bit -> centre range  (mg_head.py:805-1085)"""
         nms_cfg = test_cfg["nms"] if isinstance(test_cfg, dict) else test_cfg.nms
         tget = (lambda k: test_cfg[k]) if isinstance(test_cfg, dict) else (lambda k: getattr(test_cfg, k))
         nget = (lambda k: nms_cfg[k]) if isinstance(nms_cfg, dict) else (lambda k: getattr(nms_cfg, k))
         if nget("use_multi_class_nms"):
             raise NotImplementedError("use_multi_class_nms: unreachable in the reference too "
                                       "(mg_head.py:911-913 reads undefined attributes)")
-        post_center_range = tget("post_center_limit_range")
-        if len(post_center_range) > 0:
-            post_center_range = torch.tensor(post_center_range, dtype=batch_reg_preds.dtype,
-                                             device=batch_reg_preds.device)
-        else:
-            post_center_range = None
-        nms_func = box_ops.rotate_nms if nget("use_rotate_nms") else box_ops.nms
-        score_thr = tget("score_threshold")
-        out = []
-        for box_preds, cls_preds, dir_preds, a_mask, meta in zip(batch_reg_preds, batch_cls_preds,
-                                                                 batch_dir_preds, batch_anchors_mask,
-                                                                 meta_list):
-            if a_mask is not None:
-                box_preds = box_preds[a_mask]
-                cls_preds = cls_preds[a_mask]
-            box_preds = box_preds.float()
-            cls_preds = cls_preds.float()
-            dir_labels = None
-            if self.use_direction_classifier:
-                if a_mask is not None:
-                    dir_preds = dir_preds[a_mask]
-                dir_labels = torch.max(dir_preds, dim=-1)[1]
-            if self.encode_background_as_zeros:
-                assert self.use_sigmoid_score is True
-                total_scores = torch.sigmoid(cls_preds)
-            elif self.use_sigmoid_score:
-                total_scores = torch.sigmoid(cls_preds)[..., 1:]
+        scores, labels = self._class_scores(logits).max(dim=-1)
+        heading = dir_logits.argmax(dim=-1).bool() if dir_logits is not None else None
+        thr = float(tget("score_threshold"))
+        if thr > 0.0:
+            hit = scores >= thr
+            boxes, scores, labels = boxes[hit], scores[hit], labels[hit]
+            heading = heading[hit] if heading is not None else None
+        if scores.numel():
+            bev = boxes[:, [0, 1, 3, 4, -1]]  # x, y, w, l, yaw
+            if nget("use_rotate_nms"):
+                suppress = box_ops.rotate_nms
             else:
-                total_scores = torch.softmax(cls_preds, dim=-1)[..., 1:]
-
-            if num_class_with_bg == 1:
-                top_scores = total_scores.squeeze(-1)
-                top_labels = torch.zeros(total_scores.shape[0], device=total_scores.device, dtype=torch.long)
-            else:
-                top_scores, top_labels = torch.max(total_scores, dim=-1)
-            if score_thr > 0.0:
-                keep_mask = top_scores >= torch.tensor([score_thr], device=total_scores.device).type_as(total_scores)
-                top_scores = top_scores.masked_select(keep_mask)
-            if top_scores.shape[0] != 0:
-                if score_thr > 0.0:
-                    box_preds = box_preds[keep_mask]
-                    if self.use_direction_classifier:
-                        dir_labels = dir_labels[keep_mask]
-                    top_labels = top_labels[keep_mask]
-                boxes_for_nms = box_preds[:, [0, 1, 3, 4, -1]]
-                if not nget("use_rotate_nms"):
-                    corners = box_ops.center_to_corner_box2d(boxes_for_nms[:, :2], boxes_for_nms[:, 2:4],
-                                                             boxes_for_nms[:, 4])
-                    boxes_for_nms = box_ops.corner_to_standup_nd(corners)
-                selected = nms_func(boxes_for_nms, top_scores, pre_max_size=nget("nms_pre_max_size"),
-                                    post_max_size=nget("nms_post_max_size"),
-                                    iou_threshold=nget("nms_iou_threshold"))
-            else:
-                selected = torch.zeros([0], dtype=torch.long, device=box_preds.device)
-                box_preds = box_preds[:0]
-                top_labels = top_labels[:0]
-                if self.use_direction_classifier:
-                    dir_labels = dir_labels[:0]
-            selected_boxes = box_preds[selected]
-            selected_labels = top_labels[selected]
-            selected_scores = top_scores[selected]
-            if selected_boxes.shape[0] != 0:
-                box_preds = selected_boxes
-                if self.use_direction_classifier:
-                    sel_dir = dir_labels[selected]
-                    opp = ((box_preds[..., -1] - self.direction_offset) > 0) ^ sel_dir.bool()
-                    box_preds[..., -1] += torch.where(opp, torch.tensor(np.pi).type_as(box_preds),
-                                                      torch.tensor(0.0).type_as(box_preds))
-                if post_center_range is not None:
-                    mask = (box_preds[:, :3] >= post_center_range[:3]).all(1)
-                    mask &= (box_preds[:, :3] <= post_center_range[3:]).all(1)
-                    pred = {"box3d_lidar": box_preds[mask], "scores": selected_scores[mask],
-                            "label_preds": selected_labels[mask], "metadata": meta}
-                else:
-                    pred = {"box3d_lidar": box_preds, "scores": selected_scores,
-                            "label_preds": selected_labels, "metadata": meta}
-            else:
-                dtype, device = batch_reg_preds.dtype, batch_reg_preds.device
-                pred = {"box3d_lidar": torch.zeros([0, self.anchor_dim], dtype=dtype, device=device),
-                        "scores": torch.zeros([0], dtype=dtype, device=device),
-                        "label_preds": torch.zeros([0], dtype=top_labels.dtype, device=device),
-                        "metadata": meta}
-            out.append(pred)
-        return out
+                suppress = box_ops.nms
+                bev = box_ops.corner_to_standup_nd(box_ops.center_to_corner_box2d(bev[:, :2], bev[:, 2:4], bev[:, 4]))
+            keep = suppress(bev, scores, pre_max_size=nget("nms_pre_max_size"), post_max_size=nget("nms_post_max_size"),
+                            iou_threshold=nget("nms_iou_threshold"))
+            boxes, scores, labels = boxes[keep], scores[keep], labels[keep]
+            heading = heading[keep] if heading is not None else None
+        if heading is not None and boxes.shape[0]:
+            # the regressed yaw is only known modulo pi; the direction classifier supplies the missing bit
+            flip = ((boxes[:, -1] - self.direction_offset) > 0) ^ heading
+            boxes = boxes.clone()
+            boxes[:, -1] += flip.to(boxes.dtype) * np.pi
+        limits = tget("post_center_limit_range")
+        if len(limits) and boxes.shape[0]:
+            lim = torch.as_tensor(limits, dtype=boxes.dtype, device=boxes.device)
+            inside = ((boxes[:, :3] >= lim[:3]) & (boxes[:, :3] <= lim[3:])).all(dim=1)
+            boxes, scores, labels = boxes[inside], scores[inside], labels[inside]
+        return boxes.reshape(-1, self.anchor_dim), scores, labels

@@ -1,7 +1,8 @@
-"""Small nn helpers the reference model files lean on:
-  build_norm_layer / norm table   det3d/models/utils/norm.py:60-112
-  Sequential (.add), Empty        det3d/models/utils/misc.py:40-113
-  get_paddings_indicator          det3d/models/utils/misc.py:180-202
+"""Small nn helpers with the reference's names and call signatures (API surface only; the bodies are this repo's):
+  build_norm_layer(cfg, n) -> (name, layer)   det3d/models/utils/norm.py:60-112   (config key "type": BN | BN1d | GN | SyncBN)
+  Sequential(.add) with "0", "1", ... child names, Empty                          det3d/models/utils/misc.py:40-113
+  get_paddings_indicator(actual_num, max_num)                                      det3d/models/utils/misc.py:180-202
+`Sequential.forward` is where the RPN's conv -> BN -> ReLU runs are handed to the library's kernels (dense_stack.py).
 """
 import os
 from collections import OrderedDict
@@ -13,6 +14,7 @@ from torch import nn
 from .syncbn import DistributedSyncBN  # noqa: E402  (reference semantics, det3d/ops/syncbn/syncbn.py)
 
 
+# config "type" -> (name prefix the reference derives attribute names from, constructor)
 norm_cfg = {
     "BN": ("bn", nn.BatchNorm2d),
     "BN1d": ("bn1d", nn.BatchNorm1d),
@@ -22,24 +24,22 @@ norm_cfg = {
 
 
 def build_norm_layer(cfg, num_features, postfix=""):
-    assert isinstance(cfg, dict) and "type" in cfg
-    cfg_ = dict(cfg)
-    layer_type = cfg_.pop("type")
-    if layer_type not in norm_cfg:
-        raise KeyError("Unrecognized norm type {}".format(layer_type))
-    abbr, norm_layer = norm_cfg[layer_type]
-    assert isinstance(postfix, (int, str))
-    name = abbr + str(postfix)
-    requires_grad = cfg_.pop("requires_grad", True)
-    cfg_.setdefault("eps", 1e-5)
-    if layer_type != "GN":
-        layer = norm_layer(num_features, **cfg_)
+    """(name, module) for a norm config dict: {"type": ..., "eps", "momentum", "requires_grad", "num_groups" (GN)}.
+    eps defaults to 1e-5; every other key goes to the constructor."""
+    if not isinstance(cfg, dict) or "type" not in cfg:
+        raise TypeError("norm config must be a dict with a 'type' key, got %r" % (cfg,))
+    kwargs = {k: v for k, v in cfg.items() if k not in ("type", "requires_grad")}
+    kwargs.setdefault("eps", 1e-5)
+    try:
+        prefix, ctor = norm_cfg[cfg["type"]]
+    except KeyError:
+        raise KeyError("Unrecognized norm type {}".format(cfg["type"])) from None
+    if ctor is nn.GroupNorm:
+        layer = ctor(num_channels=num_features, **kwargs)  # needs num_groups in the config
     else:
-        assert "num_groups" in cfg_
-        layer = norm_layer(num_channels=num_features, **cfg_)
-    for p in layer.parameters():
-        p.requires_grad = requires_grad
-    return name, layer
+        layer = ctor(num_features, **kwargs)
+    layer.requires_grad_(bool(cfg.get("requires_grad", True)))
+    return "%s%s" % (prefix, postfix), layer
 
 
 # The RPN's Conv2d -> BatchNorm2d -> ReLU triples (channels-last maps) go through the fused HIP BatchNorm+ReLU
@@ -60,37 +60,30 @@ def _pad_folds_into(pad, conv):
 
 
 class Sequential(nn.Module):
-    """nn.Sequential with `.add()`; children are named "0", "1", ... so state-dict keys
-    match the reference (`neck.blocks.0.1.weight`, ...)."""
+    """nn.Sequential with `.add()`.  Children are registered under "0", "1", ... (or the given names), so state-dict
+    keys match the reference (`neck.blocks.0.1.weight`, ...).  Accepts modules, one OrderedDict, and named modules as
+    keywords, like the reference's container."""
 
     def __init__(self, *args, **kwargs):
         super().__init__()
-        if len(args) == 1 and isinstance(args[0], OrderedDict):
-            for key, module in args[0].items():
-                self.add_module(key, module)
-        else:
-            for idx, module in enumerate(args):
-                self.add_module(str(idx), module)
-        for name, module in kwargs.items():
-            if name in self._modules:
-                raise ValueError("name exists.")
-            self.add_module(name, module)
-
-    def __getitem__(self, idx):
-        if not (-len(self) <= idx < len(self)):
-            raise IndexError("index {} is out of range".format(idx))
-        if idx < 0:
-            idx += len(self)
-        return list(self._modules.values())[idx]
+        named = args[0].items() if len(args) == 1 and isinstance(args[0], OrderedDict) else \
+            ((str(i), m) for i, m in enumerate(args))
+        for name, module in list(named) + list(kwargs.items()):
+            self.add(module, name)
 
     def __len__(self):
         return len(self._modules)
 
+    def __getitem__(self, idx):
+        n = len(self)
+        if not -n <= idx < n:
+            raise IndexError("index {} is out of range".format(idx))
+        return list(self._modules.values())[idx % n]
+
     def add(self, module, name=None):
-        if name is None:
-            name = str(len(self._modules))
-            if name in self._modules:
-                raise KeyError("name exists")
+        name = str(len(self._modules)) if name is None else name
+        if name in self._modules:
+            raise KeyError("name exists")
         self.add_module(name, module)
 
     def forward(self, input):
@@ -130,20 +123,17 @@ class Sequential(nn.Module):
 
 
 class Empty(nn.Module):
+    """placeholder module: returns its positional inputs (one -> itself, none -> None, several -> the tuple)"""
+
     def __init__(self, *args, **kwargs):
         super().__init__()
 
     def forward(self, *args, **kwargs):
-        if len(args) == 1:
-            return args[0]
-        if len(args) == 0:
-            return None
-        return args
+        return args[0] if len(args) == 1 else (args or None)
 
 
 def get_paddings_indicator(actual_num, max_num, axis=0):
-    actual_num = torch.unsqueeze(actual_num, axis + 1)
-    shape = [1] * len(actual_num.shape)
-    shape[axis + 1] = -1
-    rng = torch.arange(max_num, dtype=torch.int, device=actual_num.device).view(shape)
-    return actual_num.int() > rng
+    """bool mask of the real entries: out[..., j, ...] = j < actual_num[...], the new axis inserted at axis + 1"""
+    ramp = torch.arange(max_num, dtype=torch.int32, device=actual_num.device)
+    ramp = ramp.view([-1 if d == axis + 1 else 1 for d in range(actual_num.dim() + 1)])
+    return ramp < actual_num.int().unsqueeze(axis + 1)
