@@ -51,7 +51,7 @@ SIGNATURES = {
     "d3d_bn_bwd_dx": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]),
     "d3d_conv2d_supported": (i32, [i32, i32, i32, i32]),
     "d3d_conv2d_stats_ws_floats": (sz, [i32, i32, i32, i32]),
-    "d3d_conv2d_nhwc_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "d3d_conv2d_nhwc_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
     "d3d_conv2d_pack_weights": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "d3d_split_planes": (i32, [vp, i64, vp, vp, vp]),
     "d3d_conv2d_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
@@ -102,6 +102,11 @@ class ConvEpilogue(ctypes.Structure):
     """D3dConvEpilogue of include/d3d.h (device pointers as integers)"""
     _fields_ = [("stats", vp), ("bn_x", vp), ("bn_mean", vp), ("bn_invstd", vp), ("bn_gamma", vp),
                 ("bn_beta", vp), ("bn_relu", i32), ("bn_partial", vp), ("ws_floats", i32)]
+
+
+class DenseBnBackward(ctypes.Structure):
+    """D3dDenseBnBackward of include/d3d.h"""
+    _fields_ = [("x", vp), ("mean", vp), ("invstd", vp), ("gamma", vp), ("beta", vp), ("relu", i32)]
 
 
 def lib():

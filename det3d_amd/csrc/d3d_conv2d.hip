@@ -41,9 +41,15 @@ struct Conv2dGeom {
 };
 
 struct Conv2dEpi {
-  float *stats;        // [2 * cout] result (sum | sum of squares), then one fold workspace per 128-channel tile; or nullptr
+  float *stats;        // [2 * cout] result, then one fold workspace per 128-channel tile; or nullptr
   unsigned *counters;  // ticket words, `ctr_stride` per 128-channel tile
   int fold_g, ws_stride, ctr_stride;
+  // what is summed per output channel: (sum y | sum y^2) of the produced rows -- BatchNorm statistics -- or, when
+  // bn_x is set (a data-gradient launch: the rows produced are dL/dz of the BatchNorm + ReLU that made this conv's
+  // input), (sum dz * xhat | sum dz) of that layer = what d3d_bn_bwd_reduce computes, with x = its pre-BN activations
+  const void *bn_x;
+  const float *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;
+  int bn_relu;
 };
 
 __device__ __forceinline__ uint16_t c2_f32_to_bf16(float f) {
@@ -233,19 +239,38 @@ __global__ void __launch_bounds__(128 * WPX, (WPX == 2 ? 2 : 1))
 #pragma unroll
       for (int r = 0; r < 16; ++r) s1[i][r] = s2[i][r] = 0.f;
   }
+  const bool want_bnb = want_stats && ep.bn_x != nullptr;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int m = m0 + wpx * 64 + j * 32 + (lane & 31);
-    const bool live = m < G.m;
+  for (int i = 0; i < 2; ++i) {
+    const int co_base = n0 + wco * 64 + i * 32 + 4 * (lane >> 5);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int co_base = n0 + wco * 64 + i * 32 + 4 * (lane >> 5);
+    for (int g = 0; g < 4; ++g) {
+      const int co = co_base + 8 * g;
+      // BatchNorm-backward mode: per-channel coefficients of z = x * zs + zb (the ReLU mask) and xhat = x * is + mi,
+      // the arithmetic of bn_bwd_reduce_kernel / bn_bwd_dx_kernel (d3d_bn.hip)
+      float is[4], mi[4], zs[4], zb[4];
+      if (want_bnb) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = co_base + 8 * g;
+        for (int e = 0; e < 4; ++e) {
+          const float gm = ep.bn_gamma ? ep.bn_gamma[co + e] : 1.f, bt = ep.bn_beta ? ep.bn_beta[co + e] : 0.f;
+          is[e] = ep.bn_invstd[co + e];
+          mi[e] = -ep.bn_mean[co + e] * is[e];
+          zs[e] = gm * is[e];
+          zb[e] = fmaf(mi[e], gm, bt);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m = m0 + wpx * 64 + j * 32 + (lane & 31);
+        const bool live = m < G.m;
         float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (OUT_F32) {
           if (live) *(float4 *)((float *)y + (int64_t)m * G.cout + co) = make_float4(v[0], v[1], v[2], v[3]);
+          if (want_bnb && live) {
+            const float4 xr = *(const float4 *)((const float *)ep.bn_x + (int64_t)m * G.cout + co);
+            x[0] = xr.x; x[1] = xr.y; x[2] = xr.z; x[3] = xr.w;
+          }
         } else {
           const uint16_t h0 = c2_f32_to_bf16(v[0]), h1 = c2_f32_to_bf16(v[1]), h2 = c2_f32_to_bf16(v[2]),
                          h3 = c2_f32_to_bf16(v[3]);
@@ -257,12 +282,23 @@ __global__ void __launch_bounds__(128 * WPX, (WPX == 2 ? 2 : 1))
           }
           v[0] = __uint_as_float((uint32_t)h0 << 16); v[1] = __uint_as_float((uint32_t)h1 << 16);
           v[2] = __uint_as_float((uint32_t)h2 << 16); v[3] = __uint_as_float((uint32_t)h3 << 16);
+          if (want_bnb && live) {
+            const uint2 xr = *(const uint2 *)((const uint16_t *)ep.bn_x + (int64_t)m * G.cout + co);
+            x[0] = __uint_as_float(xr.x << 16); x[1] = __uint_as_float(xr.x & 0xffff0000u);
+            x[2] = __uint_as_float(xr.y << 16); x[3] = __uint_as_float(xr.y & 0xffff0000u);
+          }
         }
-        if (want_stats && live) {  // statistics of the values as stored
+        if (want_stats && live) {  // sums over the values as stored
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            s1[i][4 * g + e] += v[e];
-            s2[i][4 * g + e] = fmaf(v[e], v[e], s2[i][4 * g + e]);
+            if (want_bnb) {
+              const float dz = (ep.bn_relu && fmaf(x[e], zs[e], zb[e]) <= 0.f) ? 0.f : v[e];
+              s1[i][4 * g + e] = fmaf(dz, fmaf(x[e], is[e], mi[e]), s1[i][4 * g + e]);
+              s2[i][4 * g + e] += dz;
+            } else {
+              s1[i][4 * g + e] += v[e];
+              s2[i][4 * g + e] = fmaf(v[e], v[e], s2[i][4 * g + e]);
+            }
           }
         }
       }
@@ -609,7 +645,8 @@ static int c2_geom(const char *who, Conv2dGeom &G, int batch, int h, int w, int 
 
 extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo, void *y,
                                    int batch, int h, int w, int cin, int cout, int ksz, int stride, int pad,
-                                   int mode, float *stats_ws, size_t stats_ws_floats, d3d_stream_t stream_) {
+                                   int mode, float *stats_ws, size_t stats_ws_floats, const D3dDenseBnBackward *bn,
+                                   d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = c2_check("d3d_conv2d_nhwc_fwd", batch, h, w, cin, cout, ksz, stride, pad, mode);
   if (rc) return rc;
@@ -622,7 +659,14 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
   const int wpx = (variant & 2) ? 4 : 2;
   const int bm = 64 * wpx;
   const int nb = (G.m + bm - 1) / bm;
-  Conv2dEpi ep = {nullptr, nullptr, 16, 0, 0};
+  Conv2dEpi ep = {};
+  ep.fold_g = 16;
+  D3D_REQUIRE(!bn || stats_ws, "d3d_conv2d_nhwc_fwd: the BatchNorm-backward sums need the statistics workspace");
+  D3D_REQUIRE(!bn || (bn->x && bn->mean && bn->invstd), "d3d_conv2d_nhwc_fwd: bn needs x, mean, invstd");
+  if (bn) {
+    ep.bn_x = bn->x; ep.bn_mean = bn->mean; ep.bn_invstd = bn->invstd; ep.bn_gamma = bn->gamma; ep.bn_beta = bn->beta;
+    ep.bn_relu = bn->relu;
+  }
   if (stats_ws) {
     D3D_REQUIRE(nb <= D3D_FOLD_MAX_BLOCKS, "d3d_conv2d_nhwc_fwd: %d pixel tiles > %d for the statistics fold", nb,
                 D3D_FOLD_MAX_BLOCKS);

@@ -15,6 +15,7 @@
 //   launch 2: everything else
 #include "d3d_common.h"
 #include "d3d_fill.h"
+#include "d3d_fold.h"
 
 #define LOSS_MAX_CODE 10
 #define LOSS_MAX_CLS 8
@@ -81,9 +82,11 @@ __global__ void __launch_bounds__(256)
                      const void *__restrict__ dir_preds, int bf16, const int32_t *__restrict__ labels,
                      const float *__restrict__ reg_targets, const float *__restrict__ anchors, LossCfg C,
                      const float *__restrict__ npos, void *__restrict__ g_box, void *__restrict__ g_cls,
-                     void *__restrict__ g_dir, float *__restrict__ scalars) {
-  __shared__ float red[LOSS_NSCALAR];
-  for (int i = threadIdx.x; i < LOSS_NSCALAR; i += blockDim.x) red[i] = 0.f;
+                     void *__restrict__ g_dir, float *__restrict__ scalars, float *__restrict__ fold_ws,
+                     unsigned *__restrict__ counters, int fold_g) {
+  __shared__ float rows[4][LOSS_NSCALAR];  // one row per wave
+  __shared__ float tot[LOSS_NSCALAR];
+  __shared__ int fold_flag;
   __syncthreads();
   float acc[LOSS_NSCALAR];
 #pragma unroll
@@ -176,20 +179,27 @@ __global__ void __launch_bounds__(256)
     }
   }
   acc[0] = acc[1] + acc[2] + acc[3] * C.w_dir;
+  // logged scalars: lanes by shuffles, the block's four waves in wave order, the blocks through the fixed-order fold
+  // (d3d_fold.h) -- the loss VALUE repeats bit for bit like the gradients do (round 2 summed it with float atomics)
 #pragma unroll
   for (int i = 0; i < LOSS_NSCALAR; ++i) {
-    if (i == 6 || i == 7) continue;
-    float v = acc[i];
+    float v = (i == 6 || i == 7) ? 0.f : acc[i];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(&red[i], v);
+    if ((threadIdx.x & 63) == 0) rows[threadIdx.x >> 6][i] = v;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < LOSS_NSCALAR; i += blockDim.x)
-    if (i != 6 && i != 7 && red[i] != 0.f) atomicAdd(&scalars[i], red[i]);
+  if (threadIdx.x < LOSS_NSCALAR) tot[threadIdx.x] = rows[0][threadIdx.x] + rows[1][threadIdx.x] + rows[2][threadIdx.x] + rows[3][threadIdx.x];
+  __syncthreads();
+  if (d3d_fold_block<256>(tot, LOSS_NSCALAR, fold_ws, counters, fold_g, &fold_flag)) {
+    const int i = threadIdx.x;
+    if (i < LOSS_NSCALAR && i != 6 && i != 7) scalars[i] = fold_ws[i];  // [6], [7]: exact counts from loss_count_kernel
+  }
 }
 
+#define LOSS_MAX_BLOCKS 1024
 extern "C" size_t d3d_head_loss_workspace_bytes(int batch) {
-  return d3d_align_up((size_t)batch * sizeof(float)) + 256;
+  // per-frame positive counts, then the fold workspace of the logged scalars
+  return d3d_align_up((size_t)batch * sizeof(float)) + d3d_fold_ws_floats(LOSS_MAX_BLOCKS, LOSS_NSCALAR) * sizeof(float) + 256;
 }
 
 extern "C" int d3d_head_loss(const void *box_preds, const void *cls_preds, const void *dir_preds, int dtype,
@@ -235,10 +245,14 @@ extern "C" int d3d_head_loss(const void *box_preds, const void *cls_preds, const
   C.w_loc = loc_weight, C.w_cls = cls_weight, C.w_dir = dir_weight;
   int64_t items = (int64_t)batch * num_anchors;
   int nb = (int)((items + 255) / 256);
-  if (nb > 1024) nb = 1024;
+  if (nb > LOSS_MAX_BLOCKS) nb = LOSS_MAX_BLOCKS;
+  const D3dFoldPlan fp = d3d_fold_plan(nb, LOSS_NSCALAR);
+  float *fold_ws = (float *)((char *)workspace + d3d_align_up((size_t)batch * sizeof(float)));
+  unsigned *counters = d3d_fold_counters(d3d_fold_counter_words(fp));
+  if (!counters) return D3D_EHIP;
   hipLaunchKernelGGL(loss_main_kernel, dim3(nb), dim3(256), 0, stream, box_preds, cls_preds, dir_preds,
                      dtype == D3D_BF16, labels, reg_targets, anchors, C, npos, grad_box, grad_cls, grad_dir,
-                     scalars);
+                     scalars, fold_ws, counters, fp.g);
   D3D_LAUNCH_TRY("loss_main_kernel");
   return D3D_OK;
 }

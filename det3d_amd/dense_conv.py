@@ -13,6 +13,7 @@ Weights keep nn.Conv2d's parameter layout [cout, cin, kh, kw] f32 (checkpoint co
 [tap][cout][cin] (forward) and [mirrored tap][cin][cout] (data gradient of stride-1 layers) are cached per
 parameter version like the sparse conv's.
 """
+import ctypes
 import weakref
 
 import torch
@@ -79,9 +80,11 @@ def _out_hw(h, w, ksz, stride, pad):
     return (h + 2 * pad - ksz) // stride + 1, (w + 2 * pad - ksz) // stride + 1
 
 
-def conv2d_raw(x_hi, x_lo, w_hi, w_lo, ksz, stride, pad, mode, want_stats=False):
+def conv2d_raw(x_hi, x_lo, w_hi, w_lo, ksz, stride, pad, mode, want_stats=False, bn_backward=None):
     """x_hi (and x_lo in split mode): [B,H,W,Cin] bf16 contiguous; w_*: [ksz*ksz, Cout, Cin] bf16.
-    Returns (y [B,Ho,Wo,Cout] bf16 | f32, stats workspace or None: its first 2*Cout floats are sum | sum of squares)"""
+    Returns (y [B,Ho,Wo,Cout] bf16 | f32, workspace or None: its first 2*Cout floats are sum | sum of squares of y).
+    bn_backward = (x, mean, invstd, gamma, beta, relu): a data-gradient launch -- the workspace then starts with
+    sum dz*xhat | sum dz of the BatchNorm(+ReLU) whose output fed the convolution (d3d_bn_bwd_reduce's result)."""
     L = _lib.lib()
     b, h, w, cin = x_hi.shape
     cout = w_hi.shape[1]
@@ -90,13 +93,21 @@ def conv2d_raw(x_hi, x_lo, w_hi, w_lo, ksz, stride, pad, mode, want_stats=False)
     y = torch.empty((b, ho, wo, cout), dtype=torch.float32 if mode == "split" else torch.bfloat16, device=dev)
     ws = None
     nws = 0
+    bn = None
+    if bn_backward is not None:
+        bx, bmean, binv, bgamma, bbeta, brelu = bn_backward
+        assert tuple(bx.shape) == (b, ho, wo, cout) and bx.dtype == (torch.float32 if mode == "split" else torch.bfloat16)
+        bn = _lib.DenseBnBackward(x=bx.data_ptr(), mean=bmean.data_ptr(), invstd=binv.data_ptr(),
+                                  gamma=_lib.ptr(bgamma), beta=_lib.ptr(bbeta), relu=int(brelu))
+        want_stats = True
     if want_stats:
         nws = L.d3d_conv2d_stats_ws_floats(b, ho, wo, cout)
         if nws == 0:
             raise _lib.D3dError("conv2d statistics epilogue: unsupported shape")
         ws = torch.empty((nws,), dtype=torch.float32, device=dev)
     rc = L.d3d_conv2d_nhwc_fwd(x_hi.data_ptr(), _lib.ptr(x_lo), w_hi.data_ptr(), _lib.ptr(w_lo), y.data_ptr(), b, h, w,
-                               cin, cout, ksz, stride, pad, _MODES[mode], _lib.ptr(ws), nws, _lib.stream_ptr(dev))
+                               cin, cout, ksz, stride, pad, _MODES[mode], _lib.ptr(ws), nws,
+                               ctypes.byref(bn) if bn is not None else None, _lib.stream_ptr(dev))
     _lib.check(rc, "d3d_conv2d_nhwc_fwd")
     return y, ws
 

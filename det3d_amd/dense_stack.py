@@ -5,8 +5,9 @@ Reference: the RPN blocks and deblocks, det3d/models/necks/rpn.py:58-100 (`Seque
 BN, ReLU, [Conv2d(3x3, padding=1), BN, ReLU] * n)`), cuDNN kernels behind nn.Conv2d / nn.BatchNorm2d.  Per layer:
 
   forward   conv (BN statistics in its epilogue)  ->  bn_apply (+ReLU), written in the next conv's operand format
-  backward  bn_bwd_reduce -> bn_bwd_dx (written in the conv operand format) -> wgrad (two-pass) -> dgrad (= the
-            forward kernel on the mirrored taps)
+  backward  bn_bwd_dx (written in the conv operand format) -> wgrad (two-pass) -> dgrad (= the forward kernel on the
+            mirrored taps, with the previous layer's BatchNorm-backward sums in its epilogue; only the last layer
+            of a run needs the stand-alone bn_bwd_reduce sweep)
 
 Two precisions, chosen by the dtype of the incoming map:
   bfloat16 (the step runs under autocast)  : bf16 operands and activations, f32 accumulation
@@ -26,6 +27,7 @@ from . import dense_conv as dc
 
 ENABLED = os.environ.get("D3D_DENSE_CONV", "1") != "0"
 FP32_MODE = os.environ.get("D3D_RPN_FP32", "split")  # "split" | "exact" (MIOpen f32)
+FUSE_BN_BACKWARD = os.environ.get("D3D_DENSE_FUSE_BN_BWD", "1") != "0"  # BN-backward sums in the dgrad epilogue
 
 
 class _Layer:
@@ -180,15 +182,18 @@ class _DenseStackFn(torch.autograd.Function):
         if not dy.is_contiguous():
             dy = dy.contiguous()
         grads = []
+        partial = None  # BN-backward sums of layer li, left behind by the dgrad epilogue of layer li + 1
         for li in range(len(layers) - 1, -1, -1):
             ly = layers[li]
             bn = ly.bn
             a_hi, a_lo, y, save = rec[li]
             n, cout = y.shape[0] * y.shape[1] * y.shape[2], ly.cout
-            partial = torch.empty((L.d3d_bn_reduce_ws_floats(n, cout, dt),), dtype=torch.float32, device=dev)
-            rc = L.d3d_bn_bwd_reduce(y.data_ptr(), dy.data_ptr(), n, cout, dt, bn.weight.data_ptr(), bn.bias.data_ptr(),
-                                     save[0].data_ptr(), save[1].data_ptr(), int(ly.relu), partial.data_ptr(), st)
-            _lib.check(rc, "d3d_bn_bwd_reduce")
+            if partial is None:
+                partial = torch.empty((L.d3d_bn_reduce_ws_floats(n, cout, dt),), dtype=torch.float32, device=dev)
+                rc = L.d3d_bn_bwd_reduce(y.data_ptr(), dy.data_ptr(), n, cout, dt, bn.weight.data_ptr(),
+                                         bn.bias.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), int(ly.relu),
+                                         partial.data_ptr(), st)
+                _lib.check(rc, "d3d_bn_bwd_reduce")
             gbn = torch.empty((2, cout), dtype=torch.float32, device=dev)
             if split:
                 g_hi = torch.empty(y.shape, dtype=torch.bfloat16, device=dev)
@@ -205,9 +210,17 @@ class _DenseStackFn(torch.autograd.Function):
                                      g_hi.data_ptr(), gbn[0].data_ptr(), gbn[1].data_ptr(), st)
                 _lib.check(rc, "d3d_bn_bwd_dx")
             gw = dc.wgrad_raw(g_hi, g_lo, a_hi, a_lo, ly.ksz, 1, ly.pad, mode)
+            partial = None
             if li > 0 or ctx.need_in_grad:
                 wd_hi, wd_lo = dc._packed(ly.conv.weight, "dgrad", mode)
-                dy, _ = dc.conv2d_raw(g_hi, g_lo, wd_hi, wd_lo, ly.ksz, 1, ly.ksz - 1 - ly.pad, mode)
+                bnb = None
+                if li > 0 and FUSE_BN_BACKWARD:
+                    # the rows this launch produces are dL/dz of layer li - 1's BatchNorm + ReLU: reduce its sums here
+                    pl = layers[li - 1]
+                    _, _, py, psave = rec[li - 1]
+                    bnb = (py, psave[0], psave[1], pl.bn.weight, pl.bn.bias, pl.relu)
+                dy, partial = dc.conv2d_raw(g_hi, g_lo, wd_hi, wd_lo, ly.ksz, 1, ly.ksz - 1 - ly.pad, mode,
+                                            bn_backward=bnb)
             else:
                 dy = None
             grads.append([gw, gbn[0], gbn[1]])

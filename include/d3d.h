@@ -266,11 +266,21 @@ int d3d_channel_affine_bwd(const void *x, const void *dy, int n, int c, int dtyp
  * d3d_split_planes: f32 [n] -> the hi / lo planes of the split format. */
 #define D3D_CONV_BF16 0
 #define D3D_CONV_SPLIT 1
+/* With `bn` set, d3d_conv2d_nhwc_fwd is a DATA-GRADIENT launch whose produced rows are dL/dz of the BatchNorm(+ReLU)
+ * that made the convolution's input (rpn.py:124-142): instead of the statistics of the produced rows, the epilogue
+ * leaves sum dz * xhat | sum dz in stats_ws[0 .. 2*cout) -- what d3d_bn_bwd_reduce computes -- with x = that layer's
+ * pre-BN activations [batch, ho, wo, cout] in this launch's OUTPUT element type, its saved mean / invstd and its
+ * gamma / beta (NULL = 1 / 0), dz = dy masked by the ReLU when relu != 0. */
+typedef struct D3dDenseBnBackward {
+  const void *x;
+  const float *mean, *invstd, *gamma, *beta;
+  int relu;
+} D3dDenseBnBackward;
 int d3d_conv2d_supported(int cin, int cout, int ksz, int stride);
 size_t d3d_conv2d_stats_ws_floats(int batch, int ho, int wo, int cout);
 int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo, void *y, int batch,
                         int h, int w, int cin, int cout, int ksz, int stride, int pad, int mode, float *stats_ws,
-                        size_t stats_ws_floats, d3d_stream_t stream);
+                        size_t stats_ws_floats, const D3dDenseBnBackward *bn, d3d_stream_t stream);
 int d3d_conv2d_pack_weights(const float *weight, int cout, int cin, int ksz, void *fwd_hi, void *fwd_lo,
                             void *dgrad_hi, void *dgrad_lo, d3d_stream_t stream);
 int d3d_split_planes(const float *x, int64_t n, void *hi, void *lo, d3d_stream_t stream);

@@ -184,3 +184,35 @@ def test_dense_stack_is_the_torch_module_stack(dtype):
         finally:
             dense_stack.ENABLED = prev
     close(ye, yer, "eval output")
+
+
+@pytest.mark.parametrize("mode", ["bf16", "split"])
+def test_data_gradient_epilogue_reduces_the_previous_batchnorm_backward_sums(mode):
+    """bn_backward: the dgrad launch's rows are dL/dz of the BatchNorm + ReLU in front of the convolution; its epilogue
+    must leave what d3d_bn_bwd_reduce computes from the same rows (sum dz * xhat | sum dz), bit-reproducibly."""
+    from det3d_amd import _lib
+    from det3d_amd import dense_conv as dc
+
+    L = _lib.lib()
+    b, h, w, c = 2, 30, 26, 128
+    g = torch.Generator(device="cuda").manual_seed(5)
+    weight = torch.nn.Parameter(torch.randn((128, c, 3, 3), device="cuda", generator=g) * 0.03)
+    gy = torch.randn((b, h, w, 128), device="cuda", generator=g)
+    tdt = torch.float32 if mode == "split" else torch.bfloat16
+    x = (torch.randn((b, h, w, c), device="cuda", generator=g) * 1.3 + 0.2).to(tdt)  # the previous layer's pre-BN rows
+    mean, var = x.float().mean((0, 1, 2)), x.float().var((0, 1, 2), unbiased=False)
+    invstd = torch.rsqrt(var + 1e-3)
+    gamma = torch.rand(c, device="cuda", generator=g) + 0.5
+    beta = torch.randn(c, device="cuda", generator=g) * 0.3
+    w_hi, w_lo = dc._packed(weight, "dgrad", mode)
+    g_hi, g_lo = dc.split_planes(gy) if mode == "split" else (gy.to(torch.bfloat16), None)
+    dy, ws = dc.conv2d_raw(g_hi, g_lo, w_hi, w_lo, 3, 1, 1, mode, bn_backward=(x, mean, invstd, gamma, beta, True))
+    dy2, ws2 = dc.conv2d_raw(g_hi, g_lo, w_hi, w_lo, 3, 1, 1, mode, bn_backward=(x, mean, invstd, gamma, beta, True))
+    assert torch.equal(dy, dy2) and torch.equal(ws[:2 * c], ws2[:2 * c])
+    n = b * h * w
+    dt = _lib.D3D_F32 if mode == "split" else _lib.D3D_BF16
+    ref = torch.empty(L.d3d_bn_reduce_ws_floats(n, c, dt), device="cuda")
+    _lib.check(L.d3d_bn_bwd_reduce(x.data_ptr(), dy.data_ptr(), n, c, dt, gamma.data_ptr(), beta.data_ptr(),
+                                   mean.data_ptr(), invstd.data_ptr(), 1, ref.data_ptr(), _lib.stream_ptr(x.device)), "reduce")
+    got, want = ws[:2 * c].double(), ref[:2 * c].double()
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-4
