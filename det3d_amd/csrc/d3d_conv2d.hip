@@ -465,23 +465,24 @@ __global__ void __launch_bounds__(256, 2)
   const int i16 = lane & 15;
   const int prow = ((lane >> 5) << 3) + (i16 >> 2);                 // pixel row within a 16-pixel substep (first read)
   const int chan = (((lane >> 4) & 1) << 4) + ((i16 & 3) << 2);     // channel within a 32-channel tile
-  auto frag = [&](const unsigned char *plane, int tile32, int kk) -> c2_bf16x8 {
-    typedef __attribute__((ext_vector_type(4))) short s4;
-    const int ch = tile32 * 32 + chan;  // channel within the 128-wide staged tile
-    s4 lo, hi;
-    {
-      const int r = kk * 16 + prow;
-      const int byte = r * 256 + ((((ch * 2) >> 4) ^ ((r & 3) << 2)) << 4) + ((ch * 2) & 15);
-      lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)(plane + byte));
-    }
-    {
-      const int r = kk * 16 + prow + 4;
-      const int byte = r * 256 + ((((ch * 2) >> 4) ^ ((r & 3) << 2)) << 4) + ((ch * 2) & 15);
-      hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)(plane + byte));
-    }
-    typedef __attribute__((ext_vector_type(8))) short s8;
-    s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(c2_bf16x8, v);
+  // The reads are inline asm: through the builtin, hipcc orders every transposing read behind the LDS-DMA
+  // instructions of the NEXT stage that were issued just before (s_waitcnt vmcnt(0) in front of the first read: the
+  // loads it should overlap with were drained first).  The stage being read was waited for at the top of the loop
+  // (vmcnt(0) + barrier); the asm block below waits for its own reads (lgkmcnt) before the MFMAs use them.
+  typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+  // byte offset inside a plane of this lane's 8 bytes for (32-channel tile, substep 0, first read); the second read is
+  // 4 pixel rows (1024 B) further, a substep 16 rows (4096 B): the swizzle term (r & 3) is the same for all of them
+  uint32_t fo[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ch = t * 32 + chan;
+    fo[t] = (uint32_t)(prow * 256 + ((((ch * 2) >> 4) ^ ((prow & 3) << 2)) << 4) + ((ch * 2) & 15));
+  }
+  auto tr_read = [&](uint32_t addr) -> u2 {
+    u2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
   };
 
   if (nks > 0) stage(0);
@@ -490,16 +491,41 @@ __global__ void __launch_bounds__(256, 2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (ks + 1 < nks) stage(buf ^ 1);
-    const unsigned char *sg = smem + buf * STAGE, *sx = sg + NP * PLANE;
 #pragma unroll
     for (int kk = 0; kk < KP / 16; ++kk) {
+      u2 gr[2][NP][2], xr[2][NP][2];  // [tile][plane][first / second read]
+      const uint32_t gbase = lds_base + (uint32_t)(buf * STAGE + kk * 4096);
+      const uint32_t xbase = gbase + (uint32_t)(NP * PLANE);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            gr[t][p][h] = tr_read(gbase + (uint32_t)(p * PLANE + h * 1024) + fo[wco * 2 + t]);
+            xr[t][p][h] = tr_read(xbase + (uint32_t)(p * PLANE + h * 1024) + fo[wci * 2 + t]);
+          }
+      // wait for the reads; the operands are tied to the wait so that no MFMA is scheduled in front of it
+      if constexpr (SPLIT)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(gr[0][0][0]), "+v"(gr[0][0][1]), "+v"(gr[1][0][0]), "+v"(gr[1][0][1]), "+v"(xr[0][0][0]),
+                       "+v"(xr[0][0][1]), "+v"(xr[1][0][0]), "+v"(xr[1][0][1]), "+v"(gr[0][NP - 1][0]),
+                       "+v"(gr[0][NP - 1][1]), "+v"(gr[1][NP - 1][0]), "+v"(gr[1][NP - 1][1]), "+v"(xr[0][NP - 1][0]),
+                       "+v"(xr[0][NP - 1][1]), "+v"(xr[1][NP - 1][0]), "+v"(xr[1][NP - 1][1]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(gr[0][0][0]), "+v"(gr[0][0][1]), "+v"(gr[1][0][0]), "+v"(gr[1][0][1]), "+v"(xr[0][0][0]),
+                       "+v"(xr[0][0][1]), "+v"(xr[1][0][0]), "+v"(xr[1][0][1]));
       c2_bf16x8 ga[2][NP], xb[2][NP];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          ga[t][p] = frag(sg + p * PLANE, wco * 2 + t, kk);
-          xb[t][p] = frag(sx + p * PLANE, wci * 2 + t, kk);
+          typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+          const u4 gv = {gr[t][p][0][0], gr[t][p][0][1], gr[t][p][1][0], gr[t][p][1][1]};
+          const u4 xv = {xr[t][p][0][0], xr[t][p][0][1], xr[t][p][1][0], xr[t][p][1][1]};
+          ga[t][p] = __builtin_bit_cast(c2_bf16x8, gv);
+          xb[t][p] = __builtin_bit_cast(c2_bf16x8, xv);
         }
 #pragma unroll
       for (int i = 0; i < 2; ++i)

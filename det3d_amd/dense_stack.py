@@ -27,7 +27,11 @@ from . import dense_conv as dc
 
 ENABLED = os.environ.get("D3D_DENSE_CONV", "1") != "0"
 FP32_MODE = os.environ.get("D3D_RPN_FP32", "split")  # "split" | "exact" (MIOpen f32)
-FUSE_BN_BACKWARD = os.environ.get("D3D_DENSE_FUSE_BN_BWD", "1") != "0"  # BN-backward sums in the dgrad epilogue
+# BN-backward sums in the dgrad epilogue.  OFF: measured on the [4, 200, 176, 128] maps the epilogue (x re-read with
+# 16-byte accesses at pixel stride + the 62-shuffle butterfly) adds ~35 us to a split-mode data-gradient launch while the
+# streaming d3d_bn_bwd_reduce it replaces takes 29 us (gpurun_out r3j11 vs r3j5); the forward statistics epilogue
+# (+11-19 us against 11-20 us for d3d_bn_stats) is break-even and stays on because it saves the launches.
+FUSE_BN_BACKWARD = os.environ.get("D3D_DENSE_FUSE_BN_BWD", "0") == "1"
 
 
 class _Layer:

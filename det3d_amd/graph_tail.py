@@ -109,7 +109,8 @@ class GraphedTail:
         # the weight gradients (split-K igemm with atomics) rely on zero-initialisation that is not part of the
         # captured work, so every replay accumulated onto the previous one -- gradient norm inf after a few
         # steps (tools/diag_nan.py).  Immediate-mode solvers replay correctly.
-        with ctx, torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=False):
+        with ctx, torch.backends.cudnn.flags(enabled=True, benchmark=False,
+                                             deterministic=torch.backends.cudnn.deterministic):
             graphed = torch.cuda.make_graphed_callables(tail, sample, num_warmup_iters=3, allow_unused_input=True)
         with torch.no_grad():
             sd = tail.state_dict()

@@ -69,6 +69,10 @@ def _run(model, examples, graphed, dtype):
     prev = graph_tail.GRAPH_TAIL
     graph_tail.GRAPH_TAIL = graphed
     out = []
+    # everything this repo launches sums in a fixed order; the head's 1x1 convolutions are MIOpen's, whose default
+    # weight-gradient solvers use atomics: ask for its deterministic ones so that whole steps can be compared bit for bit
+    det = torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=True)
+    det.__enter__()
     try:
         for ex in examples:
             model.zero_grad(set_to_none=True)
@@ -80,6 +84,7 @@ def _run(model, examples, graphed, dtype):
             out.append((float(loss), [float(v) for v in losses["loc_loss_reduced"]],
                         {k: p.grad.float().clone() for k, p in model.named_parameters() if p.grad is not None}))
     finally:
+        det.__exit__(None, None, None)
         graph_tail.GRAPH_TAIL = prev
     return out
 
@@ -146,6 +151,8 @@ def test_prefetched_geometry_is_the_inline_geometry():
     pf = GeometryPrefetcher(make, model, dev)
     prev_g = graph_tail.GRAPH_TAIL
     graph_tail.GRAPH_TAIL = False
+    det = torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=True)  # see _run
+    det.__enter__()
     try:
         for i in range(3):
             ex_a = make(i)
@@ -170,6 +177,7 @@ def test_prefetched_geometry_is_the_inline_geometry():
                 # same kernels on the same geometry, every sum in a fixed order: bit-equal
                 assert torch.equal(g, model.get_parameter(k).grad), k
     finally:
+        det.__exit__(None, None, None)
         graph_tail.GRAPH_TAIL = prev_g
 
 
