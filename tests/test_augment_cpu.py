@@ -79,14 +79,18 @@ def _object_noise_batch(z, frames, num_try=40):
         dict(loc_noises=loc, rot_noises=rot), torch.from_numpy(valid)
 
 
-def test_per_object_noise_reproduces_the_reference_function():
+def check_per_object_noise(device):
     """f2: noise_per_object_v3_ (core/sampler/preprocess.py:587-709) on a collated batch: the same candidate is
     accepted for every box (collision tests incl. the boxes already moved), boxes and the points inside them land
-    where the reference's numba functions put them (tests/golden/object_noise.npz, made by running those functions)."""
+    where the reference's numba functions put them (tests/golden/object_noise.npz, made by running those functions).
+    `device`: where the batch lives (tests/test_pipeline_gpu.py runs the same check on CUDA tensors)."""
     z = np.load(os.path.join(GOLDEN, "object_noise.npz"))
     frames = [0, 1, 2]
     pts, off, gt, count, params, valid = _object_noise_batch(z, frames)
+    pts, off, gt, valid = pts.to(device), off.to(device), gt.to(device), valid.to(device)
     new_pts, new_gt, selected = augment.noise_per_object(pts, off, gt, count, params, valid_mask=valid)
+    assert new_pts.device.type == new_gt.device.type == torch.device(device).type
+    new_pts, new_gt, selected, gt = new_pts.cpu(), new_gt.cpu(), selected.cpu(), gt.cpu()
     for i, f in enumerate(frames):
         n = int(count[i])
         ref_gt, ref_pts = z["f%d_gt_out" % f], z["f%d_points_out" % f]
@@ -99,6 +103,10 @@ def test_per_object_noise_reproduces_the_reference_function():
         assert (selected[i, :n].numpy() >= 0).tolist() == moved.tolist()
         assert not moved[5] and int(selected[i, 5]) == -1      # valid_mask False: an obstacle that stays put
     assert (selected[:, -2:] == -1).all()
+
+
+def test_per_object_noise_reproduces_the_reference_function():
+    check_per_object_noise("cpu")
 
 
 def test_per_object_noise_never_leaves_boxes_colliding():

@@ -27,9 +27,15 @@ def _db(z):
 
 
 def test_device_gt_sampler_reproduces_the_reference_sampler():
+    check_gt_sampler("cpu")
+
+
+def check_gt_sampler(device):
+    """`device`: where the database and the frame's cloud live (tests/test_pipeline_gpu.py: "cuda")"""
     z = np.load(os.path.join(GOLDEN, "gt_sampler.npz"))
     np.random.seed(123)
-    sampler = DeviceGTSampler(_db(z), GROUPS, PREP, rate=1.0, device="cpu")
+    sampler = DeviceGTSampler(_db(z), GROUPS, PREP, rate=1.0, device=device)
+    assert sampler.points.device.type == torch.device(device).type
     for frame in range(4):
         gt, names, pts = z["f%d_gt" % frame], z["f%d_names" % frame], z["f%d_points" % frame]
         s = sampler.sample_all(gt, names)
@@ -38,10 +44,11 @@ def test_device_gt_sampler_reproduces_the_reference_sampler():
         assert np.array_equal(s["gt_boxes"], z["f%d_s_gt_boxes" % frame])
         assert np.array_equal(s["difficulty"], z["f%d_s_difficulty" % frame])
         assert np.array_equal(s["group_ids"], z["f%d_s_group_ids" % frame]) and s["gt_masks"].all()
-        assert np.allclose(s["points"].numpy(), z["f%d_s_points" % frame], atol=1e-6)
-        pasted, boxes, all_names, mask = sampler.paste(torch.from_numpy(pts), gt, names, s)
+        assert np.allclose(s["points"].cpu().numpy(), z["f%d_s_points" % frame], atol=1e-6)
+        pasted, boxes, all_names, mask = sampler.paste(torch.from_numpy(pts).to(device), gt, names, s)
         ref = z["f%d_pasted_points" % frame]
-        assert pasted.shape == ref.shape and np.allclose(pasted.numpy(), ref, atol=1e-6), frame
+        assert pasted.device.type == torch.device(device).type
+        assert pasted.shape == ref.shape and np.allclose(pasted.cpu().numpy(), ref, atol=1e-6), frame
         assert len(boxes) == len(all_names) == len(mask) == len(gt) + len(s["gt_names"])
         # the sampled boxes collide neither with the frame's boxes nor with each other
         from det3d_amd.augment import _bev_corners, _box_collision

@@ -12,6 +12,8 @@ from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 
+from test_preprocess_cpu import setup  # noqa: E402,F401  (fixture: synthetic GT database on disk + config factory)
+
 
 @pytest.mark.parametrize("tag,flip,rot", [("kitti", "y", [-0.78539816, 0.78539816]), ("nusc", "both", [-0.3925, 0.3925])])
 def test_device_augmentation_reproduces_the_reference_functions(tag, flip, rot):
@@ -75,3 +77,63 @@ def test_bn_folded_detector_matches_the_unfolded_one_on_the_gpu(name):
         for k in w:
             scale = float(w[k].abs().max())
             assert float((w[k] - g[k]).abs().max()) < 1e-4 * max(scale, 1.0), k
+
+
+def test_per_object_noise_on_the_gpu_reproduces_the_reference_function():
+    """f2 on the device: noise_per_object_v3_ (core/sampler/preprocess.py:587-709) on a collated CUDA batch -- same
+    accepted candidates, boxes and points as the reference's numba functions (tests/golden/object_noise.npz)"""
+    from test_augment_cpu import check_per_object_noise
+
+    check_per_object_noise("cuda")
+
+
+def test_gt_database_sampling_on_the_gpu_reproduces_the_reference_sampler():
+    """f2 on the device: DataBaseSamplerV2 (core/sampler/sample_ops.py) with the database resident in HBM: same
+    objects / survivors / pasted cloud over four consecutive frames (tests/golden/gt_sampler.npz)"""
+    from test_gt_sampler_cpu import check_gt_sampler
+
+    check_gt_sampler("cuda")
+
+
+def test_preprocess_step_on_the_gpu_matches_the_reference_step(setup):
+    """f2 on the device: the whole Preprocess step (datasets/pipelines/preprocess.py:215-217 shuffle included) with
+    the cloud on the GPU: same boxes, names and points IN THE SAME ORDER (tests/golden/preprocess.npz)"""
+    from test_preprocess_cpu import check_kitti_train_step
+
+    check_kitti_train_step(setup, "cuda")
+
+
+def test_preprocessed_frames_go_through_the_geometry_prefetcher(setup):
+    """the device pipeline in front of the training step: Preprocess (sampling, noise, global augmentation, shuffle)
+    on the side stream of GeometryPrefetcher, its output straight into the device voxelizer -- no host copy of the
+    cloud between augmentation and voxelization"""
+    from det3d_amd import pipelines, synthetic
+    from det3d_amd.prefetch import GeometryPrefetcher
+
+    z, tmp, cfg, _ = setup
+    np.random.seed(7)
+    step = pipelines.Preprocess(cfg=cfg("train"), device="cuda", root_path=str(tmp))
+    dev = torch.device("cuda", 0)
+    template = synthetic.KittiCarSynthetic(n_points=2000, n_seeds=1).device_batch(0, 1, dev)  # anchors of the config
+
+    def make_example(f):
+        res = dict(type="KittiDataset", metadata=dict(image_prefix=str(tmp), num_point_features=4),
+                   lidar=dict(points=z["kitti%d_points" % f].copy(),
+                              annotations=dict(boxes=z["kitti%d_gt" % f].copy(), names=z["kitti%d_names" % f].copy())))
+        res, _ = step(res, {})
+        pts = res["lidar"]["points"]
+        assert pts.is_cuda
+        an = res["lidar"]["annotations"]
+        cars = torch.from_numpy(an["gt_boxes"][an["gt_names"] == "Car"].astype(np.float32)).to(dev)
+        batch = dict(template, points=pts.float().contiguous(),
+                     frame_offsets=torch.tensor([0, len(pts)], dtype=torch.int32, device=dev),
+                     gt_boxes=cars[None].contiguous(), gt_count=torch.tensor([len(cars)], dtype=torch.int32, device=dev))
+        return synthetic.make_example(batch, synthetic.KITTI_CAR, device_targets=True)
+
+    pf = GeometryPrefetcher(make_example, None, dev)
+    for f in range(2):
+        ex = pf.prepare(f)
+        torch.cuda.synchronize()
+        assert ex["coordinates"].is_cuda and int(ex["coordinates"].shape[0]) > 0
+        assert ex["labels"][0].shape[0] == 1 and int(ex["labels"][0].max()) >= 0
+        assert torch.isfinite(ex["voxel_mean"]).all()

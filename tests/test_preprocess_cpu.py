@@ -46,9 +46,14 @@ def setup(tmp_path):
 
 
 def test_kitti_train_step_matches_the_reference_step(setup):
+    check_kitti_train_step(setup, "cpu")
+
+
+def check_kitti_train_step(setup, device):
+    """`device`: where the step keeps the cloud and the GT database (tests/test_pipeline_gpu.py: "cuda")"""
     z, tmp, cfg, _ = setup
     np.random.seed(2024)
-    step = pipelines.Preprocess(cfg=cfg("train"), device="cpu", root_path=str(tmp))
+    step = pipelines.Preprocess(cfg=cfg("train"), device=device, root_path=str(tmp))
     for f in range(2):   # two frames in a row: the database samplers are stateful
         res = dict(type="KittiDataset", metadata=dict(image_prefix=str(tmp), num_point_features=4),
                    lidar=dict(points=z["kitti%d_points" % f].copy(),
@@ -59,7 +64,8 @@ def test_kitti_train_step_matches_the_reference_step(setup):
         assert a["gt_names"].tolist() == z["kitti%d_out_names" % f].tolist(), f
         assert np.array_equal(a["gt_classes"], z["kitti%d_out_classes" % f]) and a["gt_classes"].dtype == np.int32
         assert np.allclose(a["gt_boxes"], z["kitti%d_out_boxes" % f], atol=3e-5), np.abs(a["gt_boxes"] - z["kitti%d_out_boxes" % f]).max()
-        got, ref = res["lidar"]["points"].numpy(), z["kitti%d_out_points" % f]
+        assert res["lidar"]["points"].device.type == str(device).split(":")[0]
+        got, ref = res["lidar"]["points"].cpu().numpy(), z["kitti%d_out_points" % f]
         assert got.shape == ref.shape
         assert np.allclose(got, ref, atol=1e-4), (f, np.abs(got - ref).max())   # row for row: same shuffle
 
