@@ -1,7 +1,7 @@
-"""profiles/round2_pmc_spconv.json from the per-counter summaries of tools/pmc_spconv.sh: HBM traffic per launch of
+"""profiles/round3_pmc_spconv.json from the per-counter summaries of tools/pmc_spconv.sh: HBM traffic per launch of
 the roofline kernel (read side doubled per MI355X_MICROARCH.md: gfx950's FETCH_SIZE tallies 128-B requests at 64 B)
 stamped with the sha of the kernel source, so bench.py can refuse a stale file; MFMA-busy fraction of the dense conv
-kernels.  usage: pmc_json.py <dir with round2_pmc_*.txt>"""
+kernels.  usage: pmc_json.py <dir with round3_pmc_*.txt>"""
 import hashlib
 import json
 import os
@@ -33,14 +33,17 @@ def pick(rs, pat):
     return None
 
 
-fetch, write, mfma = rows("round2_pmc_fetch_size.txt"), rows("round2_pmc_write_size.txt"), rows("round2_pmc_sq_valu_mfma_busy_cycles.txt")
-pat = r"spconv_fwd_(group|mfma)_kernel<64, 64, \d+, \d+, \d+(, true)?>"
+fetch, write, mfma = rows("round3_pmc_fetch_size.txt"), rows("round3_pmc_write_size.txt"), rows("round3_pmc_sq_valu_mfma_busy_cycles.txt")
+# the roofline kernel of the default (f32, split arithmetic) step; D3D_PMC_DTYPE=bf16 for the autocast step
+DT = os.environ.get("D3D_PMC_DTYPE", "fp32")
+pat = r"spconv_fwd_mfma_kernel<64, 64, \d+, \d+, \d+, false>" if DT == "fp32" else \
+    r"spconv_fwd_(group|mfma)_kernel<64, 64, \d+, \d+, \d+(, true)?>"
 f, w = pick(fetch, pat), pick(write, pat)
 out = {"_comment": "separate rocprofv3 --kernel-trace --pmc passes over `bench.py --steps 3 --warmup 3` (tools/pmc_spconv.sh); "
                    "FETCH_SIZE / WRITE_SIZE in KiB per launch, read side x2 (MI355X_MICROARCH.md, gfx950), write side as is",
        "kernel": (re.match(r"(?:void )?(spconv_fwd_\w+)<", f[3]).group(1) + "<64,64>") if f else "spconv_fwd_group_kernel<64,64>",
        "kernel_source_sha16": hashlib.sha256(open(os.path.join(ROOT, "det3d_amd", "csrc", "d3d_spconv.hip"), "rb").read()).hexdigest()[:16],
-       "workload": {"name": "c2-20k", "frames_per_gpu": 4, "points_per_frame": 20000, "dtype": "bf16"}}
+       "workload": {"name": "c2-20k", "frames_per_gpu": 4, "points_per_frame": 20000, "dtype": DT}}
 if f and w:
     out.update(fetch_size_kib_per_launch=f[1], write_size_kib_per_launch=w[1], fetch_correction=2.0,
                launches=f[0], avg_us_under_pmc=f[2], traffic_bytes_per_launch=int((2.0 * f[1] + w[1]) * 1024))
@@ -57,12 +60,12 @@ if mfma:
         inst = row[0] / disp[row[3]] if row[3] in disp and disp[row[3]] else 32.0
         return row[1] * inst / (1024.0 * row[2] * 1e-6 * 2.4e9)
 
-    conv = [r for r in mfma if re.search(r"igemm|grouped_conv|batched_gemm", r[3])]
+    conv = [r for r in mfma if re.search(r"conv2d_nhwc_kernel|conv2d_wgrad_kernel|igemm|grouped_conv|batched_gemm", r[3])]
     tot_t = sum(r[0] * r[2] for r in conv)
     out["rpn_mfma_busy"] = dict(
         kernels={r[3][:60]: round(busy_frac(r), 3) for r in conv[:8]},
         time_weighted_frac=round(sum(busy_frac(r) * r[0] * r[2] for r in conv) / tot_t, 4) if tot_t else None,
-        note="SQ_VALU_MFMA_BUSY_CYCLES of the MIOpen / CK conv kernels, summed over the counter's instances, divided by "
+        note="SQ_VALU_MFMA_BUSY_CYCLES of the dense conv kernels (csrc/d3d_conv2d.hip; MIOpen for the head), summed over the counter's instances, divided by "
              "duration x 2.4 GHz x 1024 SIMDs: the share of SIMD cycles with the MFMA pipe busy")
     mine = pick(mfma, pat)
     if mine:
@@ -70,5 +73,5 @@ if mfma:
     wgm = pick(mfma, r"spconv_wgrad_tile_kernel<64, 64, 9")
     if wgm:
         out.setdefault("wgrad_64x64", {})["mfma_busy_frac"] = round(busy_frac(wgm), 4)
-json.dump(out, open(os.path.join(d, "round2_pmc_spconv.json"), "w"), indent=1)
-print("wrote", os.path.join(d, "round2_pmc_spconv.json"))
+json.dump(out, open(os.path.join(d, "round3_pmc_spconv.json"), "w"), indent=1)
+print("wrote", os.path.join(d, "round3_pmc_spconv.json"))
