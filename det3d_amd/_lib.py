@@ -56,6 +56,11 @@ SIGNATURES = {
     "d3d_split_planes": (i32, [vp, i64, vp, vp, vp]),
     "d3d_conv2d_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "d3d_conv2d_nhwc_wgrad": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "d3d_head_conv_supported": (i32, [i32, i32]),
+    "d3d_head_conv_fwd": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i32, vp]),
+    "d3d_head_conv_dgrad": (i32, [vp, vp, i32, i64, i32, i32, vp, vp, vp]),
+    "d3d_head_conv_wgrad_ws_floats": (sz, [i64]),
+    "d3d_head_conv_wgrad": (i32, [vp, vp, vp, i32, i64, i32, i32, vp, sz, vp]),
     "d3d_channel_affine": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp]),
     "d3d_channel_affine_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]),
     "d3d_pfn_fwd": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp, vp, vp, vp, f32, f32,

@@ -131,6 +131,94 @@ def create_loss(loc_loss_ftor, cls_loss_ftor, box_preds, cls_preds, cls_targets,
     return loc_losses, cls_losses
 
 
+FUSE_HEAD_CONV = os.environ.get("D3D_FUSE_HEAD_CONV", "1") != "0"
+
+
+def _head_conv_ok(x, convs):
+    """the configuration d3d_head_conv_* implements: a CUDA channels-last f32 / bf16 map of 128 channels, plain 1x1
+    convolutions with f32 parameters, at most 32 output channels in total"""
+    if not (FUSE_HEAD_CONV and torch.is_tensor(x) and x.is_cuda and x.dim() == 4):
+        return False
+    if x.dtype == torch.float32:
+        if torch.is_autocast_enabled("cuda"):
+            return False
+    elif x.dtype != torch.bfloat16:
+        return False
+    if x.shape[1] == 1 or not x.is_contiguous(memory_format=torch.channels_last):
+        return False
+    for c in convs:
+        if type(c) is not nn.Conv2d or c.kernel_size != (1, 1) or c.stride != (1, 1) or c.padding != (0, 0) or \
+                c.groups != 1 or c.weight.dtype != torch.float32 or (c.bias is not None and c.bias.dtype != torch.float32):
+            return False
+    from . import _lib
+
+    return bool(_lib.lib().d3d_head_conv_supported(int(x.shape[1]), sum(c.out_channels for c in convs)))
+
+
+def _ptr_array(tensors):
+    import ctypes
+
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
+
+
+class _HeadConvFn(torch.autograd.Function):
+    """conv_box / conv_cls / conv_dir of a task group on a channels-last map: outputs [B, H, W, n_k] (what
+    `.permute(0, 2, 3, 1).contiguous()` of the reference's NCHW conv outputs is, mg_head.py:223-231)"""
+
+    @staticmethod
+    def forward(ctx, x, count, *params):
+        from . import _lib
+
+        L = _lib.lib()
+        b, cin, h, w = x.shape
+        m = b * h * w
+        weights = [params[2 * k].detach() for k in range(count)]
+        biases = [params[2 * k + 1] for k in range(count)]
+        n = [int(wt.shape[0]) for wt in weights]
+        outs = [torch.empty((b, h, w, nk), dtype=x.dtype, device=x.device) for nk in n]
+        dt = _lib.D3D_BF16 if x.dtype == torch.bfloat16 else _lib.D3D_F32
+        bias_arr = _ptr_array([bb.detach() if bb is not None else None for bb in biases])
+        rc = L.d3d_head_conv_fwd(x.data_ptr(), m, cin, dt, _ptr_array(weights), bias_arr, _ptr_array(outs),
+                                 _lib.i32_array(n), count, _lib.stream_ptr(x.device))
+        _lib.check(rc, "d3d_head_conv_fwd")
+        ctx.save_for_backward(x, *weights)
+        ctx.meta = (count, n, [bb is not None for bb in biases])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        from . import _lib
+
+        L = _lib.lib()
+        count, n, has_bias = ctx.meta
+        x, weights = ctx.saved_tensors[0], list(ctx.saved_tensors[1:])
+        b, cin, h, w = x.shape
+        m = b * h * w
+        dev = x.device
+        st = _lib.stream_ptr(dev)
+        dt = _lib.D3D_BF16 if x.dtype == torch.bfloat16 else _lib.D3D_F32
+        g = [(go if go is not None else torch.zeros((b, h, w, nk), dtype=x.dtype, device=dev)).to(x.dtype).contiguous()
+             for go, nk in zip(gouts, n)]
+        garr, narr = _ptr_array(g), _lib.i32_array(n)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxr = torch.empty((b, h, w, cin), dtype=x.dtype, device=dev)
+            rc = L.d3d_head_conv_dgrad(garr, narr, count, m, cin, dt, _ptr_array(weights), dxr.data_ptr(), st)
+            _lib.check(rc, "d3d_head_conv_dgrad")
+            dx = dxr.permute(0, 3, 1, 2)
+        nws = L.d3d_head_conv_wgrad_ws_floats(m)
+        ws = torch.empty((nws,), dtype=torch.float32, device=dev)
+        rc = L.d3d_head_conv_wgrad(x.data_ptr(), garr, narr, count, m, cin, dt, ws.data_ptr(), nws, st)
+        _lib.check(rc, "d3d_head_conv_wgrad")
+        dw, db = ws[: 32 * cin].view(32, cin), ws[32 * cin: 32 * cin + 32]
+        grads, first = [], 0
+        for k in range(count):
+            grads.append(dw[first: first + n[k]].reshape(n[k], cin, 1, 1))
+            grads.append(db[first: first + n[k]] if has_bias[k] else None)
+            first += n[k]
+        return (dx, None) + tuple(grads)
+
+
 @HEADS.register_module
 class Head(nn.Module):
     def __init__(self, num_input, num_pred, num_cls, use_dir=False, num_dir=0, header=True, name="",
@@ -143,10 +231,15 @@ class Head(nn.Module):
             self.conv_dir = nn.Conv2d(num_input, num_dir, 1)
 
     def forward(self, x):
-        ret = {"box_preds": self.conv_box(x).permute(0, 2, 3, 1).contiguous(),
-               "cls_preds": self.conv_cls(x).permute(0, 2, 3, 1).contiguous()}
+        convs = [self.conv_box, self.conv_cls] + ([self.conv_dir] if self.use_dir else [])
+        if _head_conv_ok(x, convs):
+            # one launch for the three 1x1 convolutions of the task group (csrc/d3d_head.hip): the map is read once
+            outs = _HeadConvFn.apply(x, len(convs), *[t for c in convs for t in (c.weight, c.bias)])
+        else:
+            outs = [c(x).permute(0, 2, 3, 1).contiguous() for c in convs]
+        ret = {"box_preds": outs[0], "cls_preds": outs[1]}
         if self.use_dir:
-            ret["dir_cls_preds"] = self.conv_dir(x).permute(0, 2, 3, 1).contiguous()
+            ret["dir_cls_preds"] = outs[2]
         return ret
 
 

@@ -1,0 +1,337 @@
+// The prediction convolutions of a MultiGroupHead task group -- conv_box / conv_cls / conv_dir, three 1x1 Conv2d
+// with bias on the same [B, 128, H, W] map (det3d/models/bbox_heads/mg_head.py:193-232, 553-560; cuDNN in the
+// reference, MIOpen here until round 3) -- as ONE launch per direction.
+//
+// They are not GEMM-shaped work worth the matrix pipe: 128 input channels against 2 + 14 + 4 = 20 outputs, i.e.
+// 5 KFLOP per pixel against 512 bytes of input -- a streaming pass over the map.  MIOpen ran them as 9 igemm
+// launches per step plus 9 zero-fill and ~12 cast launches, summed their weight gradients with atomics (the last
+// nondeterministic kernel of the step) and had no precision between bf16 and f32.  Here: exact f32 FMA arithmetic on
+// the VALU for either input format, the map read once for all three convolutions, and a fixed-order two-level sum
+// for the weight / bias gradients.
+//   fwd    y_k[p, :] = x[p, :] @ W_k^T + b_k          x [M, 128] f32 | bf16 (channels-last rows), y_k same type
+//   dgrad  dx[p, :]  = sum_k g_k[p, :] @ W_k           one pass writes the SUM over the three convolutions
+//   wgrad  dW_k = g_k^T @ x, db_k = sum_p g_k          per-block partials folded by d3d_fold_block
+// The kernels read the convolutions' own parameter tensors (weight [n_k, 128, 1, 1], bias [n_k]) and write / read three
+// separate prediction tensors (the loss kernel and the decoder want them contiguous); ctot = sum n_k <= 32.
+#include "d3d_common.h"
+#include "d3d_fold.h"
+
+#define HC_CIN 128
+#define HC_MAXC 32       // total output channels of a task group (padded)
+#define HC_TP 64         // pixels per tile
+#define HC_XROW (HC_CIN + 4)   // padded f32 row of the staged map tile: 16-byte aligned, conflict-free column walks
+
+struct HcSeg {           // one convolution's slice of the concatenated channel axis
+  void *ptr[3];          // output (fwd) / gradient (dgrad, wgrad) tensors [M, n_k]
+  int n[3], first[3];    // channels, first concatenated channel
+  int count;
+};
+
+struct HcW {             // the convolutions' own parameter tensors: weight [n_k, 128] f32, bias [n_k] f32 or NULL
+  const float *w[3], *b[3];
+};
+
+// W_k rows -> LDS [HC_MAXC][128] in concatenated channel order, zero rows behind ctot
+__device__ __forceinline__ void hc_stage_w(const HcW &P, const HcSeg &S, float *ws) {
+  for (int e = threadIdx.x; e < HC_MAXC * HC_CIN / 4; e += 256) {
+    const int row = e / (HC_CIN / 4), c4 = e % (HC_CIN / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (k < S.count && row >= S.first[k] && row < S.first[k] + S.n[k])
+        v = ((const float4 *)P.w[k])[(row - S.first[k]) * (HC_CIN / 4) + c4];
+    ((float4 *)ws)[e] = v;
+  }
+}
+
+__device__ __forceinline__ float hc_bf16(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t hc_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// map tile [HC_TP][128] -> LDS as f32 rows of HC_XROW floats (rows past m are zero)
+template <bool BF16>
+__device__ __forceinline__ void hc_stage_x(const void *__restrict__ x, int64_t p0, int64_t m, float *xs) {
+  // 64 rows x 32 float4 slots = 2048 slots, 8 per thread
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int slot = threadIdx.x + j * 256;
+    const int row = slot >> 5, c4 = slot & 31;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p0 + row < m) {
+      if (BF16) {
+        const uint2 r = *(const uint2 *)((const uint16_t *)x + (p0 + row) * HC_CIN + c4 * 4);
+        v = make_float4(hc_bf16((uint16_t)(r.x & 0xffffu)), hc_bf16((uint16_t)(r.x >> 16)),
+                        hc_bf16((uint16_t)(r.y & 0xffffu)), hc_bf16((uint16_t)(r.y >> 16)));
+      } else {
+        v = *(const float4 *)((const float *)x + (p0 + row) * HC_CIN + c4 * 4);
+      }
+    }
+    *(float4 *)(xs + row * HC_XROW + c4 * 4) = v;
+  }
+}
+
+// gradient tile [HC_TP][ctot] (from the up-to-three tensors) -> LDS f32 [HC_TP][HC_MAXC], zero padded
+template <bool BF16>
+__device__ __forceinline__ void hc_stage_g(const HcSeg &S, int64_t p0, int64_t m, float *gs) {
+  for (int e = threadIdx.x; e < HC_TP * HC_MAXC; e += 256) {
+    const int row = e / HC_MAXC, c = e % HC_MAXC;
+    float v = 0.f;
+    if (p0 + row < m) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (k < S.count && c >= S.first[k] && c < S.first[k] + S.n[k]) {
+          const int64_t i = (p0 + row) * S.n[k] + (c - S.first[k]);
+          v = BF16 ? hc_bf16(((const uint16_t *)S.ptr[k])[i]) : ((const float *)S.ptr[k])[i];
+        }
+    }
+    gs[e] = v;
+  }
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+    head_conv_fwd_kernel(const void *__restrict__ x, HcW P, HcSeg S, int ctot, int64_t m) {
+  __shared__ __attribute__((aligned(16))) float xs[HC_TP * HC_XROW];
+  __shared__ __attribute__((aligned(16))) float ws[HC_MAXC * HC_CIN];
+  const int64_t p0 = (int64_t)blockIdx.x * HC_TP;
+  hc_stage_w(P, S, ws);
+  hc_stage_x<BF16>(x, p0, m, xs);
+  __syncthreads();
+  // thread = (pixel, group of 8 output channels); the group index is wave-uniform: weight reads are LDS broadcasts
+  const int px = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (cg * 8 < ctot) {
+    const float *xr = xs + px * HC_XROW;
+#pragma unroll 4
+    for (int c4 = 0; c4 < HC_CIN / 4; ++c4) {
+      const float4 xv = *(const float4 *)(xr + c4 * 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 wv = *(const float4 *)(ws + (cg * 8 + j) * HC_CIN + c4 * 4);
+        acc[j] = fmaf(xv.x, wv.x, acc[j]);
+        acc[j] = fmaf(xv.y, wv.y, acc[j]);
+        acc[j] = fmaf(xv.z, wv.z, acc[j]);
+        acc[j] = fmaf(xv.w, wv.w, acc[j]);
+      }
+    }
+  }
+  const int64_t p = p0 + px;
+  if (p >= m) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    if (c >= ctot) break;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (k < S.count && c >= S.first[k] && c < S.first[k] + S.n[k]) {
+        const float v = acc[j] + (P.b[k] ? P.b[k][c - S.first[k]] : 0.f);
+        const int64_t i = p * S.n[k] + (c - S.first[k]);
+        if (BF16) ((uint16_t *)S.ptr[k])[i] = hc_to_bf16(v);
+        else ((float *)S.ptr[k])[i] = v;
+      }
+  }
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+    head_conv_dgrad_kernel(HcW P, HcSeg S, int ctot, int64_t m, void *__restrict__ dx) {
+  __shared__ __attribute__((aligned(16))) float gs[HC_TP * HC_MAXC];
+  __shared__ __attribute__((aligned(16))) float ws[HC_MAXC * HC_CIN];
+  const int64_t p0 = (int64_t)blockIdx.x * HC_TP;
+  hc_stage_w(P, S, ws);
+  hc_stage_g<BF16>(S, p0, m, gs);
+  __syncthreads();
+  // thread = (4 input channels, group of 8 pixels)
+  const int c4 = threadIdx.x & 31, pg = threadIdx.x >> 5;
+  float4 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int co = 0; co < ctot; ++co) {
+    const float4 wv = *(const float4 *)(ws + co * HC_CIN + c4 * 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float g = gs[(pg * 8 + j) * HC_MAXC + co];
+      acc[j].x = fmaf(g, wv.x, acc[j].x);
+      acc[j].y = fmaf(g, wv.y, acc[j].y);
+      acc[j].z = fmaf(g, wv.z, acc[j].z);
+      acc[j].w = fmaf(g, wv.w, acc[j].w);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int64_t p = p0 + pg * 8 + j;
+    if (p >= m) break;
+    if (BF16) {
+      uint2 pk;
+      pk.x = (uint32_t)hc_to_bf16(acc[j].x) | ((uint32_t)hc_to_bf16(acc[j].y) << 16);
+      pk.y = (uint32_t)hc_to_bf16(acc[j].z) | ((uint32_t)hc_to_bf16(acc[j].w) << 16);
+      *(uint2 *)((uint16_t *)dx + p * HC_CIN + c4 * 4) = pk;
+    } else {
+      *(float4 *)((float *)dx + p * HC_CIN + c4 * 4) = acc[j];
+    }
+  }
+}
+
+// per block: a contiguous range of pixels; thread = (input channel, half of the output channels); the block's
+// [HC_MAXC x 128] weight partial + [HC_MAXC] bias partial go through the fixed-order fold
+#define HC_WG_NVAL (HC_MAXC * HC_CIN + HC_MAXC)
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+    head_conv_wgrad_kernel(const void *__restrict__ x, HcSeg S, int ctot, int64_t m, int64_t pixels_per_block,
+                           float *__restrict__ ws, unsigned *__restrict__ counters, int fold_g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *xs = smem;                                  // [HC_TP][HC_XROW]
+  float *gs = xs + HC_TP * HC_XROW;                  // [HC_TP][HC_MAXC]
+  float *tot = gs + HC_TP * HC_MAXC;                 // [HC_WG_NVAL], then the fold's flag word
+  const int ci = threadIdx.x & 127, ch = threadIdx.x >> 7;  // output channels ch * 16 .. + 16
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  float bsum = 0.f;  // threads 0 .. 31 of the block: bias gradient of output channel threadIdx.x
+  const int64_t pb = (int64_t)blockIdx.x * pixels_per_block;
+  int64_t pe = pb + pixels_per_block;
+  if (pe > m) pe = m;
+  for (int64_t p0 = pb; p0 < pe; p0 += HC_TP) {
+    __syncthreads();
+    hc_stage_x<BF16>(x, p0, pe, xs);
+    hc_stage_g<BF16>(S, p0, pe, gs);
+    __syncthreads();
+    for (int r = 0; r < HC_TP; ++r) {
+      const float xv = xs[r * HC_XROW + ci];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 g4 = *(const float4 *)(gs + r * HC_MAXC + ch * 16 + q * 4);
+        acc[q * 4 + 0] = fmaf(g4.x, xv, acc[q * 4 + 0]);
+        acc[q * 4 + 1] = fmaf(g4.y, xv, acc[q * 4 + 1]);
+        acc[q * 4 + 2] = fmaf(g4.z, xv, acc[q * 4 + 2]);
+        acc[q * 4 + 3] = fmaf(g4.w, xv, acc[q * 4 + 3]);
+      }
+    }
+    if (threadIdx.x < HC_MAXC)
+      for (int r = 0; r < HC_TP; ++r) bsum += gs[r * HC_MAXC + threadIdx.x];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) tot[(ch * 16 + j) * HC_CIN + ci] = acc[j];
+  if (threadIdx.x < HC_MAXC) tot[HC_MAXC * HC_CIN + threadIdx.x] = bsum;
+  __syncthreads();
+  d3d_fold_block<256>(tot, HC_WG_NVAL, ws, counters, fold_g, (int *)(tot + HC_WG_NVAL));
+}
+
+// ---------------------------------------------------------------------------------------------------- host side
+static int hc_segments(const char *who, HcSeg &S, void *const *ptrs, const int *n, int count, int &ctot) {
+  D3D_REQUIRE(count >= 1 && count <= 3, "%s: %d convolutions (1..3)", who, count);
+  ctot = 0;
+  S.count = count;
+  for (int k = 0; k < 3; ++k) {
+    S.ptr[k] = k < count ? ptrs[k] : nullptr;
+    S.n[k] = k < count ? n[k] : 0;
+    S.first[k] = ctot;
+    if (k < count) {
+      D3D_REQUIRE(ptrs[k] && n[k] >= 1, "%s: convolution %d: null tensor or %d channels", who, k, n[k]);
+      ctot += n[k];
+    }
+  }
+  D3D_REQUIRE(ctot <= HC_MAXC, "%s: %d output channels in total (<= %d)", who, ctot, HC_MAXC);
+  return D3D_OK;
+}
+
+extern "C" int d3d_head_conv_supported(int cin, int ctot) { return cin == HC_CIN && ctot >= 1 && ctot <= HC_MAXC; }
+
+static int hc_params(const char *who, HcW &P, const float *const *weights, const float *const *biases, int count) {
+  D3D_REQUIRE(weights, "%s: null weights", who);
+  for (int k = 0; k < 3; ++k) {
+    P.w[k] = k < count ? weights[k] : nullptr;
+    P.b[k] = (k < count && biases) ? biases[k] : nullptr;
+    D3D_REQUIRE(k >= count || P.w[k], "%s: null weight %d", who, k);
+  }
+  return D3D_OK;
+}
+
+extern "C" int d3d_head_conv_fwd(const void *x, int64_t m, int cin, int dtype, const float *const *weights,
+                                 const float *const *biases, void *const *y, const int *n, int count,
+                                 d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  D3D_REQUIRE(dtype == D3D_F32 || dtype == D3D_BF16, "d3d_head_conv_fwd: dtype %d", dtype);
+  D3D_REQUIRE(cin == HC_CIN && m >= 1 && x && y && n, "d3d_head_conv_fwd: cin %d (must be %d), m %lld", cin,
+              HC_CIN, (long long)m);
+  HcSeg S;
+  HcW P;
+  int ctot;
+  if (int rc = hc_segments("d3d_head_conv_fwd", S, y, n, count, ctot)) return rc;
+  if (int rc = hc_params("d3d_head_conv_fwd", P, weights, biases, count)) return rc;
+  const unsigned nb = (unsigned)((m + HC_TP - 1) / HC_TP);
+  if (dtype == D3D_BF16)
+    hipLaunchKernelGGL(head_conv_fwd_kernel<true>, dim3(nb), dim3(256), 0, stream, x, P, S, ctot, m);
+  else
+    hipLaunchKernelGGL(head_conv_fwd_kernel<false>, dim3(nb), dim3(256), 0, stream, x, P, S, ctot, m);
+  D3D_LAUNCH_TRY("head_conv_fwd_kernel");
+  return D3D_OK;
+}
+
+extern "C" int d3d_head_conv_dgrad(void *const *g, const int *n, int count, int64_t m, int cin, int dtype,
+                                   const float *const *weights, void *dx, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  D3D_REQUIRE(dtype == D3D_F32 || dtype == D3D_BF16, "d3d_head_conv_dgrad: dtype %d", dtype);
+  D3D_REQUIRE(cin == HC_CIN && m >= 1 && g && dx && n, "d3d_head_conv_dgrad: arguments");
+  HcSeg S;
+  HcW P;
+  int ctot;
+  if (int rc = hc_segments("d3d_head_conv_dgrad", S, g, n, count, ctot)) return rc;
+  if (int rc = hc_params("d3d_head_conv_dgrad", P, weights, nullptr, count)) return rc;
+  const unsigned nb = (unsigned)((m + HC_TP - 1) / HC_TP);
+  if (dtype == D3D_BF16)
+    hipLaunchKernelGGL(head_conv_dgrad_kernel<true>, dim3(nb), dim3(256), 0, stream, P, S, ctot, m, dx);
+  else
+    hipLaunchKernelGGL(head_conv_dgrad_kernel<false>, dim3(nb), dim3(256), 0, stream, P, S, ctot, m, dx);
+  D3D_LAUNCH_TRY("head_conv_dgrad_kernel");
+  return D3D_OK;
+}
+
+static int hc_wgrad_blocks(int64_t m) {
+  int64_t nb = (m + 4 * HC_TP - 1) / (4 * HC_TP);  // >= 4 tiles per block
+  if (nb > 512) nb = 512;
+  return nb < 1 ? 1 : (int)nb;
+}
+extern "C" size_t d3d_head_conv_wgrad_ws_floats(int64_t m) {
+  if (m < 1) return 0;
+  return d3d_fold_ws_floats(hc_wgrad_blocks(m), HC_WG_NVAL);
+}
+// ws[0 .. 32*128) = dW [32][128] (rows >= ctot are zero), ws[32*128 .. +32) = db
+extern "C" int d3d_head_conv_wgrad(const void *x, void *const *g, const int *n, int count, int64_t m, int cin,
+                                   int dtype, float *ws, size_t ws_floats, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  D3D_REQUIRE(dtype == D3D_F32 || dtype == D3D_BF16, "d3d_head_conv_wgrad: dtype %d", dtype);
+  D3D_REQUIRE(cin == HC_CIN && m >= 1 && x && g && n && ws, "d3d_head_conv_wgrad: arguments");
+  HcSeg S;
+  int ctot;
+  if (int rc = hc_segments("d3d_head_conv_wgrad", S, g, n, count, ctot)) return rc;
+  const int nb = hc_wgrad_blocks(m);
+  if (ws_floats < d3d_fold_ws_floats(nb, HC_WG_NVAL))
+    return d3d_set_error(D3D_ECAPACITY, "d3d_head_conv_wgrad: workspace %zu floats < %zu", ws_floats,
+                         d3d_fold_ws_floats(nb, HC_WG_NVAL));
+  const D3dFoldPlan fp = d3d_fold_plan(nb, HC_WG_NVAL);
+  unsigned *counters = d3d_fold_counters(d3d_fold_counter_words(fp));
+  if (!counters) return D3D_EHIP;
+  int64_t ppb = (m + nb - 1) / nb;
+  ppb = (ppb + HC_TP - 1) / HC_TP * HC_TP;
+  const size_t lds = (size_t)(HC_TP * HC_XROW + HC_TP * HC_MAXC + HC_WG_NVAL + 4) * sizeof(float);
+  const unsigned grid = (unsigned)((m + ppb - 1) / ppb);
+  D3D_REQUIRE((int)grid <= nb, "d3d_head_conv_wgrad: grid %u > planned %d", grid, nb);
+  // the fold plan was made for `nb` blocks; launch exactly the planned count (trailing blocks see no pixels)
+  if (dtype == D3D_BF16) {
+    D3D_HIP_TRY(hipFuncSetAttribute((const void *)head_conv_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(head_conv_wgrad_kernel<true>, dim3(nb), dim3(256), lds, stream, x, S, ctot, m, ppb, ws, counters, fp.g);
+  } else {
+    D3D_HIP_TRY(hipFuncSetAttribute((const void *)head_conv_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(head_conv_wgrad_kernel<false>, dim3(nb), dim3(256), lds, stream, x, S, ctot, m, ppb, ws, counters, fp.g);
+  }
+  D3D_LAUNCH_TRY("head_conv_wgrad_kernel");
+  return D3D_OK;
+}

@@ -290,6 +290,27 @@ int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const void *x_hi, 
                           void *workspace, size_t workspace_bytes, d3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * The prediction convolutions of one MultiGroupHead task group: conv_box / conv_cls / conv_dir, 1x1 Conv2d with bias on
+ * the same channels-last map (det3d/models/bbox_heads/mg_head.py:193-232 `Head`, :553-560), as ONE launch per
+ * direction; exact f32 FMA arithmetic for f32 or bf16 maps; the weight / bias gradients are summed in a fixed order.
+ *   x        dev [m, cin] rows of the map (m = batch*H*W), dtype D3D_F32 | D3D_BF16; cin = 128
+ *   weights  HOST array of `count` (1..3) dev pointers, weight k = [n[k], cin] f32 (nn.Conv2d's [n, cin, 1, 1])
+ *   biases   HOST array of dev pointers [n[k]] f32 (entries or the array may be NULL)
+ *   y / g    HOST array of dev pointers [m, n[k]] in x's dtype: predictions (fwd) or their gradients
+ *   dx       dev [m, cin]: the SUM of the data gradients of the `count` convolutions
+ *   wgrad    ws[0 .. 32*cin) = dW in concatenated channel order ([sum n][cin], zero rows up to 32),
+ *            ws[32*cin .. 32*cin + 32) = db; ws needs d3d_head_conv_wgrad_ws_floats(m) floats (fold workspace)
+ *   sum n <= 32 (d3d_head_conv_supported). */
+int d3d_head_conv_supported(int cin, int ctot);
+int d3d_head_conv_fwd(const void *x, int64_t m, int cin, int dtype, const float *const *weights,
+                      const float *const *biases, void *const *y, const int *n, int count, d3d_stream_t stream);
+int d3d_head_conv_dgrad(void *const *g, const int *n, int count, int64_t m, int cin, int dtype,
+                        const float *const *weights, void *dx, d3d_stream_t stream);
+size_t d3d_head_conv_wgrad_ws_floats(int64_t m);
+int d3d_head_conv_wgrad(const void *x, void *const *g, const int *n, int count, int64_t m, int cin, int dtype,
+                        float *ws, size_t ws_floats, d3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * PillarFeatureNet with one (last) PFNLayer: det3d/models/readers/pillar_encoder.py:115-155
  * (decorate + mask) and :42-57 (Linear(c+5 -> f, no bias), BatchNorm1d over all m*t rows, ReLU,
  * max over t), fused; nothing of size [m, t, *] is materialised.

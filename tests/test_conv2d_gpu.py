@@ -216,3 +216,54 @@ def test_data_gradient_epilogue_reduces_the_previous_batchnorm_backward_sums(mod
                                    mean.data_ptr(), invstd.data_ptr(), 1, ref.data_ptr(), _lib.stream_ptr(x.device)), "reduce")
     got, want = ws[:2 * c].double(), ref[:2 * c].double()
     assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("use_dir", [True, False])
+def test_head_convolutions_in_one_launch(dtype, use_dir):
+    """csrc/d3d_head.hip behind bbox_heads.Head: conv_box / conv_cls / conv_dir (mg_head.py:193-232) as one launch per
+    direction -- predictions, input gradient, weight and bias gradients against nn.Conv2d in float64, twice for
+    bit-reproducibility; pixel count not a multiple of the 64-pixel tile."""
+    import copy
+
+    from det3d_amd import bbox_heads
+
+    torch.manual_seed(1)
+    head = bbox_heads.Head(128, 14, 2, use_dir=use_dir, num_dir=4).cuda()
+    ref = copy.deepcopy(head).double()
+    x = torch.randn(2, 128, 21, 19, device="cuda").contiguous(memory_format=torch.channels_last)
+    xa = x.detach().clone().to(dtype).requires_grad_(True)
+    calls = []
+    orig = bbox_heads._HeadConvFn.apply
+    outs = head(xa)
+    keys = ["box_preds", "cls_preds"] + (["dir_cls_preds"] if use_dir else [])
+    gs = [torch.randn(outs[k].shape, device="cuda").to(dtype) for k in keys]
+    assert all(outs[k].dtype == dtype and outs[k].is_contiguous() and outs[k].shape[:3] == (2, 21, 19) for k in keys)
+    torch.autograd.backward([outs[k] for k in keys], gs)
+    xr = xa.detach().double().requires_grad_(True)
+    prev = bbox_heads.FUSE_HEAD_CONV
+    bbox_heads.FUSE_HEAD_CONV = False
+    try:
+        outr = ref(xr)
+    finally:
+        bbox_heads.FUSE_HEAD_CONV = prev
+    torch.autograd.backward([outr[k] for k in keys], [g.double() for g in gs])
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+
+    def close(a, b, what, t=tol):
+        err, scale = float((a.double() - b).abs().max()), float(b.abs().max())
+        assert err <= t * scale + 1e-7, (what, err, scale)
+
+    for k in keys:
+        close(outs[k], outr[k], k)
+    close(xa.grad, xr.grad, "input gradient")
+    for (k, p), (_, q) in zip(head.named_parameters(), ref.named_parameters()):
+        close(p.grad, q.grad, k, 2e-5)  # f32 accumulation over the pixels of exact products
+    # the same step again: bit-equal
+    g1 = {k: p.grad.clone() for k, p in head.named_parameters()}
+    head.zero_grad()
+    xb = x.detach().clone().to(dtype).requires_grad_(True)
+    outs2 = head(xb)
+    torch.autograd.backward([outs2[k] for k in keys], gs)
+    assert all(torch.equal(outs[k], outs2[k]) for k in keys) and torch.equal(xa.grad, xb.grad)
+    assert all(torch.equal(g1[k], p.grad) for k, p in head.named_parameters())
