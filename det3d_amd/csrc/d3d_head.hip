@@ -10,11 +10,10 @@
 // for the weight / bias gradients.
 //   fwd    y_k[p, :] = x[p, :] @ W_k^T + b_k          x [M, 128] f32 | bf16 (channels-last rows), y_k same type
 //   dgrad  dx[p, :]  = sum_k g_k[p, :] @ W_k           one pass writes the SUM over the three convolutions
-//   wgrad  dW_k = g_k^T @ x, db_k = sum_p g_k          per-block partials folded by d3d_fold_block
+//   wgrad  dW_k = g_k^T @ x, db_k = sum_p g_k          per-block partial slabs, summed in a fixed order by a second launch
 // The kernels read the convolutions' own parameter tensors (weight [n_k, 128, 1, 1], bias [n_k]) and write / read three
 // separate prediction tensors (the loss kernel and the decoder want them contiguous); ctot = sum n_k <= 32.
 #include "d3d_common.h"
-#include "d3d_fold.h"
 
 #define HC_CIN 128
 #define HC_MAXC 32       // total output channels of a task group (padded)
@@ -178,17 +177,18 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// per block: a contiguous range of pixels; thread = (input channel, half of the output channels); the block's
-// [HC_MAXC x 128] weight partial + [HC_MAXC] bias partial go through the fixed-order fold
+// per block: a contiguous range of pixels; thread = (input channel, half of the output channels); the block writes its
+// [HC_MAXC x 128] weight partial + [HC_MAXC] bias partial as one slab, head_conv_wgrad_reduce_kernel sums the slabs in
+// a fixed order.  (The in-kernel ticket fold of d3d_fold.h is built for [2C]-sized vectors: with 4128 values per block
+// its narrow write-through stores and the last block's serial reads cost 60 us here, measured.)
 #define HC_WG_NVAL (HC_MAXC * HC_CIN + HC_MAXC)
 template <bool BF16>
 __global__ void __launch_bounds__(256)
     head_conv_wgrad_kernel(const void *__restrict__ x, HcSeg S, int ctot, int64_t m, int64_t pixels_per_block,
-                           float *__restrict__ ws, unsigned *__restrict__ counters, int fold_g) {
+                           float *__restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *xs = smem;                                  // [HC_TP][HC_XROW]
   float *gs = xs + HC_TP * HC_XROW;                  // [HC_TP][HC_MAXC]
-  float *tot = gs + HC_TP * HC_MAXC;                 // [HC_WG_NVAL], then the fold's flag word
   const int ci = threadIdx.x & 127, ch = threadIdx.x >> 7;  // output channels ch * 16 .. + 16
   float acc[16];
 #pragma unroll
@@ -216,12 +216,35 @@ __global__ void __launch_bounds__(256)
     if (threadIdx.x < HC_MAXC)
       for (int r = 0; r < HC_TP; ++r) bsum += gs[r * HC_MAXC + threadIdx.x];
   }
-  __syncthreads();
+  float *slab = part + (size_t)blockIdx.x * HC_WG_NVAL;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) tot[(ch * 16 + j) * HC_CIN + ci] = acc[j];
-  if (threadIdx.x < HC_MAXC) tot[HC_MAXC * HC_CIN + threadIdx.x] = bsum;
+  for (int j = 0; j < 16; ++j) slab[(ch * 16 + j) * HC_CIN + ci] = acc[j];
+  if (threadIdx.x < HC_MAXC) slab[HC_MAXC * HC_CIN + threadIdx.x] = bsum;
+}
+
+// out[e] = sum over slabs of part[s][e]: 8 slab groups walked in parallel, folded through LDS in group order
+__global__ void __launch_bounds__(256)
+    head_conv_wgrad_reduce_kernel(const float4 *__restrict__ part, int slabs, float4 *__restrict__ out) {
+  __shared__ float4 red[8][32];
+  constexpr int N4 = HC_WG_NVAL / 4;
+  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < N4)
+    for (int s0 = g; s0 < slabs; s0 += 8) {
+      const float4 u = part[(size_t)s0 * N4 + e];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+    }
+  red[g][el] = a;
   __syncthreads();
-  d3d_fold_block<256>(tot, HC_WG_NVAL, ws, counters, fold_g, (int *)(tot + HC_WG_NVAL));
+  if (g == 0 && e < N4) {
+    float4 r = red[0][el];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      r.x += red[j][el].x; r.y += red[j][el].y; r.z += red[j][el].z; r.w += red[j][el].w;
+    }
+    out[e] = r;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------- host side
@@ -301,7 +324,7 @@ static int hc_wgrad_blocks(int64_t m) {
 }
 extern "C" size_t d3d_head_conv_wgrad_ws_floats(int64_t m) {
   if (m < 1) return 0;
-  return d3d_fold_ws_floats(hc_wgrad_blocks(m), HC_WG_NVAL);
+  return (size_t)HC_WG_NVAL * (1 + (size_t)hc_wgrad_blocks(m));  // result | one slab per block
 }
 // ws[0 .. 32*128) = dW [32][128] (rows >= ctot are zero), ws[32*128 .. +32) = db
 extern "C" int d3d_head_conv_wgrad(const void *x, void *const *g, const int *n, int count, int64_t m, int cin,
@@ -313,25 +336,20 @@ extern "C" int d3d_head_conv_wgrad(const void *x, void *const *g, const int *n, 
   int ctot;
   if (int rc = hc_segments("d3d_head_conv_wgrad", S, g, n, count, ctot)) return rc;
   const int nb = hc_wgrad_blocks(m);
-  if (ws_floats < d3d_fold_ws_floats(nb, HC_WG_NVAL))
+  if (ws_floats < d3d_head_conv_wgrad_ws_floats(m))
     return d3d_set_error(D3D_ECAPACITY, "d3d_head_conv_wgrad: workspace %zu floats < %zu", ws_floats,
-                         d3d_fold_ws_floats(nb, HC_WG_NVAL));
-  const D3dFoldPlan fp = d3d_fold_plan(nb, HC_WG_NVAL);
-  unsigned *counters = d3d_fold_counters(d3d_fold_counter_words(fp));
-  if (!counters) return D3D_EHIP;
+                         d3d_head_conv_wgrad_ws_floats(m));
   int64_t ppb = (m + nb - 1) / nb;
   ppb = (ppb + HC_TP - 1) / HC_TP * HC_TP;
-  const size_t lds = (size_t)(HC_TP * HC_XROW + HC_TP * HC_MAXC + HC_WG_NVAL + 4) * sizeof(float);
-  const unsigned grid = (unsigned)((m + ppb - 1) / ppb);
-  D3D_REQUIRE((int)grid <= nb, "d3d_head_conv_wgrad: grid %u > planned %d", grid, nb);
-  // the fold plan was made for `nb` blocks; launch exactly the planned count (trailing blocks see no pixels)
-  if (dtype == D3D_BF16) {
-    D3D_HIP_TRY(hipFuncSetAttribute((const void *)head_conv_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(head_conv_wgrad_kernel<true>, dim3(nb), dim3(256), lds, stream, x, S, ctot, m, ppb, ws, counters, fp.g);
-  } else {
-    D3D_HIP_TRY(hipFuncSetAttribute((const void *)head_conv_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(head_conv_wgrad_kernel<false>, dim3(nb), dim3(256), lds, stream, x, S, ctot, m, ppb, ws, counters, fp.g);
-  }
+  const size_t lds = (size_t)(HC_TP * HC_XROW + HC_TP * HC_MAXC) * sizeof(float);
+  float *part = ws + HC_WG_NVAL;
+  if (dtype == D3D_BF16)
+    hipLaunchKernelGGL(head_conv_wgrad_kernel<true>, dim3(nb), dim3(256), lds, stream, x, S, ctot, m, ppb, part);
+  else
+    hipLaunchKernelGGL(head_conv_wgrad_kernel<false>, dim3(nb), dim3(256), lds, stream, x, S, ctot, m, ppb, part);
   D3D_LAUNCH_TRY("head_conv_wgrad_kernel");
+  hipLaunchKernelGGL(head_conv_wgrad_reduce_kernel, dim3((HC_WG_NVAL / 4 + 31) / 32), dim3(256), 0, stream,
+                     (const float4 *)part, nb, (float4 *)ws);
+  D3D_LAUNCH_TRY("head_conv_wgrad_reduce_kernel");
   return D3D_OK;
 }
