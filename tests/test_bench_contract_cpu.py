@@ -33,7 +33,7 @@ def test_driver_flags_parse(monkeypatch):
     assert a.gpus == 1 and a.steps >= 10 and a.warmup >= 1 and not a.no_gc_freeze
 
 
-@pytest.mark.parametrize("name", ["round1_bench_v5.json", "round2_bench_final.json"])
+@pytest.mark.parametrize("name", ["round1_bench_v5.json", "round2_bench_final.json", "round3_bench_driver_flags.json"])
 def test_recorded_bench_line_has_the_contract_fields(name):
     d = json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -47,6 +47,22 @@ def test_recorded_bench_line_has_the_contract_fields(name):
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["value"] - d["config"]["frames_per_gpu"] * d["n_gpus"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-2
+    if name.startswith("round3"):
+        import math
+
+        # round 3: the headline IS the precision that meets the 1e-3 contract; bf16 autocast is the second line
+        assert d["dtype"].startswith("f32") and d["precision"]["fp32_within_tolerance"] is True
+        assert d["precision"]["fp32_max_abs_err"] < 1e-3 < d["precision"]["bf16_max_abs_err"]
+        assert d["bf16"]["dtype"] == "bf16" and d["bf16"]["value"] > d["value"] > 450
+        assert math.isfinite(d["config"]["final_loss"]) and math.isfinite(d["config"]["final_grad_norm"])
+        assert r["kernel"] == "spconv_fwd_mfma_kernel<64,64>" and r["traffic"] > 0 and r["traffic_measured_in_run"] is False
+        m = d["rpn_mfma"]
+        assert m["bound"] == "mfma" and m["convs_on_library_kernels"] == 7 and m["gflop_per_step_left_on_miopen"] == 0.0
+        assert abs(m["frac"] - m["mfma_issued_TFLOPs"] / m["peak_TFLOPs"]) < 1e-3
+        # every single-GPU configuration at its configured batch size
+        assert {"c2-60k", "c4", "c5", "c3"} <= set(d["workloads"])
+        assert "16 frames/GPU" in d["workloads"]["c4"]["workload"] and "6 frames/GPU" in d["workloads"]["c5"]["workload"]
+        assert all(math.isfinite(w["final_loss"]) for w in d["workloads"].values())
     if name.startswith("round2"):
         import math
 
