@@ -78,13 +78,15 @@ template <int BK> struct C2Tile {
 //      behind the wave's own MFMAs)
 //  HB: half-depth K steps (32 channels in bf16, 16 in split mode): half the LDS per block, four blocks per CU instead of
 //      two -- more waves to cover the wait + barrier at the top of every K step, at twice the barriers per FLOP
-template <int CIN, bool SPLIT, bool OUT_F32, int WPX, bool ILV, bool HB = false>
-__global__ void __launch_bounds__(128 * WPX, (WPX == 2 ? (HB ? 4 : 2) : (HB ? 2 : 1)))
+//  PXT: 32-pixel MFMA tiles per wave (2 -> 64 x 64 wave tiles; 1 -> 64 x 32: with WPX = 4 the same 128-pixel block on 8
+//      waves, twice the waves per CU to cover the waits of the two-stage loop, 1.5x the LDS fragment reads)
+template <int CIN, bool SPLIT, bool OUT_F32, int WPX, bool ILV, bool HB = false, int PXT = 2>
+__global__ void __launch_bounds__(128 * WPX, (WPX * PXT == 4 ? (HB ? 4 : 2) : (HB ? 2 : 1)))
     conv2d_nhwc_kernel(const void *__restrict__ x_hi, const void *__restrict__ x_lo, const void *__restrict__ w_hi,
                        const void *__restrict__ w_lo, void *__restrict__ y, Conv2dGeom G, Conv2dEpi ep) {
   constexpr int BK = (SPLIT ? 32 : 64) / (HB ? 2 : 1);
   using T = C2Tile<BK>;
-  constexpr int WAVES = 2 * WPX, NTH = WAVES * 64, BM = 64 * WPX;
+  constexpr int WAVES = 2 * WPX, NTH = WAVES * 64, BM = 32 * PXT * WPX;
   constexpr int KC = CIN / BK;                 // K steps per tap
   constexpr int NP = SPLIT ? 2 : 1;            // planes per operand
   constexpr int APLANE = BM * T::RB, BPLANE = 128 * T::RB;
@@ -173,24 +175,27 @@ __global__ void __launch_bounds__(128 * WPX, (WPX == 2 ? (HB ? 4 : 2) : (HB ? 2 
     }
   };
 
-  c2_f32x16 acc[2][2];  // [cout tile][pixel tile]
+  c2_f32x16 acc[2][PXT];  // [cout tile][pixel tile]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < PXT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // fragment addresses: lane reads row (lane & 31) of a 32-row tile, k-chunk (lane >> 5) of each 16-wide substep
   const int frow = lane & 31, fk = lane >> 5;
-  int a_rd[2], b_rd[2];  // byte offsets of (row, chunk 0) + the row's swizzle, per tile
-  int a_sw[2], b_sw[2];
+  int a_rd[2], b_rd[PXT];  // byte offsets of (row, chunk 0) + the row's swizzle, per tile
+  int a_sw[2], b_sw[PXT];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int wr = wco * 64 + t * 32 + frow;  // weight-tile row (cout)
-    const int xr = wpx * 64 + t * 32 + frow;  // activation-tile row (pixel)
     a_rd[t] = wr * T::RB;
     a_sw[t] = T::swz(wr);
+  }
+#pragma unroll
+  for (int t = 0; t < PXT; ++t) {
+    const int xr = wpx * (32 * PXT) + t * 32 + frow;  // activation-tile row (pixel)
     b_rd[t] = xr * T::RB;
     b_sw[t] = T::swz(xr);
   }
@@ -208,20 +213,21 @@ __global__ void __launch_bounds__(128 * WPX, (WPX == 2 ? (HB ? 4 : 2) : (HB ? 2 
 #pragma unroll
     for (int kk = 0; kk < KSUB; ++kk) {
       const int chunk = kk * 2 + fk;
-      c2_bf16x8 wa[2][NP], xb[2][NP];
+      c2_bf16x8 wa[2][NP], xb[PXT][NP];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int p = 0; p < NP; ++p) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
+        for (int t = 0; t < 2; ++t)
           wa[t][p] = *(const c2_bf16x8 *)(sb + p * BPLANE + a_rd[t] + ((chunk ^ a_sw[t]) << 4));
+#pragma unroll
+        for (int t = 0; t < PXT; ++t)
           xb[t][p] = *(const c2_bf16x8 *)(sa + p * APLANE + b_rd[t] + ((chunk ^ b_sw[t]) << 4));
-        }
       }
       if (ILV && more) stage(ks + 1, buf ^ 1, kk, KSUB);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < PXT; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][0], xb[j][0], acc[i][j], 0, 0, 0);
           if constexpr (SPLIT) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][0], xb[j][1], acc[i][j], 0, 0, 0);
@@ -262,8 +268,8 @@ __global__ void __launch_bounds__(128 * WPX, (WPX == 2 ? (HB ? 4 : 2) : (HB ? 2 
         }
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int m = m0 + wpx * 64 + j * 32 + (lane & 31);
+      for (int j = 0; j < PXT; ++j) {
+        const int m = m0 + wpx * (32 * PXT) + j * 32 + (lane & 31);
         const bool live = m < G.m;
         float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
         float x[4] = {0.f, 0.f, 0.f, 0.f};
@@ -363,8 +369,10 @@ __global__ void __launch_bounds__(128 * WPX, (WPX == 2 ? (HB ? 4 : 2) : (HB ? 2 
 // (ds_read_b64_tr_b16: four pixels of one channel per lane).  One block per (pixel split, tap, 128 x 128 weight tile):
 // a block owns one tap, one 128 x 128 weight tile and a contiguous range of pixels; it writes ONE partial tile, the
 // partial tiles are summed in a fixed order by conv2d_wgrad_reduce_kernel: deterministic, no atomics.
-template <bool SPLIT>
-__global__ void __launch_bounds__(256, 2)
+// WCI: waves along the input-channel axis of the 128 x 128 weight tile (2 -> four waves of 64 x 64; 4 -> eight waves of
+// 64 x 32: twice the waves per CU to cover the waits of the two-stage loop, as in the forward kernel)
+template <bool SPLIT, int WCI>
+__global__ void __launch_bounds__(128 * WCI, 2)
     conv2d_wgrad_kernel(const void *__restrict__ g_hi, const void *__restrict__ g_lo, const void *__restrict__ x_hi,
                         const void *__restrict__ x_lo, float *__restrict__ part, Conv2dGeom G, int cin,
                         int pixels_per_split, int nsplit) {
@@ -372,11 +380,12 @@ __global__ void __launch_bounds__(256, 2)
   constexpr int NP = SPLIT ? 2 : 1;
   constexpr int PLANE = KP * 256;              // KP rows of 128 channels (256 B)
   constexpr int STAGE = 2 * NP * PLANE;        // g planes then x planes
-  constexpr int INSTR = PLANE / 1024 / 4;      // LDS-DMA instructions per wave and plane
+  constexpr int CIT = 4 / WCI;                 // 32-channel MFMA tiles per wave along cin
+  constexpr int INSTR = PLANE / 1024 / (2 * WCI);  // LDS-DMA instructions per wave and plane
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wco = wave >> 1, wci = wave & 1;
+  const int wco = wave / WCI, wci = wave % WCI;
   // 1-D grid; XCD-aware order with the tap fastest: the 9 taps of a pixel range read the same g rows and (shifted) x
   // rows, and consecutive logical ids stay on one XCD, i.e. behind one L2
   int logical;
@@ -450,11 +459,11 @@ __global__ void __launch_bounds__(256, 2)
     }
   };
 
-  c2_f32x16 acc[2][2];  // [co tile][ci tile]
+  c2_f32x16 acc[2][CIT];  // [co tile][ci tile]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < CIT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -495,44 +504,49 @@ __global__ void __launch_bounds__(256, 2)
     if (ks + 1 < nks) stage(buf ^ 1);
 #pragma unroll
     for (int kk = 0; kk < KP / 16; ++kk) {
-      u2 gr[2][NP][2], xr[2][NP][2];  // [tile][plane][first / second read]
+      u2 gr[2][NP][2], xr[CIT][NP][2];  // [tile][plane][first / second read]
       const uint32_t gbase = lds_base + (uint32_t)(buf * STAGE + kk * 4096);
       const uint32_t xbase = gbase + (uint32_t)(NP * PLANE);
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int p = 0; p < NP; ++p)
 #pragma unroll
-        for (int p = 0; p < NP; ++p)
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            gr[t][p][h] = tr_read(gbase + (uint32_t)(p * PLANE + h * 1024) + fo[wco * 2 + t]);
-            xr[t][p][h] = tr_read(xbase + (uint32_t)(p * PLANE + h * 1024) + fo[wci * 2 + t]);
-          }
-      // wait for the reads; the operands are tied to the wait so that no MFMA is scheduled in front of it
-      if constexpr (SPLIT)
+          for (int t = 0; t < 2; ++t) gr[t][p][h] = tr_read(gbase + (uint32_t)(p * PLANE + h * 1024) + fo[wco * 2 + t]);
+#pragma unroll
+          for (int t = 0; t < CIT; ++t) xr[t][p][h] = tr_read(xbase + (uint32_t)(p * PLANE + h * 1024) + fo[wci * CIT + t]);
+        }
+      // wait for the reads; the operands are tied to the wait (first statement) / ordered behind it (second, empty
+      // statement: volatile asm statements keep their order) so that no MFMA is scheduled in front of it
+      if constexpr (NP == 2)
         asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(gr[0][0][0]), "+v"(gr[0][0][1]), "+v"(gr[1][0][0]), "+v"(gr[1][0][1]), "+v"(xr[0][0][0]),
-                       "+v"(xr[0][0][1]), "+v"(xr[1][0][0]), "+v"(xr[1][0][1]), "+v"(gr[0][NP - 1][0]),
-                       "+v"(gr[0][NP - 1][1]), "+v"(gr[1][NP - 1][0]), "+v"(gr[1][NP - 1][1]), "+v"(xr[0][NP - 1][0]),
-                       "+v"(xr[0][NP - 1][1]), "+v"(xr[1][NP - 1][0]), "+v"(xr[1][NP - 1][1]));
+                     : "+v"(gr[0][0][0]), "+v"(gr[0][0][1]), "+v"(gr[1][0][0]), "+v"(gr[1][0][1]), "+v"(gr[0][1][0]),
+                       "+v"(gr[0][1][1]), "+v"(gr[1][1][0]), "+v"(gr[1][1][1]));
       else
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(gr[0][0][0]), "+v"(gr[0][0][1]), "+v"(gr[1][0][0]), "+v"(gr[1][0][1]), "+v"(xr[0][0][0]),
-                       "+v"(xr[0][0][1]), "+v"(xr[1][0][0]), "+v"(xr[1][0][1]));
-      c2_bf16x8 ga[2][NP], xb[2][NP];
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gr[0][0][0]), "+v"(gr[0][0][1]), "+v"(gr[1][0][0]), "+v"(gr[1][0][1]));
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < CIT; ++t)
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+        for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(xr[t][p][0]), "+v"(xr[t][p][1]));
+      c2_bf16x8 ga[2][NP], xb[CIT][NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
           const u4 gv = {gr[t][p][0][0], gr[t][p][0][1], gr[t][p][1][0], gr[t][p][1][1]};
-          const u4 xv = {xr[t][p][0][0], xr[t][p][0][1], xr[t][p][1][0], xr[t][p][1][1]};
           ga[t][p] = __builtin_bit_cast(c2_bf16x8, gv);
+        }
+#pragma unroll
+        for (int t = 0; t < CIT; ++t) {
+          const u4 xv = {xr[t][p][0][0], xr[t][p][0][1], xr[t][p][1][0], xr[t][p][1][1]};
           xb[t][p] = __builtin_bit_cast(c2_bf16x8, xv);
         }
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < CIT; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[i][0], xb[j][0], acc[i][j], 0, 0, 0);
           if constexpr (SPLIT) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[i][0], xb[j][1], acc[i][j], 0, 0, 0);
@@ -546,8 +560,8 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int ci = ci0 + wci * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < CIT; ++j) {
+      const int ci = ci0 + wci * (32 * CIT) + j * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + wco * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -628,8 +642,12 @@ __global__ void __launch_bounds__(256)
 
 // ---------------------------------------------------------------------------------------------------- host side
 // tiling variant of the forward kernel (d3d_set_tuning knob 7, D3D_CONV2D_VARIANT): bit 0 = interleaved LDS-DMA issue,
-// bit 1 = 256-pixel tiles (8 waves, one block per CU), bit 2 = half-depth K steps (twice the blocks per CU)
-int g_c2_variant = getenv("D3D_CONV2D_VARIANT") ? atoi(getenv("D3D_CONV2D_VARIANT")) : 0;
+// bit 1 = 256-pixel tiles (8 waves, one block per CU), bit 2 = half-depth K steps (twice the blocks per CU),
+// 8 = 128-pixel tiles on 8 waves (64 x 32 wave tiles; the default: 62.6 vs 67.7 us bf16, 143.8 vs 150.5 us split on the
+// [4,200,176,128] map), 9 = 8 + interleaved issue
+int g_c2_variant = getenv("D3D_CONV2D_VARIANT") ? atoi(getenv("D3D_CONV2D_VARIANT")) : 8;
+// waves per block of the weight-gradient kernel (knob 8, D3D_CONV2D_WGRAD_WAVES): 8 (64 x 32 wave tiles) or 4
+int g_c2_wgrad_waves = getenv("D3D_CONV2D_WGRAD_WAVES") ? atoi(getenv("D3D_CONV2D_WGRAD_WAVES")) : 8;
 
 static int c2_check(const char *who, int batch, int h, int w, int cin, int cout, int ksz, int stride, int pad,
                     int mode) {
@@ -684,8 +702,9 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
   rc = c2_geom("d3d_conv2d_nhwc_fwd", G, batch, h, w, cin, cout, ksz, stride, pad);
   if (rc) return rc;
   const int variant = g_c2_variant;
-  const int wpx = (variant & 2) ? 4 : 2;
-  const int bm = 64 * wpx;
+  const bool w8 = variant == 8 || variant == 9;  // 128-pixel tiles on 8 waves
+  const int wpx = ((variant & 2) || w8) ? 4 : 2;
+  const int bm = w8 ? 128 : 64 * wpx;
   const int nb = (G.m + bm - 1) / bm;
   Conv2dEpi ep = {};
   ep.fold_g = 16;
@@ -709,23 +728,25 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
     ep.counters = d3d_fold_counters(ep.ctr_stride * (cout / 128));
     if (!ep.counters) return D3D_EHIP;
   }
-  const bool hb = (variant & 4) != 0;
+  const bool hb = variant == 4;
   size_t lds = 2 * (size_t)((split ? 2 : 1) * (bm + 128) * (split ? 64 : 128)) / (hb ? 2 : 1);  // two stages of A + B planes
   if (stats_ws && lds < (size_t)(wpx * 256 + 256 + 4) * 4) lds = (size_t)(wpx * 256 + 256 + 4) * 4;  // epilogue scratch
-#define C2_LAUNCH(CIN, SPLIT, WPX, ILV, HB)                                                                     \
+#define C2_LAUNCH(CIN, SPLIT, WPX, ILV, HB, PXT)                                                                \
   do {                                                                                                          \
-    D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_nhwc_kernel<CIN, SPLIT, SPLIT, WPX, ILV, HB>,          \
+    D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_nhwc_kernel<CIN, SPLIT, SPLIT, WPX, ILV, HB, PXT>,     \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
-    hipLaunchKernelGGL((conv2d_nhwc_kernel<CIN, SPLIT, SPLIT, WPX, ILV, HB>), dim3(nb, cout / 128),             \
+    hipLaunchKernelGGL((conv2d_nhwc_kernel<CIN, SPLIT, SPLIT, WPX, ILV, HB, PXT>), dim3(nb, cout / 128),        \
                        dim3(128 * WPX), lds, stream, x_hi, x_lo, w_hi, w_lo, y, G, ep);                         \
   } while (0)
 #define C2_VARIANTS(CIN, SPLIT)                                         \
   do {                                                                  \
-    if (variant == 1) C2_LAUNCH(CIN, SPLIT, 2, true, false);            \
-    else if (variant == 2) C2_LAUNCH(CIN, SPLIT, 4, false, false);      \
-    else if (variant == 3) C2_LAUNCH(CIN, SPLIT, 4, true, false);       \
-    else if (variant == 4) C2_LAUNCH(CIN, SPLIT, 2, false, true);       \
-    else C2_LAUNCH(CIN, SPLIT, 2, false, false);                        \
+    if (variant == 1) C2_LAUNCH(CIN, SPLIT, 2, true, false, 2);         \
+    else if (variant == 2) C2_LAUNCH(CIN, SPLIT, 4, false, false, 2);   \
+    else if (variant == 3) C2_LAUNCH(CIN, SPLIT, 4, true, false, 2);    \
+    else if (variant == 4) C2_LAUNCH(CIN, SPLIT, 2, false, true, 2);    \
+    else if (variant == 8) C2_LAUNCH(CIN, SPLIT, 4, false, false, 1);   \
+    else if (variant == 9) C2_LAUNCH(CIN, SPLIT, 4, true, false, 1);    \
+    else C2_LAUNCH(CIN, SPLIT, 2, false, false, 2);                     \
   } while (0)
 #define C2_CASE(CIN)                             \
   if (cin == CIN) {                              \
@@ -784,15 +805,19 @@ extern "C" int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const v
   const int nsplit = (G.m + pps - 1) / pps;
   const size_t lds = 2 * (size_t)(2 * (split ? 2 : 1) * kp * 256);
   const dim3 grid(nsplit * ksz * ksz * (cout / 128) * (cin / 128));
-  if (split) {
-    D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((conv2d_wgrad_kernel<true>), grid, dim3(256), lds, stream, g_hi, g_lo, x_hi, x_lo,
-                       (float *)workspace, G, cin, pps, nsplit);
+#define C2_WG(SPLIT, WCI)                                                                                     \
+  do {                                                                                                        \
+    D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_wgrad_kernel<SPLIT, WCI>,                            \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+    hipLaunchKernelGGL((conv2d_wgrad_kernel<SPLIT, WCI>), grid, dim3(128 * WCI), lds, stream, g_hi, g_lo, x_hi, \
+                       x_lo, (float *)workspace, G, cin, pps, nsplit);                                        \
+  } while (0)
+  if (g_c2_wgrad_waves == 4) {
+    if (split) C2_WG(true, 2); else C2_WG(false, 2);
   } else {
-    D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((conv2d_wgrad_kernel<false>), grid, dim3(256), lds, stream, g_hi, g_lo, x_hi, x_lo,
-                       (float *)workspace, G, cin, pps, nsplit);
+    if (split) C2_WG(true, 4); else C2_WG(false, 4);
   }
+#undef C2_WG
   D3D_LAUNCH_TRY("conv2d_wgrad_kernel");
   const int64_t n4 = (int64_t)ksz * ksz * cout * cin / 4;
   hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, stream,

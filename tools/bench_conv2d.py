@@ -38,7 +38,7 @@ def main():
         flop = 2.0 * b * ho * wo * cout * cin * k * k
         row = {"shape": [b, h, w, cin, cout, k, s, p], "gflop": flop / 1e9}
         from det3d_amd import _lib
-        variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
+        variants = [int(v) for v in os.environ.get("VARIANTS", "8").split(",")]
         for mode in ("bf16", "split"):
             w_hi, w_lo = dc._packed(wt, "fwd", mode)
             if mode == "bf16":
@@ -49,15 +49,18 @@ def main():
                 _lib.lib().d3d_set_tuning(7, v)
                 t = timeit(lambda: dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, mode))
                 ts = timeit(lambda: dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, mode, want_stats=True))
-                tag = mode + ("_v%d" % v if v else "")
+                tag = mode + "_v%d" % v
                 row[tag + "_fwd_us"] = round(t, 1)
                 row[tag + "_fwd_stats_us"] = round(ts, 1)
                 row[tag + "_fwd_TF"] = round(flop / t / 1e6, 1)
             _lib.lib().d3d_set_tuning(7, variants[0])
             if cin % 128 == 0:
-                tw = timeit(lambda: dc.wgrad_raw(g_hi, g_lo, x_hi, x_lo, k, s, p, mode))
-                row[mode + "_wgrad_us"] = round(tw, 1)
-                row[mode + "_wgrad_TF"] = round(flop / tw / 1e6, 1)
+                for wv in [int(v) for v in os.environ.get("WGRAD_WAVES", "8").split(",")]:
+                    _lib.lib().d3d_set_tuning(8, wv)
+                    tw = timeit(lambda: dc.wgrad_raw(g_hi, g_lo, x_hi, x_lo, k, s, p, mode))
+                    row[mode + "_wgrad%d_us" % wv] = round(tw, 1)
+                    row[mode + "_wgrad%d_TF" % wv] = round(flop / tw / 1e6, 1)
+                _lib.lib().d3d_set_tuning(8, 8)
         # MIOpen through torch, channels-last
         for dt, nm in ((torch.bfloat16, "miopen_bf16"), (torch.float32, "miopen_f32")):
             xm = x.permute(0, 3, 1, 2).to(dt).contiguous(memory_format=torch.channels_last).requires_grad_(True)
