@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(256)
 // bit 1 = 256-pixel tiles (8 waves, one block per CU), bit 2 = half-depth K steps (twice the blocks per CU),
 // 8 = 128-pixel tiles on 8 waves (64 x 32 wave tiles; the default: 62.6 vs 67.7 us bf16, 143.8 vs 150.5 us split on the
 // [4,200,176,128] map), 9 = 8 + interleaved issue
-int g_c2_variant = getenv("D3D_CONV2D_VARIANT") ? atoi(getenv("D3D_CONV2D_VARIANT")) : 8;
+int g_c2_variant = getenv("D3D_CONV2D_VARIANT") ? atoi(getenv("D3D_CONV2D_VARIANT")) : -1;  // -1: 8 for bf16, 9 for split
 // waves per block of the weight-gradient kernel (knob 8, D3D_CONV2D_WGRAD_WAVES): 8 (64 x 32 wave tiles) or 4
 int g_c2_wgrad_waves = getenv("D3D_CONV2D_WGRAD_WAVES") ? atoi(getenv("D3D_CONV2D_WGRAD_WAVES")) : 8;
 
@@ -701,7 +701,9 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
   Conv2dGeom G;
   rc = c2_geom("d3d_conv2d_nhwc_fwd", G, batch, h, w, cin, cout, ksz, stride, pad);
   if (rc) return rc;
-  const int variant = g_c2_variant;
+  // measured on the [4,200,176,128] map (profiles/round3_conv2d_variants.txt): bf16 62.3 (8) / 70.7 (9) / 66.6 (0) us,
+  // split 145.6 (8) / 138.7 (9) / 146.9 (0) us
+  const int variant = g_c2_variant >= 0 ? g_c2_variant : (split ? 9 : 8);
   const bool w8 = variant == 8 || variant == 9;  // 128-pixel tiles on 8 waves
   const int wpx = ((variant & 2) || w8) ? 4 : 2;
   const int bm = w8 ? 128 : 64 * wpx;
