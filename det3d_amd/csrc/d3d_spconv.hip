@@ -886,7 +886,7 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
   // stage is what hides the L2 gather latency; it is bounded by the 128 VGPRs of a 4-waves-per-SIMD block.
   // D3D_FWD_VARIANT (tools/tune_fwd.py) selects alternative 64->64 tilings.
   const int fwd_variant = g_fwd_variant >= 0 ? g_fwd_variant : fwd_variant_env();
-  if (fwd_variant && cin == 64 && cout == 64 && dtype == D3D_BF16) {
+  if (fwd_variant && fwd_variant < 50 && cin == 64 && cout == 64 && dtype == D3D_BF16) {
 #define FWD_VAR(V, MT, WV, DP) \
     if (fwd_variant == V) return launch_fwd<64, 64, MT, WV, DP, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
     FWD_VAR(40, 2, 8, 3)  // the per-offset-barrier kernel that was the default before the grouped one
@@ -923,6 +923,17 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
     FWD_GROUP(35, 1, 8, 5)
 #undef FWD_GROUP
   }
+  if (fwd_variant >= 50 && cin == 64 && cout == 64 && dtype == D3D_F32) {  // f32 (split arithmetic) tilings
+#define FWD32_VAR(V, MT, WV, DP) \
+    if (fwd_variant == V) return launch_fwd<64, 64, MT, WV, DP, false>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    FWD32_VAR(50, 1, 16, 2)
+    FWD32_VAR(51, 1, 16, 3)
+    FWD32_VAR(52, 2, 8, 2)
+    FWD32_VAR(53, 1, 8, 3)
+    FWD32_VAR(54, 2, 16, 1)
+    FWD32_VAR(55, 1, 16, 1)
+#undef FWD32_VAR
+  }
   FWD_CASE(16, 16, 2, 8, 5, 4)
   FWD_CASE(16, 32, 2, 8, 5, 4)
   FWD_CASE(32, 16, 2, 8, 5, 3)
@@ -930,7 +941,7 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
   FWD_CASE(32, 64, 2, 8, 4, 2)
   FWD_CASE(64, 32, 1, 16, 5, 2)
   // 64 -> 64 bf16 (16 of the 39 launches of a KITTI step): grouped barriers, profiles/round2_tune_fwd.txt
-  if (cin == 64 && cout == 64 && dtype == D3D_BF16 && fwd_variant == 0)
+  if (cin == 64 && cout == 64 && dtype == D3D_BF16 && (fwd_variant == 0 || fwd_variant >= 50))
     return launch_fwd_group<64, 64, 2, 8, 2>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
   FWD_CASE(64, 64, 2, 8, 3, 1)
   FWD_CASE(64, 128, 1, 16, 3, 1)

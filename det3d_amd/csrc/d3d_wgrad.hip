@@ -362,14 +362,14 @@ static int wg_launch(const void *feat, const void *dout, const int32_t *nbr, int
 #define WG_ARGS feat, dout, nbr, cap, n_out, kvol, p, part, stream
 // (channels) -> the offset group wg_kgroup() picks for a 27-offset kernel with its prefetch depth, plus the
 // 3-offset ((3,1,1) kernels) and 1-offset fallbacks
-#define WG_CASE(CI, CO, KGMAIN, DMAIN)                                                                 \
+#define WG_CASE(CI, CO, KGMAIN, DMAIN, DF32)                                                              \
   if (cin == CI && cout == CO) {                                                                       \
     if (bf16) {                                                                                        \
       if (p.kg == KGMAIN) return wg_launch<CI, CO, KGMAIN, DMAIN, true>(WG_ARGS);                      \
       if (p.kg == 3) return wg_launch<CI, CO, 3, 3, true>(WG_ARGS);                                    \
       if (p.kg == 1) return wg_launch<CI, CO, 1, 1, true>(WG_ARGS);                                    \
     } else {                                                                                           \
-      if (p.kg == KGMAIN) return wg_launch<CI, CO, KGMAIN, 3, false>(WG_ARGS);                         \
+      if (p.kg == KGMAIN) return wg_launch<CI, CO, KGMAIN, DF32, false>(WG_ARGS);                      \
       if (p.kg == 3) return wg_launch<CI, CO, 3, 3, false>(WG_ARGS);                                   \
       if (p.kg == 1) return wg_launch<CI, CO, 1, 1, false>(WG_ARGS);                                   \
     }                                                                                                  \
@@ -379,13 +379,13 @@ static int wg_dispatch(const void *feat, const void *dout, const int32_t *nbr, i
                        int cin, int cout, bool bf16, const WgPlan &p, float *part, hipStream_t stream) {
   // prefetch depth: DEPTH stages x 16 KB of gathered rows in flight per CU, bounded by the 128 VGPRs a
   // 16-wave block leaves each lane (accumulators: 4 * KG * TPW)
-  WG_CASE(16, 16, 9, 3)
-  WG_CASE(16, 32, 9, 3)
-  WG_CASE(32, 32, 9, 3)
-  WG_CASE(32, 64, 9, 3)
-  WG_CASE(64, 64, 9, 9)
-  WG_CASE(64, 128, 9, 3)
-  WG_CASE(128, 128, 3, 3)
+  WG_CASE(16, 16, 9, 3, 3)
+  WG_CASE(16, 32, 9, 3, 3)
+  WG_CASE(32, 32, 9, 3, 3)
+  WG_CASE(32, 64, 9, 3, 3)
+  WG_CASE(64, 64, 9, 9, 9)
+  WG_CASE(64, 128, 9, 3, 3)
+  WG_CASE(128, 128, 3, 3, 3)
   return d3d_set_error(D3D_EINVAL, "wgrad tile kernel: unsupported channels %d -> %d (kg %d)", cin, cout, p.kg);
 }
 
