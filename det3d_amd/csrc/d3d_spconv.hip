@@ -943,6 +943,10 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
   // 64 -> 64 bf16 (16 of the 39 launches of a KITTI step): grouped barriers, profiles/round2_tune_fwd.txt
   if (cin == 64 && cout == 64 && dtype == D3D_BF16 && (fwd_variant == 0 || fwd_variant >= 50))
     return launch_fwd_group<64, 64, 2, 8, 2>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+  // f32 features (split arithmetic): one tile per wave, 16 waves -- 97.6 us against 112.6 us for MT2 x 8 waves on the
+  // 126k-site layer (tools/tune_fwd_f32.py, profiles/round3_tune_fwd_f32.txt)
+  if (cin == 64 && cout == 64 && dtype == D3D_F32)
+    return launch_fwd<64, 64, 1, 16, 1, false>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
   FWD_CASE(64, 64, 2, 8, 3, 1)
   FWD_CASE(64, 128, 1, 16, 3, 1)
   FWD_CASE(128, 64, 1, 16, 3, 1)

@@ -32,7 +32,7 @@ FP32_MODE = os.environ.get("D3D_RPN_FP32", "split")  # "split" | "exact" (MIOpen
 # streaming d3d_bn_bwd_reduce it replaces takes 29 us (gpurun_out r3j11 vs r3j5); the forward statistics epilogue
 # (+11-19 us against 11-20 us for d3d_bn_stats) is break-even and stays on because it saves the launches.
 FUSE_BN_BACKWARD = os.environ.get("D3D_DENSE_FUSE_BN_BWD", "0") == "1"
-STATS_EPILOGUE_BF16 = os.environ.get("D3D_DENSE_STATS_EPILOGUE_BF16", "0") == "1"
+STATS_EPILOGUE_BF16 = os.environ.get("D3D_DENSE_STATS_EPILOGUE_BF16", "1") == "1"
 
 
 class _Layer:
@@ -138,9 +138,10 @@ class _DenseStackFn(torch.autograd.Function):
         for li, ly in enumerate(layers):
             bn = ly.bn
             w_hi, w_lo = dc._packed(ly.conv.weight, "fwd", mode)
-            # BatchNorm statistics: from the conv's epilogue in split mode (+12 us on the launch against ~20 us for the
-            # sweep over the f32 map), from the stand-alone sweep in bf16 (+22 us against 11 us: measured,
-            # profiles/round3_conv2d_variants.txt `fwd_stats_us`)
+            # BatchNorm statistics from the conv's epilogue.  Alone the bf16 launch pays +22 us for it against 11 us for
+            # the stand-alone sweep (profiles/round3_conv2d_variants.txt `fwd_stats_us`), but end to end the step is
+            # faster with the epilogue (789 vs 717 frames/s, gpurun_out r3j17 / r3j18): 7 launches and 7 allocations
+            # less on a step whose host side is 70 % of its wall time
             epi = training and (split or STATS_EPILOGUE_BF16)
             y, ws = dc.conv2d_raw(a_hi, a_lo, w_hi, w_lo, ly.ksz, 1, ly.pad, mode, want_stats=epi)
             n = y.shape[0] * y.shape[1] * y.shape[2]
