@@ -827,12 +827,17 @@ static int launch_fwd(const void *feat, const void *wpack, const float *bias, co
   return D3D_OK;
 }
 
+// f32 features run one tile per wave on 16 waves (D3D_F32_WIDE=0: the bf16 tiling with the f32 depth DF): the split
+// arithmetic keeps twice the fragment registers per tile, and 16 waves per CU cover the gather latency better than
+// deeper pipelines on 8 (64->64: 97.6 vs 112.6 us, profiles/round3_tune_fwd_f32.txt)
+static const int g_f32_wide = getenv("D3D_F32_WIDE") ? atoi(getenv("D3D_F32_WIDE")) : 1;
 #define FWD_CASE(CI, CO, MT, WV, DB, DF)                                                            \
   if (cin == CI && cout == CO) {                                                                    \
-    return dtype == D3D_BF16 ? launch_fwd<CI, CO, MT, WV, DB, true>(feat, wpack, bias, nbr, cap,    \
-                                                                    n_out, kvol, out, ep, stream)   \
-                             : launch_fwd<CI, CO, MT, WV, DF, false>(feat, wpack, bias, nbr, cap,   \
-                                                                     n_out, kvol, out, ep, stream); \
+    if (dtype == D3D_BF16)                                                                          \
+      return launch_fwd<CI, CO, MT, WV, DB, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream); \
+    if (g_f32_wide && CI >= 32)                                                                     \
+      return launch_fwd<CI, CO, 1, 16, (DF > 2 ? 2 : DF), false>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream); \
+    return launch_fwd<CI, CO, MT, WV, DF, false>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream); \
   }
 
 // channel pairs with an MFMA tiling below (FWD_CASE list): only these can carry the epilogue reductions
