@@ -827,10 +827,11 @@ static int launch_fwd(const void *feat, const void *wpack, const float *bias, co
   return D3D_OK;
 }
 
-// f32 features run one tile per wave on 16 waves (D3D_F32_WIDE=0: the bf16 tiling with the f32 depth DF): the split
-// arithmetic keeps twice the fragment registers per tile, and 16 waves per CU cover the gather latency better than
-// deeper pipelines on 8 (64->64: 97.6 vs 112.6 us, profiles/round3_tune_fwd_f32.txt)
-static const int g_f32_wide = getenv("D3D_F32_WIDE") ? atoi(getenv("D3D_F32_WIDE")) : 1;
+// D3D_F32_WIDE=1 runs f32 features one tile per wave on 16 waves.  Alone on the 126k-site 64->64 layer that is faster
+// (97.6 vs 112.6 us, profiles/round3_tune_fwd_f32.txt), inside the step it is not: 64->64 90 vs 79 us, 32->32 79 vs
+// 64 us, 32->64 73 vs 56 us, 498 vs 503 frames/s (gpurun_out/r3j20) -- the step's layers are smaller and share the GPU
+// with the geometry stream.  Off.
+static const int g_f32_wide = getenv("D3D_F32_WIDE") ? atoi(getenv("D3D_F32_WIDE")) : 0;
 #define FWD_CASE(CI, CO, MT, WV, DB, DF)                                                            \
   if (cin == CI && cout == CO) {                                                                    \
     if (dtype == D3D_BF16)                                                                          \
@@ -948,10 +949,6 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
   // 64 -> 64 bf16 (16 of the 39 launches of a KITTI step): grouped barriers, profiles/round2_tune_fwd.txt
   if (cin == 64 && cout == 64 && dtype == D3D_BF16 && (fwd_variant == 0 || fwd_variant >= 50))
     return launch_fwd_group<64, 64, 2, 8, 2>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
-  // f32 features (split arithmetic): one tile per wave, 16 waves -- 97.6 us against 112.6 us for MT2 x 8 waves on the
-  // 126k-site layer (tools/tune_fwd_f32.py, profiles/round3_tune_fwd_f32.txt)
-  if (cin == 64 && cout == 64 && dtype == D3D_F32)
-    return launch_fwd<64, 64, 1, 16, 1, false>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
   FWD_CASE(64, 64, 2, 8, 3, 1)
   FWD_CASE(64, 128, 1, 16, 3, 1)
   FWD_CASE(128, 64, 1, 16, 3, 1)
