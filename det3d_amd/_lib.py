@@ -39,6 +39,11 @@ SIGNATURES = {
     "d3d_conv_epilogue_ws_floats": (sz, [i32, i32]),
     "d3d_bn_reduce_ws_floats": (sz, [i32, i32, i32]),
     "d3d_sparse_conv_fwd_ex": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "d3d_dgrad_plan_ints": (sz, [i32]),
+    "d3d_dgrad_plan_supported": (i32, [vp, vp]),
+    "d3d_dgrad_plan_build": (i32, [vp, vp, i32, vp, vp, vp, vp, sz, vp]),
+    "d3d_sparse_conv_dgrad_plan_supported": (i32, [i32, i32, i32]),
+    "d3d_sparse_conv_dgrad_planned": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "d3d_sparse_conv_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "d3d_sparse_conv_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
     "d3d_bn_relu_fwd": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp, vp, vp, vp]),
@@ -90,7 +95,7 @@ SIGNATURES = {
     "d3d_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
 }
 
-ABI_VERSION = 4  # include/d3d.h D3D_ABI_VERSION
+ABI_VERSION = 5  # include/d3d.h D3D_ABI_VERSION
 D3D_F32 = 0
 D3D_BF16 = 1
 D3D_CONV_BF16, D3D_CONV_SPLIT = 0, 1

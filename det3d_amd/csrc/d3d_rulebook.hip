@@ -19,6 +19,7 @@
 #include "d3d_scan.h"
 #include <stdlib.h>
 #include "d3d_fill.h"
+#include "d3d_rowplan.h"
 
 struct RbGeom {
   int batch;
@@ -445,5 +446,171 @@ extern "C" int d3d_conv_rulebook(const int32_t *coords_in, const int32_t *n_in_d
                      n_in_dev, cap_in, G, bitmap, wordprefix, cap_out, nbr_out, nbr_in,
                      pair_count);
   D3D_LAUNCH_TRY("rb_conv_fill_kernel");
+  return D3D_OK;
+}
+
+// ===================================================================== row plan of a strided data gradient
+// (d3d_rowplan.h)  Three launches on the geometry stream: class histogram per 1024 rows, one-block scan (which also
+// writes the class boundaries and the offset lists), stable scatter.  No atomics: the plan is a pure function of the
+// coordinates, so the summation order of the planned launch's BatchNorm epilogue is reproducible.
+struct PlanGeom {
+  int k[3], s[3], p[3];
+  int ncls, kvol;
+};
+
+__device__ __forceinline__ int plan_class(const PlanGeom &G, int4 c) {
+  const int in[3] = {c.y, c.z, c.w};
+  int cls = 0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) cls = cls * G.s[j] + (in[j] + G.p[j]) % G.s[j];
+  return cls;
+}
+
+// wave counts of each class in wc[wave][class]; returns this row's rank among the rows of its class in its wave
+__device__ __forceinline__ int plan_wave_rank(int cls, int (*wc)[D3D_PLAN_MAX_CLASSES]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int rank = 0;
+#pragma unroll
+  for (int c = 0; c < D3D_PLAN_MAX_CLASSES; ++c) {
+    const unsigned long long m = __ballot(cls == c);
+    if (cls == c) rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wc[wave][c] = __popcll(m);
+  }
+  return rank;
+}
+
+__global__ void __launch_bounds__(D3D_PLAN_SORT_ROWS)
+    dplan_hist_kernel(const int4 *coords, const int32_t *n_dev, int cap, PlanGeom G, int32_t *blockhist) {
+  __shared__ int wc[D3D_PLAN_SORT_ROWS / 64][D3D_PLAN_MAX_CLASSES];
+  int n = *n_dev;
+  n = n < cap ? n : cap;
+  const int r = blockIdx.x * D3D_PLAN_SORT_ROWS + threadIdx.x;
+  plan_wave_rank(r < n ? plan_class(G, coords[r]) : -1, wc);
+  __syncthreads();
+  if (threadIdx.x < D3D_PLAN_MAX_CLASSES) {
+    int s = 0;
+    for (int w = 0; w < D3D_PLAN_SORT_ROWS / 64; ++w) s += wc[w][threadIdx.x];
+    blockhist[blockIdx.x * D3D_PLAN_MAX_CLASSES + threadIdx.x] = s;
+  }
+}
+
+// wave c turns the block counts of class c into exclusive offsets inside the class; then the header of the plan
+__global__ void __launch_bounds__(64 * D3D_PLAN_MAX_CLASSES)
+    dplan_scan_kernel(int32_t *blockhist, int nb, PlanGeom G, int32_t *plan) {
+  __shared__ int tot[D3D_PLAN_MAX_CLASSES];
+  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int carry = 0;
+  for (int b0 = 0; b0 < nb; b0 += 64) {
+    const int b = b0 + lane;
+    const int v = b < nb ? blockhist[b * D3D_PLAN_MAX_CLASSES + c] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (b < nb) blockhist[b * D3D_PLAN_MAX_CLASSES + c] = carry + incl - v;
+    carry += __shfl(incl, 63, 64);
+  }
+  if (lane == 0) tot[c] = carry;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    plan[0] = G.ncls;
+    int s = 0;
+    for (int j = 0; j <= D3D_PLAN_MAX_CLASSES; ++j) {
+      plan[D3D_PLAN_START + j] = s;
+      if (j < G.ncls) s += tot[j];
+    }
+  }
+  if ((int)threadIdx.x <= G.ncls) {
+    int cls = (int)threadIdx.x;
+    int32_t *L = plan + D3D_PLAN_LISTS + cls * D3D_PLAN_LIST_WORDS;
+    const bool every = cls == G.ncls;
+    int r[3];
+    for (int j = 2; j >= 0; --j) {
+      r[j] = cls % G.s[j];
+      cls /= G.s[j];
+    }
+    int cnt = 0;
+    unsigned long long packed[2] = {0ull, 0ull};
+    for (int k = 0; k < G.kvol; ++k) {
+      const int kk[3] = {k / (G.k[1] * G.k[2]), (k / G.k[2]) % G.k[1], k % G.k[2]};
+      bool ok = true;
+      for (int j = 0; j < 3; ++j) ok &= every || kk[j] % G.s[j] == r[j];
+      if (ok) {
+        if (cnt < 24) packed[cnt / 12] |= (unsigned long long)k << (5 * (cnt % 12));
+        L[1 + cnt++] = k;
+      }
+    }
+    if (cnt == 0) L[1 + cnt++] = 0;  // a class no offset reaches (kernel smaller than the stride): one empty stage
+    L[0] = cnt;
+    *(unsigned long long *)(L + D3D_PLAN_LIST_PACKED) = packed[0];
+    *(unsigned long long *)(L + D3D_PLAN_LIST_PACKED + 2) = packed[1];
+  }
+}
+
+__global__ void __launch_bounds__(D3D_PLAN_SORT_ROWS)
+    dplan_scatter_kernel(const int4 *coords, const int32_t *n_dev, int cap, PlanGeom G, const int32_t *blockoff,
+                         int32_t *plan) {
+  __shared__ int wc[D3D_PLAN_SORT_ROWS / 64][D3D_PLAN_MAX_CLASSES];
+  int n = *n_dev;
+  n = n < cap ? n : cap;
+  const int r = blockIdx.x * D3D_PLAN_SORT_ROWS + threadIdx.x;
+  const int cls = r < n ? plan_class(G, coords[r]) : -1;
+  const int rank = plan_wave_rank(cls, wc);
+  __syncthreads();
+  if (cls < 0) return;
+  int pre = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) pre += wc[w][cls];
+  plan[D3D_PLAN_PERM + plan[D3D_PLAN_START + cls] + blockoff[blockIdx.x * D3D_PLAN_MAX_CLASSES + cls] + pre + rank] = r;
+}
+
+static int plan_blocks(int cap_in) { return (cap_in + D3D_PLAN_SORT_ROWS - 1) / D3D_PLAN_SORT_ROWS; }
+
+extern "C" size_t d3d_dgrad_plan_ints(int cap_in) {
+  if (cap_in < 1) return 0;
+  return (size_t)D3D_PLAN_PERM + (size_t)cap_in + (size_t)plan_blocks(cap_in) * D3D_PLAN_MAX_CLASSES;
+}
+
+extern "C" int d3d_dgrad_plan_supported(const int32_t *ksize, const int32_t *stride) {
+  if (!ksize || !stride) return 0;
+  const int ncls = stride[0] * stride[1] * stride[2];
+  const int kvol = ksize[0] * ksize[1] * ksize[2];
+  for (int j = 0; j < 3; ++j)
+    if (ksize[j] < 1 || stride[j] < 1) return 0;
+  return ncls >= 2 && ncls <= D3D_PLAN_MAX_CLASSES && kvol <= D3D_PLAN_MAX_KVOL;
+}
+
+extern "C" int d3d_dgrad_plan_build(const int32_t *coords_in, const int32_t *n_in_dev, int cap_in,
+                                    const int32_t *ksize, const int32_t *stride, const int32_t *padding,
+                                    int32_t *plan, size_t plan_ints, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  D3D_REQUIRE(coords_in && n_in_dev && ksize && stride && padding && plan, "d3d_dgrad_plan_build: null pointer");
+  D3D_REQUIRE(cap_in >= 1, "d3d_dgrad_plan_build: cap_in %d", cap_in);
+  D3D_REQUIRE(d3d_dgrad_plan_supported(ksize, stride),
+              "d3d_dgrad_plan_build: strides %d,%d,%d / kernel %d,%d,%d outside the plan's classes (ask "
+              "d3d_dgrad_plan_supported)", stride[0], stride[1], stride[2], ksize[0], ksize[1], ksize[2]);
+  if (plan_ints < d3d_dgrad_plan_ints(cap_in))
+    return d3d_set_error(D3D_ECAPACITY, "d3d_dgrad_plan_build: plan of %zu words < %zu", plan_ints,
+                         d3d_dgrad_plan_ints(cap_in));
+  PlanGeom G;
+  for (int j = 0; j < 3; ++j) {
+    D3D_REQUIRE(padding[j] >= 0, "d3d_dgrad_plan_build: padding");
+    G.k[j] = ksize[j];
+    G.s[j] = stride[j];
+    G.p[j] = padding[j];
+  }
+  G.ncls = stride[0] * stride[1] * stride[2];
+  G.kvol = ksize[0] * ksize[1] * ksize[2];
+  const int nb = plan_blocks(cap_in);
+  int32_t *blockhist = plan + D3D_PLAN_PERM + cap_in;
+  hipLaunchKernelGGL(dplan_hist_kernel, dim3(nb), dim3(D3D_PLAN_SORT_ROWS), 0, stream, (const int4 *)coords_in,
+                     n_in_dev, cap_in, G, blockhist);
+  D3D_LAUNCH_TRY("dplan_hist_kernel");
+  hipLaunchKernelGGL(dplan_scan_kernel, dim3(1), dim3(64 * D3D_PLAN_MAX_CLASSES), 0, stream, blockhist, nb, G, plan);
+  D3D_LAUNCH_TRY("dplan_scan_kernel");
+  hipLaunchKernelGGL(dplan_scatter_kernel, dim3(nb), dim3(D3D_PLAN_SORT_ROWS), 0, stream, (const int4 *)coords_in,
+                     n_in_dev, cap_in, G, blockhist, plan);
+  D3D_LAUNCH_TRY("dplan_scatter_kernel");
   return D3D_OK;
 }

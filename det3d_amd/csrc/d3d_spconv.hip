@@ -23,6 +23,7 @@
 #include "d3d_common.h"
 #include "d3d_fill.h"
 #include "d3d_fold.h"
+#include "d3d_rowplan.h"
 #include "d3d_spconv_internal.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -91,8 +92,9 @@ __device__ __forceinline__ void spconv_split8(const uint4 &f0, const uint4 &f1, 
 
 // the ABI's epilogue request + what the launcher adds for the deterministic cross-block fold (d3d_fold.h)
 struct ConvEpiDev : D3dConvEpilogue {
-  unsigned *counters;  // ticket words of this launch
-  int fold_g;          // blocks per fold group
+  unsigned *counters;       // ticket words of this launch
+  int fold_g;               // blocks per fold group
+  const int32_t *row_plan;  // d3d_rowplan.h (planned launches only)
 };
 
 // fold plan of a reducing launch: capacity check of the caller's buffer, ticket words from the library's ring
@@ -247,11 +249,16 @@ __device__ __forceinline__ void spconv_fwd_epilogue(f32x4_t (&acc)[MT][COUT / 16
 //     exactly as deep as they are: slot d holds gather(k+DEPTH), idx(k+2*DEPTH), W(k+1+DEPTH).
 // A 16-wave block with ~100 VGPRs runs once per CU with DEPTH x WAVES x MT x 16 rows in flight (64->64,
 // DEPTH 5: 160 KB per CU, against 64 KB for the 8-waves-per-SIMD / depth-1 version).
-template <int CIN, int COUT, int MT, int WAVES, int DEPTH, bool BF16>
+//
+// PLAN (round 3, d3d_rowplan.h): the data gradient of a strided layer.  Tile rows go through the plan's permutation
+// (rows of one parity class are consecutive), and a block whose rows share a class walks only that class's offsets:
+// stage j of the loop is offset list[j], `kvol` becomes the length of the list.  Stages past the end of a short list
+// gather nothing (out-of-range offsets) instead of re-reading the last offset.
+template <int CIN, int COUT, int MT, int WAVES, int DEPTH, bool BF16, bool PLAN = false>
 __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
     spconv_fwd_mfma_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
                            const float *__restrict__ bias, const int32_t *__restrict__ nbr,
-                           int cap, int n_out, int kvol, void *__restrict__ out_, ConvEpiDev ep,
+                           int cap, int n_out, int kvol_, void *__restrict__ out_, ConvEpiDev ep,
                            int xcd_remap) {
   // f32 features (BF16 = false) are multiplied in SPLIT arithmetic (round 3): a gathered f32 fragment is split in
   // registers into two bf16 vectors hi = bf16(v), lo = bf16(v - hi) (16 mantissa bits), the weights arrive
@@ -298,6 +305,37 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
     site[m] = row0 + m * 16 + lr;
     live[m] = site[m] < n_out;
   }
+  int kvol = kvol_;                 // stages of the offset loop
+  // PLAN: stage -> kernel offset, 5 bits per stage in two scalar registers (a load inside the loop would be a vector
+  // load -- hipcc keeps loads behind a barrier off the scalar cache -- and its wait would drain the gather pipeline);
+  // a block across a class boundary walks every offset: identity
+  unsigned long long kp0 = 0, kp1 = 0;
+  bool kident = true;
+  if constexpr (PLAN) {
+    const int32_t *pl = ep.row_plan;  // uniform addresses: scalar loads
+    const int ncls = pl[0];
+    const int rfirst = tile_block * (WAVES * MT * 16);
+    int rlast = rfirst + WAVES * MT * 16;
+    rlast = (rlast < n_out ? rlast : n_out) - 1;
+    int cf = 0, cl = 0;
+#pragma unroll
+    for (int c = 1; c < D3D_PLAN_MAX_CLASSES; ++c) {
+      const int st = pl[D3D_PLAN_START + c];
+      cf += (c < ncls && rfirst >= st) ? 1 : 0;
+      cl += (c < ncls && rlast >= st) ? 1 : 0;
+    }
+    const int32_t *klist = pl + D3D_PLAN_LISTS + (cf == cl ? cf : ncls) * D3D_PLAN_LIST_WORDS;
+    kvol = klist[0];
+    kident = kvol == kvol_;
+    kp0 = *(const unsigned long long *)(klist + D3D_PLAN_LIST_PACKED);
+    kp1 = *(const unsigned long long *)(klist + D3D_PLAN_LIST_PACKED + 2);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) site[m] = live[m] ? pl[D3D_PLAN_PERM + site[m]] : 0;
+  }
+  auto stage_offset = [&](int j) -> int {
+    if (!PLAN || kident) return j;
+    return (int)((j < 12 ? kp0 >> (5 * j) : kp1 >> (5 * (j - 12))) & 31ull);
+  };
   // gathered-row fragment of one (tile, k-step): EPL elements = 16 B (8 bf16 | 4 f32), 8 B (4 bf16, Cin = 16) or
   // 32 B (8 f32)
   struct Frag32 { uint4 a, b; };
@@ -312,17 +350,19 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
   // a valid entry; the value is then ignored through `live` or never used)
   auto load_idx = [&](int k, int (&ix)[MT]) {
     k = k < kmax ? k : kmax;
+    k = stage_offset(k);
     const int32_t *nk = nbr + (int64_t)k * cap;  // uniform base, 32-bit lane offset
 #pragma unroll
-    for (int m = 0; m < MT; ++m) ix[m] = nk[(uint32_t)(live[m] ? site[m] : n_out - 1)];
+    for (int m = 0; m < MT; ++m) ix[m] = nk[(uint32_t)(live[m] ? site[m] : (PLAN ? 0 : n_out - 1))];
   };
   // returns the wave's ballot of lanes with a real neighbour: a (tile group, offset) stage whose 16*MT sites all
   // miss the neighbour skips its LDS reads and MFMAs (corner offsets of submanifold layers are mostly empty)
-  auto gather = [&](const int (&ix)[MT], FragT (&f)[MT][KS]) -> unsigned long long {
+  auto gather = [&](int k, const int (&ix)[MT], FragT (&f)[MT][KS]) -> unsigned long long {
     bool any = false;
+    const bool stage = !PLAN || k <= kmax;  // PLAN: lists are short, a stage past the end must not re-gather
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const bool ok = live[m] && ix[m] >= 0;
+      const bool ok = live[m] && ix[m] >= 0 && stage;
       any |= ok;
       const uint32_t base = ok ? (uint32_t)ix[m] * (uint32_t)(CIN * ESZ) + lane_off : D3D_OOB_OFFSET;
 #pragma unroll
@@ -343,6 +383,7 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
   const unsigned char *wg = (const unsigned char *)wpack_;
   auto load_w = [&](int k, d3d_u32x4 (&w)[WPT]) {  // first-class vectors: arrays of HIP's uint4 struct stay in scratch
     k = k < kmax ? k : kmax;
+    k = stage_offset(k);
     const unsigned char *wk = wg + (size_t)k * (WVEC * 16);  // uniform
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
@@ -373,7 +414,7 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
     for (int d = 0; d < DEPTH; ++d) load_w(d + 1, wr[d]);
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-      okm[d] = gather(ix[d], fr[d]);
+      okm[d] = gather(d, ix[d], fr[d]);
       load_idx(d + DEPTH, ix[d]);
     }
     publish_w(0, w0);
@@ -435,7 +476,7 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
       // three slots this stage freed; all loads unconditional, in consumption order
       publish_w((k + 1) & 1, wr[d]);
       load_w(k + 1 + DEPTH, wr[d]);
-      okm[d] = gather(ix[d], fr[d]);   // offset k + DEPTH (its indices arrived DEPTH stages ago)
+      okm[d] = gather(k + DEPTH, ix[d], fr[d]);   // offset k + DEPTH (its indices arrived DEPTH stages ago)
       load_idx(k + 2 * DEPTH, ix[d]);
       d3d_lds_barrier();
     }
@@ -812,7 +853,7 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-template <int CIN, int COUT, int MT, int WAVES, int DEPTH, bool BF16>
+template <int CIN, int COUT, int MT, int WAVES, int DEPTH, bool BF16, bool PLAN = false>
 static int launch_fwd(const void *feat, const void *wpack, const float *bias, const int32_t *nbr,
                       int cap, int n_out, int kvol, void *out, ConvEpiDev ep, hipStream_t stream) {
   const int rows_per_block = WAVES * MT * 16;
@@ -821,7 +862,7 @@ static int launch_fwd(const void *feat, const void *wpack, const float *bias, co
   const int remap = g_xcd_remap && nb >= 16 && !reduces;  // every block of a reducing launch takes a fold ticket
   if (remap) nb = (nb + 7) / 8 * 8;
   if (int rc = epi_prepare(ep, nb, COUT)) return rc;
-  hipLaunchKernelGGL((spconv_fwd_mfma_kernel<CIN, COUT, MT, WAVES, DEPTH, BF16>), dim3(nb),
+  hipLaunchKernelGGL((spconv_fwd_mfma_kernel<CIN, COUT, MT, WAVES, DEPTH, BF16, PLAN>), dim3(nb),
                      dim3(WAVES * 64), 0, stream, feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, remap);
   D3D_LAUNCH_TRY("spconv_fwd_mfma_kernel");
   return D3D_OK;
@@ -865,13 +906,48 @@ extern "C" int d3d_sparse_conv_fwd(const void *feat, const void *wpack, const fl
   return d3d_sparse_conv_fwd_ex(feat, wpack, bias, nbr, cap, n_out, kvol, cin, cout, dtype, out, nullptr, stream_);
 }
 
+static int sparse_conv_fwd_impl(const void *feat, const void *wpack, const float *bias, const int32_t *nbr, int cap,
+                                int n_out, int kvol, int cin, int cout, int dtype, void *out,
+                                const D3dConvEpilogue *epilogue, const int32_t *row_plan, d3d_stream_t stream_);
+
 extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const float *bias,
                                       const int32_t *nbr, int cap, int n_out, int kvol, int cin,
                                       int cout, int dtype, void *out, const D3dConvEpilogue *epilogue,
                                       d3d_stream_t stream_) {
+  return sparse_conv_fwd_impl(feat, wpack, bias, nbr, cap, n_out, kvol, cin, cout, dtype, out, epilogue, nullptr,
+                              stream_);
+}
+
+// channel pairs (gradient channels -> input channels) of the strided layers in the shipped backbones
+// (scn.py:113-150: 16->32, 32->64, 64->64; :347-407: 64->128, 128->128), either precision
+extern "C" int d3d_sparse_conv_dgrad_plan_supported(int cin, int cout, int dtype) {
+  if (dtype != D3D_F32 && dtype != D3D_BF16) return 0;
+  static const int pairs[][2] = {{32, 16}, {64, 32}, {64, 64}, {128, 64}, {128, 128}};
+  for (auto &pr : pairs)
+    if (pr[0] == cin && pr[1] == cout) return 1;
+  return 0;
+}
+
+extern "C" int d3d_sparse_conv_dgrad_planned(const void *dout, const void *wpack, const int32_t *nbr_in, int cap_in,
+                                             int n_in, int kvol, int cin, int cout, int dtype, void *din,
+                                             const D3dConvEpilogue *epilogue, const int32_t *plan,
+                                             d3d_stream_t stream_) {
+  D3D_REQUIRE(plan, "d3d_sparse_conv_dgrad_planned: null plan");
+  D3D_REQUIRE(d3d_sparse_conv_dgrad_plan_supported(cin, cout, dtype),
+              "d3d_sparse_conv_dgrad_planned: no planned tiling for channels %d -> %d (ask "
+              "d3d_sparse_conv_dgrad_plan_supported)", cin, cout);
+  D3D_REQUIRE(kvol <= D3D_PLAN_MAX_KVOL, "d3d_sparse_conv_dgrad_planned: kernel volume %d", kvol);
+  return sparse_conv_fwd_impl(dout, wpack, nullptr, nbr_in, cap_in, n_in, kvol, cin, cout, dtype, din, epilogue, plan,
+                              stream_);
+}
+
+static int sparse_conv_fwd_impl(const void *feat, const void *wpack, const float *bias, const int32_t *nbr, int cap,
+                                int n_out, int kvol, int cin, int cout, int dtype, void *out,
+                                const D3dConvEpilogue *epilogue, const int32_t *row_plan, d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ConvEpiDev ep = {};
   if (epilogue) *(D3dConvEpilogue *)&ep = *epilogue;
+  ep.row_plan = row_plan;
   D3D_REQUIRE(!(ep.stats && ep.bn_partial), "d3d_sparse_conv_fwd_ex: one reduction per launch (stats or bn_partial)");
   D3D_REQUIRE(!ep.bn_partial || (ep.bn_x && ep.bn_mean && ep.bn_invstd),
               "d3d_sparse_conv_fwd_ex: bn_partial needs bn_x, bn_mean, bn_invstd");
@@ -891,6 +967,22 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
   // (Cin, Cout) -> tiles per wave, waves per block, pipeline depth for bf16 / f32.  Depth x gathered bytes per
   // stage is what hides the L2 gather latency; it is bounded by the 128 VGPRs of a 4-waves-per-SIMD block.
   // D3D_FWD_VARIANT (tools/tune_fwd.py) selects alternative 64->64 tilings.
+  if (row_plan) {
+    // three to four stages per block on average: depth 2 (1 where the f32 fragments of two tiles fill the registers).
+    // Block shapes from profiles/round3_dgrad_plan.txt: `<64,32>` f32 67.6 us on 16 waves, 55.2 on 8, 59.5 on 4.
+#define PLAN_CASE(CI, CO, MT, WV, DB, DF)                                                                         \
+    if (cin == CI && cout == CO)                                                                                  \
+      return dtype == D3D_BF16                                                                                    \
+                 ? launch_fwd<CI, CO, MT, WV, DB, true, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream) \
+                 : launch_fwd<CI, CO, MT, WV, DF, false, true>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    PLAN_CASE(32, 16, 1, 4, 2, 2)
+    PLAN_CASE(64, 32, 1, 8, 2, 2)
+    PLAN_CASE(64, 64, 2, 8, 2, 1)
+    PLAN_CASE(128, 64, 1, 16, 2, 1)
+    PLAN_CASE(128, 128, 1, 16, 2, 1)
+#undef PLAN_CASE
+    return d3d_set_error(D3D_EINVAL, "planned data gradient: channels %d -> %d", cin, cout);
+  }
   const int fwd_variant = g_fwd_variant >= 0 ? g_fwd_variant : fwd_variant_env();
   if (fwd_variant && fwd_variant < 50 && cin == 64 && cout == 64 && dtype == D3D_BF16) {
 #define FWD_VAR(V, MT, WV, DP) \

@@ -154,7 +154,6 @@ class _StackFn(torch.autograd.Function):
             gin = None
             reduced_next = False
             if li > 0 or ctx.needs_input_grad[0]:
-                nbr, cap = (rb.nbr_out, rb.cap_out) if rb.subm else (rb.nbr_in, rb.cap_in)
                 gin = torch.empty((rb.n_in, pad_cin), dtype=dtype, device=dev)
                 ep = None
                 if li > 0 and fused and pad_cin == cin and sp.has_epilogue(cout, pad_cin, dtype):
@@ -165,10 +164,7 @@ class _StackFn(torch.autograd.Function):
                                            bn_beta=_lib.ptr(pl.bn.bias), bn_relu=int(pl.relu),
                                            bn_partial=ppartial.data_ptr(), ws_floats=ppartial.numel())
                     reduced_next = True
-                rc = sp._timed("dgrad", cout, pad_cin, rb.n_in, rb, dev, lambda: L.d3d_sparse_conv_fwd_ex(
-                    gout.data_ptr(), wd.data_ptr(), None, nbr.data_ptr(), cap, rb.n_in, rb.kvol, cout, pad_cin, dt,
-                    gin.data_ptr(), ctypes.byref(ep) if ep is not None else None, st))
-                _lib.check(rc, "d3d_sparse_conv_fwd(dgrad)")
+                sp.launch_dgrad(rb, gout, wd, cout, pad_cin, gin, ep, st)
                 if pad_cin != cin:
                     gin = gin[:, :cin].contiguous()
             gw = torch.empty((rb.kvol, pad_cin, cout), dtype=torch.float32, device=dev)

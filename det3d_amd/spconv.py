@@ -53,6 +53,7 @@ def _timed(kind, cin, cout, n_out, rb, dev, fn):
     return rc
 
 
+DGRAD_PLAN = os.environ.get("D3D_DGRAD_PLAN", "1") != "0"  # strided data gradients in parity-class row order (csrc/d3d_rowplan.h)
 FUSE_BN_STATS = os.environ.get("D3D_FUSE_BN_STATS", "1") != "0"  # BN batch statistics from the producing conv's epilogue, BN-backward reductions from the
 #                       consuming conv's dgrad epilogue (d3d_sparse_conv_fwd_ex): 2 instead of 4 BN sweeps per layer
 
@@ -193,6 +194,7 @@ class Rulebook:
         self.out_indices = out_indices
         self.out_shape = out_shape
         self.subm = subm
+        self.dgrad_plan = None      # int32 row plan of the strided data gradient (csrc/d3d_rowplan.h) or None
 
     def pair_counts(self):
         """pairs per kernel offset, int64 [kvol] on the device.  Counted on demand from the
@@ -269,6 +271,16 @@ def build_conv_rulebook(indices, n_dev, n, cap_in, batch, in_shape, ksize, strid
                              wsb, _lib.stream_ptr(dev))
     _lib.check(rc, "d3d_conv_rulebook")
     rb = Rulebook(kvol, cap_in, cap_out, nbr_out, nbr_in, pc, n, None, coords_out, out_shape, False)
+    if DGRAD_PLAN and L.d3d_dgrad_plan_supported(_lib.i32_array(ksize), _lib.i32_array(stride)):
+        # rows of the data gradient in parity-class order: 27 / 8 offsets per block instead of 27 (three small
+        # launches next to the rulebook's, on the same stream)
+        words = L.d3d_dgrad_plan_ints(cap_in)
+        plan = torch.empty((words,), dtype=torch.int32, device=dev)
+        rc = L.d3d_dgrad_plan_build(indices.data_ptr(), n_dev.data_ptr(), cap_in, _lib.i32_array(ksize),
+                                    _lib.i32_array(stride), _lib.i32_array(padding), plan.data_ptr(), words,
+                                    _lib.stream_ptr(dev))
+        _lib.check(rc, "d3d_dgrad_plan_build")
+        rb.dgrad_plan = plan
     return rb, n_out_dev
 
 
@@ -279,6 +291,25 @@ def finalize_conv_rulebook(rb, n_in, n_out):
     rb.n_out = n_out
     rb.out_indices = rb.out_indices[:n_out]
     return rb
+
+
+def launch_dgrad(rb, gout, wd, cout, pad_cin, gin, ep, stream):
+    """data gradient of one sparse conv: the gather kernel over the table that is stationary in the INPUT rows
+    (submanifold: the forward table with mirrored weights; strided: nbr_in, in parity-class row order when the
+    rulebook carries a plan)"""
+    L = _lib.lib()
+    dt = _DT[gout.dtype]
+    nbr, cap = (rb.nbr_out, rb.cap_out) if rb.subm else (rb.nbr_in, rb.cap_in)
+    epp = ctypes.byref(ep) if ep is not None else None
+    if not rb.subm and rb.dgrad_plan is not None and L.d3d_sparse_conv_dgrad_plan_supported(cout, pad_cin, dt):
+        rc = _timed("dgrad", cout, pad_cin, rb.n_in, rb, gout.device, lambda: L.d3d_sparse_conv_dgrad_planned(
+            gout.data_ptr(), wd.data_ptr(), nbr.data_ptr(), cap, rb.n_in, rb.kvol, cout, pad_cin, dt,
+            gin.data_ptr(), epp, rb.dgrad_plan.data_ptr(), stream))
+    else:
+        rc = _timed("dgrad", cout, pad_cin, rb.n_in, rb, gout.device, lambda: L.d3d_sparse_conv_fwd_ex(
+            gout.data_ptr(), wd.data_ptr(), None, nbr.data_ptr(), cap, rb.n_in, rb.kvol, cout, pad_cin, dt,
+            gin.data_ptr(), epp, stream))
+    _lib.check(rc, "d3d_sparse_conv_fwd(dgrad)")
 
 
 # --------------------------------------------------------------------- autograd
@@ -345,10 +376,6 @@ class _SparseConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wd = ctx.wd  # packed in the forward: W[k] as is; k mirrored for submanifold layers because
             #              (j -> i at offset k)  <=>  (i -> j at offset kvol-1-k) on the same table
-            if rb.subm:
-                nbr, cap = rb.nbr_out, rb.cap_out
-            else:
-                nbr, cap = rb.nbr_in, rb.cap_in
             gin = torch.empty((rb.n_in, pad_cin), dtype=feats.dtype, device=feats.device)
             ep = None
             link = ctx.link
@@ -359,10 +386,7 @@ class _SparseConvFn(torch.autograd.Function):
                                        bn_invstd=link.save[1].data_ptr(), bn_gamma=_lib.ptr(link.gamma),
                                        bn_beta=_lib.ptr(link.beta), bn_relu=int(link.relu),
                                        bn_partial=link.partial.data_ptr(), ws_floats=link.partial.numel())
-            rc = _timed("dgrad", cout, pad_cin, rb.n_in, rb, feats.device, lambda: L.d3d_sparse_conv_fwd_ex(
-                gout.data_ptr(), wd.data_ptr(), None, nbr.data_ptr(), cap, rb.n_in, kvol, cout, pad_cin,
-                dt, gin.data_ptr(), ctypes.byref(ep) if ep is not None else None, stream))
-            _lib.check(rc, "d3d_sparse_conv_fwd(dgrad)")
+            launch_dgrad(rb, gout, wd, cout, pad_cin, gin, ep, stream)
             if ep is not None:
                 link.reduced = True
             if pad_cin != cin:

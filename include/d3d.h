@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 4 /* 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv */
+#define D3D_ABI_VERSION 5 /* 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv; 5: planned strided data gradient */
 
 #define D3D_OK 0
 #define D3D_EINVAL -1    /* bad argument / unsupported shape           */
@@ -170,6 +170,28 @@ int d3d_set_tuning(int knob, int value);
 int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const float *bias,
                            const int32_t *nbr, int cap, int n_out, int kvol, int cin, int cout,
                            int dtype, void *out, const D3dConvEpilogue *epilogue, d3d_stream_t stream);
+
+/* Data gradient of a STRIDED layer in parity-class row order (round 3; det3d_amd/csrc/d3d_rowplan.h).
+ * The reference's backward of spconv.SparseConv3d (scn.py:113, :127, :141, :150: stride 2, and the last (3,1,1) /
+ * (2,1,1) layer) is indice_conv_backward over the same pairs; here it is the gather kernel over the input-stationary
+ * table nbr_in, in which an input row only has the offsets k = (i + p) mod s per axis.  d3d_dgrad_plan_build sorts the
+ * input rows by that class (stable; <= 8 classes) and lists each class's offsets, d3d_sparse_conv_dgrad_planned walks
+ * 1..8 offsets per block instead of 27.  Same sums in the same order per row: bit-identical to
+ * d3d_sparse_conv_fwd_ex(dout, wpack, NULL, nbr_in, ...).
+ *  plan dev int32 [d3d_dgrad_plan_ints(cap_in)], written by the build (three launches on `stream`, no host sync);
+ *  coords_in dev [n,4] int32 (batch, z, y, x), n_in_dev dev int32 [1];
+ *  d3d_dgrad_plan_supported: 2 <= stride product <= 8 and kernel volume <= 27;
+ *  d3d_sparse_conv_dgrad_plan_supported: channel pairs (gradient channels cin -> input channels cout) with a
+ *  planned tiling; the epilogue argument is as in d3d_sparse_conv_fwd_ex. */
+size_t d3d_dgrad_plan_ints(int cap_in);
+int d3d_dgrad_plan_supported(const int32_t *ksize, const int32_t *stride);
+int d3d_dgrad_plan_build(const int32_t *coords_in, const int32_t *n_in_dev, int cap_in, const int32_t *ksize,
+                         const int32_t *stride, const int32_t *padding, int32_t *plan, size_t plan_ints,
+                         d3d_stream_t stream);
+int d3d_sparse_conv_dgrad_plan_supported(int cin, int cout, int dtype);
+int d3d_sparse_conv_dgrad_planned(const void *dout, const void *wpack, const int32_t *nbr_in, int cap_in, int n_in,
+                                  int kvol, int cin, int cout, int dtype, void *din,
+                                  const D3dConvEpilogue *epilogue, const int32_t *plan, d3d_stream_t stream);
 
 /* weight gradient: dw[k][ci][co] = sum_o feat[nbr[k][o]][ci] * dout[o][co]
  *  dw dev [kvol, cin, cout] f32, overwritten.

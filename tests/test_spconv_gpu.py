@@ -525,3 +525,102 @@ def test_split_bn_entry_points_and_channel_affine_sweeps(dtype):
     dz = dy.float() * ((x.float() * scale + shift) > 0)
     ref = ca * dz + cb * x.float() + cc
     assert torch.allclose(dx.float(), ref, atol=2e-2 if dtype == torch.bfloat16 else 1e-5, rtol=1e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+# ---------------------------------------------------------------- strided data gradient in parity-class row order
+def _plan_reference(idx, ksize, stride, padding):
+    """numpy restatement of det3d_amd/csrc/d3d_rowplan.h: classes, stable order, per-class offset lists"""
+    r = (idx[:, 1:4] + np.array(padding)) % np.array(stride)
+    cls = (r[:, 0] * stride[1] + r[:, 1]) * stride[2] + r[:, 2]
+    ncls = stride[0] * stride[1] * stride[2]
+    perm = np.argsort(cls, kind="stable")
+    start = np.concatenate([[0], np.cumsum(np.bincount(cls, minlength=ncls))])
+    lists = []
+    for c in range(ncls + 1):
+        rc = [c // (stride[1] * stride[2]), (c // stride[2]) % stride[1], c % stride[2]]
+        ks = [k for k in range(ksize[0] * ksize[1] * ksize[2])
+              if c == ncls or all(kk % s == q for kk, s, q in zip(
+                  [k // (ksize[1] * ksize[2]), (k // ksize[2]) % ksize[1], k % ksize[2]], stride, rc))]
+        lists.append(ks or [0])
+    return ncls, perm, start, lists
+
+
+@pytest.mark.parametrize("gi", [1, 2, 3])
+def test_dgrad_plan_is_the_stable_class_sort(gi):
+    ksize, stride, padding, _ = GEOMS[gi]
+    rng = np.random.default_rng(40 + gi)
+    shape = [11, 60, 52]
+    idx, _ = _random_sparse(rng, 3, shape, 2500, 1)   # > 1024 rows per class: several sort blocks
+    rb = _build(idx, 3, shape, ksize, stride, padding, False)
+    assert rb.dgrad_plan is not None
+    plan = rb.dgrad_plan.cpu().numpy()
+    ncls, perm, start, lists = _plan_reference(idx, ksize, stride, padding)
+    n = len(idx)
+    assert plan[0] == ncls
+    assert np.array_equal(plan[1:2 + ncls], start)
+    assert np.array_equal(plan[304:304 + n], perm)
+    for c, ks in enumerate(lists):
+        L = plan[16 + 32 * c: 16 + 32 * (c + 1)]
+        assert L[0] == len(ks) and list(L[1:1 + len(ks)]) == ks
+        packed = [int(L[28:30].view(np.uint64)[0]), int(L[30:32].view(np.uint64)[0])]
+        for j, k in enumerate(ks[:24]):
+            assert (packed[j // 12] >> (5 * (j % 12))) & 31 == k
+    # every pair of the input-stationary table sits at an offset of its row's class list
+    t = rb.nbr_in.view(rb.kvol, rb.cap_in)[:, :n].cpu().numpy()
+    r = (idx[:, 1:4] + np.array(padding)) % np.array(stride)
+    cls = (r[:, 0] * stride[1] + r[:, 1]) * stride[2] + r[:, 2]
+    k, i = np.nonzero(t >= 0)
+    assert all(kk in lists[cls[ii]] for kk, ii in zip(k[:5000], i[:5000]))
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 64), (64, 64), (64, 128), (128, 128)])
+@pytest.mark.parametrize("gi", [1, 2, 3])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_planned_strided_dgrad_is_bit_identical(cin, cout, gi, dtype):
+    """the planned launch adds the same products in the same order per row (skipped offsets contribute exact
+    zeros): torch.equal with the 27-offset launch, with and without the BN-backward epilogue's row sums"""
+    from det3d_amd import _lib, spconv
+
+    ksize, stride, padding, _ = GEOMS[gi]
+    rng = np.random.default_rng(cin + cout + gi)
+    shape = [11, 70, 64]
+    idx, feats = _random_sparse(rng, 2, shape, 4000, cin)
+    rb = _build(idx, 2, shape, ksize, stride, padding, False)
+    n = len(idx)
+    kvol = rb.kvol
+    w = torch.from_numpy((rng.standard_normal((kvol, cin, cout)) / np.sqrt(cin * 9)).astype(np.float32)).cuda()
+    gout = torch.from_numpy(rng.standard_normal((rb.n_out, cout)).astype(np.float32)).cuda().to(dtype)
+    _, wd = spconv._packed_weights(w, kvol, cin, cout, dtype, False, True, cin)
+    stream = _lib.stream_ptr(gout.device)
+    x = torch.from_numpy(feats).cuda().to(dtype)
+    mean, invstd = x.float().mean(0), 1.0 / (x.float().var(0, unbiased=False) + 1e-3).sqrt()
+    gamma, beta = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.1
+
+    def run(planned, with_epilogue):
+        gin = torch.full((n, cin), float("nan"), dtype=dtype, device="cuda")
+        ep = part = None
+        if with_epilogue:
+            part = torch.full((int(_lib.lib().d3d_conv_epilogue_ws_floats(n, cin)),), float("nan"), device="cuda")
+            ep = _lib.ConvEpilogue(bn_x=x.data_ptr(), bn_mean=mean.data_ptr(), bn_invstd=invstd.data_ptr(),
+                                   bn_gamma=gamma.data_ptr(), bn_beta=beta.data_ptr(), bn_relu=1,
+                                   bn_partial=part.data_ptr(), ws_floats=part.numel())
+        saved, rb.dgrad_plan = rb.dgrad_plan, (rb.dgrad_plan if planned else None)
+        try:
+            spconv.launch_dgrad(rb, gout, wd, cout, cin, gin, ep, stream)
+        finally:
+            rb.dgrad_plan = saved
+        torch.cuda.synchronize()
+        return gin, (part[:2 * cin].clone() if part is not None else None)
+
+    assert _lib.lib().d3d_sparse_conv_dgrad_plan_supported(cout, cin, spconv._DT[dtype])
+    a, _ = run(False, False)
+    b, _ = run(True, False)
+    assert not torch.isnan(a.float()).any()
+    assert torch.equal(a, b)
+    a2, pa = run(False, True)
+    b2, pb = run(True, True)
+    assert torch.equal(a2, a) and torch.equal(b2, a)
+    # the epilogue's sums run over the rows in plan order: same terms, other order
+    assert torch.allclose(pa, pb, rtol=2e-4, atol=2e-3 * float(pa.abs().max()))
+    b3, pb3 = run(True, True)
+    assert torch.equal(pb3, pb)   # ... and reproducibly so
