@@ -97,6 +97,10 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip fp32 / precision / rpn / predict / stage probes")
     ap.add_argument("--cached-targets", action="store_true",
                     help="use the host-precomputed anchor targets instead of d3d_assign_targets in the step")
+    ap.add_argument("--augment", action="store_true",
+                    help="KITTI workloads: global flip / rotation / scaling of points and boxes and the per-frame point "
+                         "shuffle (det3d/datasets/pipelines/preprocess.py:200-217) on the device, inside the geometry "
+                         "stage of every step; targets are then always assigned on the device from the moved boxes")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="build the geometry (voxelize, targets, rulebooks) inline at the start of each step instead of "
                          "one batch ahead on a second stream")
@@ -272,6 +276,10 @@ class Workload:
         D.broadcast_params(model)
         self.model = model
         self.cached_targets = args.cached_targets
+        self.augment = bool(getattr(args, "augment", False)) and spec["kind"] == "kitti"
+        import numpy as np
+
+        self.aug_rng = np.random.RandomState(1234 + rank)
         if spec["kind"] == "kitti":
             n_seeds = 16
             self.ds = synthetic.KittiCarSynthetic(n_points=self.points, n_seeds=n_seeds)
@@ -292,6 +300,13 @@ class Workload:
         from det3d_amd import synthetic
 
         b = self.batches[i % self.n_batches]
+        if self.augment:
+            from det3d_amd import augment
+
+            prm = augment.sample_global_params(self.batch, flip="y", rng=self.aug_rng)
+            pts, gt = augment.apply_global_augmentation(b["points"], b["frame_offsets"], b["gt_boxes"], prm)
+            b = dict(b, points=augment.shuffle_points(pts, b["frame_offsets"]), gt_boxes=gt)
+            return synthetic.make_example(b, self.vox_cfg, fused_mean=True, device_targets=targets)
         if self.spec["kind"] == "kitti":
             return synthetic.make_example(b, self.vox_cfg, fused_mean=True, device_targets=targets and not self.cached_targets)
         return self.ds.make_example(b, targets=targets)
@@ -838,7 +853,7 @@ def main():
                    "timed_region_s": round(elapsed, 3),
                    "burn_in_steps": getattr(wl, "burn_in_steps", 0),
                    "graphed_tail": bool(wl.model.__dict__.get("_graph_tails")),
-                   "geometry_prefetch": not args.no_prefetch,
+                   "geometry_prefetch": not args.no_prefetch, "augment": bool(args.augment),
                    "host_ms_per_step": getattr(wl, "host_ms", None)},
     }
     if rank == 0 and records:

@@ -484,6 +484,7 @@ __global__ void __launch_bounds__(D3D_PLAN_SORT_ROWS)
   __shared__ int wc[D3D_PLAN_SORT_ROWS / 64][D3D_PLAN_MAX_CLASSES];
   int n = *n_dev;
   n = n < cap ? n : cap;
+  if ((int)blockIdx.x * D3D_PLAN_SORT_ROWS >= n) return;  // capacity-sized grid: the scan only reads blocks with rows
   const int r = blockIdx.x * D3D_PLAN_SORT_ROWS + threadIdx.x;
   plan_wave_rank(r < n ? plan_class(G, coords[r]) : -1, wc);
   __syncthreads();
@@ -496,8 +497,11 @@ __global__ void __launch_bounds__(D3D_PLAN_SORT_ROWS)
 
 // wave c turns the block counts of class c into exclusive offsets inside the class; then the header of the plan
 __global__ void __launch_bounds__(64 * D3D_PLAN_MAX_CLASSES)
-    dplan_scan_kernel(int32_t *blockhist, int nb, PlanGeom G, int32_t *plan) {
+    dplan_scan_kernel(int32_t *blockhist, const int32_t *n_dev, int cap, PlanGeom G, int32_t *plan) {
   __shared__ int tot[D3D_PLAN_MAX_CLASSES];
+  int n = *n_dev;
+  n = n < cap ? n : cap;
+  const int nb = (n + D3D_PLAN_SORT_ROWS - 1) / D3D_PLAN_SORT_ROWS;
   const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int carry = 0;
   for (int b0 = 0; b0 < nb; b0 += 64) {
@@ -555,6 +559,7 @@ __global__ void __launch_bounds__(D3D_PLAN_SORT_ROWS)
   __shared__ int wc[D3D_PLAN_SORT_ROWS / 64][D3D_PLAN_MAX_CLASSES];
   int n = *n_dev;
   n = n < cap ? n : cap;
+  if ((int)blockIdx.x * D3D_PLAN_SORT_ROWS >= n) return;
   const int r = blockIdx.x * D3D_PLAN_SORT_ROWS + threadIdx.x;
   const int cls = r < n ? plan_class(G, coords[r]) : -1;
   const int rank = plan_wave_rank(cls, wc);
@@ -607,7 +612,8 @@ extern "C" int d3d_dgrad_plan_build(const int32_t *coords_in, const int32_t *n_i
   hipLaunchKernelGGL(dplan_hist_kernel, dim3(nb), dim3(D3D_PLAN_SORT_ROWS), 0, stream, (const int4 *)coords_in,
                      n_in_dev, cap_in, G, blockhist);
   D3D_LAUNCH_TRY("dplan_hist_kernel");
-  hipLaunchKernelGGL(dplan_scan_kernel, dim3(1), dim3(64 * D3D_PLAN_MAX_CLASSES), 0, stream, blockhist, nb, G, plan);
+  hipLaunchKernelGGL(dplan_scan_kernel, dim3(1), dim3(64 * D3D_PLAN_MAX_CLASSES), 0, stream, blockhist, n_in_dev, cap_in,
+                     G, plan);
   D3D_LAUNCH_TRY("dplan_scan_kernel");
   hipLaunchKernelGGL(dplan_scatter_kernel, dim3(nb), dim3(D3D_PLAN_SORT_ROWS), 0, stream, (const int4 *)coords_in,
                      n_in_dev, cap_in, G, blockhist, plan);
