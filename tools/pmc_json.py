@@ -36,8 +36,9 @@ def pick(rs, pat):
 fetch, write, mfma = rows("round3_pmc_fetch_size.txt"), rows("round3_pmc_write_size.txt"), rows("round3_pmc_sq_valu_mfma_busy_cycles.txt")
 # the roofline kernel of the default (f32, split arithmetic) step; D3D_PMC_DTYPE=bf16 for the autocast step
 DT = os.environ.get("D3D_PMC_DTYPE", "fp32")
-pat = r"spconv_fwd_mfma_kernel<64, 64, \d+, \d+, \d+, false>" if DT == "fp32" else \
-    r"spconv_fwd_(group|mfma)_kernel<64, 64, \d+, \d+, \d+(, true)?>"
+# (the trailing `false` of the mfma kernel = not the planned variant of the strided data gradients)
+pat = r"spconv_fwd_mfma_kernel<64, 64, \d+, \d+, \d+, false, false>" if DT == "fp32" else \
+    r"spconv_fwd_(group_kernel<64, 64, \d+, \d+, \d+>|mfma_kernel<64, 64, \d+, \d+, \d+, true, false>)"
 f, w = pick(fetch, pat), pick(write, pat)
 out = {"_comment": "separate rocprofv3 --kernel-trace --pmc passes over `bench.py --steps 3 --warmup 3` (tools/pmc_spconv.sh); "
                    "FETCH_SIZE / WRITE_SIZE in KiB per launch, read side x2 (MI355X_MICROARCH.md, gfx950), write side as is",
