@@ -532,8 +532,9 @@ def stage_probe(wl, dev):
         feats = ex_t["voxel_mean"]
         shape = [int(s) for s in ex_t["shape"][0]]
         st = spconv.SparseConvTensor(feats, ex_t["coordinates"], [shape[2] + 1, shape[1], shape[0]], wl.batch)
-        bb.middle_conv.plan(st)  # untimed: the step builds its geometry on the side stream, this stream's allocator
-        torch.cuda.synchronize()  # pool has never seen these sizes
+        for _ in range(3):  # untimed: the step builds its geometry on the side stream, so this stream's allocator pool
+            bb.middle_conv.plan(st)  # has never seen these sizes (36, 28, 13 ms, then 0.57: tools/diag_plan_time.py)
+        torch.cuda.synchronize()
         e[0].record()
         d = bb.middle_conv.plan(st)
         e[1].record()
