@@ -44,6 +44,7 @@ SIGNATURES = {
     "d3d_dgrad_plan_build": (i32, [vp, vp, i32, vp, vp, vp, vp, sz, vp]),
     "d3d_sparse_conv_dgrad_plan_supported": (i32, [i32, i32, i32]),
     "d3d_sparse_conv_dgrad_planned": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "d3d_adam_step": (i32, [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
     "d3d_sparse_conv_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "d3d_sparse_conv_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
     "d3d_bn_relu_fwd": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp, vp, vp, vp]),
@@ -117,6 +118,12 @@ class ConvEpilogue(ctypes.Structure):
 class DenseBnBackward(ctypes.Structure):
     """D3dDenseBnBackward of include/d3d.h"""
     _fields_ = [("x", vp), ("mean", vp), ("invstd", vp), ("gamma", vp), ("beta", vp), ("relu", i32)]
+
+
+class AdamHyper(ctypes.Structure):
+    """D3dAdamHyper of include/d3d.h"""
+    _fields_ = [("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("decay", f32), ("max_norm", f32),
+                ("grad_scale", f32), ("step", i32)]
 
 
 def lib():

@@ -24,6 +24,7 @@ SOURCES = [
     "d3d_bn.hip",
     "d3d_conv2d.hip",
     "d3d_head.hip",
+    "d3d_optim.hip",
     "d3d_pfn.hip",
     "d3d_dense.hip",
     "d3d_assign.hip",

@@ -1,0 +1,135 @@
+// The optimizer step of the training hot path in two launches: global-norm gradient clipping, true weight decay
+// and Adam over every parameter tensor of the model.
+//
+// Reference: det3d/solver/fastai_optim.py (OptimWrapper.step: `p.data.mul_(1 - wd * lr)` for every parameter when
+// true_wd, then torch.optim.Adam.step with the one-cycle momentum as beta1), gradient clipping
+// det3d/torchie/trainer/hooks/optimizer.py (clip_grad_norm_, max_norm 35 in the shipped configs).  In PyTorch that is
+// ~12 multi-tensor launches (norms, norm of norms, clamp, scale, decay, two fused-Adam launches) with a host-side
+// tensor-list walk in front of each: at 84 parameter tensors the device sat idle for 0.65 ms of a 7.7 ms step around
+// them (profiles/round3_kernel_stats_fp32.txt, gap table).  Here:
+//
+//   adam_norm_kernel    one block per chunk of CHUNK elements of one tensor: sum of squares of the (scaled) gradient,
+//                       added in a fixed order -> partial[chunk]
+//   adam_update_kernel  every block adds ALL partials in the same fixed order (a few thousand floats out of L2), so
+//                       every block holds the identical total without a cross-block rendezvous; clip coefficient,
+//                       decay, moments, update for its chunk; block 0 publishes the norm
+//
+// Deterministic (no atomics), no host synchronisation, no scratch beyond the partials.  The gradient tensors are new
+// allocations every step (autograd), so their addresses travel as kernel arguments; everything else about the
+// tensors is static and sits in a device table the caller uploads once.
+#include <math.h>
+
+#include "d3d_common.h"
+
+#define ADAM_THREADS 256
+
+struct AdamGrads {
+  const float *g[D3D_ADAM_MAX_TENSORS];
+};
+
+// fixed-order block sum: lanes by xor butterfly, waves in wave order; every thread returns the total
+__device__ __forceinline__ float adam_block_sum(float s, float *red) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[wave] = s;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < ADAM_THREADS / 64; ++w) t += red[w];
+  __syncthreads();
+  return t;
+}
+
+__global__ void __launch_bounds__(ADAM_THREADS)
+    adam_norm_kernel(const int64_t *__restrict__ tensors, const int32_t *__restrict__ chunks, int chunk0, int tensor0,
+                     int chunk_elems, AdamGrads grads, float grad_scale, float *__restrict__ partial) {
+  __shared__ float red[ADAM_THREADS / 64];
+  const int c = chunk0 + (int)blockIdx.x;
+  const int t = chunks[2 * c], off = chunks[2 * c + 1];
+  const int64_t numel = tensors[4 * t + 3];
+  const int n = (int)(numel - off < chunk_elems ? numel - off : chunk_elems);
+  const float *g = grads.g[t - tensor0] + off;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += ADAM_THREADS) {
+    const float v = g[i] * grad_scale;
+    s = fmaf(v, v, s);
+  }
+  s = adam_block_sum(s, red);
+  if (threadIdx.x == 0) partial[c] = s;
+}
+
+__global__ void __launch_bounds__(ADAM_THREADS)
+    adam_update_kernel(const int64_t *__restrict__ tensors, const int32_t *__restrict__ chunks, int chunk0, int tensor0,
+                       int chunk_elems, int n_chunks_total, AdamGrads grads, D3dAdamHyper hp, float step_size,
+                       float bc2_sqrt, const float *__restrict__ partial, float *__restrict__ grad_norm) {
+  __shared__ float red[ADAM_THREADS / 64];
+  float s = 0.f;
+  for (int j = threadIdx.x; j < n_chunks_total; j += ADAM_THREADS) s += partial[j];
+  const float total = sqrtf(adam_block_sum(s, red));
+  if (blockIdx.x == 0 && threadIdx.x == 0 && chunk0 == 0) grad_norm[0] = total;
+  float coef = hp.grad_scale;
+  if (hp.max_norm > 0.f) {
+    const float k = hp.max_norm / (total + 1e-6f);  // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max = 1)
+    coef *= k < 1.f ? k : 1.f;
+  }
+  const int c = chunk0 + (int)blockIdx.x;
+  const int t = chunks[2 * c], off = chunks[2 * c + 1];
+  const int64_t numel = tensors[4 * t + 3];
+  const int n = (int)(numel - off < chunk_elems ? numel - off : chunk_elems);
+  float *p = (float *)tensors[4 * t + 0] + off;
+  float *m = (float *)tensors[4 * t + 1] + off;
+  float *v = (float *)tensors[4 * t + 2] + off;
+  const float *g = grads.g[t - tensor0] + off;
+  const float w1 = 1.f - hp.beta1, w2 = 1.f - hp.beta2;
+  for (int i = threadIdx.x; i < n; i += ADAM_THREADS) {
+    const float gi = g[i] * coef;
+    const float mi = fmaf(gi - m[i], w1, m[i]);            // lerp(m, g, 1 - beta1)
+    const float vi = fmaf(w2 * gi, gi, hp.beta2 * v[i]);
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + hp.eps;
+    p[i] = fmaf(-step_size, mi / denom, p[i] * hp.decay);  // true weight decay first, then the Adam update
+  }
+}
+
+extern "C" int d3d_adam_step(const int64_t *tensors, int n_tensors, const int32_t *chunks, int n_chunks,
+                             int chunk_elems, const int32_t *tensor_chunk_start, const uint64_t *grads_host,
+                             const D3dAdamHyper *hyper, float *partial, float *grad_norm, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  D3D_REQUIRE(tensors && chunks && tensor_chunk_start && grads_host && hyper && partial && grad_norm,
+              "d3d_adam_step: null pointer");
+  D3D_REQUIRE(n_tensors >= 1 && n_chunks >= n_tensors && chunk_elems >= ADAM_THREADS,
+              "d3d_adam_step: n_tensors=%d n_chunks=%d chunk_elems=%d", n_tensors, n_chunks, chunk_elems);
+  const D3dAdamHyper hp = *hyper;
+  D3D_REQUIRE(hp.step >= 1 && hp.beta1 >= 0.f && hp.beta1 < 1.f && hp.beta2 >= 0.f && hp.beta2 < 1.f && hp.eps > 0.f,
+              "d3d_adam_step: step=%d beta1=%g beta2=%g eps=%g", hp.step, hp.beta1, hp.beta2, hp.eps);
+  // bias corrections in double on the host, like torch.optim.Adam
+  const double bc1 = 1.0 - pow((double)hp.beta1, (double)hp.step);
+  const double bc2 = 1.0 - pow((double)hp.beta2, (double)hp.step);
+  const float step_size = (float)((double)hp.lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  // gradient addresses ride in the kernel arguments, D3D_ADAM_MAX_TENSORS tensors per launch
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int t0 = 0; t0 < n_tensors; t0 += D3D_ADAM_MAX_TENSORS) {
+      const int t1 = t0 + D3D_ADAM_MAX_TENSORS < n_tensors ? t0 + D3D_ADAM_MAX_TENSORS : n_tensors;
+      AdamGrads G;
+      for (int t = t0; t < t1; ++t) {
+        D3D_REQUIRE(grads_host[t] != 0, "d3d_adam_step: tensor %d has no gradient", t);
+        G.g[t - t0] = (const float *)(uintptr_t)grads_host[t];
+      }
+      const int c0 = tensor_chunk_start[t0], c1 = tensor_chunk_start[t1];
+      D3D_REQUIRE(c0 >= 0 && c1 > c0 && c1 <= n_chunks, "d3d_adam_step: chunk range %d..%d of %d", c0, c1, n_chunks);
+      if (pass == 0) {
+        hipLaunchKernelGGL(adam_norm_kernel, dim3(c1 - c0), dim3(ADAM_THREADS), 0, stream, tensors, chunks, c0, t0,
+                           chunk_elems, G, hp.grad_scale, partial);
+        D3D_LAUNCH_TRY("adam_norm_kernel");
+      } else {
+        hipLaunchKernelGGL(adam_update_kernel, dim3(c1 - c0), dim3(ADAM_THREADS), 0, stream, tensors, chunks, c0, t0,
+                           chunk_elems, n_chunks, G, hp, step_size, bc2_sqrt, partial, grad_norm);
+        D3D_LAUNCH_TRY("adam_update_kernel");
+      }
+    }
+  }
+  return D3D_OK;
+}

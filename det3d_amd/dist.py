@@ -218,13 +218,29 @@ class OverlappedGradBuckets:
                 self.handles[b] = dist.all_reduce(flat, async_op=True)
             self.next_launch += 1
 
-    def finish(self, max_norm=None):
-        """after backward: wait for the exchanges, mean, optional global-norm clip; returns the gradient norm"""
+    def _wait(self):
         self._launch_ready(force=True)  # buckets with parameters that received no gradient
         self.armed = False
         for h in self.handles:
             if h is not None:
                 h.wait()
+
+    def _repoint(self):
+        for b, ps in enumerate(self.buckets):
+            off = 0
+            for p in ps:
+                p.grad = self.flats[b][off: off + p.numel()].view(p.shape)
+                off += p.numel()
+
+    def finish_sums(self):
+        """after backward: wait for the exchanges and point every p.grad at its slice of the SUMS over ranks -- the
+        fused optimizer step (fused_adam.FusedAdam) takes the mean, the norm and the clip from there"""
+        self._wait()
+        self._repoint()
+
+    def finish(self, max_norm=None):
+        """after backward: wait for the exchanges, mean, optional global-norm clip; returns the gradient norm"""
+        self._wait()
         w = world_size()
         if w > 1:
             torch._foreach_div_(self.flats, float(w))
@@ -233,11 +249,7 @@ class OverlappedGradBuckets:
         if max_norm is not None:
             coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
             torch._foreach_mul_(self.flats, coef)
-        for b, ps in enumerate(self.buckets):
-            off = 0
-            for p in ps:
-                p.grad = self.flats[b][off: off + p.numel()].view(p.shape)
-                off += p.numel()
+        self._repoint()
         return total
 
 

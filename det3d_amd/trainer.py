@@ -72,21 +72,30 @@ class TrainStep:
             self.bucket = d3d_dist.LocalGradClip(self.params)
         kw = dict(lr=self.sched.low_lr, betas=(moms[0], 0.99), weight_decay=0.0)
         dev = self.params[0].device
-        try:
-            self.opt = torch.optim.Adam(self.params, fused=dev.type == "cuda", **kw)
-        except (RuntimeError, TypeError):
-            self.opt = torch.optim.Adam(self.params, foreach=True, **kw)
+        # parameters on the GPU: clip + decay + Adam are the two launches of d3d_adam_step (fused_adam.py); the torch
+        # optimizer below is the CPU plumbing path (BASELINE configs[0], the gloo tests)
+        self.fused = None
+        if dev.type == "cuda" and os.environ.get("D3D_FUSED_ADAM", "1") != "0":  # 0: the PyTorch launch sequence (A/B)
+            from .fused_adam import FusedAdam
+
+            self.fused = FusedAdam(self.params, beta2=0.99)
+            self.opt = None
+        else:
+            try:
+                self.opt = torch.optim.Adam(self.params, fused=dev.type == "cuda", **kw)
+            except (RuntimeError, TypeError):
+                self.opt = torch.optim.Adam(self.params, foreach=True, **kw)
         self.global_step = 0
         self.last = {}
 
     # ---- resume (the reference keeps epoch / iter / optimizer in the checkpoint: trainer.py save_checkpoint,
     # resume :470-499); here the schedule position is the global step
     def state_dict(self):
-        return dict(global_step=self.global_step, optimizer=self.opt.state_dict())
+        return dict(global_step=self.global_step, optimizer=(self.fused or self.opt).state_dict())
 
     def load_state_dict(self, state):
         self.global_step = int(state["global_step"])
-        self.opt.load_state_dict(state["optimizer"])
+        (self.fused or self.opt).load_state_dict(state["optimizer"])
 
     def _ctx(self):
         if self.autocast_dtype is None:
@@ -95,23 +104,35 @@ class TrainStep:
 
     def __call__(self, example):
         lr, mom = self.sched.at(self.global_step)
-        for g in self.opt.param_groups:
-            g["lr"] = lr
-            g["betas"] = (mom, g["betas"][1])
         self.bucket.zero()
         with self._ctx():
             losses = self.model(example, return_loss=True)
         loss = sum(losses["loss"])
         loss.backward()
-        if self.overlap:
-            gnorm = self.bucket.finish(self.grad_clip)  # exchanges were started by the hooks during backward
+        if self.fused is not None:
+            # the exchanged sums (or the local gradients) as they are: mean over ranks, clipping, true weight decay
+            # and Adam happen inside the two launches
+            if self.overlap:
+                self.bucket.finish_sums()  # exchanges were started by the hooks during backward
+                scale = 1.0 / d3d_dist.world_size()
+            else:
+                self.bucket.gather()
+                self.bucket.allreduce_mean()
+                scale = 1.0
+            gnorm = self.fused.step(lr, mom, decay=1.0 - self.wd * lr, max_norm=self.grad_clip, grad_scale=scale)
         else:
-            self.bucket.gather()  # one cat; p.grad become slices of the flat buffer
-            self.bucket.allreduce_mean()
-            gnorm = self.bucket.clip_norm_(self.grad_clip)
-        with torch.no_grad():
-            torch._foreach_mul_(self.params, 1.0 - self.wd * lr)  # true weight decay, bn_wd=True
-        self.opt.step()
+            for g in self.opt.param_groups:
+                g["lr"] = lr
+                g["betas"] = (mom, g["betas"][1])
+            if self.overlap:
+                gnorm = self.bucket.finish(self.grad_clip)
+            else:
+                self.bucket.gather()  # one cat; p.grad become slices of the flat buffer
+                self.bucket.allreduce_mean()
+                gnorm = self.bucket.clip_norm_(self.grad_clip)
+            with torch.no_grad():
+                torch._foreach_mul_(self.params, 1.0 - self.wd * lr)  # true weight decay, bn_wd=True
+            self.opt.step()
         self.global_step += 1
         self.last = dict(loss=loss.detach(), grad_norm=gnorm, lr=lr, losses=losses)
         return loss.detach()

@@ -204,6 +204,34 @@ int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const int32_t *nbr
                           void *workspace, size_t workspace_bytes, d3d_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Optimizer step of the training hot path (round 3): global-norm gradient clipping + true weight decay + Adam over
+ * all parameter tensors in two launches.  Replaces, for f32 parameters on the device, OptimWrapper.step of
+ * det3d/solver/fastai_optim.py (p.data.mul_(1 - wd * lr), then torch.optim.Adam.step with the one-cycle momentum as
+ * beta1) and clip_grad_norm_ of det3d/torchie/trainer/hooks/optimizer.py:
+ *    g  = grad * grad_scale * min(1, max_norm / (||grad * grad_scale||_2 + 1e-6))        (max_norm <= 0: no clipping)
+ *    m  = m + (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2
+ *    p  = p * decay - lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ *  tensors dev int64 [n_tensors, 4]: address of the parameter, of exp_avg, of exp_avg_sq (f32, numel elements each),
+ *          numel -- static, uploaded once by the caller;
+ *  chunks dev int32 [n_chunks, 2]: (tensor, first element) of every chunk of chunk_elems (>= 256) elements, tensor by
+ *          tensor; tensor_chunk_start HOST int32 [n_tensors + 1]: first chunk of every tensor;
+ *  grads_host HOST uint64 [n_tensors]: device addresses of this step's gradient tensors (they travel as kernel
+ *          arguments, D3D_ADAM_MAX_TENSORS per launch);
+ *  partial dev f32 [n_chunks] scratch; grad_norm dev f32 [1]: the norm before clipping.
+ * Deterministic (fixed-order sums), no host synchronisation. */
+#define D3D_ADAM_MAX_TENSORS 448
+typedef struct D3dAdamHyper {
+  float lr, beta1, beta2, eps;
+  float decay;      /* the parameter is multiplied by this before the update: 1 - wd * lr (true weight decay) */
+  float max_norm;   /* global-norm clipping threshold, <= 0 disables */
+  float grad_scale; /* gradients are multiplied by this first (1 / world size for summed gradients) */
+  int step;         /* 1-based step count of the bias corrections */
+} D3dAdamHyper;
+int d3d_adam_step(const int64_t *tensors, int n_tensors, const int32_t *chunks, int n_chunks, int chunk_elems,
+                  const int32_t *tensor_chunk_start, const uint64_t *grads_host, const D3dAdamHyper *hyper,
+                  float *partial, float *grad_norm, d3d_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * BatchNorm1d (+ReLU) over the active sites: replaces the nn.BatchNorm1d / nn.ReLU module
  * pairs that spconv.SparseSequential applies to `.features` after every sparse conv
  * (det3d/models/backbones/scn.py:106-157; residual blocks :76-87), F.batch_norm semantics

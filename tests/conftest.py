@@ -18,7 +18,7 @@ def pytest_configure(config):
 # parity files, then the model-level goldens, then the distributed paths, and the optional features (hipGraph tail)
 # last.  Files not listed keep their alphabetical place between the kernel files and the end-to-end ones.
 _GPU_ORDER = ["test_voxelize_gpu", "test_spconv_gpu", "test_determinism_gpu", "test_conv2d_gpu", "test_nms_gpu",
-              "test_iou3d_gpu", "test_loss_gpu", "test_pfn_gpu", "test_assign_gpu", "test_pipeline_gpu",
+              "test_iou3d_gpu", "test_loss_gpu", "test_optim_gpu", "test_pfn_gpu", "test_assign_gpu", "test_pipeline_gpu",
               "test_e2e_gpu", "test_dist_gpu", "test_graph_tail_gpu"]
 
 

@@ -1,0 +1,120 @@
+"""d3d_adam_step (csrc/d3d_optim.hip) through det3d_amd.fused_adam.FusedAdam: clip + true weight decay + Adam in two
+launches against (1) the update written out in float64 numpy and (2) the PyTorch sequence it replaces --
+clip_grad_norm_, `p.mul_(1 - wd * lr)`, torch.optim.Adam with betas[0] rewritten each step
+(det3d/solver/fastai_optim.py:155-171, hooks/optimizer.py:10-13).  A floating-point kernel: tolerance 2e-6 relative
+to the parameter scale per step (f32 rounding of a different but equivalent operation order)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1,), (7,), (64,), (3, 3, 3, 16, 16), (4097,), (128, 128, 3, 3), (100003,), (2, 5)]
+
+
+def _setup(seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    params = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in SHAPES]
+    grads = [[(torch.randn(s, generator=g) * scale).cuda() for s in SHAPES] for _ in range(4)]
+    return params, grads
+
+
+def _reference(params, grads, lrs, moms, wd, max_norm, grad_scale, beta2=0.99, eps=1e-8):
+    p = [x.detach().double().cpu().numpy().copy() for x in params]
+    m = [np.zeros_like(x) for x in p]
+    v = [np.zeros_like(x) for x in p]
+    norms = []
+    for t, (gs, lr, b1) in enumerate(zip(grads, lrs, moms), 1):
+        g64 = [g.double().cpu().numpy() * grad_scale for g in gs]
+        total = np.sqrt(sum((g * g).sum() for g in g64))
+        norms.append(total)
+        coef = min(1.0, max_norm / (total + 1e-6)) if max_norm else 1.0
+        for i in range(len(p)):
+            g = g64[i] * coef
+            m[i] = m[i] + (g - m[i]) * (1 - b1)
+            v[i] = beta2 * v[i] + (1 - beta2) * g * g
+            p[i] = p[i] * (1 - wd * lr) - lr / (1 - b1 ** t) * m[i] / (np.sqrt(v[i]) / np.sqrt(1 - beta2 ** t) + eps)
+    return p, m, v, norms
+
+
+@pytest.mark.parametrize("max_norm,scale", [(35.0, 0.01), (35.0, 1.0), (None, 1.0)])
+@pytest.mark.parametrize("grad_scale", [1.0, 0.5])
+def test_fused_step_matches_the_update_in_float64(max_norm, scale, grad_scale):
+    from det3d_amd.fused_adam import FusedAdam
+
+    params, grads = _setup(1, scale)
+    lrs, moms, wd = [3e-4, 1e-3, 3e-3, 2e-3], [0.95, 0.92, 0.88, 0.85], 0.01
+    ref_p, ref_m, ref_v, ref_norm = _reference(params, grads, lrs, moms, wd, max_norm, grad_scale)
+    opt = FusedAdam(params)
+    for gs, lr, b1, rn in zip(grads, lrs, moms, ref_norm):
+        for p, g in zip(params, gs):
+            p.grad = g.clone()
+        norm = opt.step(lr, b1, decay=1.0 - wd * lr, max_norm=max_norm, grad_scale=grad_scale)
+        assert abs(float(norm) - rn) <= 2e-6 * rn
+    clipped = max_norm is not None and ref_norm[0] > max_norm
+    assert clipped == (scale >= 1.0 and max_norm is not None)   # the case list covers both sides of the threshold
+    for i, p in enumerate(params):
+        tol = 4e-6 * max(1.0, float(np.abs(ref_p[i]).max()))
+        assert np.abs(p.detach().cpu().numpy() - ref_p[i]).max() <= tol, (i, SHAPES[i])
+        assert np.allclose(opt._m[i].cpu().numpy().reshape(ref_m[i].shape), ref_m[i], rtol=1e-5, atol=1e-7 * scale)
+        assert np.allclose(opt._v[i].cpu().numpy().reshape(ref_v[i].shape), ref_v[i], rtol=1e-5, atol=1e-9 * scale * scale)
+
+
+def test_fused_step_against_the_torch_sequence_and_its_checkpoint_layout():
+    from det3d_amd.fused_adam import FusedAdam
+
+    params, grads = _setup(2, 3.0)
+    twins = [p.detach().clone().requires_grad_(True) for p in params]
+    lrs, moms, wd, max_norm = [3e-4, 1e-3, 3e-3, 2e-3], [0.95, 0.92, 0.88, 0.85], 0.01, 35.0
+    opt = FusedAdam(params)
+    ref = torch.optim.Adam(twins, lr=lrs[0], betas=(moms[0], 0.99), weight_decay=0.0, foreach=True)
+    for step, (gs, lr, b1) in enumerate(zip(grads, lrs, moms)):
+        for p, q, g in zip(params, twins, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        opt.step(lr, b1, decay=1.0 - wd * lr, max_norm=max_norm)
+        for grp in ref.param_groups:
+            grp["lr"], grp["betas"] = lr, (b1, 0.99)
+        torch.nn.utils.clip_grad_norm_(twins, max_norm)
+        with torch.no_grad():
+            torch._foreach_mul_(twins, 1.0 - wd * lr)
+        ref.step()
+        if step == 1:   # resume both from the OTHER one's checkpoint half way
+            sd_f, sd_t = opt.state_dict(), ref.state_dict()
+            opt2 = FusedAdam(params)
+            opt2.load_state_dict(sd_t)
+            ref.load_state_dict(dict(state=sd_f["state"], param_groups=sd_t["param_groups"]))
+            opt = opt2
+    for p, q in zip(params, twins):
+        assert torch.allclose(p, q, rtol=0, atol=4e-6 * max(1.0, float(q.abs().max())))
+
+
+def test_fused_step_is_reproducible_and_loud():
+    from det3d_amd import _lib
+    from det3d_amd.fused_adam import FusedAdam
+
+    outs = []
+    for _ in range(2):
+        params, grads = _setup(3, 10.0)
+        opt = FusedAdam(params)
+        torch.empty(1 << 22, device="cuda").normal_()   # other allocations / timing between the runs
+        for gs in grads:
+            for p, g in zip(params, gs):
+                p.grad = g.clone()
+            opt.step(1e-3, 0.9, decay=0.999, max_norm=35.0)
+        outs.append([p.detach().clone() for p in params])
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    params, _ = _setup(4)
+    opt = FusedAdam(params)
+    with pytest.raises(_lib.D3dError):
+        opt.step(1e-3, 0.9)          # no gradients
+    with pytest.raises(_lib.D3dError):
+        FusedAdam([torch.zeros(4, dtype=torch.float64, device="cuda", requires_grad=True)])
+    # a channels-last gradient (library convolutions produce them) is taken through a contiguous copy
+    w = torch.randn(8, 4, 3, 3, device="cuda", requires_grad=True)
+    o2 = FusedAdam([w])
+    g = torch.randn(8, 4, 3, 3, device="cuda").contiguous(memory_format=torch.channels_last)
+    w0 = w.detach().clone()
+    w.grad = g
+    o2.step(1e-2, 0.9)
+    expect = w0 - 1e-2 * torch.sign(g)           # first Adam step: lr * g / |g|
+    assert torch.allclose(w.detach(), expect, atol=1e-5)
