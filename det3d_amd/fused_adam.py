@@ -86,6 +86,10 @@ class FusedAdam:
                              self._chunk_start.ctypes.data, g.ctypes.data, ctypes.byref(hp), self._partial.data_ptr(),
                              self._norm.data_ptr(), _lib.stream_ptr(self.device))
         _lib.check(rc, "d3d_adam_step")
+        # the kernel wrote the parameters behind autograd's back: bump their version counters, or everything keyed on
+        # `_version` -- the packed-weight caches of the conv layers, autograd's saved-tensor checks -- keeps serving
+        # the values of the previous step
+        torch.autograd.graph.increment_version(self.params)
         return self._norm[0]
 
     # ---- torch.optim.Adam's checkpoint layout
