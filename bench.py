@@ -271,8 +271,7 @@ class Workload:
         self.cfg = cfg = Config.fromfile(os.path.join(ROOT, "det3d_amd", "configs", spec["config"]))
         torch.manual_seed(0)
         model = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(dev).train()
-        if hasattr(model.backbone, "middle_conv"):
-            model.backbone.dense_channels_last = not args.no_channels_last
+        model.backbone.dense_channels_last = not args.no_channels_last
         D.broadcast_params(model)
         self.model = model
         self.cached_targets = args.cached_targets

@@ -189,6 +189,12 @@ class PointPillarsScatter(nn.Module):
             # pillars are a one-cell-deep sparse tensor: d3d_dense_scatter (HIP) with D = 1
             idx = torch.stack([coords[:, 0], torch.zeros_like(coords[:, 0]), coords[:, 2], coords[:, 3]], 1)
             st = spconv.SparseConvTensor(voxel_features, idx.int(), [1, self.ny, self.nx], batch_size)
+            # the canvas written channels-last by the kernel, like SpMiddleFHD's dense map: the neck's BatchNorm2d then
+            # runs on the library's sweeps, its 128 / 256-channel stride-1 convs on the library's implicit GEMM, and
+            # MIOpen's own kernels for the rest take NHWC as it is (an NCHW canvas cost the nuScenes PointPillars step
+            # 64 layout transposes = 1.5 ms of 17.5, and kept every layer of the neck on MIOpen)
+            if getattr(self, "dense_channels_last", True):
+                return st.dense_2d(channels_last=True).view(batch_size, self.nchannels, self.ny, self.nx)
             return st.dense().view(batch_size, self.nchannels, self.ny, self.nx)
         canvas = torch.zeros(batch_size, self.nchannels, self.nx * self.ny, dtype=voxel_features.dtype,
                              device=voxel_features.device)

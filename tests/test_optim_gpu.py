@@ -85,7 +85,7 @@ def test_fused_step_against_the_torch_sequence_and_its_checkpoint_layout():
             ref.load_state_dict(dict(state=sd_f["state"], param_groups=sd_t["param_groups"]))
             opt = opt2
     for p, q in zip(params, twins):
-        assert torch.allclose(p, q, rtol=0, atol=4e-6 * max(1.0, float(q.abs().max())))
+        assert torch.allclose(p, q, rtol=0, atol=4e-6 * max(1.0, float(q.detach().abs().max())))
 
 
 def test_fused_step_is_reproducible_and_loud():
@@ -142,17 +142,20 @@ def test_training_steps_with_the_fused_optimizer_follow_the_torch_sequence(monke
         step = TrainStep(model, total_steps=10, autocast_dtype=None)
         assert (step.fused is not None) == (fused == "1")
         p0 = [p.detach().clone() for p in model.parameters()]
-        losses, norms = [], []
-        for _ in range(3):
+        losses, norms, first = [], [], None
+        for i in range(3):
             losses.append(float(step(ex)))
             norms.append(float(step.last["grad_norm"]))
-        runs[fused] = (losses, norms, [p.detach() - q for p, q in zip(model.parameters(), p0)])
+            if i == 0:
+                first = [p.detach() - q for p, q in zip(model.parameters(), p0)]
+        runs[fused] = (losses, norms, first)
     (la, na, pa), (lb, nb, pb) = runs["1"], runs["0"]
     assert la[0] == lb[0] and lb[2] < 0.9 * lb[0]           # same start, and the steps do move the loss
     assert np.allclose(la, lb, rtol=2e-3), (la, lb)
     assert np.allclose(na, nb, rtol=5e-3), (na, nb)
-    # the accumulated updates agree in L2 (single elements whose gradient is ~0 take Adam's +-lr either way once the
-    # two trajectories differ in the last bits)
-    num = sum(float((x - y).square().sum()) for x, y in zip(pa, pb)) ** 0.5
-    den = sum(float(y.square().sum()) for y in pb) ** 0.5
-    assert num < 2e-2 * den, (num, den)
+    # the first update, tensor by tensor (same gradients on both sides): f32 rounding of two operation orders.  Later
+    # updates are not compared element-wise: an element whose gradient is ~0 takes Adam's +-0.75 lr on rounding noise,
+    # in either implementation
+    for x, y in zip(pa, pb):
+        assert float((x - y).abs().max()) <= 1e-7 + 1e-5 * float(y.abs().max())
+    assert max(float(y.abs().max()) for y in pb) > 1e-4
