@@ -55,7 +55,17 @@ def _dp_worker(rank, world, port, backend, q):
         loss.backward()
         total = step.bucket.finish(max_norm=None)
         torch.cuda.synchronize()
-        q.put((rank, [p.grad.float().cpu().numpy() for p in model.parameters()], float(total), float(loss)))
+        grads = [p.grad.float().cpu().numpy() for p in model.parameters()]
+        # two whole training steps (overlapped exchange of the SUMS, then mean + clip + decay + Adam in the two
+        # launches of d3d_adam_step with grad_scale = 1 / world): every rank must hold the same parameters afterwards
+        assert step.fused is not None
+        losses = [float(step(ex)) for _ in range(2)]
+        torch.cuda.synchronize()
+        digest = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy().tobytes()
+        import hashlib
+
+        q.put((rank, grads, float(total), float(loss), hashlib.sha256(digest).hexdigest(), losses,
+               float(step.last["grad_norm"])))
         D.barrier()
         torch.distributed.destroy_process_group()
     except Exception:
@@ -101,7 +111,7 @@ def test_two_ranks_one_gpu_data_parallel_gradients_are_the_mean(backend):
         g = [p.grad.float().cpu().numpy() / world for p in model.parameters()]
         ref = g if ref is None else [a + b for a, b in zip(ref, g)]
     for r in range(world):
-        grads, total, loss = res[r]
+        grads, total, loss = res[r][:3]
         assert np.isfinite(total) and np.isfinite(loss)
         for a, b in zip(grads, ref):
             scale = np.abs(b).max() + 1e-9
@@ -111,6 +121,10 @@ def test_two_ranks_one_gpu_data_parallel_gradients_are_the_mean(backend):
             assert np.abs(a - b).max() < 1e-4 * scale + 1e-7
     for a, b in zip(res[0][0], res[1][0]):
         assert np.array_equal(a, b)  # both ranks hold bit-identical means
+    # ... and after two optimizer steps bit-identical parameters (a15: replicas stay replicas), having seen the same
+    # global gradient norm; each rank's loss is its own frame's
+    assert res[0][3] == res[1][3]
+    assert res[0][5] == res[1][5] and all(np.isfinite(res[r][4]).all() for r in range(world))
 
 
 def _syncbn_worker(rank, world, port, dtype_name, relu, q):
