@@ -104,6 +104,9 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true",
                     help="build the geometry (voxelize, targets, rulebooks) inline at the start of each step instead of "
                          "one batch ahead on a second stream")
+    ap.add_argument("--no-prefetch-thread", action="store_true",
+                    help="build the next batch's geometry on the thread that enqueues the step (its two host syncs then "
+                         "block that thread) instead of a worker thread")
     ap.add_argument("--no-gc-freeze", action="store_true",
                     help="do not gc.freeze() after warm-up (shows the cost of full CPython collections)")
     ap.add_argument("--no-channels-last", action="store_true",
@@ -316,7 +319,7 @@ class Workload:
 
 
 def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, freeze=True, burn_in_s=0.0,
-                 prefetch=True):
+                 prefetch=True, prefetch_thread=True):
     """W untimed warm-up steps, then exactly `steps` steps bracketed by barrier + synchronize; returns
     (max-over-ranks elapsed seconds, launch records of the sampled steps, final loss)."""
     from det3d_amd import dist as D
@@ -328,6 +331,7 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
     # geometry of batch i+1 (voxelize, targets, rulebooks: both host syncs of a step) on a second stream while batch
     # i trains; --no-prefetch builds it inline at the start of each step
     pf = GeometryPrefetcher(wl.example, wl.model, dev, enabled=prefetch)
+    threaded = prefetch and prefetch_thread  # the builds (and their two host syncs) on a worker thread
     host = {"enqueue": 0.0, "geometry": 0.0}
 
     def drain():
@@ -338,14 +342,21 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
             spconv.LAUNCH_LOG.clear()
 
     state = {"ex": pf.prepare(0)}
+    if threaded:
+        state["next"] = pf.submit(1)
 
     def one(i):
-        """step i on the example prepared earlier, then the preparation of example i+1"""
+        """step i on the example prepared earlier, then the preparation of example i+1 (threaded: example i+1 was
+        submitted a step ago and is built while step i is enqueued; example i+2 is submitted here)"""
         drain()
         t_a = time.perf_counter()
         out = wl.step_fn(state["ex"])
         t_b = time.perf_counter()
-        state["ex"] = pf.prepare(i + 1)
+        if threaded:
+            state["ex"] = state["next"].result()
+            state["next"] = pf.submit(i + 2)
+        else:
+            state["ex"] = pf.prepare(i + 1)
         t_c = time.perf_counter()
         host["enqueue"] += t_b - t_a
         host["geometry"] += t_c - t_b
@@ -394,6 +405,8 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
         if i == sample_from and launch_filter is not None:
             spconv.LAUNCH_LOG = []
         loss = one(burn + warmup + i)  # K steps and K geometry builds (the last one for a step that is not run)
+    if threaded:
+        state["next"].result()  # the K-th build of the region is complete (enqueued) before the clock stops
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
@@ -402,6 +415,7 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
     alloc["reserved_MB"] = int(ms1.get("reserved_bytes.all.current", 0) >> 20)
     note("%s %s timed region done: %.3f s for %d steps; allocator during it: %s" % (wl.name, wl.dtype, elapsed, steps, alloc))
     drain()
+    pf.close()
     spconv.LAUNCH_LOG = None
     spconv.LAUNCH_FILTER = None
     wl.host_ms = {k: round(1e3 * v / max(steps, 1), 3) for k, v in host.items()}
@@ -832,7 +846,7 @@ def main():
         dominant = None  # PointPillars has no sparse convolutions
     elapsed, records, loss = timed_region(wl, args.steps, args.warmup, rank, world, dev, note, dominant,
                                           freeze=not args.no_gc_freeze, burn_in_s=args.burn_in,
-                                          prefetch=not args.no_prefetch)
+                                          prefetch=not args.no_prefetch, prefetch_thread=not args.no_prefetch_thread)
     frames = args.steps * wl.batch * world
     value = frames / elapsed
     gnorm = float(wl.step_fn.last["grad_norm"])
@@ -854,7 +868,8 @@ def main():
                    "timed_region_s": round(elapsed, 3),
                    "burn_in_steps": getattr(wl, "burn_in_steps", 0),
                    "graphed_tail": bool(wl.model.__dict__.get("_graph_tails")),
-                   "geometry_prefetch": not args.no_prefetch, "augment": bool(args.augment),
+                   "geometry_prefetch": not args.no_prefetch,
+                   "geometry_thread": not (args.no_prefetch or args.no_prefetch_thread), "augment": bool(args.augment),
                    "host_ms_per_step": getattr(wl, "host_ms", None)},
     }
     if rank == 0 and records:
@@ -890,7 +905,8 @@ def main():
             note("%s line ..." % other)
             k2 = max(min(args.steps, 60), 5)
             wl2 = Workload(head, args, dev, rank, world, other, k2 + 3, batch=wl.batch, points=wl.points)
-            el2, rec2, _ = timed_region(wl2, k2, 3, rank, world, dev, note, dominant, freeze=False, burn_in_s=0.5)
+            el2, rec2, _ = timed_region(wl2, k2, 3, rank, world, dev, note, dominant, freeze=False, burn_in_s=0.5,
+                                       prefetch=not args.no_prefetch, prefetch_thread=not args.no_prefetch_thread)
             o2 = {"value": round(k2 * wl.batch / el2, 2), "unit": "frames/s", "ms_per_step": round(1e3 * el2 / k2, 3),
                   "steps": k2, "warmup": 3, "dtype": other,
                   "note": ("the same workload and step under bf16 autocast: bf16 activations and operands, f32 "

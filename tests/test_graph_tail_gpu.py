@@ -176,7 +176,19 @@ def test_prefetched_geometry_is_the_inline_geometry():
             for k, g in ga.items():
                 # same kernels on the same geometry, every sum in a fixed order: bit-equal
                 assert torch.equal(g, model.get_parameter(k).grad), k
+            # the same again with the build on the prefetcher's worker thread, two builds in flight
+            pend = [pf.submit(i), pf.submit((i + 1) % 4)]
+            ex_c = pend[0].result()
+            assert "sparse_plan" in ex_c and torch.equal(ex_c["coordinates"], ex_b["coordinates"])
+            model.zero_grad(set_to_none=True)
+            lc = sum(model(ex_c, return_loss=True)["loss"])
+            lc.backward()
+            assert float(lc) == float(la)
+            for k, g in ga.items():
+                assert torch.equal(g, model.get_parameter(k).grad), k
+            assert torch.equal(pend[1].result()["coordinates"], make((i + 1) % 4)["coordinates"])
     finally:
+        pf.close()
         det.__exit__(None, None, None)
         graph_tail.GRAPH_TAIL = prev_g
 
