@@ -303,33 +303,25 @@ class MultiGroupHead(nn.Module):
     # ------------------------------------------------------------------- loss
     def prepare_loss_weights(self, labels, loss_norm=dict(type="NormByNumPositives", pos_cls_weight=1.0,
                                                          neg_cls_weight=1.0), dtype=torch.float32):
+        """per-anchor weights of the classification and the box terms, and the mask of the anchors that count
+        (label >= 0).  The four normalisations of mg_head.py:505-560, from their definitions: the box term is always
+        averaged over the frame's positives; the classification term is divided by the positives
+        (NormByNumPositives), by the counted anchors (NormByNumExamples), by the size of the anchor's own class --
+        positives or negatives -- (NormByNumPosNeg) or not at all (DontNorm)."""
+        pos, neg = (labels > 0).to(dtype), (labels == 0).to(dtype)
+        n_pos = pos.sum(1, keepdim=True)
+        cls_w = pos * loss_norm["pos_cls_weight"] + neg * loss_norm["neg_cls_weight"]
+        reg_w = pos / n_pos.clamp(min=1.0)
         kind = loss_norm["type"]
-        pos_w, neg_w = loss_norm["pos_cls_weight"], loss_norm["neg_cls_weight"]
-        cared = labels >= 0
-        positives = labels > 0
-        negatives = labels == 0
-        cls_weights = negatives.type(dtype) * neg_w + pos_w * positives.type(dtype)
-        reg_weights = positives.type(dtype)
-        if kind == "NormByNumExamples":
-            num_examples = torch.clamp(cared.type(dtype).sum(1, keepdim=True), min=1.0)
-            cls_weights = cls_weights / num_examples
-            reg_weights = reg_weights / torch.clamp(positives.sum(1, keepdim=True).type(dtype), min=1.0)
-        elif kind == "NormByNumPositives":
-            pos_normalizer = torch.clamp(positives.sum(1, keepdim=True).type(dtype), min=1.0)
-            reg_weights = reg_weights / pos_normalizer
-            cls_weights = cls_weights / pos_normalizer
+        if kind == "NormByNumPositives":
+            cls_w = cls_w / n_pos.clamp(min=1.0)
+        elif kind == "NormByNumExamples":
+            cls_w = cls_w / (labels >= 0).to(dtype).sum(1, keepdim=True).clamp(min=1.0)
         elif kind == "NormByNumPosNeg":
-            pos_neg = torch.stack([positives, negatives], dim=-1).type(dtype)
-            normalizer = pos_neg.sum(1, keepdim=True)
-            cls_normalizer = torch.clamp((pos_neg * normalizer).sum(-1), min=1.0)
-            normalizer = torch.clamp(normalizer, min=1.0)
-            reg_weights = reg_weights / normalizer[:, 0:1, 0]
-            cls_weights = cls_weights / cls_normalizer
-        elif kind == "DontNorm":
-            reg_weights = reg_weights / torch.clamp(positives.sum(1, keepdim=True).type(dtype), min=1.0)
-        else:
+            cls_w = cls_w / (pos * n_pos + neg * neg.sum(1, keepdim=True)).clamp(min=1.0)
+        elif kind != "DontNorm":
             raise ValueError("unknown loss norm type %s" % kind)
-        return cls_weights, reg_weights, cared
+        return cls_w, reg_w, labels >= 0
 
     def _fused_loss_ok(self, preds_dict, labels):
         """the configuration d3d_head_loss implements (every shipped config), on device tensors"""

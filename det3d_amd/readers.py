@@ -10,7 +10,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import _lib
-from .nn_utils import build_norm_layer, get_paddings_indicator
+from .nn_utils import build_norm_layer
 from .registry import READERS
 
 FUSE_PFN = True  # single-layer PillarFeatureNet on CUDA goes through d3d_pfn_fwd / d3d_pfn_bwd
@@ -81,30 +81,44 @@ class VoxelFeatureExtractorV3(nn.Module):
         return points_mean.contiguous()
 
 
+def decorate_pillars(points, counts, coors, cell, origin, with_distance=False):
+    """[M, T, C] padded pillars -> [M, T, C + 5 (+1)] rows: the point, its offset from the pillar's mean point (x, y,
+    z), its offset from the pillar's cell centre (x, y), optionally its range; padded slots zeroed.
+    (what PillarFeatureNet.forward computes in front of its layers, pillar_encoder.py:115-150)
+    cell = (vx, vy); origin = centre of cell (0, 0)."""
+    m, t, _ = points.shape
+    real = (torch.arange(t, device=points.device).unsqueeze(0) < counts.view(m, 1)).unsqueeze(-1)
+    xyz = points[..., :3]
+    centroid = xyz.sum(1, keepdim=True) / counts.to(points.dtype).view(m, 1, 1)
+    ij = torch.stack([coors[:, 3], coors[:, 2]], 1).to(points.dtype)                 # (x index, y index) of the pillar
+    centre = ij * points.new_tensor(cell) + points.new_tensor(origin)
+    cols = [points, xyz - centroid, points[..., :2] - centre.unsqueeze(1)]
+    if with_distance:
+        cols.append(xyz.norm(dim=2, keepdim=True))
+    return torch.cat(cols, 2) * real.to(points.dtype)
+
+
 class PFNLayer(nn.Module):
+    """Linear -> BatchNorm over all M*T point rows -> ReLU -> max over the T slots of a pillar
+    (registry / state-dict names of pillar_encoder.py:17-60: `linear`, `norm`)."""
+
     def __init__(self, in_channels, out_channels, norm_cfg=None, last_layer=False):
         super().__init__()
         self.name = "PFNLayer"
         self.last_vfe = last_layer
-        if not self.last_vfe:
-            out_channels = out_channels // 2
-        self.units = out_channels
-        if norm_cfg is None:
-            norm_cfg = dict(type="BN1d", eps=1e-3, momentum=0.01)
-        self.norm_cfg = norm_cfg
+        self.units = out_channels if last_layer else out_channels // 2   # inner layers concatenate [x, max x]
+        self.norm_cfg = norm_cfg if norm_cfg is not None else dict(type="BN1d", eps=1e-3, momentum=0.01)
         self.linear = nn.Linear(in_channels, self.units, bias=False)
         self.norm = build_norm_layer(self.norm_cfg, self.units)[1]
 
     def forward(self, inputs):
-        x = self.linear(inputs)
-        # BN over the channel axis of [M, T, C]: statistics over all M*T rows
-        x = self.norm(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
-        x = F.relu(x)
-        x_max = torch.max(x, dim=1, keepdim=True)[0]
+        m, t, _ = inputs.shape
+        y = self.linear(inputs)
+        y = F.relu(self.norm(y.transpose(1, 2)).transpose(1, 2))   # the norm layer sees [M, C, T]: per-channel statistics
+        top = y.amax(1, keepdim=True)
         if self.last_vfe:
-            return x_max
-        x_repeat = x_max.repeat(1, inputs.shape[1], 1)
-        return torch.cat([x, x_repeat], dim=2)
+            return top
+        return torch.cat([y, top.expand(m, t, self.units)], 2)
 
 
 @READERS.register_module
@@ -151,19 +165,8 @@ class PillarFeatureNet(nn.Module):
                                bn.running_mean, bn.running_var, bn.momentum, bn.eps, bn.training,
                                (float(self.vx), float(self.vy), float(self.x_offset), float(self.y_offset)))
             return out.squeeze()
-        dtype = features.dtype
-        points_mean = features[:, :, :3].sum(dim=1, keepdim=True) / \
-            num_voxels.type_as(features).view(-1, 1, 1)
-        f_cluster = features[:, :, :3] - points_mean
-        f_center = torch.zeros_like(features[:, :, :2])
-        f_center[:, :, 0] = features[:, :, 0] - (coors[:, 3].to(dtype).unsqueeze(1) * self.vx + self.x_offset)
-        f_center[:, :, 1] = features[:, :, 1] - (coors[:, 2].to(dtype).unsqueeze(1) * self.vy + self.y_offset)
-        parts = [features, f_cluster, f_center]
-        if self._with_distance:
-            parts.append(torch.norm(features[:, :, :3], 2, 2, keepdim=True))
-        features = torch.cat(parts, dim=-1)
-        mask = get_paddings_indicator(num_voxels, features.shape[1], axis=0)
-        features = features * torch.unsqueeze(mask, -1).type_as(features)
-        for pfn in self.pfn_layers:
-            features = pfn(features)
-        return features.squeeze()
+        x = decorate_pillars(features, num_voxels, coors, (self.vx, self.vy), (self.x_offset, self.y_offset),
+                             self._with_distance)
+        for layer in self.pfn_layers:
+            x = layer(x)
+        return x.squeeze()
