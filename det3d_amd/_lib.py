@@ -69,10 +69,11 @@ SIGNATURES = {
     "d3d_head_conv_wgrad": (i32, [vp, vp, vp, i32, i64, i32, i32, vp, sz, vp]),
     "d3d_channel_affine": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp]),
     "d3d_channel_affine_bwd": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]),
+    "d3d_pfn_ws_floats": (sz, [i32, i32, i32]),
     "d3d_pfn_fwd": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp, vp, vp, vp, f32, f32,
-                          i32, vp, vp, vp, vp, vp, vp]),
+                          i32, vp, vp, vp, vp, vp, sz, vp]),
     "d3d_pfn_bwd": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, vp, vp, vp, vp, vp, vp,
-                          vp, vp, vp, vp]),
+                          vp, vp, vp, vp, sz, vp]),
     "d3d_dense_scatter": (i32, [vp, vp, i32, i32, i32, _i32p, i32, i32, vp, vp]),
     "d3d_dense_gather": (i32, [vp, vp, i32, i32, i32, _i32p, i32, i32, vp, vp]),
     "d3d_assign_targets_workspace_bytes": (sz, [i32, i32, i32]),
@@ -96,7 +97,7 @@ SIGNATURES = {
     "d3d_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
 }
 
-ABI_VERSION = 5  # include/d3d.h D3D_ABI_VERSION
+ABI_VERSION = 6  # include/d3d.h D3D_ABI_VERSION
 D3D_F32 = 0
 D3D_BF16 = 1
 D3D_CONV_BF16, D3D_CONV_SPLIT = 0, 1

@@ -7,8 +7,11 @@
 // the lane keeps its weight row W[c][0..K) in registers and walks only the pillar's REAL points
 // (padded rows are exact zeros after the mask: they add nothing to the BN sums but count in N = M*T,
 // and they compete in the max with relu(shift)).
-//   fwd  : pfn_stats (sum, sumsq per channel)  ->  pfn_apply (normalise, ReLU, max/argmax over T)
-//   bwd  : pfn_bwd_reduce (dbeta, dgamma from the argmax rows)  ->  pfn_bwd_weight (dW)
+//   fwd  : pfn_stats (sum, sumsq per channel)  ->  fold  ->  pfn_apply (normalise, ReLU, max/argmax over T)
+//   bwd  : pfn_bwd_reduce (dbeta, dgamma from the argmax rows)  ->  fold  ->  pfn_bwd_weight (dW)  ->  fold
+// Round 3: the per-channel sums are deterministic.  Every wave leaves ONE slab of partial sums (it walks its pillars in
+// a fixed order) and pfn_fold_kernel adds the slabs in ascending wave order; rounds 1-2 added them with float atomics
+// (2048 waves x 640 same-address atomics made pfn_bwd_weight the slowest launch of the PointPillars step: 620 us).
 // All f32 (the reader runs before any bf16 cast); HBM-bound on reading the voxel rows once per pass.
 #include "d3d_common.h"
 #include "d3d_fill.h"
@@ -61,7 +64,7 @@ template <int C>
 __global__ void __launch_bounds__(256)
     pfn_stats_kernel(PfnGeom G, const float *__restrict__ vox, const int32_t *__restrict__ num_points,
                      const int4 *__restrict__ coors, const float *__restrict__ weight,
-                     float *__restrict__ stats) {
+                     float *__restrict__ slabs) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -85,9 +88,43 @@ __global__ void __launch_bounds__(256)
       q = fmaf(x, x, q);
     }
   }
-  if (lane < G.f) {
-    atomicAdd(&stats[lane], s);
-    atomicAdd(&stats[G.f + lane], q);
+  if (lane < G.f) {  // slab of this wave: [sum f | sumsq f]
+    slabs[(int64_t)wave * 2 * G.f + lane] = s;
+    slabs[(int64_t)wave * 2 * G.f + G.f + lane] = q;
+  }
+}
+
+// out[i] = sum over slabs w = 0 .. nslabs-1 (ascending) of slabs[w][i]: 16 waves per block share the slab range, each
+// adds its contiguous share in order, the shares are combined in wave order
+#define PFN_FOLD_WAVES 16
+__global__ void __launch_bounds__(64 * PFN_FOLD_WAVES)
+    pfn_fold_kernel(const float *__restrict__ slabs, int nslabs, int nval, float *__restrict__ out, int split,
+                    float *__restrict__ out2) {  // values i >= split go to out2[i - split]
+  __shared__ float part[PFN_FOLD_WAVES][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = (int)blockIdx.x * 64 + lane;
+  const int per = (nslabs + PFN_FOLD_WAVES - 1) / PFN_FOLD_WAVES;
+  const int w0 = wave * per, w1 = (w0 + per < nslabs) ? w0 + per : nslabs;
+  float s = 0.f;
+  if (i < nval) {
+    int w = w0;
+    for (; w + 8 <= w1; w += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = slabs[(int64_t)(w + j) * nval + i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; w < w1; ++w) s += slabs[(int64_t)w * nval + i];
+  }
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && i < nval) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < PFN_FOLD_WAVES; ++j) t += part[j][lane];
+    if (i < split) out[i] = t;
+    else out2[i - split] = t;
   }
 }
 
@@ -185,7 +222,7 @@ __global__ void __launch_bounds__(256)
                           const float *__restrict__ weight, const float *__restrict__ mean_,
                           const float *__restrict__ invstd_, const float *__restrict__ out,
                           const float *__restrict__ dout, const int32_t *__restrict__ argmax,
-                          float *__restrict__ dgamma, float *__restrict__ dbeta) {
+                          float *__restrict__ slabs) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -208,9 +245,9 @@ __global__ void __launch_bounds__(256)
     sb += dz;
     sg = fmaf(dz, (x - mu) * is, sg);
   }
-  if (on) {
-    atomicAdd(&dgamma[lane], sg);
-    atomicAdd(&dbeta[lane], sb);
+  if (on) {  // slab of this wave: [dgamma f | dbeta f]
+    slabs[(int64_t)wave * 2 * G.f + lane] = sg;
+    slabs[(int64_t)wave * 2 * G.f + G.f + lane] = sb;
   }
 }
 
@@ -224,7 +261,7 @@ __global__ void __launch_bounds__(256)
                           const float *__restrict__ mean_, const float *__restrict__ invstd_,
                           const float *__restrict__ out, const float *__restrict__ dout,
                           const int32_t *__restrict__ argmax, const float *__restrict__ dgamma,
-                          const float *__restrict__ dbeta, float *__restrict__ dweight) {
+                          const float *__restrict__ dbeta, float *__restrict__ slabs) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -260,9 +297,9 @@ __global__ void __launch_bounds__(256)
       for (int j = 0; j < K; ++j) acc[j] = fmaf(dx, feat[j], acc[j]);
     }
   }
-  if (on)
+  if (on)  // slab of this wave: dW in nn.Linear layout [f][K]
 #pragma unroll
-    for (int j = 0; j < K; ++j) atomicAdd(&dweight[lane * K + j], acc[j]);
+    for (int j = 0; j < K; ++j) slabs[(int64_t)wave * G.f * K + lane * K + j] = acc[j];
 }
 
 static int pfn_geom(PfnGeom &G, int m, int t, int c, int f, float vx, float vy, float xo, float yo,
@@ -294,9 +331,23 @@ static int pfn_geom(PfnGeom &G, int m, int t, int c, int f, float vx, float vy, 
   } while (0)
 
 static int pfn_blocks(int m) {
-  int waves = m < 2048 ? m : 2048;  // <= 2048 waves: few same-address atomics, 8 waves per CU
+  int waves = m < 2048 ? m : 2048;  // <= 2048 waves (8 per CU), each leaves one slab
   int nb = (waves + 3) / 4;
   return nb < 1 ? 1 : nb;
+}
+
+// floats of the scratch either direction needs: [2f] folded statistics | one slab of max(2f, f (c + 5)) per wave
+extern "C" size_t d3d_pfn_ws_floats(int m, int c, int f) {
+  if (m < 1 || c < 3 || c > 5 || f < 1 || f > 64) return 0;
+  const size_t slab = (size_t)f * (size_t)(c + 5 > 2 ? c + 5 : 2);
+  return (size_t)2 * f + (size_t)pfn_blocks(m) * 4 * slab;
+}
+
+static int pfn_fold(const float *slabs, int nslabs, int nval, float *out, int split, float *out2, hipStream_t stream) {
+  hipLaunchKernelGGL(pfn_fold_kernel, dim3((nval + 63) / 64), dim3(64 * PFN_FOLD_WAVES), 0, stream, slabs, nslabs, nval,
+                     out, split, out2);
+  D3D_LAUNCH_TRY("pfn_fold_kernel");
+  return D3D_OK;
 }
 
 extern "C" int d3d_pfn_fwd(const float *voxels, const int32_t *num_points, const int32_t *coors, int m,
@@ -304,7 +355,7 @@ extern "C" int d3d_pfn_fwd(const float *voxels, const int32_t *num_points, const
                            const float *weight, int f, const float *gamma, const float *beta,
                            float *running_mean, float *running_var, float momentum, float eps,
                            int training, float *out, int32_t *argmax, float *save_mean,
-                           float *save_invstd, float *stats_ws, d3d_stream_t stream_) {
+                           float *save_invstd, float *stats_ws, size_t stats_ws_floats, d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PfnGeom G;
   int rc = pfn_geom(G, m, t, c, f, vx, vy, x_offset, y_offset, "d3d_pfn_fwd");
@@ -314,9 +365,13 @@ extern "C" int d3d_pfn_fwd(const float *voxels, const int32_t *num_points, const
               "d3d_pfn_fwd: training needs stats_ws, eval needs running stats");
   const int nb = pfn_blocks(m);
   if (training) {
-    D3D_HIP_TRY(d3d_fill_async(stream, stats_ws, 0, (size_t)2 * f * sizeof(float)));
-    PFN_DISPATCH(pfn_stats_kernel, G, voxels, num_points, (const int4 *)coors, weight, stats_ws);
+    if (stats_ws_floats < d3d_pfn_ws_floats(m, c, f))
+      return d3d_set_error(D3D_ECAPACITY, "d3d_pfn_fwd: stats_ws of %zu floats < %zu (d3d_pfn_ws_floats)",
+                           stats_ws_floats, d3d_pfn_ws_floats(m, c, f));
+    float *slabs = stats_ws + 2 * f;
+    PFN_DISPATCH(pfn_stats_kernel, G, voxels, num_points, (const int4 *)coors, weight, slabs);
     D3D_LAUNCH_TRY("pfn_stats_kernel");
+    if (int frc = pfn_fold(slabs, nb * 4, 2 * f, stats_ws, 2 * f, nullptr, stream)) return frc;
   }
   PFN_DISPATCH(pfn_apply_kernel, G, voxels, num_points, (const int4 *)coors, weight, gamma, beta,
                running_mean, running_var, momentum, eps, training, stats_ws, out, argmax, save_mean,
@@ -330,26 +385,25 @@ extern "C" int d3d_pfn_bwd(const float *voxels, const int32_t *num_points, const
                            const float *weight, int f, const float *gamma, const float *save_mean,
                            const float *save_invstd, const float *out, const float *dout,
                            const int32_t *argmax, float *dweight, float *dgamma, float *dbeta,
-                           d3d_stream_t stream_) {
+                           float *workspace, size_t workspace_floats, d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PfnGeom G;
   int rc = pfn_geom(G, m, t, c, f, vx, vy, x_offset, y_offset, "d3d_pfn_bwd");
   if (rc) return rc;
   D3D_REQUIRE(voxels && num_points && coors && weight && save_mean && save_invstd && out && dout &&
-                  argmax && dweight && dgamma && dbeta,
+                  argmax && dweight && dgamma && dbeta && workspace,
               "d3d_pfn_bwd: null pointer");
+  if (workspace_floats < d3d_pfn_ws_floats(m, c, f))
+    return d3d_set_error(D3D_ECAPACITY, "d3d_pfn_bwd: workspace of %zu floats < %zu (d3d_pfn_ws_floats)",
+                         workspace_floats, d3d_pfn_ws_floats(m, c, f));
   const int nb = pfn_blocks(m);
-  {
-    const D3dFillSeg segs[3] = {{dweight, 0, (size_t)f * G.k * sizeof(float)},
-                                {dgamma, 0, (size_t)f * sizeof(float)},
-                                {dbeta, 0, (size_t)f * sizeof(float)}};
-    D3D_HIP_TRY(d3d_fill_async(stream, segs, 3));
-  }
+  float *slabs = workspace + 2 * f;  // (the first 2 f floats mirror the forward's layout and stay unused here)
   PFN_DISPATCH(pfn_bwd_reduce_kernel, G, voxels, num_points, (const int4 *)coors, weight, save_mean,
-               save_invstd, out, dout, argmax, dgamma, dbeta);
+               save_invstd, out, dout, argmax, slabs);
   D3D_LAUNCH_TRY("pfn_bwd_reduce_kernel");
+  if (int frc = pfn_fold(slabs, nb * 4, 2 * f, dgamma, f, dbeta, stream)) return frc;
   PFN_DISPATCH(pfn_bwd_weight_kernel, G, voxels, num_points, (const int4 *)coors, weight, gamma,
-               save_mean, save_invstd, out, dout, argmax, dgamma, dbeta, dweight);
+               save_mean, save_invstd, out, dout, argmax, dgamma, dbeta, slabs);
   D3D_LAUNCH_TRY("pfn_bwd_weight_kernel");
-  return D3D_OK;
+  return pfn_fold(slabs, nb * 4, f * G.k, dweight, f * G.k, nullptr, stream);
 }

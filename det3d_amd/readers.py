@@ -17,7 +17,7 @@ FUSE_PFN = True  # single-layer PillarFeatureNet on CUDA goes through d3d_pfn_fw
 
 
 class _PFNFn(torch.autograd.Function):
-    """decorate + Linear + BatchNorm1d + ReLU + max over T in two launches (d3d_pfn_fwd)."""
+    """decorate + Linear + BatchNorm1d + ReLU + max over T in three launches (d3d_pfn_fwd: statistics slabs, fixed-order fold, apply)."""
 
     @staticmethod
     def forward(ctx, voxels, num_points, coors, weight, gamma, beta, running_mean, running_var, momentum,
@@ -31,13 +31,14 @@ class _PFNFn(torch.autograd.Function):
         dev = voxels.device
         out = torch.empty((m, f), dtype=torch.float32, device=dev)
         argmax = torch.empty((m, f), dtype=torch.int32, device=dev)
-        save = torch.empty((4, f), dtype=torch.float32, device=dev)
+        save = torch.empty((2, f), dtype=torch.float32, device=dev)
+        ws = torch.empty((L.d3d_pfn_ws_floats(m, c, f),), dtype=torch.float32, device=dev)  # slabs of the fixed-order sums
         w = weight.detach().float().contiguous()
         vx, vy, xo, yo = geom
         rc = L.d3d_pfn_fwd(voxels.data_ptr(), num_points.data_ptr(), coors.data_ptr(), m, t, c, vx, vy, xo, yo,
                            w.data_ptr(), f, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
                            _lib.ptr(running_var), float(momentum), float(eps), int(training), out.data_ptr(),
-                           argmax.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), save[2].data_ptr(),
+                           argmax.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), ws.data_ptr(), ws.numel(),
                            _lib.stream_ptr(dev))
         _lib.check(rc, "d3d_pfn_fwd")
         ctx.save_for_backward(voxels, num_points, coors, w, gamma, save, out, argmax)
@@ -57,10 +58,11 @@ class _PFNFn(torch.autograd.Function):
         dout = dout.float().contiguous()
         dw = torch.empty_like(w)
         g = torch.empty((2, f), dtype=torch.float32, device=w.device)
+        ws = torch.empty((L.d3d_pfn_ws_floats(m, c, f),), dtype=torch.float32, device=w.device)
         rc = L.d3d_pfn_bwd(voxels.data_ptr(), num_points.data_ptr(), coors.data_ptr(), m, t, c, vx, vy, xo, yo,
                            w.data_ptr(), f, _lib.ptr(gamma), save[0].data_ptr(), save[1].data_ptr(),
                            out.data_ptr(), dout.data_ptr(), argmax.data_ptr(), dw.data_ptr(), g[0].data_ptr(),
-                           g[1].data_ptr(), _lib.stream_ptr(w.device))
+                           g[1].data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(w.device))
         _lib.check(rc, "d3d_pfn_bwd")
         return None, None, None, dw, g[0], g[1], None, None, None, None, None, None
 

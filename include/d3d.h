@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 5 /* 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv; 5: planned strided data gradient */
+#define D3D_ABI_VERSION 6 /* 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv; 5: planned strided data gradient, d3d_adam_step; 6: deterministic PillarFeatureNet sums (workspace arguments) */
 
 #define D3D_OK 0
 #define D3D_EINVAL -1    /* bad argument / unsupported shape           */
@@ -367,19 +367,24 @@ int d3d_head_conv_wgrad(const void *x, void *const *g, const int *n, int count, 
  *  voxels dev [m,t,c] f32 zero padded, num_points dev [m] i32, coors dev [m,4] i32 (b,z,y,x)
  *  weight dev [f, c+5] f32 (nn.Linear layout), gamma/beta/running_* dev [f] f32, f <= 64, c in 3..5
  *  out dev [m,f] f32; argmax dev [m,f] i32 (row index of the max, >= num_points for a padded row)
- *  training=1: batch statistics via stats_ws dev [2f], running stats updated, save_* written
+ *  training=1: batch statistics via stats_ws, running stats updated, save_* written
  *  bwd overwrites dweight [f,c+5], dgamma [f], dbeta [f]  (points carry no gradient)
+ *  stats_ws / workspace: dev f32 scratch of d3d_pfn_ws_floats(m, c, f) floats, need not be zeroed.  Every wave of a
+ *  reducing launch leaves one slab of partial sums there and a second launch adds the slabs in a fixed order: the
+ *  sums are bit-reproducible (ABI 6; before: float atomics).
  */
+size_t d3d_pfn_ws_floats(int m, int c, int f);
 int d3d_pfn_fwd(const float *voxels, const int32_t *num_points, const int32_t *coors, int m, int t,
                 int c, float vx, float vy, float x_offset, float y_offset, const float *weight, int f,
                 const float *gamma, const float *beta, float *running_mean, float *running_var,
                 float momentum, float eps, int training, float *out, int32_t *argmax,
-                float *save_mean, float *save_invstd, float *stats_ws, d3d_stream_t stream);
+                float *save_mean, float *save_invstd, float *stats_ws, size_t stats_ws_floats,
+                d3d_stream_t stream);
 int d3d_pfn_bwd(const float *voxels, const int32_t *num_points, const int32_t *coors, int m, int t,
                 int c, float vx, float vy, float x_offset, float y_offset, const float *weight, int f,
                 const float *gamma, const float *save_mean, const float *save_invstd,
                 const float *out, const float *dout, const int32_t *argmax, float *dweight,
-                float *dgamma, float *dbeta, d3d_stream_t stream);
+                float *dgamma, float *dbeta, float *workspace, size_t workspace_floats, d3d_stream_t stream);
 
 /* SparseConvTensor.dense() (spconv; call sites scn.py:192-195,363-367):
  * scatter feat[n,c] to dense [batch, c, D, H, W] (zero elsewhere; the caller
