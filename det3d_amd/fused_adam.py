@@ -18,6 +18,19 @@ import torch
 from . import _lib
 
 
+def plan_chunks(numels, min_chunk=4096, max_chunks=4096):
+    """chunk size (a multiple of 256 elements) and the chunk list of `d3d_adam_step`: every tensor is cut into chunks of
+    that size, tensor by tensor -> (chunk_elems, [(tensor, first element)], first chunk of every tensor + total)"""
+    total = sum(numels)
+    chunk = max(min_chunk, -(-total // max_chunks))
+    chunk = (chunk + 255) // 256 * 256
+    chunks, start = [], [0]
+    for t, n in enumerate(numels):
+        chunks += [(t, o) for o in range(0, max(n, 1), chunk)]
+        start.append(len(chunks))
+    return chunk, chunks, start
+
+
 class FusedAdam:
     MIN_CHUNK = 4096      # elements per block of the two kernels
     MAX_CHUNKS = 4096     # the update kernel's blocks each re-add all chunk partials: keep that list short
@@ -43,13 +56,7 @@ class FusedAdam:
         self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
         self._m = [self.exp_avg[o: o + n] for o, n in zip(offs, self.numel)]
         self._v = [self.exp_avg_sq[o: o + n] for o, n in zip(offs, self.numel)]
-        total = sum(self.numel)
-        chunk = max(self.MIN_CHUNK, -(-total // self.MAX_CHUNKS))
-        self.chunk = (chunk + 255) // 256 * 256
-        chunks, start = [], [0]
-        for t, n in enumerate(self.numel):
-            chunks += [(t, o) for o in range(0, max(n, 1), self.chunk)]
-            start.append(len(chunks))
+        self.chunk, chunks, start = plan_chunks(self.numel, self.MIN_CHUNK, self.MAX_CHUNKS)
         self.n_chunks = len(chunks)
         self._chunk_start = np.asarray(start, np.int32)
         self._chunks = torch.from_numpy(np.asarray(chunks, np.int32).reshape(-1, 2)).to(dev)

@@ -102,3 +102,36 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "libd3d_oracle" not in src, f
+
+
+def test_host_side_planning_helpers(hip_lib):
+    """size / support predicates that run on the host alone (no device call): row plans of the strided data gradients,
+    PillarFeatureNet and conv-epilogue scratch sizes, the chunk plan of the fused optimizer step"""
+    import ctypes
+
+    from det3d_amd import _lib
+    from det3d_amd.fused_adam import plan_chunks
+
+    arr = lambda v: (ctypes.c_int32 * 3)(*v)
+    L = hip_lib
+    assert L.d3d_dgrad_plan_supported(arr([3, 3, 3]), arr([2, 2, 2])) == 1      # scn.py:113 / :127 / :141
+    assert L.d3d_dgrad_plan_supported(arr([3, 1, 1]), arr([2, 1, 1])) == 1      # the last (3,1,1) / (2,1,1) layer
+    assert L.d3d_dgrad_plan_supported(arr([3, 3, 3]), arr([1, 1, 1])) == 0      # nothing to sort
+    assert L.d3d_dgrad_plan_supported(arr([3, 3, 3]), arr([3, 2, 2])) == 0      # 12 classes > 8
+    assert L.d3d_dgrad_plan_supported(arr([4, 4, 4]), arr([2, 2, 2])) == 0      # 64 offsets > 27
+    assert L.d3d_dgrad_plan_ints(1000) == 304 + 1000 + 8
+    assert L.d3d_dgrad_plan_ints(1025) == 304 + 1025 + 16 and L.d3d_dgrad_plan_ints(0) == 0
+    for cin, cout, ok in [(64, 32, 1), (32, 16, 1), (64, 64, 1), (128, 64, 1), (128, 128, 1), (16, 16, 0), (32, 64, 0)]:
+        assert L.d3d_sparse_conv_dgrad_plan_supported(cin, cout, _lib.D3D_F32) == ok
+        assert L.d3d_sparse_conv_dgrad_plan_supported(cin, cout, _lib.D3D_BF16) == ok
+    # one slab of max(2f, f (c + 5)) floats per wave (<= 2048 waves, rounded to blocks of 4) behind the 2f results
+    assert L.d3d_pfn_ws_floats(100, 4, 64) == 128 + 100 * 64 * 9
+    assert L.d3d_pfn_ws_floats(50000, 5, 64) == 128 + 2048 * 64 * 10
+    assert L.d3d_pfn_ws_floats(10, 6, 64) == 0 and L.d3d_pfn_ws_floats(10, 4, 65) == 0
+    assert L.d3d_conv_epilogue_ws_floats(0, 64) == 0 and L.d3d_conv_epilogue_ws_floats(1000, 64) >= 128 * (1 + 16)
+    # optimizer chunks: tensor by tensor, multiples of 256 elements, at most ~4096 chunks of >= 4096 elements
+    chunk, chunks, start = plan_chunks([1, 4096, 4097, 10])
+    assert chunk == 4096 and chunks == [(0, 0), (1, 0), (2, 0), (2, 4096), (3, 0)] and start == [0, 1, 2, 4, 5]
+    chunk, chunks, start = plan_chunks([40_000_000, 5])
+    assert chunk % 256 == 0 and chunk >= 40_000_005 / 4096 and len(chunks) <= 4097 and start[-1] == len(chunks)
+    assert all(o % chunk == 0 for _, o in chunks)
