@@ -905,7 +905,7 @@ def main():
             note("%s line ..." % other)
             k2 = max(min(args.steps, 60), 5)
             wl2 = Workload(head, args, dev, rank, world, other, k2 + 3, batch=wl.batch, points=wl.points)
-            el2, rec2, _ = timed_region(wl2, k2, 3, rank, world, dev, note, dominant, freeze=False, burn_in_s=0.5,
+            el2, rec2, _ = timed_region(wl2, k2, 3, rank, world, dev, note, dominant, freeze=not args.no_gc_freeze, burn_in_s=0.5,
                                        prefetch=not args.no_prefetch, prefetch_thread=not args.no_prefetch_thread)
             o2 = {"value": round(k2 * wl.batch / el2, 2), "unit": "frames/s", "ms_per_step": round(1e3 * el2 / k2, 3),
                   "steps": k2, "warmup": 3, "dtype": other,
