@@ -41,6 +41,7 @@ def join_planes(hi, lo):
     return hi.float() + lo.float()
 
 
+_CAPTURE_PACK = {}  # same key -> (weakref, capturing stream handle, None, packs): see _packed
 _PACK = {}  # (id(weight), mode) -> (weakref, version, data_ptr, {"fwd": (hi, lo), "dgrad": (hi, lo)})
 
 
@@ -50,7 +51,15 @@ def _packed(weight, kind, mode):
     changes (optimizer steps bump `_version`; writes through `.data` move no version, so the pointer is checked too)."""
     key = (id(weight), mode)
     hit = _PACK.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+    # under hipGraph capture the pack launch must be PART of the graph (a replay has to see the weights of its own
+    # step, and the captured kernels must read capture-owned buffers): one pack per (weight, capture), kept in a side
+    # table that dies with the capture -- never the eager cache, whose buffers an eager step would free under the graph
+    capturing = weight.is_cuda and torch.cuda.is_current_stream_capturing()
+    if capturing:
+        hit = _CAPTURE_PACK.get(key)
+        if hit is not None and hit[0]() is weight and hit[1] == torch.cuda.current_stream(weight.device).cuda_stream:
+            return hit[3][kind]
+    elif hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
         return hit[3][kind]
     w = weight.detach()
     if w.dtype != torch.float32 or not w.is_contiguous():
@@ -65,6 +74,11 @@ def _packed(weight, kind, mode):
                                             _lib.ptr(d_lo), _lib.stream_ptr(dev))
     _lib.check(rc, "d3d_conv2d_pack_weights")
     out = {"fwd": (f_hi, f_lo), "dgrad": (d_hi, d_lo)}
+    if capturing:
+        # the graph's private memory pool keeps f_* / d_* alive for the graph's lifetime; the entry only serves the
+        # second request (fwd, then dgrad) of the same capture
+        _CAPTURE_PACK[key] = (weakref.ref(weight), torch.cuda.current_stream(dev).cuda_stream, None, out)
+        return out[kind]
     if len(_PACK) > 256:
         for k in [k for k, v in _PACK.items() if v[0]() is None]:
             del _PACK[k]

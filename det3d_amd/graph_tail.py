@@ -108,10 +108,18 @@ class GraphedTail:
         # MIOpen find mode (cudnn.benchmark) must be off while warming up and capturing: the solvers it picks for
         # the weight gradients (split-K igemm with atomics) rely on zero-initialisation that is not part of the
         # captured work, so every replay accumulated onto the previous one -- gradient norm inf after a few
-        # steps (tools/diag_nan.py).  Immediate-mode solvers replay correctly.
-        with ctx, torch.backends.cudnn.flags(enabled=True, benchmark=False,
-                                             deterministic=torch.backends.cudnn.deterministic):
-            graphed = torch.cuda.make_graphed_callables(tail, sample, num_warmup_iters=3, allow_unused_input=True)
+        # steps (round-2 diagnosis).  Immediate-mode solvers replay correctly.
+        from . import dense_conv
+
+        # packed conv weights: a capture packs into its own buffers with its own launch (dense_conv._packed), so that a
+        # replay convolves with the weights of ITS step; entries of an earlier capture must not satisfy this one
+        dense_conv._CAPTURE_PACK.clear()
+        try:
+            with ctx, torch.backends.cudnn.flags(enabled=True, benchmark=False,
+                                                 deterministic=torch.backends.cudnn.deterministic):
+                graphed = torch.cuda.make_graphed_callables(tail, sample, num_warmup_iters=3, allow_unused_input=True)
+        finally:
+            dense_conv._CAPTURE_PACK.clear()  # the graphs' private pool owns the buffers from here on
         with torch.no_grad():
             sd = tail.state_dict()
             for k, v in buffers.items():

@@ -261,6 +261,23 @@ def assign_targets_task_device(anchors, num_classes, per_class, matched, unmatch
     return labels, targets, weights
 
 
+class _SeededFrames:
+    """frames[s] = make(s), generated on first use: a rank of an N-GPU job only pays for the seeds it reads"""
+
+    def __init__(self, n, make):
+        self.n, self.make, self.cache = int(n), make, {}
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, s):
+        s = int(s) % self.n
+        f = self.cache.get(s)
+        if f is None:
+            f = self.cache[s] = self.make(s)
+        return f
+
+
 class KittiCarSynthetic:
     """Cycles seeded frames of the KITTI-car SECOND geometry (BASELINE.json configs[1])."""
 
@@ -274,12 +291,14 @@ class KittiCarSynthetic:
         anc = create_anchors_3d_range(self.feature_size, self.cfg["anchor_ranges"], self.cfg["sizes"],
                                       self.cfg["rotations"])
         self.anchors = anc.reshape(-1, 7)
-        self.frames = []
-        for s in range(n_seeds):
+
+        def make(s):
             pts, gt = kitti_like_cloud(s, n_points, n_cars)
             lab, tgt, w = assign_targets(self.anchors, gt, self.cfg["matched_threshold"],
                                          self.cfg["unmatched_threshold"])
-            self.frames.append(dict(points=pts, gt=gt, labels=lab, reg_targets=tgt, reg_weights=w))
+            return dict(points=pts, gt=gt, labels=lab, reg_targets=tgt, reg_weights=w)
+
+        self.frames = _SeededFrames(n_seeds, make)
 
     def host_batch(self, step, batch_size, rank=0, world=1):
         idx = [(step * batch_size * world + rank * batch_size + i) % len(self.frames) for i in range(batch_size)]
@@ -403,8 +422,8 @@ class TaskGroupSynthetic:
             anchors, k, r, hi_t, lo_t = task_anchors(self.feature_size, gens)
             self.tasks.append(dict(gens=gens, anchors=anchors, k=k, r=r, matched=hi_t, unmatched=lo_t))
         lo, hi = np.array(vg.range[:3]), np.array(vg.range[3:])
-        self.frames = []
-        for s in range(n_seeds):
+
+        def make(s):
             rng = np.random.default_rng(1000 + s)
             per_task, all_boxes = [], []
             for t in self.tasks:
@@ -424,7 +443,9 @@ class TaskGroupSynthetic:
                 all_boxes.append(g)
             pts = spinning_lidar_cloud(s, n_points, vg.range, self.channels, beams, sweeps,
                                        boxes=np.concatenate(all_boxes))
-            self.frames.append(dict(points=pts, gt=per_task))
+            return dict(points=pts, gt=per_task)
+
+        self.frames = _SeededFrames(n_seeds, make)
 
     def device_batch(self, step, batch_size, device, rank=0, world=1):
         idx = [(step * batch_size * world + rank * batch_size + i) % len(self.frames) for i in range(batch_size)]

@@ -255,3 +255,41 @@ def test_single_rank_rccl_smoke():
     assert all(np.isfinite(out["losses"])) and np.isfinite(out["gnorm"]) and out["xgrad_finite"]
     assert out["losses"][-1] < out["losses"][0]
     assert out["syncbn_err"] < 5.0 / out["n"] + 1e-4
+
+
+def _torchrun_bench(n, workload, extra_env=None, extra_args=(), timeout=900):
+    """`python -m torch.distributed.run --nproc-per-node n bench.py --gpus n ...` exactly as the driver launches it
+    (plus D3D_DIST_BACKEND=gloo so that n ranks can share the one GPU of a test box); returns the parsed JSON line."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, D3D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(n), "--steps", "3", "--warmup", "1", "--burn-in", "0.3", "--no-cpu-baseline",
+           "--workload", workload] + list(extra_args)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE JSON line, got %d" % len(lines)
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("workload", ["c2-20k", "c3", "c4"])
+def test_bench_under_torchrun_with_two_ranks(workload):
+    """e / a15 / a16: the multi-rank branch of bench.py as the driver runs it (tools/train.py:73-110 launch contract;
+    det3d/torchie/apis/train.py:281-302 the step): two ranks under torch.distributed.run on the one GPU, gloo carrying
+    the collectives.  c2-20k exercises the overlapped gradient buckets + fused Adam, c3 / c4 add the cross-rank
+    BatchNorm exchange inside the timed step.  Both ranks must exit 0, rank 0 prints one line for n_gpus = 2."""
+    import math
+
+    small = {"c2-20k": (), "c3": ("--batch", "2"), "c4": ("--batch", "2")}[workload]
+    d = _torchrun_bench(2, workload, extra_args=small)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and math.isfinite(d["config"]["final_loss"]) and math.isfinite(d["config"]["final_grad_norm"])
+    # whole-job value: frames of BOTH ranks over the max-over-ranks time
+    assert abs(d["value"] - 2 * d["config"]["frames_per_gpu"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-2
+    assert "cpu_baseline" not in d and "workloads" not in d  # N > 1: the contract line only

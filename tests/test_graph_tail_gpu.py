@@ -138,6 +138,50 @@ def test_graphed_tail_multi_task_head_and_train_step():
     assert min(losses[1:]) < losses[0]
 
 
+def test_graphed_tail_follows_the_optimizer_steps_bit_for_bit():
+    """the packed weights of the neck's convolutions are cached per parameter version; a capture that
+    hit the cache would bake the capture-time weights into the graph, and every replay after an optimizer step would
+    convolve with stale weights.  Several whole TrainStep steps, graphed against eager, on copies of one model: the
+    losses of every step and every parameter afterwards must be bit-equal (the pack launch is part of the graph)."""
+    from det3d_amd import graph_tail
+    from det3d_amd.trainer import TrainStep
+
+    cfg, eager = _model("kitti_car_second.py")
+    graphed = copy.deepcopy(eager)
+    examples = _kitti_examples(2)
+
+    def train(model, on):
+        prev = graph_tail.GRAPH_TAIL
+        graph_tail.GRAPH_TAIL = on
+        try:
+            step = TrainStep(model, total_steps=20, lr_max=3e-3, autocast_dtype=None)
+            with torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=True):
+                return [float(step(examples[i % 2])) for i in range(5)]
+        finally:
+            graph_tail.GRAPH_TAIL = prev
+
+    la = train(eager, False)
+    lb = train(graphed, True)
+    assert "_graph_tails" in graphed.__dict__, graphed.__dict__.get("_graph_tail_failed")
+    assert la == lb, (la, lb)
+    assert la[0] != la[2]  # the weights did move between two visits of the same batch
+    pa, pb = dict(eager.named_parameters()), dict(graphed.named_parameters())
+    bad = [k for k in pa if not torch.equal(pa[k], pb[k])]
+    assert not bad, bad[:6]
+    # an eager pass afterwards (validation) re-packs into the eager cache and must leave the graphs intact
+    graph_tail.GRAPH_TAIL = False
+    try:
+        with torch.no_grad():
+            graphed(examples[0], return_loss=True)
+    finally:
+        graph_tail.GRAPH_TAIL = True
+    try:
+        step = TrainStep(graphed, total_steps=20, lr_max=3e-3, autocast_dtype=None)
+        assert torch.isfinite(torch.tensor(float(step(examples[0]))))
+    finally:
+        graph_tail.GRAPH_TAIL = False
+
+
 def test_prefetched_geometry_is_the_inline_geometry():
     """prefetch.GeometryPrefetcher: example + rulebooks built on the side stream give the same step as the inline
     path, and the backbone really consumes the prefetched plan (no second planning pass)."""

@@ -1,0 +1,83 @@
+#!/bin/bash
+# The one gpurun entry point of this repository:  gpurun -- 'bash tools/gpu_job.sh <tag> <stage> [<stage> ...]'
+# Every stage writes under gpurun_out/<tag>/ (merged back by gpurun); what is worth keeping is copied into profiles/
+# by hand afterwards.  Stages:
+#   tests            the driver's round-end sequence: pytest -m gpu -x, smoke()
+#   tests:<expr>     pytest -m gpu -k <expr>
+#   bench            bench.py at the driver's flags (--gpus 1 --steps 20 --warmup 5)
+#   bench300         300 timed steps, no extras
+#   multirank        VERDICT r3 item 1: torchrun x2 over gloo on the one GPU (c2 / c3 / c4), 1-rank RCCL bench, and the
+#                    per-rank host budget (taskset to cores/8)
+#   prof[:<workload>]  rocprofv3 --kernel-trace --stats of the bench step -> kernel + gap tables
+#   conv2d           tools/bench_conv2d.py (dense conv kernel variants)
+#   py:<script> ...  python <script> (rest of the line), log to <tag>/<script>.log
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+TAG=${1:-job}; shift
+O=$PWD/gpurun_out/$TAG
+mkdir -p "$O"
+port() { python -c "import socket; s=socket.socket(); s.bind(('127.0.0.1',0)); print(s.getsockname()[1])"; }
+show() { python tools/show_bench.py "$1" 2>/dev/null | head -${2:-3}; }
+
+while [ $# -gt 0 ]; do
+  st=$1; shift
+  echo "=== stage $st"
+  case "$st" in
+    tests)
+      timeout 1500 python -m pytest tests/ -x -q -m gpu > $O/tests.log 2>&1; echo "pytest rc=$?"; tail -3 $O/tests.log
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 ;;
+    tests:*)
+      timeout 1500 python -m pytest tests/ -x -q -m gpu -k "${st#tests:}" > $O/tests_k.log 2>&1; echo "pytest rc=$?"; tail -15 $O/tests_k.log ;;
+    bench)
+      timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> $O/bench.err; echo "bench rc=$?"
+      show $O/bench_driver_flags.json 6 ;;
+    bench300)
+      timeout 400 python bench.py --gpus 1 --steps 300 --warmup 10 --no-cpu-baseline --no-extras > $O/bench_300steps.json 2> $O/bench300.err
+      show $O/bench_300steps.json 2 ;;
+    multirank)
+      NC=$(nproc); PER=$(( NC / 8 )); [ $PER -lt 1 ] && PER=1
+      echo "host cores: $NC, per-rank share on an 8-GPU node: $PER" | tee $O/multirank.txt
+      B="--steps 20 --warmup 3 --no-cpu-baseline --no-extras"
+      # (a) plain single process, the reference point
+      timeout 300 python bench.py --gpus 1 $B > $O/mr_plain.json 2> $O/mr_plain.err
+      # (b) the same with every collective of the step issued on a 1-rank RCCL communicator
+      D3D_DIST_SINGLE=1 D3D_DIST_BACKEND=nccl RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$(port) \
+        timeout 300 python bench.py --gpus 1 $B > $O/mr_rccl1.json 2> $O/mr_rccl1.err
+      # (c) the per-rank host budget: the process and its threads pinned to cores/8 CPUs
+      taskset -c 0-$((PER-1)) timeout 300 python bench.py --gpus 1 $B > $O/mr_taskset.json 2> $O/mr_taskset.err
+      D3D_DIST_SINGLE=1 D3D_DIST_BACKEND=nccl RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$(port) \
+        taskset -c 0-$((PER-1)) timeout 300 python bench.py --gpus 1 $B > $O/mr_taskset_rccl1.json 2> $O/mr_taskset_rccl1.err
+      # (d) two ranks under torch.distributed.run on ONE GPU over gloo: the driver's launch line
+      for wl in c2-20k c4 c3; do
+        D3D_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+          --master-port $(port) bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline --workload $wl \
+          > $O/mr_torchrun2_$wl.json 2> $O/mr_torchrun2_$wl.err; echo "torchrun2 $wl rc=$?"
+      done
+      python - "$O" <<'PY' | tee -a $O/multirank.txt
+import json, sys, os
+O = sys.argv[1]
+def line(f):
+    try:
+        return json.loads([l for l in open(os.path.join(O, f)) if l.startswith("{")][-1])
+    except Exception as e:
+        return None
+for f in ("mr_plain", "mr_rccl1", "mr_taskset", "mr_taskset_rccl1", "mr_torchrun2_c2-20k", "mr_torchrun2_c4", "mr_torchrun2_c3"):
+    d = line(f + ".json")
+    if d is None:
+        print("%-22s FAILED (see %s.err)" % (f, f)); continue
+    c = d["config"]
+    print("%-22s n_gpus=%d %8.1f frames/s %7.3f ms/step  host %s  loss %s -> %s" % (
+        f, d["n_gpus"], d["value"], d["ms_per_step"], c.get("host_ms_per_step"), c.get("first_loss"), c.get("final_loss")))
+PY
+      ;;
+    prof|prof:*)
+      wl=${st#prof}; wl=${wl#:}; wl=${wl:-c2-20k}
+      bash tools/profile_step.sh $O/kernel_stats_$wl.txt --workload $wl; head -45 $O/kernel_stats_$wl.txt ;;
+    conv2d)
+      timeout 600 python tools/bench_conv2d.py > $O/conv2d.txt 2>&1; tail -40 $O/conv2d.txt ;;
+    py:*)
+      s=${st#py:}; n=$(basename $s .py)
+      timeout 900 python $s "$@" > $O/$n.log 2>&1; echo "$s rc=$?"; tail -40 $O/$n.log; set -- ;;
+    *) echo "unknown stage $st" ;;
+  esac
+done
