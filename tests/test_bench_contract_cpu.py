@@ -27,7 +27,9 @@ def test_driver_flags_parse(monkeypatch):
 
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "7", "--warmup", "3"])
     a = bench.parse()
-    assert (a.gpus, a.steps, a.warmup, a.batch, a.points, a.dtype) == (8, 7, 3, 4, 20000, "fp32")
+    assert (a.gpus, a.steps, a.warmup, a.batch, a.points, a.dtype) == (8, 7, 3, None, None, "fp32")
+    # --batch / --points default to the workload's configured values (the headline: 4 frames x 20000 points per GPU)
+    assert (bench.WORKLOADS[a.workload]["batch"], bench.WORKLOADS[a.workload]["points"]) == (4, 20000)
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
     assert a.gpus == 1 and a.steps >= 10 and a.warmup >= 1 and not a.no_gc_freeze
