@@ -964,7 +964,10 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        # also for the 1-rank group of D3D_DIST_SINGLE=1: an RCCL watchdog thread that outlives the HIP runtime's
+        # teardown aborts the process ("watchdog thread terminated with exception: HIP error")
+        torch.cuda.synchronize()
         torch.distributed.destroy_process_group()
 
 

@@ -180,7 +180,20 @@ class OverlappedGradBuckets:
         if cur:
             self.buckets.append(cur)
         self.where = {id(p): b for b, ps in enumerate(self.buckets) for p in ps}
-        self.flats = [None] * len(self.buckets)
+        # persistent exchange buffers: one flat f32 buffer per bucket, allocated once, every parameter's slice starting
+        # on a 16-byte boundary (vector loads in d3d_adam_step; RCCL's 16-byte chunks), and the per-parameter views built
+        # once.  (Round 3 concatenated into a NEW buffer every step: three allocations that the communication stream
+        # then held on to through recordStream -- the caching allocator kept growing, and the 1-rank RCCL step ran 15 %
+        # behind the plain one, profiles/round4_multirank.txt.)
+        self.flats, self.views = [], []
+        for ps in self.buckets:
+            offs, n = [], 0
+            for p in ps:
+                offs.append(n)
+                n += (p.numel() + 3) // 4 * 4
+            flat = torch.zeros((n,), dtype=ps[0].dtype, device=ps[0].device)
+            self.flats.append(flat)
+            self.views.append([flat[o: o + p.numel()].view(p.shape) for o, p in zip(offs, ps)])
         self.handles = [None] * len(self.buckets)
         self.ready = [0] * len(self.buckets)
         self.next_launch = 0
@@ -191,7 +204,6 @@ class OverlappedGradBuckets:
         """call before backward: forget the previous step's gradients and arm the hooks"""
         for p in self.params:
             p.grad = None
-        self.flats = [None] * len(self.buckets)
         self.handles = [None] * len(self.buckets)
         self.ready = [0] * len(self.buckets)
         self.next_launch = 0
@@ -208,14 +220,17 @@ class OverlappedGradBuckets:
         while self.next_launch < len(self.buckets) and \
                 (force or self.ready[self.next_launch] >= len(self.buckets[self.next_launch])):
             b = self.next_launch
-            grads = []
-            for p in self.buckets[b]:
-                g = p.grad
-                grads.append((torch.zeros_like(p) if g is None else g).reshape(-1))
-            flat = torch.cat(grads)
-            self.flats[b] = flat
+            dst, src = [], []
+            for p, v in zip(self.buckets[b], self.views[b]):
+                if p.grad is None:
+                    v.zero_()  # a parameter that received no gradient this step
+                else:
+                    dst.append(v)
+                    src.append(p.grad)
+            if dst:
+                torch._foreach_copy_(dst, src)  # one multi-tensor launch into the bucket's slices
             if exchanging():
-                self.handles[b] = dist.all_reduce(flat, async_op=True)
+                self.handles[b] = dist.all_reduce(self.flats[b], async_op=True)
             self.next_launch += 1
 
     def _wait(self):
@@ -226,11 +241,9 @@ class OverlappedGradBuckets:
                 h.wait()
 
     def _repoint(self):
-        for b, ps in enumerate(self.buckets):
-            off = 0
-            for p in ps:
-                p.grad = self.flats[b][off: off + p.numel()].view(p.shape)
-                off += p.numel()
+        for ps, vs in zip(self.buckets, self.views):
+            for p, v in zip(ps, vs):
+                p.grad = v
 
     def finish_sums(self):
         """after backward: wait for the exchanges and point every p.grad at its slice of the SUMS over ranks -- the

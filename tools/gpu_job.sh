@@ -40,13 +40,20 @@ while [ $# -gt 0 ]; do
       B="--steps 20 --warmup 3 --no-cpu-baseline --no-extras"
       # (a) plain single process, the reference point
       timeout 300 python bench.py --gpus 1 $B > $O/mr_plain.json 2> $O/mr_plain.err
-      # (b) the same with every collective of the step issued on a 1-rank RCCL communicator
-      D3D_DIST_SINGLE=1 D3D_DIST_BACKEND=nccl RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$(port) \
-        timeout 300 python bench.py --gpus 1 $B > $O/mr_rccl1.json 2> $O/mr_rccl1.err
+      # (b) the same with every collective of the step issued on a 1-rank RCCL communicator; bucket-count and
+      #     record-stream variants (D3D_DP_BUCKETS=0: one flat all-reduce after backward)
+      R1="D3D_DIST_SINGLE=1 D3D_DIST_BACKEND=nccl RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1"
+      env $R1 MASTER_PORT=$(port) timeout 300 python bench.py --gpus 1 $B > $O/mr_rccl1.json 2> $O/mr_rccl1.err
+      env $R1 MASTER_PORT=$(port) D3D_DP_BUCKETS=1 timeout 300 python bench.py --gpus 1 $B > $O/mr_rccl1_b1.json 2> $O/mr_rccl1_b1.err
+      env $R1 MASTER_PORT=$(port) D3D_DP_BUCKETS=0 timeout 300 python bench.py --gpus 1 $B > $O/mr_rccl1_b0.json 2> $O/mr_rccl1_b0.err
+      env $R1 MASTER_PORT=$(port) TORCH_NCCL_AVOID_RECORD_STREAMS=1 timeout 300 python bench.py --gpus 1 $B > $O/mr_rccl1_nors.json 2> $O/mr_rccl1_nors.err
       # (c) the per-rank host budget: the process and its threads pinned to cores/8 CPUs
       taskset -c 0-$((PER-1)) timeout 300 python bench.py --gpus 1 $B > $O/mr_taskset.json 2> $O/mr_taskset.err
-      D3D_DIST_SINGLE=1 D3D_DIST_BACKEND=nccl RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$(port) \
-        taskset -c 0-$((PER-1)) timeout 300 python bench.py --gpus 1 $B > $O/mr_taskset_rccl1.json 2> $O/mr_taskset_rccl1.err
+      env $R1 MASTER_PORT=$(port) taskset -c 0-$((PER-1)) timeout 300 python bench.py --gpus 1 $B > $O/mr_taskset_rccl1.json 2> $O/mr_taskset_rccl1.err
+      if [ "$MR_PROF" = "1" ]; then
+        env $R1 MASTER_PORT=$(port) bash tools/profile_step.sh $O/kernel_stats_rccl1.txt > $O/prof_rccl1.log 2>&1
+        bash tools/profile_step.sh $O/kernel_stats_plain.txt > $O/prof_plain.log 2>&1
+      fi
       # (d) two ranks under torch.distributed.run on ONE GPU over gloo: the driver's launch line
       for wl in c2-20k c4 c3; do
         D3D_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
@@ -61,7 +68,7 @@ def line(f):
         return json.loads([l for l in open(os.path.join(O, f)) if l.startswith("{")][-1])
     except Exception as e:
         return None
-for f in ("mr_plain", "mr_rccl1", "mr_taskset", "mr_taskset_rccl1", "mr_torchrun2_c2-20k", "mr_torchrun2_c4", "mr_torchrun2_c3"):
+for f in ("mr_plain", "mr_rccl1", "mr_rccl1_b1", "mr_rccl1_b0", "mr_rccl1_nors", "mr_taskset", "mr_taskset_rccl1", "mr_torchrun2_c2-20k", "mr_torchrun2_c4", "mr_torchrun2_c3"):
     d = line(f + ".json")
     if d is None:
         print("%-22s FAILED (see %s.err)" % (f, f)); continue
