@@ -362,6 +362,8 @@ __global__ void __launch_bounds__(128 * WPX, (WPX * PXT == 4 ? (HB ? 4 : 2) : (H
   }
 }
 
+#include "d3d_conv2d_halo.h"
+
 // ---------------------------------------------------------------------------------------------------- weight gradient
 //   dW[tap][co][ci] = sum_p g[p][co] * x[pix(p, tap)][ci]         (stride 1)
 // A GEMM whose K dimension is the pixel axis, which is NOT contiguous in either operand (channels are): tiles of
@@ -671,7 +673,10 @@ extern "C" size_t d3d_conv2d_stats_ws_floats(int batch, int ho, int wo, int cout
   if (m < 1 || cout < 128 || cout % 128) return 0;
   const int64_t nb = (m + 127) / 128;
   if (nb > D3D_FOLD_MAX_BLOCKS) return 0;
-  return 2 * (size_t)cout + (size_t)(cout / 128) * d3d_fold_ws_floats((int)nb, 256);
+  // either tiling of the forward kernels: 128-pixel runs, or 16 x 16 patches (conv2d_halo_kernel)
+  const int64_t nh = (int64_t)batch * ((ho + 15) / 16) * ((wo + 15) / 16);
+  size_t a = d3d_fold_ws_floats((int)nb, 256), b = d3d_fold_ws_floats((int)nh, 256);
+  return 2 * (size_t)cout + (size_t)(cout / 128) * (a > b ? a : b);
 }
 
 static int c2_geom(const char *who, Conv2dGeom &G, int batch, int h, int w, int cin, int cout, int ksz, int stride,
@@ -703,7 +708,58 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
   if (rc) return rc;
   // measured on the [4,200,176,128] map (profiles/round3_conv2d_variants.txt): bf16 62.3 (8) / 70.7 (9) / 66.6 (0) us,
   // split 145.6 (8) / 138.7 (9) / 146.9 (0) us
-  const int variant = g_c2_variant >= 0 ? g_c2_variant : (split ? 9 : 8);
+  int variant = g_c2_variant >= 0 ? g_c2_variant : (split ? 9 : 8);
+  // 16 / 17: the halo-patch kernel (d3d_conv2d_halo.h; 3x3 stride-1 layers in split mode), with / without the staggered
+  // wave groups; other layers under these settings take the round-3 default
+  const bool halo = (variant == 16 || variant == 17) && split && ksz == 3 && stride == 1;
+  if ((variant == 16 || variant == 17) && !halo) variant = split ? 9 : 8;
+  if (halo) {
+    const int tiles_x = (G.wo + 15) / 16, tiles_y = (G.ho + 15) / 16;
+    const int nt = batch * tiles_x * tiles_y;
+    Conv2dEpi eh = {};
+    eh.fold_g = 16;
+    D3D_REQUIRE(!bn || stats_ws, "d3d_conv2d_nhwc_fwd: the BatchNorm-backward sums need the statistics workspace");
+    D3D_REQUIRE(!bn || (bn->x && bn->mean && bn->invstd), "d3d_conv2d_nhwc_fwd: bn needs x, mean, invstd");
+    if (bn) {
+      eh.bn_x = bn->x; eh.bn_mean = bn->mean; eh.bn_invstd = bn->invstd; eh.bn_gamma = bn->gamma; eh.bn_beta = bn->beta;
+      eh.bn_relu = bn->relu;
+    }
+    if (stats_ws) {
+      D3D_REQUIRE(nt <= D3D_FOLD_MAX_BLOCKS, "d3d_conv2d_nhwc_fwd: %d patches > %d for the statistics fold", nt,
+                  D3D_FOLD_MAX_BLOCKS);
+      const size_t need = d3d_conv2d_stats_ws_floats(batch, G.ho, G.wo, cout);
+      if (need == 0 || stats_ws_floats < need)
+        return d3d_set_error(D3D_ECAPACITY, "d3d_conv2d_nhwc_fwd: statistics workspace %zu floats < %zu", stats_ws_floats, need);
+      const D3dFoldPlan fp = d3d_fold_plan(nt, 256);
+      eh.stats = stats_ws;
+      eh.fold_g = fp.g;
+      eh.ws_stride = (int)d3d_fold_ws_floats(nt, 256);
+      eh.ctr_stride = d3d_fold_counter_words(fp);
+      eh.counters = d3d_fold_counters(eh.ctr_stride * (cout / 128));
+      if (!eh.counters) return D3D_EHIP;
+    }
+    constexpr int HALO_XI = (18 * 18 + 15) / 16;
+    const size_t hlds = 2 * (size_t)(2 * HALO_XI * 1024) + 3 * (size_t)(2 * 128 * 64);
+#define C2_HALO(CIN, STG)                                                                                        \
+  do {                                                                                                          \
+    D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_halo_kernel<CIN, 16, 16, STG>,                         \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)hlds));                   \
+    hipLaunchKernelGGL((conv2d_halo_kernel<CIN, 16, 16, STG>), dim3(nt, cout / 128), dim3(512), hlds, stream,   \
+                       x_hi, x_lo, w_hi, w_lo, (float *)y, G, eh, tiles_x, tiles_y);                            \
+  } while (0)
+#define C2_HALO_CASE(CIN)                        \
+  if (cin == CIN) {                              \
+    if (variant == 16) C2_HALO(CIN, true);       \
+    else C2_HALO(CIN, false);                    \
+  }
+    C2_HALO_CASE(64)
+    C2_HALO_CASE(128)
+    C2_HALO_CASE(256)
+#undef C2_HALO_CASE
+#undef C2_HALO
+    D3D_LAUNCH_TRY("conv2d_halo_kernel");
+    return D3D_OK;
+  }
   const bool w8 = variant == 8 || variant == 9;  // 128-pixel tiles on 8 waves
   const int wpx = ((variant & 2) || w8) ? 4 : 2;
   const int bm = w8 ? 128 : 64 * wpx;

@@ -18,7 +18,7 @@ def init_dist(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if (world > 1 or SINGLE_RANK_COLLECTIVES) and not dist.is_initialized():
+    if (world > 1 or SINGLE_RANK_COLLECTIVES or GROUP_ONLY) and not dist.is_initialized():
         if backend is None:
             # D3D_DIST_BACKEND=gloo lets several ranks share one GPU (flow test without RCCL)
             backend = os.environ.get("D3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -38,6 +38,11 @@ def world_size():
 # backend "nccl" init, asynchronous all-reduce handles on the communication stream, the packed SyncBN exchange --
 # executes on the one GPU a test box has (tests/test_dist_gpu.py::test_single_rank_rccl_smoke).
 SINGLE_RANK_COLLECTIVES = os.environ.get("D3D_DIST_SINGLE", "0") == "1"
+# diagnosis of the exchange path's cost on one GPU (tools/gpu_job.sh multirank): D3D_DIST_SINGLE=2 creates the
+# 1-rank process group and nothing else (the step stays the plain one); D3D_DIST_NOCOLL=1 runs the exchanging step
+# (hooks, bucket copies, re-pointed gradients) without issuing the collectives
+GROUP_ONLY = os.environ.get("D3D_DIST_SINGLE", "0") == "2"
+NO_COLLECTIVES = os.environ.get("D3D_DIST_NOCOLL", "0") == "1"
 
 
 def exchanging():
@@ -229,7 +234,7 @@ class OverlappedGradBuckets:
                     src.append(p.grad)
             if dst:
                 torch._foreach_copy_(dst, src)  # one multi-tensor launch into the bucket's slices
-            if exchanging():
+            if exchanging() and not NO_COLLECTIVES:
                 self.handles[b] = dist.all_reduce(self.flats[b], async_op=True)
             self.next_launch += 1
 

@@ -19,6 +19,32 @@ GEOMS = [  # batch, h, w, cin, cout, ksz, stride, pad
 ]
 
 
+HALO_GEOMS = [  # 3x3 stride-1 layers for the halo-patch kernel (csrc/d3d_conv2d_halo.h): 16 x 16 patches
+    (2, 20, 24, 128, 128, 3, 1, 1),      # 2 x 2 patches per image, both partial
+    (1, 13, 11, 128, 128, 3, 1, 1),      # one partial patch
+    (3, 37, 50, 128, 128, 3, 1, 1),      # 3 x 4 patches, odd sizes, 36 tiles over the 8 XCD ranges
+    (1, 18, 20, 256, 128, 3, 1, 1),      # eight 32-channel chunks
+    (1, 10, 14, 256, 256, 3, 1, 1),      # two 128-channel output tiles
+    (2, 16, 32, 64, 128, 3, 1, 1),       # two chunks, whole patches only
+    (1, 20, 22, 128, 128, 3, 1, 0),      # no padding: 18 x 20 output
+    (1, 14, 18, 128, 128, 3, 1, 2),      # full padding: 16 x 20 output (the data gradient of a pad-0 layer)
+]
+
+
+@pytest.fixture
+def conv2d_variant():
+    """d3d_set_tuning knob 7 (D3D_CONV2D_VARIANT) for the duration of one test"""
+    from det3d_amd import _lib
+
+    L = _lib.lib()
+
+    def set_variant(v):
+        L.d3d_set_tuning(7, int(v))
+
+    yield set_variant
+    L.d3d_set_tuning(7, -1)
+
+
 def _ref_conv(x, w, stride, pad):
     """x [B,H,W,C], w [Co,Ci,k,k] (both float64) -> [B,Ho,Wo,Co]"""
     return torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, None, stride, pad).permute(0, 2, 3, 1).contiguous()
@@ -186,13 +212,82 @@ def test_dense_stack_is_the_torch_module_stack(dtype):
     close(ye, yer, "eval output")
 
 
+@pytest.mark.parametrize("variant", [16, 17])
+@pytest.mark.parametrize("geom", HALO_GEOMS)
+def test_halo_patch_forward_matches_conv2d(geom, variant, conv2d_variant):
+    """the second-generation 3x3 kernel (halo patch in LDS, staggered wave groups = 16 / one barrier per K step = 17):
+    output against float64 conv2d on the same operands, the statistics epilogue, bit-reproducibility, and agreement
+    with the round-3 kernel to the precision of the split format"""
+    from det3d_amd import dense_conv as dc
+
+    b, h, w, cin, cout, k, s, p = geom
+    g = torch.Generator(device="cuda").manual_seed(hash(geom) % 1000)
+    x = torch.randn((b, h, w, cin), device="cuda", generator=g)
+    wt = torch.randn((cout, cin, k, k), device="cuda", generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    wt[1, 2] += 0.5
+    wt[:, :, 0, 1] *= 1.7  # every tap distinguishable
+    wt[:, :, 2, 0] *= 0.4
+    weight = torch.nn.Parameter(wt)
+    w_hi, w_lo = dc._packed(weight, "fwd", "split")
+    x_hi, x_lo = dc.split_planes(x)
+    conv2d_variant(9)
+    y_old, _ = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, "split", want_stats=True)
+    conv2d_variant(variant)
+    y, ws = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, "split", want_stats=True)
+    ref = _ref_conv(x.double(), wt.double(), s, p)
+    assert y.shape == ref.shape
+    err, scale = float((y.double() - ref).abs().max()), float(ref.abs().max())
+    assert err <= 3e-5 * scale, (err, scale)
+    assert float((y - y_old).abs().max()) <= 3e-6 * scale  # same products, another summation order
+    yd = y.double().reshape(-1, cout)
+    stats = ws[:2 * cout].double()
+    assert torch.allclose(stats[:cout], yd.sum(0), rtol=1e-4, atol=1e-3 * yd.shape[0] ** 0.5)
+    assert torch.allclose(stats[cout:], (yd * yd).sum(0), rtol=1e-4, atol=1e-3)
+    for _ in range(3):
+        y2, ws2 = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, "split", want_stats=True)
+        assert torch.equal(y, y2) and torch.equal(ws[:2 * cout], ws2[:2 * cout])
+    y3, _ = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, "split", want_stats=False)
+    assert torch.equal(y, y3)
+
+
+@pytest.mark.parametrize("variant", [16, 17])
+def test_halo_patch_kernel_on_the_benched_map_repeats_bit_for_bit(variant, conv2d_variant):
+    """[4,200,176,128] -> 128: 572 patches on 256 CUs (several rounds of blocks, every XCD range, partial patches on
+    the lower edge), sampled against float64 and repeated: LDS-DMA hand-offs that are only ALMOST ordered show up as
+    rare wrong tiles that come and go with load"""
+    from det3d_amd import dense_conv as dc
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((4, 200, 176, 128), device="cuda", generator=g)
+    wt = torch.randn((128, 128, 3, 3), device="cuda", generator=g) * 0.03
+    w_hi, w_lo = dc._packed(torch.nn.Parameter(wt), "fwd", "split")
+    x_hi, x_lo = dc.split_planes(x)
+    conv2d_variant(variant)
+    y, ws = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, 3, 1, 1, "split", want_stats=True)
+    ref = _ref_conv(x[1:2].double(), wt.double(), 1, 1)
+    err, scale = float((y[1:2].double() - ref).abs().max()), float(ref.abs().max())
+    assert err <= 3e-5 * scale, (err, scale)
+    conv2d_variant(9)
+    y_old, _ = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, 3, 1, 1, "split")
+    assert float((y - y_old).abs().max()) <= 3e-6 * scale
+    conv2d_variant(variant)
+    for _ in range(20):
+        y2, ws2 = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, 3, 1, 1, "split", want_stats=True)
+        assert torch.equal(y, y2) and torch.equal(ws[:256], ws2[:256])
+
+
+@pytest.mark.parametrize("variant", [None, 16, 17])
 @pytest.mark.parametrize("mode", ["bf16", "split"])
-def test_data_gradient_epilogue_reduces_the_previous_batchnorm_backward_sums(mode):
+def test_data_gradient_epilogue_reduces_the_previous_batchnorm_backward_sums(mode, variant, conv2d_variant):
     """bn_backward: the dgrad launch's rows are dL/dz of the BatchNorm + ReLU in front of the convolution; its epilogue
     must leave what d3d_bn_bwd_reduce computes from the same rows (sum dz * xhat | sum dz), bit-reproducibly."""
     from det3d_amd import _lib
     from det3d_amd import dense_conv as dc
 
+    if variant is not None:
+        if mode != "split":
+            pytest.skip("the halo-patch kernel serves the split mode")
+        conv2d_variant(variant)
     L = _lib.lib()
     b, h, w, c = 2, 30, 26, 128
     g = torch.Generator(device="cuda").manual_seed(5)

@@ -1,5 +1,6 @@
 """dense conv kernels (csrc/d3d_conv2d.hip) against MIOpen at the RPN's shapes: us per launch, TFLOP/s.
-    python tools/bench_conv2d.py [--shape B H W CIN COUT K S P]"""
+    python tools/bench_conv2d.py [--shape B H W CIN COUT K S P]
+    env: VARIANTS=9,16,17 (d3d_set_tuning knob 7), WGRAD_WAVES=8,4, MODES=bf16,split, NO_MIOPEN=1"""
 import json
 import os
 import sys
@@ -39,7 +40,7 @@ def main():
         row = {"shape": [b, h, w, cin, cout, k, s, p], "gflop": flop / 1e9}
         from det3d_amd import _lib
         variants = [int(v) for v in os.environ.get("VARIANTS", "8").split(",")]
-        for mode in ("bf16", "split"):
+        for mode in os.environ.get("MODES", "bf16,split").split(","):
             w_hi, w_lo = dc._packed(wt, "fwd", mode)
             if mode == "bf16":
                 x_hi, x_lo, g_hi, g_lo = x.to(torch.bfloat16), None, gy.to(torch.bfloat16), None
@@ -62,7 +63,7 @@ def main():
                     row[mode + "_wgrad%d_TF" % wv] = round(flop / tw / 1e6, 1)
                 _lib.lib().d3d_set_tuning(8, 8)
         # MIOpen through torch, channels-last
-        for dt, nm in ((torch.bfloat16, "miopen_bf16"), (torch.float32, "miopen_f32")):
+        for dt, nm in (() if os.environ.get("NO_MIOPEN") else ((torch.bfloat16, "miopen_bf16"), (torch.float32, "miopen_f32"))):
             xm = x.permute(0, 3, 1, 2).to(dt).contiguous(memory_format=torch.channels_last).requires_grad_(True)
             wm = wt.detach().to(dt).contiguous(memory_format=torch.channels_last).requires_grad_(True)
             gm = gy.permute(0, 3, 1, 2).to(dt).contiguous(memory_format=torch.channels_last)

@@ -47,6 +47,11 @@ while [ $# -gt 0 ]; do
       env $R1 MASTER_PORT=$(port) D3D_DP_BUCKETS=1 timeout 300 python bench.py --gpus 1 $B > $O/mr_rccl1_b1.json 2> $O/mr_rccl1_b1.err
       env $R1 MASTER_PORT=$(port) D3D_DP_BUCKETS=0 timeout 300 python bench.py --gpus 1 $B > $O/mr_rccl1_b0.json 2> $O/mr_rccl1_b0.err
       env $R1 MASTER_PORT=$(port) TORCH_NCCL_AVOID_RECORD_STREAMS=1 timeout 300 python bench.py --gpus 1 $B > $O/mr_rccl1_nors.json 2> $O/mr_rccl1_nors.err
+      # where the 1-rank cost comes from: more hardware queues; the exchanging step without the collectives; the group alone
+      env $R1 MASTER_PORT=$(port) GPU_MAX_HW_QUEUES=8 timeout 300 python bench.py --gpus 1 $B > $O/mr_rccl1_q8.json 2> $O/mr_rccl1_q8.err
+      env $R1 MASTER_PORT=$(port) D3D_DIST_NOCOLL=1 timeout 300 python bench.py --gpus 1 $B > $O/mr_rccl1_nocoll.json 2> $O/mr_rccl1_nocoll.err
+      env $R1 D3D_DIST_SINGLE=2 MASTER_PORT=$(port) timeout 300 python bench.py --gpus 1 $B > $O/mr_group_only.json 2> $O/mr_group_only.err
+      GPU_MAX_HW_QUEUES=8 timeout 300 python bench.py --gpus 1 $B > $O/mr_plain_q8.json 2> $O/mr_plain_q8.err
       # (c) the per-rank host budget: the process and its threads pinned to cores/8 CPUs
       taskset -c 0-$((PER-1)) timeout 300 python bench.py --gpus 1 $B > $O/mr_taskset.json 2> $O/mr_taskset.err
       env $R1 MASTER_PORT=$(port) taskset -c 0-$((PER-1)) timeout 300 python bench.py --gpus 1 $B > $O/mr_taskset_rccl1.json 2> $O/mr_taskset_rccl1.err
@@ -68,7 +73,7 @@ def line(f):
         return json.loads([l for l in open(os.path.join(O, f)) if l.startswith("{")][-1])
     except Exception as e:
         return None
-for f in ("mr_plain", "mr_rccl1", "mr_rccl1_b1", "mr_rccl1_b0", "mr_rccl1_nors", "mr_taskset", "mr_taskset_rccl1", "mr_torchrun2_c2-20k", "mr_torchrun2_c4", "mr_torchrun2_c3"):
+for f in ("mr_plain", "mr_rccl1", "mr_rccl1_b1", "mr_rccl1_b0", "mr_rccl1_nors", "mr_rccl1_q8", "mr_rccl1_nocoll", "mr_group_only", "mr_plain_q8", "mr_taskset", "mr_taskset_rccl1", "mr_torchrun2_c2-20k", "mr_torchrun2_c4", "mr_torchrun2_c3"):
     d = line(f + ".json")
     if d is None:
         print("%-22s FAILED (see %s.err)" % (f, f)); continue
@@ -81,7 +86,7 @@ PY
       wl=${st#prof}; wl=${wl#:}; wl=${wl:-c2-20k}
       bash tools/profile_step.sh $O/kernel_stats_$wl.txt --workload $wl; head -45 $O/kernel_stats_$wl.txt ;;
     conv2d)
-      timeout 600 python tools/bench_conv2d.py > $O/conv2d.txt 2>&1; tail -40 $O/conv2d.txt ;;
+      timeout 600 python tools/bench_conv2d.py > $O/conv2d.txt 2>&1; tail -40 $O/conv2d.txt | cut -c1-900 ;;
     py:*)
       s=${st#py:}; n=$(basename $s .py)
       timeout 900 python $s "$@" > $O/$n.log 2>&1; echo "$s rc=$?"; tail -40 $O/$n.log; set -- ;;
