@@ -56,7 +56,9 @@ while [ $# -gt 0 ]; do
       taskset -c 0-$((PER-1)) timeout 300 python bench.py --gpus 1 $B > $O/mr_taskset.json 2> $O/mr_taskset.err
       env $R1 MASTER_PORT=$(port) taskset -c 0-$((PER-1)) timeout 300 python bench.py --gpus 1 $B > $O/mr_taskset_rccl1.json 2> $O/mr_taskset_rccl1.err
       if [ "$MR_PROF" = "1" ]; then
+        export D3D_PROFILE_TIMELINE=1
         env $R1 MASTER_PORT=$(port) bash tools/profile_step.sh $O/kernel_stats_rccl1.txt > $O/prof_rccl1.log 2>&1
+        env $R1 MASTER_PORT=$(port) D3D_DIST_NOCOLL=1 bash tools/profile_step.sh $O/kernel_stats_nocoll.txt > $O/prof_nocoll.log 2>&1
         bash tools/profile_step.sh $O/kernel_stats_plain.txt > $O/prof_plain.log 2>&1
       fi
       # (d) two ranks under torch.distributed.run on ONE GPU over gloo: the driver's launch line
@@ -82,6 +84,12 @@ for f in ("mr_plain", "mr_rccl1", "mr_rccl1_b1", "mr_rccl1_b0", "mr_rccl1_nors",
         f, d["n_gpus"], d["value"], d["ms_per_step"], c.get("host_ms_per_step"), c.get("first_loss"), c.get("final_loss")))
 PY
       ;;
+    mrprof)
+      export D3D_PROFILE_TIMELINE=1
+      R1="D3D_DIST_SINGLE=1 D3D_DIST_BACKEND=nccl RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1"
+      env $R1 MASTER_PORT=$(port) D3D_DIST_NOCOLL=1 bash tools/profile_step.sh $O/kernel_stats_nocoll.txt > $O/prof_nocoll.log 2>&1
+      bash tools/profile_step.sh $O/kernel_stats_plain.txt > $O/prof_plain.log 2>&1
+      head -5 $O/kernel_stats_nocoll.txt | cut -c1-200 ;;
     prof|prof:*)
       wl=${st#prof}; wl=${wl#:}; wl=${wl:-c2-20k}
       bash tools/profile_step.sh $O/kernel_stats_$wl.txt --workload $wl; head -45 $O/kernel_stats_$wl.txt ;;

@@ -3,6 +3,7 @@ copies back).  usage:
     prof_summary.py kernels <db> <window_ms> <steps> <out.txt> [header...]
     prof_summary.py gaps <db> <window_ms> <steps> <out.txt>      (appends)
     prof_summary.py pmc <db> <counter> <out.txt>
+    prof_summary.py timeline <db> <window_ms> <out.txt>
 """
 import sqlite3
 import sys
@@ -56,6 +57,27 @@ def gaps(db, window_ms, steps, out):
                 f.write("%12.1f %10.1f %10.2f  %s\n" % (g / steps, c / steps, g / c, k))
 
 
+def timeline(db, window_ms, out):
+    """every kernel of the last `window_ms` of the trace, in start order: start (us from the window's first kernel),
+    duration, queue / stream ids when the view has them, name -- to see WHERE a step waits, not just how long in total"""
+    cur = sqlite3.connect(db).cursor()
+    cols = [d[0] for d in cur.execute("select * from kernels limit 0").description]
+    extra = [c for c in ("queue_id", "stream_id", "tid") if c in cols]
+    t1 = cur.execute("select max(end) from kernels").fetchone()[0]
+    w0 = t1 - int(float(window_ms) * 1e6)
+    rows = cur.execute("select start, end, name%s from kernels where start > ? order by start"
+                       % "".join(", " + c for c in extra), (w0,)).fetchall()
+    with open(out, "w") as f:
+        f.write("# columns of the kernels view: %s\n" % " ".join(cols))
+        f.write("# %10s %9s %9s %s name\n" % ("start_us", "dur_us", "gap_us", " ".join(extra)))
+        t0 = rows[0][0] if rows else 0
+        last_end = t0
+        for r in rows:
+            f.write("%12.1f %9.1f %9.1f %s %s\n" % ((r[0] - t0) / 1e3, (r[1] - r[0]) / 1e3, (r[0] - last_end) / 1e3,
+                                                   " ".join(str(v) for v in r[3:]), r[2][:70]))
+            last_end = max(last_end, r[1])
+
+
 def pmc(db, counter, out):
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select name, count(*), avg(counter_value), sum(counter_value), avg(duration)/1e3 from pmc_events "
@@ -74,5 +96,7 @@ if __name__ == "__main__":
         kernels(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6:])
     elif sys.argv[1] == "gaps":
         gaps(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
+    elif sys.argv[1] == "timeline":
+        timeline(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
