@@ -572,6 +572,8 @@ __global__ void __launch_bounds__(128 * WCI, 2)
     }
 }
 
+#include "d3d_conv2d_wgrad3.h"
+
 // dw = sum over splits of part[s], in a fixed order (8 slab groups walked in parallel, folded through LDS in group
 // order), written in nn.Conv2d's parameter layout [cout][cin][kh][kw]; part is [split][tap][cout][cin]
 __global__ void __launch_bounds__(256)
@@ -648,7 +650,9 @@ __global__ void __launch_bounds__(256)
 // 8 = 128-pixel tiles on 8 waves (64 x 32 wave tiles; the default: 62.6 vs 67.7 us bf16, 143.8 vs 150.5 us split on the
 // [4,200,176,128] map), 9 = 8 + interleaved issue
 int g_c2_variant = getenv("D3D_CONV2D_VARIANT") ? atoi(getenv("D3D_CONV2D_VARIANT")) : -1;  // -1: 8 for bf16, 9 for split
-// waves per block of the weight-gradient kernel (knob 8, D3D_CONV2D_WGRAD_WAVES): 8 (64 x 32 wave tiles) or 4
+// waves per block of the weight-gradient kernel (knob 8, D3D_CONV2D_WGRAD_WAVES): 8 (64 x 32 wave tiles) or 4;
+// 16 / 17: conv2d_wgrad3_kernel for the 3x3 stride-1 layers in split mode (staggered wave groups / one barrier per K
+// step), other layers as with 8
 int g_c2_wgrad_waves = getenv("D3D_CONV2D_WGRAD_WAVES") ? atoi(getenv("D3D_CONV2D_WGRAD_WAVES")) : 8;
 
 static int c2_check(const char *who, int batch, int h, int w, int cin, int cout, int ksz, int stride, int pad,
@@ -832,10 +836,21 @@ static int c2_wgrad_splits(int m, int blocks_per_split) {
   if (s > max_s) s = max_s;
   return s < 1 ? 1 : s;
 }
+// conv2d_wgrad3_kernel (3x3 stride 1, split mode): one block per CU over (splits x 3 kernel rows x weight tiles)
+static int c2_wgrad3_splits(int total_segs, int wtiles) {
+  int s = 256 / (3 * wtiles);
+  if (s > total_segs) s = total_segs;
+  return s < 1 ? 1 : s;
+}
 extern "C" size_t d3d_conv2d_wgrad_workspace_bytes(int batch, int ho, int wo, int cin, int cout, int ksz) {
   const int64_t m = (int64_t)batch * ho * wo;
   if (m < 1) return 0;
-  return (size_t)c2_wgrad_splits((int)m, ksz * ksz * (cin / 128) * (cout / 128)) * ksz * ksz * cout * cin * sizeof(float);
+  size_t s = (size_t)c2_wgrad_splits((int)m, ksz * ksz * (cin / 128) * (cout / 128));
+  if (ksz == 3 && cin >= 128 && cout >= 128) {
+    const size_t s3 = (size_t)c2_wgrad3_splits(batch * ho * ((wo + 31) / 32), (cin / 128) * (cout / 128));
+    if (s3 > s) s = s3;
+  }
+  return s * ksz * ksz * cout * cin * sizeof(float);
 }
 
 extern "C" int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const void *x_hi, const void *x_lo,
@@ -859,6 +874,31 @@ extern "C" int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const v
   const size_t need = d3d_conv2d_wgrad_workspace_bytes(batch, G.ho, G.wo, cin, cout, ksz);
   if (!workspace || workspace_bytes < need)
     return d3d_set_error(D3D_ECAPACITY, "d3d_conv2d_nhwc_wgrad: workspace %zu B < %zu B", workspace_bytes, need);
+  if (split && ksz == 3 && stride == 1 && (g_c2_wgrad_waves == 16 || g_c2_wgrad_waves == 17)) {
+    // second generation (d3d_conv2d_wgrad3.h): a block per (segment range, kernel row, weight tile), three taps each
+    const int total_segs = batch * G.ho * ((G.wo + 31) / 32);
+    const int wtiles = (cout / 128) * (cin / 128);
+    int ns = c2_wgrad3_splits(total_segs, wtiles);
+    const int sps = (total_segs + ns - 1) / ns;
+    ns = (total_segs + sps - 1) / sps;
+    const size_t lds3 = 3 * (size_t)(2 * 32 * 256 + 2 * 36 * 256);
+    const dim3 grid3(ns * 3 * wtiles);
+#define C2_WG3(STG)                                                                                              \
+  do {                                                                                                           \
+    D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_wgrad3_kernel<STG>,                                     \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));                    \
+    hipLaunchKernelGGL((conv2d_wgrad3_kernel<STG>), grid3, dim3(512), lds3, stream, g_hi, g_lo, x_hi, x_lo,      \
+                       (float *)workspace, G, cin, sps, ns);                                                     \
+  } while (0)
+    if (g_c2_wgrad_waves == 16) C2_WG3(true); else C2_WG3(false);
+#undef C2_WG3
+    D3D_LAUNCH_TRY("conv2d_wgrad3_kernel");
+    const int64_t n4 = (int64_t)9 * cout * cin / 4;
+    hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, stream,
+                       (const float4 *)workspace, ns, 9, cout, cin, dw);
+    D3D_LAUNCH_TRY("conv2d_wgrad_reduce_kernel");
+    return D3D_OK;
+  }
   const int kp = split ? 32 : 64;
   int pps = (G.m + splits - 1) / splits;
   pps = (pps + kp - 1) / kp * kp;

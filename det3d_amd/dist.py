@@ -24,6 +24,11 @@ def init_dist(backend=None):
             backend = os.environ.get("D3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
+        if torch.cuda.is_available():
+            # the geometry stream has to exist before the communication library creates its streams (prefetch.py)
+            from . import prefetch
+
+            prefetch.reserve_stream(torch.device("cuda", local_rank % torch.cuda.device_count()))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
     return rank, local_rank, world

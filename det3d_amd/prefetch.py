@@ -54,6 +54,38 @@ def _tensors(obj, seen):
         yield from _tensors(vars(obj), seen)
 
 
+_RESERVED = {}  # device index -> stream created by reserve_stream
+
+
+def _new_stream(dev):
+    # small kernels: by default they may cut in front of the step's (D3D_PREFETCH_PRIORITY=0: equal priority)
+    return torch.cuda.Stream(dev, priority=int(os.environ.get("D3D_PREFETCH_PRIORITY", "-1")))
+
+
+def reserve_stream(dev):
+    """Create the geometry stream NOW and submit one trivial launch on it, so that the runtime binds it to a hardware
+    queue before other libraries create their streams.  dist.init_dist calls this in front of init_process_group:
+    measured on MI355X (profiles/round4_multirank.txt), the same `Stream(priority=-1)` created AFTER the RCCL process
+    group ran its ~75 small kernels per step at 40-90 us each instead of 5-15 us -- no longer cutting in front of the
+    step's big kernels -- and the step waited 1.2 ms for its next batch's rulebooks (7.5 -> 8.8 ms)."""
+    dev = torch.device(dev)
+    if not torch.cuda.is_available() or os.environ.get("D3D_PREFETCH_RESERVE", "1") == "0":
+        return None
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _RESERVED:
+        st = _new_stream(torch.device("cuda", idx))
+        with torch.cuda.stream(st):
+            torch.zeros(1, device=torch.device("cuda", idx))
+        st.synchronize()
+        _RESERVED[idx] = st
+    return _RESERVED[idx]
+
+
+def _stream_for(dev):
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    return _RESERVED.get(idx) or _new_stream(dev)
+
+
 class GeometryPrefetcher:
     def __init__(self, make_example, detector=None, device=None, enabled=True):
         """make_example(batch) -> example dict (runs the device voxelizer etc. on the CURRENT stream);
@@ -74,8 +106,7 @@ class GeometryPrefetcher:
             return self._build(batch)
         dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
         if self.stream is None:
-            # small kernels: by default they may cut in front of the step's (D3D_PREFETCH_PRIORITY=0: equal priority)
-            self.stream = torch.cuda.Stream(dev, priority=int(os.environ.get("D3D_PREFETCH_PRIORITY", "-1")))
+            self.stream = _stream_for(dev)
         main = torch.cuda.current_stream(dev)
         if ready_event is not None:
             self.stream.wait_event(ready_event)
@@ -97,7 +128,7 @@ class GeometryPrefetcher:
             return Pending(self, None, self._build(batch), None)
         dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
         if self.stream is None:
-            self.stream = torch.cuda.Stream(dev, priority=int(os.environ.get("D3D_PREFETCH_PRIORITY", "-1")))
+            self.stream = _stream_for(dev)
         if getattr(self, "_pool", None) is None:
             self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="d3d-geometry")
 

@@ -136,6 +136,38 @@ def test_weight_gradient(geom, mode):
     assert err <= (1e-5 if mode == "bf16" else 3e-5) * scale + 1e-6, (err, scale)
 
 
+@pytest.mark.parametrize("waves", [16, 17])
+@pytest.mark.parametrize("geom", [g for g in HALO_GEOMS if g[3] % 128 == 0] + [(4, 40, 44, 128, 128, 3, 1, 1),
+                                                                             (2, 7, 70, 128, 256, 3, 1, 1)])
+def test_weight_gradient_three_taps_per_block(geom, waves):
+    """conv2d_wgrad3_kernel (csrc/d3d_conv2d_wgrad3.h; knob 8 = 16 staggered wave groups / 17 one barrier per K step):
+    a block per (segment range, kernel row, weight tile) with the three taps of the row on one staged input run --
+    against float64, against the round-3 kernel, bit-reproducible."""
+    from det3d_amd import _lib
+    from det3d_amd import dense_conv as dc
+
+    L = _lib.lib()
+    b, h, w, cin, cout, k, s, p = geom
+    g = torch.Generator(device="cuda").manual_seed(13)
+    x = torch.randn((b, h, w, cin), device="cuda", generator=g)
+    ho, wo = dc._out_hw(h, w, k, s, p)
+    gy = torch.randn((b, ho, wo, cout), device="cuda", generator=g)
+    (x_hi, x_lo), (g_hi, g_lo) = dc.split_planes(x), dc.split_planes(gy)
+    try:
+        L.d3d_set_tuning(8, 8)
+        dw_old = dc.wgrad_raw(g_hi, g_lo, x_hi, x_lo, k, s, p, "split")
+        L.d3d_set_tuning(8, waves)
+        dw = dc.wgrad_raw(g_hi, g_lo, x_hi, x_lo, k, s, p, "split")
+        for _ in range(3):
+            assert torch.equal(dw, dc.wgrad_raw(g_hi, g_lo, x_hi, x_lo, k, s, p, "split"))
+    finally:
+        L.d3d_set_tuning(8, 8)
+    ref = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (cout, cin, k, k), gy.double().permute(0, 3, 1, 2), s, p)
+    err, scale = float((dw.double() - ref).abs().max()), float(ref.abs().max())
+    assert err <= 3e-5 * scale + 1e-6, (err, scale)
+    assert float((dw - dw_old).abs().max()) <= 3e-6 * scale
+
+
 def _rpn_like(cin, widths):
     from det3d_amd.nn_utils import Sequential
     from torch import nn

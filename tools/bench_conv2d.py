@@ -57,6 +57,8 @@ def main():
             _lib.lib().d3d_set_tuning(7, variants[0])
             if cin % 128 == 0:
                 for wv in [int(v) for v in os.environ.get("WGRAD_WAVES", "8").split(",")]:
+                    if wv in (16, 17) and not (mode == "split" and k == 3 and s == 1):
+                        continue
                     _lib.lib().d3d_set_tuning(8, wv)
                     tw = timeit(lambda: dc.wgrad_raw(g_hi, g_lo, x_hi, x_lo, k, s, p, mode))
                     row[mode + "_wgrad%d_us" % wv] = round(tw, 1)

@@ -84,6 +84,29 @@ for f in ("mr_plain", "mr_rccl1", "mr_rccl1_b1", "mr_rccl1_b0", "mr_rccl1_nors",
         f, d["n_gpus"], d["value"], d["ms_per_step"], c.get("host_ms_per_step"), c.get("first_loss"), c.get("final_loss")))
 PY
       ;;
+    mrprio)
+      # does the geometry stream keep its priority next to an RCCL process group?  (profiles/round4_multirank.txt)
+      B="--steps 20 --warmup 3 --no-cpu-baseline --no-extras"
+      R1="D3D_DIST_SINGLE=1 D3D_DIST_BACKEND=nccl RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1"
+      run() { n=$1; shift; env "$@" MASTER_PORT=$(port) timeout 300 python bench.py --gpus 1 $B > $O/p_$n.json 2> $O/p_$n.err; }
+      run plain X=1
+      run plain_prio0 D3D_PREFETCH_PRIORITY=0
+      run rccl1_reserved $R1
+      run rccl1_late $R1 D3D_PREFETCH_RESERVE=0
+      run rccl1_late_hp $R1 D3D_PREFETCH_RESERVE=0 TORCH_NCCL_HIGH_PRIORITY=1
+      run nocoll_reserved $R1 D3D_DIST_NOCOLL=1
+      B="$B --no-prefetch-thread"; run rccl1_reserved_nothread $R1
+      python - "$O" <<'PY' | tee $O/mrprio.txt
+import json, sys, os, glob
+O = sys.argv[1]
+for f in sorted(glob.glob(os.path.join(O, "p_*.json")), key=os.path.getmtime):
+    try:
+        d = json.loads([l for l in open(f) if l.startswith("{")][-1])
+        print("%-26s %8.1f frames/s %7.3f ms/step  host %s" % (os.path.basename(f)[2:-5], d["value"], d["ms_per_step"], d["config"].get("host_ms_per_step")))
+    except Exception as e:
+        print("%-26s FAILED" % os.path.basename(f))
+PY
+      ;;
     mrprof)
       export D3D_PROFILE_TIMELINE=1
       R1="D3D_DIST_SINGLE=1 D3D_DIST_BACKEND=nccl RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1"
