@@ -653,7 +653,9 @@ int g_c2_variant = getenv("D3D_CONV2D_VARIANT") ? atoi(getenv("D3D_CONV2D_VARIAN
 // waves per block of the weight-gradient kernel (knob 8, D3D_CONV2D_WGRAD_WAVES): 8 (64 x 32 wave tiles) or 4;
 // 16 / 17: conv2d_wgrad3_kernel for the 3x3 stride-1 layers in split mode (staggered wave groups / one barrier per K
 // step), other layers as with 8
-int g_c2_wgrad_waves = getenv("D3D_CONV2D_WGRAD_WAVES") ? atoi(getenv("D3D_CONV2D_WGRAD_WAVES")) : 8;
+// measured (profiles/round4_conv2d_variants.txt, split): [4,200,176,128] -> 128: 166 (8) / 130 (17) / 115 us (16);
+// [4,128,128,256] -> 256: 281 / 206 / 182 us
+int g_c2_wgrad_waves = getenv("D3D_CONV2D_WGRAD_WAVES") ? atoi(getenv("D3D_CONV2D_WGRAD_WAVES")) : 16;
 
 static int c2_check(const char *who, int batch, int h, int w, int cin, int cout, int ksz, int stride, int pad,
                     int mode) {
@@ -912,7 +914,7 @@ extern "C" int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const v
     hipLaunchKernelGGL((conv2d_wgrad_kernel<SPLIT, WCI>), grid, dim3(128 * WCI), lds, stream, g_hi, g_lo, x_hi, \
                        x_lo, (float *)workspace, G, cin, pps, nsplit);                                        \
   } while (0)
-  if (g_c2_wgrad_waves == 4) {
+  if (g_c2_wgrad_waves == 4) {  // (16 / 17 on a layer conv2d_wgrad3_kernel does not serve: as 8)
     if (split) C2_WG(true, 2); else C2_WG(false, 2);
   } else {
     if (split) C2_WG(true, 4); else C2_WG(false, 4);

@@ -161,7 +161,7 @@ def test_weight_gradient_three_taps_per_block(geom, waves):
         for _ in range(3):
             assert torch.equal(dw, dc.wgrad_raw(g_hi, g_lo, x_hi, x_lo, k, s, p, "split"))
     finally:
-        L.d3d_set_tuning(8, 8)
+        L.d3d_set_tuning(8, 16)  # the default
     ref = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (cout, cin, k, k), gy.double().permute(0, 3, 1, 2), s, p)
     err, scale = float((dw.double() - ref).abs().max()), float(ref.abs().max())
     assert err <= 3e-5 * scale + 1e-6, (err, scale)

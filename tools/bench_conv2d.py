@@ -63,7 +63,7 @@ def main():
                     tw = timeit(lambda: dc.wgrad_raw(g_hi, g_lo, x_hi, x_lo, k, s, p, mode))
                     row[mode + "_wgrad%d_us" % wv] = round(tw, 1)
                     row[mode + "_wgrad%d_TF" % wv] = round(flop / tw / 1e6, 1)
-                _lib.lib().d3d_set_tuning(8, 8)
+                _lib.lib().d3d_set_tuning(8, 16)
         # MIOpen through torch, channels-last
         for dt, nm in (() if os.environ.get("NO_MIOPEN") else ((torch.bfloat16, "miopen_bf16"), (torch.float32, "miopen_f32"))):
             xm = x.permute(0, 3, 1, 2).to(dt).contiguous(memory_format=torch.channels_last).requires_grad_(True)

@@ -24,7 +24,8 @@ while [ $# -gt 0 ]; do
   echo "=== stage $st"
   case "$st" in
     tests)
-      timeout 1500 python -m pytest tests/ -x -q -m gpu > $O/tests.log 2>&1; echo "pytest rc=$?"; tail -3 $O/tests.log
+      timeout 1500 python -m pytest tests/ -x -q -m gpu -rP > $O/tests.log 2>&1; echo "pytest rc=$?"; tail -3 $O/tests.log
+      grep -h "vs float64\|max |pred - reference|\|worst gradient-norm\|ResNetFHD" $O/tests.log | cut -c1-400 > $O/tests_figures.txt; cat $O/tests_figures.txt
       timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 ;;
     tests:*)
       timeout 1500 python -m pytest tests/ -x -q -m gpu -k "${st#tests:}" > $O/tests_k.log 2>&1; echo "pytest rc=$?"; tail -15 $O/tests_k.log ;;
