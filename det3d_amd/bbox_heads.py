@@ -76,59 +76,53 @@ class _HeadLossFn(torch.autograd.Function):
         return g_box, g_cls, g_dir, None, None, None, None
 
 
-def one_hot_f(tensor, depth, dim=-1, on_value=1.0, dtype=torch.float32):
-    out = torch.zeros(*list(tensor.shape), depth, dtype=dtype, device=tensor.device)
-    out.scatter_(dim, tensor.unsqueeze(dim).long(), on_value)
-    return out
-
-
-def add_sin_difference(boxes1, boxes2):
-    """sin(a - b) = sin a cos b - cos a sin b, split over prediction / target (:29-34)"""
-    r1 = torch.sin(boxes1[..., -1:]) * torch.cos(boxes2[..., -1:])
-    r2 = torch.cos(boxes1[..., -1:]) * torch.sin(boxes2[..., -1:])
-    return torch.cat([boxes1[..., :-1], r1], dim=-1), torch.cat([boxes2[..., :-1], r2], dim=-1)
-
-
-def limit_period(val, offset=0.5, period=np.pi):
-    return val - torch.floor(val / period + offset) * period
-
-
-def get_direction_target(anchors, reg_targets, one_hot=True, dir_offset=0.0):
-    batch_size = reg_targets.shape[0]
-    anchors = anchors.view(batch_size, -1, anchors.shape[-1])
-    rot_gt = reg_targets[..., -1] + anchors[..., -1]
-    tgt = (limit_period(rot_gt - dir_offset, 0.5, np.pi * 2) > 0).long()
-    if one_hot:
-        tgt = one_hot_f(tgt, 2, dtype=anchors.dtype)
-    return tgt
-
-
-def _get_pos_neg_loss(cls_loss, labels):
-    batch_size = cls_loss.shape[0]
-    if cls_loss.shape[-1] == 1 or len(cls_loss.shape) == 2:
-        pos = ((labels > 0).type_as(cls_loss) * cls_loss.view(batch_size, -1)).sum() / batch_size
-        neg = ((labels == 0).type_as(cls_loss) * cls_loss.view(batch_size, -1)).sum() / batch_size
+def _eager_task_loss(head, preds, labels, reg_targets, anchors, num_class, batch):
+    """One task group's loss in PyTorch ops -- the CPU plumbing path (BASELINE configs[0]) and the unfused side of
+    tests/test_loss_gpu.py; on the GPU `d3d_head_loss` computes the same quantities in two launches.
+    Definitions (det3d/models/bbox_heads/mg_head.py:562-668): focal classification loss on one-hot targets without
+    the background column, smooth-L1 on the box code with the yaw residual replaced by sin(a - b) = sin a cos b -
+    cos a sin b split over prediction and target, optional direction classifier on (yaw_gt - offset) mod 2 pi > 0,
+    each summed and divided by the batch size."""
+    box = preds["box_preds"].float().reshape(batch, -1, head.box_n_dim - 2 if head.bev_only else head.box_n_dim)
+    ncol = num_class if head.encode_background_as_zeros else num_class + 1
+    cls = preds["cls_preds"].float().reshape(batch, -1, ncol)
+    cls_w, reg_w, cared = head.prepare_loss_weights(labels, loss_norm=head.loss_norm, dtype=torch.float32)
+    hot = torch.nn.functional.one_hot((labels * cared.type_as(labels)).long(), num_class + 1).to(box.dtype)
+    if head.encode_background_as_zeros:
+        hot = hot[..., 1:]
+    tgt = reg_targets
+    if head.encode_rad_error_by_sin:
+        a, b = box[..., -1:], tgt[..., -1:]
+        box = torch.cat([box[..., :-1], a.sin() * b.cos()], -1)
+        tgt = torch.cat([tgt[..., :-1], a.cos() * b.sin()], -1)
+    loc = head.loss_reg(box, tgt, weights=reg_w)
+    cl = head.loss_cls(cls, hot, weights=cls_w)
+    loc_red = loc.sum() / batch * head.loss_reg._loss_weight
+    cls_red = cl.sum() / batch * head.loss_cls._loss_weight
+    if cl.dim() == 2 or cl.shape[-1] == 1:  # one column: split by the label of the anchor
+        flat = cl.reshape(batch, -1)
+        pos, neg = (flat * (labels > 0)).sum() / batch, (flat * (labels == 0)).sum() / batch
     else:
-        pos = cls_loss[..., 1:].sum() / batch_size
-        neg = cls_loss[..., 0].sum() / batch_size
-    return pos, neg
-
-
-def create_loss(loc_loss_ftor, cls_loss_ftor, box_preds, cls_preds, cls_targets, cls_weights,
-                reg_targets, reg_weights, num_class, encode_background_as_zeros=True,
-                encode_rad_error_by_sin=True, bev_only=False, box_code_size=9):
-    batch_size = int(box_preds.shape[0])
-    box_preds = box_preds.view(batch_size, -1, box_code_size - 2 if bev_only else box_code_size)
-    cls_preds = cls_preds.view(batch_size, -1, num_class if encode_background_as_zeros else num_class + 1)
-    cls_targets = cls_targets.squeeze(-1)
-    one_hot_targets = one_hot_f(cls_targets, depth=num_class + 1, dtype=box_preds.dtype)
-    if encode_background_as_zeros:
-        one_hot_targets = one_hot_targets[..., 1:]
-    if encode_rad_error_by_sin:
-        box_preds, reg_targets = add_sin_difference(box_preds, reg_targets)
-    loc_losses = loc_loss_ftor(box_preds, reg_targets, weights=reg_weights)
-    cls_losses = cls_loss_ftor(cls_preds, one_hot_targets, weights=cls_weights)
-    return loc_losses, cls_losses
+        pos, neg = cl[..., 1:].sum() / batch, cl[..., 0].sum() / batch
+    total = loc_red + cls_red
+    dir_loss = None
+    if head.use_direction_classifier:
+        yaw = reg_targets[..., -1] + anchors.reshape(batch, -1, anchors.shape[-1])[..., -1] - head.direction_offset
+        yaw = yaw - torch.floor(yaw / (2 * np.pi) + 0.5) * (2 * np.pi)
+        dir_t = torch.nn.functional.one_hot((yaw > 0).long(), 2).to(anchors.dtype)
+        w = (labels > 0).type_as(box)
+        w = w / w.sum(-1, keepdim=True).clamp(min=1.0)
+        logits = preds["dir_cls_preds"].float().reshape(batch, -1, 2)
+        dir_loss = head.loss_aux(logits, dir_t, weights=w).sum() / batch
+        total = total + dir_loss * head.loss_aux._loss_weight
+    # logged scalars stay on the device (the reference reads ~10 of them to the host per task group, :657-666)
+    return {"loss": total,
+            "cls_pos_loss": (pos / head.loss_norm["pos_cls_weight"]).detach(),
+            "cls_neg_loss": (neg / head.loss_norm["neg_cls_weight"]).detach(),
+            "dir_loss_reduced": dir_loss.detach() if dir_loss is not None else torch.tensor(0),
+            "cls_loss_reduced": cls_red.detach().mean(), "loc_loss_reduced": loc_red.detach().mean(),
+            "loc_loss_elem": [(loc[:, :, i].sum() / batch).detach() for i in range(loc.shape[-1])],
+            "num_pos": (labels > 0)[0].sum(), "num_neg": (labels == 0)[0].sum()}
 
 
 FUSE_HEAD_CONV = os.environ.get("D3D_FUSE_HEAD_CONV", "1") != "0"
@@ -395,47 +389,8 @@ class MultiGroupHead(nn.Module):
             if self._fused_loss_ok(preds_dict, example["labels"][task_id]):
                 rets.append(self._loss_fused(example, preds_dict, task_id, batch_size_device))
                 continue
-            num_class = self.num_classes[task_id]
-            box_preds = preds_dict["box_preds"].float()
-            cls_preds = preds_dict["cls_preds"].float()
-            labels = example["labels"][task_id]
-            reg_targets = example["reg_targets"][task_id]
-            cls_weights, reg_weights, cared = self.prepare_loss_weights(labels, loss_norm=self.loss_norm,
-                                                                        dtype=torch.float32)
-            cls_targets = (labels * cared.type_as(labels)).unsqueeze(-1)
-            loc_loss, cls_loss = create_loss(self.loss_reg, self.loss_cls, box_preds, cls_preds, cls_targets,
-                                             cls_weights, reg_targets, reg_weights, num_class,
-                                             self.encode_background_as_zeros, self.encode_rad_error_by_sin,
-                                             bev_only=self.bev_only, box_code_size=self.box_n_dim)
-            loc_loss_reduced = loc_loss.sum() / batch_size_device * self.loss_reg._loss_weight
-            cls_pos_loss, cls_neg_loss = _get_pos_neg_loss(cls_loss, labels)
-            cls_pos_loss = cls_pos_loss / self.loss_norm["pos_cls_weight"]
-            cls_neg_loss = cls_neg_loss / self.loss_norm["neg_cls_weight"]
-            cls_loss_reduced = cls_loss.sum() / batch_size_device * self.loss_cls._loss_weight
-            loss = loc_loss_reduced + cls_loss_reduced
-            dir_loss = None
-            if self.use_direction_classifier:
-                dir_targets = get_direction_target(example["anchors"][task_id], reg_targets,
-                                                   dir_offset=self.direction_offset)
-                dir_logits = preds_dict["dir_cls_preds"].float().view(batch_size_device, -1, 2)
-                weights = (labels > 0).type_as(dir_logits)
-                weights = weights / torch.clamp(weights.sum(-1, keepdim=True), min=1.0)
-                dir_loss = self.loss_aux(dir_logits, dir_targets, weights=weights).sum() / batch_size_device
-                loss = loss + dir_loss * self.loss_aux._loss_weight
-            # logged scalars stay on the device (the reference does ~10 .cpu() syncs here,
-            # mg_head.py:657-666); the trainer reads them once per log interval
-            rets.append({
-                "loss": loss,
-                "cls_pos_loss": cls_pos_loss.detach(),
-                "cls_neg_loss": cls_neg_loss.detach(),
-                "dir_loss_reduced": dir_loss.detach() if dir_loss is not None else torch.tensor(0),
-                "cls_loss_reduced": cls_loss_reduced.detach().mean(),
-                "loc_loss_reduced": loc_loss_reduced.detach().mean(),
-                "loc_loss_elem": [(loc_loss[:, :, i].sum() / batch_size_device).detach()
-                                  for i in range(loc_loss.shape[-1])],
-                "num_pos": (labels > 0)[0].sum(),
-                "num_neg": (labels == 0)[0].sum(),
-            })
+            rets.append(_eager_task_loss(self, preds_dict, example["labels"][task_id], example["reg_targets"][task_id],
+                                         batch_anchors[task_id], self.num_classes[task_id], batch_size_device))
         merged = defaultdict(list)
         for ret in rets:
             for k, v in ret.items():
