@@ -674,14 +674,38 @@ extern "C" int d3d_conv2d_supported(int cin, int cout, int ksz, int stride) {
          (stride == 1 || stride == 2);
 }
 
+// conv2d_halo_kernel's grid (d3d_conv2d_halo.h): items = 16 x 16 patches x 128-channel tiles; the items past the last
+// multiple of 256 (one block per CU and round) are cut into four 32-channel blocks each when that fills the last round
+// better than whole blocks would -- at most 128 such items, i.e. two rounds of short blocks (D3D_CONV2D_TAIL=0: never)
+int g_c2_tail = getenv("D3D_CONV2D_TAIL") ? atoi(getenv("D3D_CONV2D_TAIL")) : 1;  // knob 9
+struct C2hPlan {
+  C2hGrid q;
+  int blocks;    // grid size
+  int fold_nb;   // blocks folding into one 128-channel tile's statistics (the largest over the tiles)
+};
+static C2hPlan c2h_plan(int batch, int ho, int wo, int cout) {
+  C2hPlan p;
+  p.q.tiles_x = (wo + 15) / 16;
+  p.q.tiles_y = (ho + 15) / 16;
+  p.q.ctiles = cout / 128;
+  p.q.n_items = batch * p.q.tiles_x * p.q.tiles_y * p.q.ctiles;
+  const int rem = p.q.n_items % 256;
+  const bool cut = g_c2_tail && rem > 0 && rem <= 128;
+  p.q.n_full = cut ? p.q.n_items - rem : p.q.n_items;
+  p.blocks = p.q.n_full + 4 * (p.q.n_items - p.q.n_full);
+  const int rem_items = p.q.n_items - p.q.n_full;
+  p.fold_nb = p.q.n_full / p.q.ctiles + 4 * ((rem_items + p.q.ctiles - 1) / p.q.ctiles);
+  return p;
+}
+
 extern "C" size_t d3d_conv2d_stats_ws_floats(int batch, int ho, int wo, int cout) {
   const int64_t m = (int64_t)batch * ho * wo;
   if (m < 1 || cout < 128 || cout % 128) return 0;
   const int64_t nb = (m + 127) / 128;
   if (nb > D3D_FOLD_MAX_BLOCKS) return 0;
   // either tiling of the forward kernels: 128-pixel runs, or 16 x 16 patches (conv2d_halo_kernel)
-  const int64_t nh = (int64_t)batch * ((ho + 15) / 16) * ((wo + 15) / 16);
-  size_t a = d3d_fold_ws_floats((int)nb, 256), b = d3d_fold_ws_floats((int)nh, 256);
+  const int nh = c2h_plan(batch, ho, wo, cout).fold_nb;
+  size_t a = d3d_fold_ws_floats((int)nb, 256), b = d3d_fold_ws_floats(nh, 256);
   return 2 * (size_t)cout + (size_t)(cout / 128) * (a > b ? a : b);
 }
 
@@ -722,8 +746,7 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
   const bool halo = (variant == 16 || variant == 17) && split && ksz == 3 && stride == 1;
   if ((variant == 16 || variant == 17) && !halo) variant = split ? 9 : 8;
   if (halo) {
-    const int tiles_x = (G.wo + 15) / 16, tiles_y = (G.ho + 15) / 16;
-    const int nt = batch * tiles_x * tiles_y;
+    const C2hPlan hp = c2h_plan(batch, G.ho, G.wo, cout);
     Conv2dEpi eh = {};
     eh.fold_g = 16;
     D3D_REQUIRE(!bn || stats_ws, "d3d_conv2d_nhwc_fwd: the BatchNorm-backward sums need the statistics workspace");
@@ -733,15 +756,15 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
       eh.bn_relu = bn->relu;
     }
     if (stats_ws) {
-      D3D_REQUIRE(nt <= D3D_FOLD_MAX_BLOCKS, "d3d_conv2d_nhwc_fwd: %d patches > %d for the statistics fold", nt,
-                  D3D_FOLD_MAX_BLOCKS);
+      D3D_REQUIRE(hp.fold_nb <= D3D_FOLD_MAX_BLOCKS, "d3d_conv2d_nhwc_fwd: %d blocks > %d for the statistics fold",
+                  hp.fold_nb, D3D_FOLD_MAX_BLOCKS);
       const size_t need = d3d_conv2d_stats_ws_floats(batch, G.ho, G.wo, cout);
       if (need == 0 || stats_ws_floats < need)
         return d3d_set_error(D3D_ECAPACITY, "d3d_conv2d_nhwc_fwd: statistics workspace %zu floats < %zu", stats_ws_floats, need);
-      const D3dFoldPlan fp = d3d_fold_plan(nt, 256);
+      const D3dFoldPlan fp = d3d_fold_plan(hp.fold_nb, 256);  // the group size of the largest fold serves every tile's
       eh.stats = stats_ws;
       eh.fold_g = fp.g;
-      eh.ws_stride = (int)d3d_fold_ws_floats(nt, 256);
+      eh.ws_stride = (int)d3d_fold_ws_floats(hp.fold_nb, 256);
       eh.ctr_stride = d3d_fold_counter_words(fp);
       eh.counters = d3d_fold_counters(eh.ctr_stride * (cout / 128));
       if (!eh.counters) return D3D_EHIP;
@@ -752,8 +775,8 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
   do {                                                                                                          \
     D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_halo_kernel<CIN, 16, 16, STG>,                         \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)hlds));                   \
-    hipLaunchKernelGGL((conv2d_halo_kernel<CIN, 16, 16, STG>), dim3(nt, cout / 128), dim3(512), hlds, stream,   \
-                       x_hi, x_lo, w_hi, w_lo, (float *)y, G, eh, tiles_x, tiles_y);                            \
+    hipLaunchKernelGGL((conv2d_halo_kernel<CIN, 16, 16, STG>), dim3(hp.blocks), dim3(512), hlds, stream,        \
+                       x_hi, x_lo, w_hi, w_lo, (float *)y, G, eh, hp.q);                                        \
   } while (0)
 #define C2_HALO_CASE(CIN)                        \
   if (cin == CIN) {                              \

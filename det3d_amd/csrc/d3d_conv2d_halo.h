@@ -24,6 +24,12 @@
 //        group 1 after 2t+2: one barrier more than the wait, for both.
 //   WAR  the slot requested in L(t) was last read in L(t-1), and every wave retires its reads (lgkmcnt(0)) at the end
 //        of its load part: group 1's L(t-1) ends before barrier 2t-1, group 0 requests after it.
+//
+// The last, partial round of blocks.  A launch has I = patches x (cout / 128) work items for 256 CUs with one block
+// each: [4,200,176,128] -> 128 has 572, i.e. two full rounds and a third with 60 of 256 CUs busy (measured: 0.53 of the
+// MFMA peak on maps whose item count is a multiple of 256, 0.38 on this one).  Items past the last multiple of 256 are
+// therefore cut into FOUR blocks of 32 output channels each (WCO = NI = 1: eight waves of 32 pixels x 32 channels;
+// the halo patch is staged as before, the weight tiles are a quarter): 240 short blocks fill the last round.
 // (included by d3d_conv2d.hip after Conv2dGeom / Conv2dEpi)
 #pragma once
 
@@ -34,32 +40,38 @@ template <int N> __device__ __forceinline__ void c2h_wait_vm() {
   else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
 }
 
+// how a launch's items map to blocks (host: c2h_plan; device: conv2d_halo_kernel)
+struct C2hGrid {
+  int tiles_x, tiles_y;  // patches per image
+  int ctiles;            // 128-channel output tiles
+  int n_full;            // items [0, n_full) are whole blocks; item n_full + j is blocks n_full + 4 j .. + 3
+  int n_items;           // patches * ctiles
+};
+
 // PH x PW = 256 output pixels per block; STAGGER: the two wave groups run one barrier apart (else: one barrier per K step)
-template <int CIN, int PH, int PW, bool STAGGER>
-__global__ void __launch_bounds__(512, 2)
-    conv2d_halo_kernel(const void *__restrict__ x_hi, const void *__restrict__ x_lo, const void *__restrict__ w_hi,
-                       const void *__restrict__ w_lo, float *__restrict__ y, Conv2dGeom G, Conv2dEpi ep, int tiles_x,
-                       int tiles_y) {
+// WCO waves along cout, NI 32-channel tiles per wave: (2, 2) = 128 output channels per block, (1, 1) = 32
+template <int CIN, int PH, int PW, bool STAGGER, int WCO, int NI>
+__device__ __forceinline__ void c2h_body(const void *__restrict__ x_hi, const void *__restrict__ x_lo,
+                                         const void *__restrict__ w_hi, const void *__restrict__ w_lo,
+                                         float *__restrict__ y, const Conv2dGeom &G, const Conv2dEpi &ep,
+                                         const C2hGrid &Q, int tile, int ct, int n0, int fold_b, int fold_nb,
+                                         unsigned char *smem) {
   constexpr int KC = CIN / 32;                       // 32-channel chunks (64-byte rows per plane)
   constexpr int HWID = PW + 2, HR = (PH + 2) * HWID;  // halo patch: rows of the LDS image
   constexpr int XI = (HR + 15) / 16;                  // LDS-DMA instructions per plane (16 rows of 64 B each)
   constexpr int XPLANE = XI * 1024, XBUF = 2 * XPLANE;
-  constexpr int WPLANE = 128 * 64, WSLOT = 2 * WPLANE;
+  constexpr int CT = WCO * NI * 32;                   // output channels of this block
+  constexpr int WPX = 8 / WCO, NJ = 256 / (WPX * 32); // pixel waves, 32-pixel tiles per wave
+  constexpr int WPLANE = CT * 64, WSLOT = 2 * WPLANE;
+  constexpr int WINS = CT / 16;                       // LDS-DMA instructions per weight plane (one per wave < WINS)
   constexpr int W0 = 2 * XBUF;                        // [2][XBUF] patch buffers, then [3][WSLOT] weight ring
-  static_assert(PH * PW == 256 && XI <= 24 && CIN % 32 == 0, "patch shape");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  static_assert(PH * PW == 256 && XI <= 24 && CIN % 32 == 0 && NJ >= 1, "patch shape");
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wco = wave & 1, wpx = wave >> 1, grp = wave >> 2;
-  int tile;
-  {
-    const int nb = (int)gridDim.x, q = nb >> 3, r = nb & 7, xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, img = t2 / tiles_y;
+  const int wco = wave % WCO, wpx = wave / WCO, grp = wave >> 2;
+  const int tx = tile % Q.tiles_x, t2 = tile / Q.tiles_x, ty = t2 % Q.tiles_y, img = t2 / Q.tiles_y;
   const int oy0 = ty * PH, ox0 = tx * PW;
-  const int n0 = (int)blockIdx.y * 128;
 
   // ---- staging slots.  Patch: this wave owns LDS-DMA instructions wave, wave + 8, wave + 16 (< XI) of each plane;
   // instruction i covers patch rows 16 i .. 16 i + 15, four lanes (16-byte chunks) per row, chunk c of row r at
@@ -75,10 +87,11 @@ __global__ void __launch_bounds__(512, 2)
     x_ok[pr] = i < XI && r < HR && iy >= 0 && iy < G.h && ix >= 0 && ix < G.w;
     x_off[pr] = (uint32_t)(((img * G.h + iy) * G.w + ix) * (CIN * 2) + c * 16);
   }
-  uint32_t w_off;  // weight rows 16 wave .. 16 wave + 15 of the 128-row tile
+  uint32_t w_off;  // weight rows 16 wave .. 16 wave + 15 of the CT-row tile (waves < WINS)
+  const bool w_mine = wave < WINS;
   {
     const int row = 16 * wave + (lane >> 2);
-    w_off = (uint32_t)((n0 + row) * (CIN * 2) + (((lane & 3) ^ ((row >> 2) & 3)) << 4));
+    w_off = (uint32_t)((n0 + (w_mine ? row : 0)) * (CIN * 2) + (((lane & 3) ^ ((row >> 2) & 3)) << 4));
   }
   const __amdgpu_buffer_rsrc_t xr_hi = __builtin_amdgcn_make_buffer_rsrc((void *)x_hi, 0, G.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t xr_lo = __builtin_amdgcn_make_buffer_rsrc((void *)x_lo, 0, G.x_bytes, 0x00020000);
@@ -94,6 +107,7 @@ __global__ void __launch_bounds__(512, 2)
   };
   // both planes of this wave's 16 weight rows of K step (kc, tap) into ring slot `slot`
   auto stage_w = [&](int kc, int tap, int slot) {
+    if (!w_mine) return;
     const int soff = (tap * G.cout * CIN + kc * 32) * 2;  // wave-uniform: the instruction's scalar offset
     unsigned char *dst = smem + W0 + slot * WSLOT + wave * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(wr_hi, (c2_lds_void *)dst, 16, (int)w_off, soff, 0, 0);
@@ -102,24 +116,24 @@ __global__ void __launch_bounds__(512, 2)
 
   // ---- fragment addresses.  32x32x16 operand: lane l holds row (l & 31), k-chunk (l >> 5) of a 16-channel substep
   const int frow = lane & 31, fk = lane >> 5;
-  uint32_t a_addr[2];  // weight tile i: byte offset inside a plane for substep 0 (substep 1: ^ 32)
-  int r0[2];           // pixel tile j: patch row of this lane's pixel at tap (0, 0)
+  uint32_t a_addr[NI];  // weight tile i: byte offset inside a plane for substep 0 (substep 1: ^ 32)
+  int r0[NJ];            // pixel tile j: patch row of this lane's pixel at tap (0, 0)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wco * 64 + i * 32 + frow;
+  for (int i = 0; i < NI; ++i) {
+    const int row = wco * (NI * 32) + i * 32 + frow;
     a_addr[i] = (uint32_t)(row * 64 + ((fk ^ ((row >> 2) & 3)) << 4));
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int q = wpx * 64 + j * 32 + frow;
+  for (int j = 0; j < NJ; ++j) {
+    const int q = wpx * (NJ * 32) + j * 32 + frow;
     r0[j] = (q / PW) * HWID + (q % PW);
   }
 
-  c2_f32x16 acc[2][2];  // [cout tile][pixel tile]
+  c2_f32x16 acc[NI][NJ];  // [cout tile][pixel tile]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -151,10 +165,10 @@ __global__ void __launch_bounds__(512, 2)
       const int ky = tap / 3, kx = tap % 3;
       // ---------------- load part
       const unsigned char *wb = smem + W0 + (tap % 3) * WSLOT;  // (9 kc + tap) % 3 == tap % 3
-      c2_bf16x8 wa[2][2][2], xf[2][2][2];  // [substep][tile][plane]
-      uint32_t x_addr[2];
+      c2_bf16x8 wa[2][NI][2], xf[2][NJ][2];  // [substep][tile][plane]
+      uint32_t x_addr[NJ];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int r = r0[j] + ky * HWID + kx;
         x_addr[j] = (uint32_t)((r << 6) + ((fk ^ ((r >> 2) & 3)) << 4));
       }
@@ -163,9 +177,9 @@ __global__ void __launch_bounds__(512, 2)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i) wa[kk][i][p] = *(const c2_bf16x8 *)(wb + p * WPLANE + (a_addr[i] ^ (uint32_t)(kk << 5)));
+          for (int i = 0; i < NI; ++i) wa[kk][i][p] = *(const c2_bf16x8 *)(wb + p * WPLANE + (a_addr[i] ^ (uint32_t)(kk << 5)));
 #pragma unroll
-          for (int j = 0; j < 2; ++j) xf[kk][j][p] = *(const c2_bf16x8 *)(xb + p * XPLANE + (x_addr[j] ^ (uint32_t)(kk << 5)));
+          for (int j = 0; j < NJ; ++j) xf[kk][j][p] = *(const c2_bf16x8 *)(xb + p * XPLANE + (x_addr[j] ^ (uint32_t)(kk << 5)));
         }
       // requests: one plane of one patch instruction of the NEXT chunk (taps 0-5), the weight tile of K step t + 2
       const bool do_x = tap < 6 && next_chunk && (wave + 8 * (tap >> 1) < XI);
@@ -174,7 +188,7 @@ __global__ void __launch_bounds__(512, 2)
       const bool do_w = kc2 < KC;
       if (do_w) stage_w(kc2, tap2, (tap + 2) % 3);
       // everything this wave requested BEFORE this load part has landed (the tiles of K step t + 1 among them)
-      if (do_w) {
+      if (do_w && w_mine) {
         if (do_x) c2h_wait_vm<3>(); else c2h_wait_vm<2>();
       } else {
         if (do_x) c2h_wait_vm<1>(); else c2h_wait_vm<0>();
@@ -190,19 +204,19 @@ __global__ void __launch_bounds__(512, 2)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < NJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[kk][i][0], xf[kk][j][0], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < NJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[kk][i][0], xf[kk][j][1], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < NJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[kk][i][1], xf[kk][j][0], acc[i][j], 0, 0, 0);
       }
       __builtin_amdgcn_s_setprio(0);
@@ -219,25 +233,25 @@ __global__ void __launch_bounds__(512, 2)
   // ---- epilogue.  C/D of 32x32: col (pixel) = lane & 31, row (cout) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const bool want_stats = ep.stats != nullptr;
   const bool want_bnb = want_stats && ep.bn_x != nullptr;
-  float s1[2][16], s2[2][16];
+  float s1[NI][16], s2[NI][16];
   if (want_stats) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s1[i][r] = s2[i][r] = 0.f;
   }
-  int64_t pix[2];
-  bool live[2];
+  int64_t pix[NJ];
+  bool live[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int q = wpx * 64 + j * 32 + frow;
+  for (int j = 0; j < NJ; ++j) {
+    const int q = wpx * (NJ * 32) + j * 32 + frow;
     const int oy = oy0 + q / PW, ox = ox0 + q % PW;
     live[j] = oy < G.ho && ox < G.wo;
     pix[j] = ((int64_t)(img * G.ho + oy) * G.wo + ox) * G.cout;
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int co_base = n0 + wco * 64 + i * 32 + 4 * (lane >> 5);
+  for (int i = 0; i < NI; ++i) {
+    const int co_base = n0 + wco * (NI * 32) + i * 32 + 4 * (lane >> 5);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int co = co_base + 8 * g;
@@ -253,7 +267,7 @@ __global__ void __launch_bounds__(512, 2)
         }
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
         float x[4] = {0.f, 0.f, 0.f, 0.f};
         if (live[j]) {
@@ -280,20 +294,26 @@ __global__ void __launch_bounds__(512, 2)
     }
   }
   if (want_stats) {
-    // as conv2d_nhwc_kernel: halving butterfly over the 32 pixel lanes, the four pixel waves through LDS in wave
-    // order, the blocks through the fixed-order fold
+    // as conv2d_nhwc_kernel: halving butterfly over the 32 pixel lanes (a lane ends with NV / 32 of its NV partial
+    // sums, index v = (lane & 31) * (NV / 32) + k), the pixel waves through LDS in wave order, the blocks through the
+    // fixed-order fold -- one fold per 128-channel tile `ct`; a 32-channel block hands in zeros for the other 96
+    constexpr int NV = NI * 32, NK = NV / 32;
     __syncthreads();
-    float *red = (float *)smem;  // [4 pixel waves][2][128] then tot [2][128] then flag
-    float vals[64];
+    float *red = (float *)smem;  // [WPX pixel waves][2][128] then tot [2][128] then flag
+    if (CT < 128) {
+      for (int i = threadIdx.x; i < WPX * 256; i += 512) red[i] = 0.f;
+      __syncthreads();
+    }
+    float vals[NV];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         vals[i * 32 + r * 2 + 0] = s1[i][r];
         vals[i * 32 + r * 2 + 1] = s2[i][r];
       }
 #pragma unroll
-    for (int d = 16, n = 64; d >= 1; d >>= 1, n >>= 1) {
+    for (int d = 16, n = NV; d >= 1; d >>= 1, n >>= 1) {
       const bool up = (lane & d) != 0;
 #pragma unroll
       for (int k = 0; k < n / 2; ++k) {
@@ -302,26 +322,54 @@ __global__ void __launch_bounds__(512, 2)
         vals[k] = keep + __shfl_xor(send, d, 64);
       }
     }
+    const int c_in_tile = n0 - ct * 128;  // first channel of this block inside its 128-channel tile
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int v = ((lane & 31) << 1) | k;
+    for (int k = 0; k < NK; ++k) {
+      const int v = (lane & 31) * NK + k;
       const int i = v >> 5, r = (v >> 1) & 15, stat = v & 1;
-      const int cl = wco * 64 + i * 32 + 4 * (lane >> 5) + 8 * (r >> 2) + (r & 3);
+      const int cl = c_in_tile + wco * (NI * 32) + i * 32 + 4 * (lane >> 5) + 8 * (r >> 2) + (r & 3);
       red[wpx * 256 + stat * 128 + cl] = vals[k];
     }
     __syncthreads();
-    float *tot = red + 4 * 256;
+    float *tot = red + WPX * 256;
     if (threadIdx.x < 256) {
       float t = 0.f;
 #pragma unroll
-      for (int wv = 0; wv < 4; ++wv) t += red[wv * 256 + threadIdx.x];
+      for (int wv = 0; wv < WPX; ++wv) t += red[wv * 256 + threadIdx.x];
       tot[threadIdx.x] = t;
     }
     __syncthreads();
-    float *ws = ep.stats + 2 * G.cout + (size_t)blockIdx.y * ep.ws_stride;
-    if (d3d_fold_block<512>(tot, 256, ws, ep.counters + blockIdx.y * ep.ctr_stride, ep.fold_g, (int *)(tot + 256))) {
+    float *ws = ep.stats + 2 * G.cout + (size_t)ct * ep.ws_stride;
+    if (d3d_fold_block_at<512>(tot, 256, ws, ep.counters + ct * ep.ctr_stride, ep.fold_g, (int *)(tot + 256), fold_b,
+                               fold_nb)) {
       const int i = threadIdx.x;
-      if (i < 256) ep.stats[(i >> 7) * G.cout + n0 + (i & 127)] = ws[i];
+      if (i < 256) ep.stats[(i >> 7) * G.cout + ct * 128 + (i & 127)] = ws[i];
     }
+  }
+}
+
+template <int CIN, int PH, int PW, bool STAGGER>
+__global__ void __launch_bounds__(512, 2)
+    conv2d_halo_kernel(const void *__restrict__ x_hi, const void *__restrict__ x_lo, const void *__restrict__ w_hi,
+                       const void *__restrict__ w_lo, float *__restrict__ y, Conv2dGeom G, Conv2dEpi ep, C2hGrid Q) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int bid = (int)blockIdx.x;
+  const int fold_full = Q.n_full / Q.ctiles;  // whole blocks per 128-channel tile
+  const int rem = Q.n_items - Q.n_full;       // items cut into four blocks each
+  if (bid < Q.n_full) {
+    // XCD-aware order over the whole blocks: XCD i works on the i-th contiguous eighth of the items (bijective)
+    const int nb = Q.n_full, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    const int item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tile = item / Q.ctiles, ct = item - tile * Q.ctiles;
+    const int rem_ct = rem > ct ? (rem - ct + Q.ctiles - 1) / Q.ctiles : 0;
+    c2h_body<CIN, PH, PW, STAGGER, 2, 2>(x_hi, x_lo, w_hi, w_lo, y, G, ep, Q, tile, ct, ct * 128, tile, fold_full + 4 * rem_ct,
+                                         smem);
+  } else {
+    const int j = (bid - Q.n_full) >> 2, quarter = (bid - Q.n_full) & 3;
+    const int item = Q.n_full + j;
+    const int tile = item / Q.ctiles, ct = item - tile * Q.ctiles;  // == j % ctiles: n_full is a multiple of ctiles
+    const int rem_ct = (rem - ct + Q.ctiles - 1) / Q.ctiles;
+    c2h_body<CIN, PH, PW, STAGGER, 1, 1>(x_hi, x_lo, w_hi, w_lo, y, G, ep, Q, tile, ct, ct * 128 + quarter * 32,
+                                         fold_full + (j / Q.ctiles) * 4 + quarter, fold_full + 4 * rem_ct, smem);
   }
 }

@@ -62,10 +62,11 @@ __device__ __forceinline__ float d3d_load_sc1(const float *p) {
 // threads, i.e. after a barrier).  `flag` is one LDS word.  NT = threads of the block.
 // Returns true in the ONE block that drew the last ticket: the result is then complete in ws[0..nval) (written by
 // this block's threads i = threadIdx.x, threadIdx.x + NT, ...); every other block returns false.
+// `b` of `nb`: this block's position in the fold (d3d_fold_block: its blockIdx.x of gridDim.x; a launch whose blocks
+// fold in several independent sets -- conv2d_halo_kernel: one set per 128-channel tile -- passes its own numbering)
 template <int NT>
-__device__ __forceinline__ bool d3d_fold_block(const float *vals, int nval, float *__restrict__ ws,
-                                               unsigned *__restrict__ counters, int g, int *flag) {
-  const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+__device__ __forceinline__ bool d3d_fold_block_at(const float *vals, int nval, float *__restrict__ ws,
+                                                  unsigned *__restrict__ counters, int g, int *flag, int b, int nb) {
   const int ng = (nb + g - 1) / g;
   float *slabs = ws + nval;
   float *gslabs = slabs + (size_t)nb * nval;
@@ -129,4 +130,10 @@ __device__ __forceinline__ bool d3d_fold_block(const float *vals, int nval, floa
     ws[i] = s;
   }
   return true;
+}
+
+template <int NT>
+__device__ __forceinline__ bool d3d_fold_block(const float *vals, int nval, float *__restrict__ ws,
+                                               unsigned *__restrict__ counters, int g, int *flag) {
+  return d3d_fold_block_at<NT>(vals, nval, ws, counters, g, flag, (int)blockIdx.x, (int)gridDim.x);
 }

@@ -50,9 +50,9 @@ int g_d3d_wgrad_blocks = -1;  // d3d_wgrad.hip reads these two
 // 50.6 vs 50.6-54 us on the 126k-site 64->64 layer, 578 vs 566 frames/s end to end), so it is off by default
 int g_xcd_remap = getenv("D3D_XCD_REMAP") ? atoi(getenv("D3D_XCD_REMAP")) : 0;
 extern int g_bn_variant, g_bn_skip_global, g_bn_dx_rows, g_bn_stream_blocks;  // d3d_bn.hip
-extern int g_c2_variant, g_c2_wgrad_waves;  // d3d_conv2d.hip
+extern int g_c2_variant, g_c2_wgrad_waves, g_c2_tail;  // d3d_conv2d.hip
 extern "C" int d3d_set_tuning(int knob, int value) {
-  D3D_REQUIRE(knob >= 0 && knob <= 8, "d3d_set_tuning: unknown knob %d (8 = waves of the dense weight-gradient kernel, 7 = dense conv tiling variant, 0 = forward 64->64 tiling variant, "
+  D3D_REQUIRE(knob >= 0 && knob <= 9, "d3d_set_tuning: unknown knob %d (9 = cut the last partial round of the dense 3x3 kernel into 32-channel blocks, 8 = waves of the dense weight-gradient kernel, 7 = dense conv tiling variant, 0 = forward 64->64 tiling variant, "
               "1 = target block count of the weight-gradient kernel, 2 = XCD-aware tile order on/off, 3 = BatchNorm "
               "reduction variant for large inputs, 4 = skip the BatchNorm global atomics (timing diagnosis), 5 = rows "
               "in flight in bn_bwd_dx, 6 = grid cap of the BatchNorm streaming sweeps)", knob);
@@ -64,7 +64,8 @@ extern "C" int d3d_set_tuning(int knob, int value) {
   else if (knob == 5) g_bn_dx_rows = value;
   else if (knob == 6) g_bn_stream_blocks = value;
   else if (knob == 7) g_c2_variant = value;
-  else g_c2_wgrad_waves = value;
+  else if (knob == 8) g_c2_wgrad_waves = value;
+  else g_c2_tail = value;
   return D3D_OK;
 }
 

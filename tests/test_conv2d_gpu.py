@@ -244,9 +244,22 @@ def test_dense_stack_is_the_torch_module_stack(dtype):
     close(ye, yer, "eval output")
 
 
+@pytest.fixture
+def conv2d_tail():
+    """knob 9: items of the last partial round as four 32-channel blocks (1, default) or as whole blocks (0).  The small
+    maps of these tests have fewer than 256 items, i.e. with the default EVERY item is cut: both settings are needed to
+    reach both block shapes"""
+    from det3d_amd import _lib
+
+    L = _lib.lib()
+    yield lambda v: L.d3d_set_tuning(9, int(v))
+    L.d3d_set_tuning(9, 1)
+
+
+@pytest.mark.parametrize("tail", [0, 1])
 @pytest.mark.parametrize("variant", [16, 17])
 @pytest.mark.parametrize("geom", HALO_GEOMS)
-def test_halo_patch_forward_matches_conv2d(geom, variant, conv2d_variant):
+def test_halo_patch_forward_matches_conv2d(geom, variant, tail, conv2d_variant, conv2d_tail):
     """the second-generation 3x3 kernel (halo patch in LDS, staggered wave groups = 16 / one barrier per K step = 17):
     output against float64 conv2d on the same operands, the statistics epilogue, bit-reproducibility, and agreement
     with the round-3 kernel to the precision of the split format"""
@@ -262,6 +275,7 @@ def test_halo_patch_forward_matches_conv2d(geom, variant, conv2d_variant):
     weight = torch.nn.Parameter(wt)
     w_hi, w_lo = dc._packed(weight, "fwd", "split")
     x_hi, x_lo = dc.split_planes(x)
+    conv2d_tail(tail)
     conv2d_variant(9)
     y_old, _ = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, "split", want_stats=True)
     conv2d_variant(variant)
@@ -280,6 +294,32 @@ def test_halo_patch_forward_matches_conv2d(geom, variant, conv2d_variant):
         assert torch.equal(y, y2) and torch.equal(ws[:2 * cout], ws2[:2 * cout])
     y3, _ = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, "split", want_stats=False)
     assert torch.equal(y, y3)
+
+
+def test_halo_patch_tail_blocks_with_two_channel_tiles(conv2d_variant):
+    """[2,96,112,128] -> 256: 2 x 6 x 7 patches x 2 channel tiles = 168 items... cut entirely; [3,112,176] -> 256: 3 x 7 x 11 x 2
+    = 462 items = 256 whole blocks + 206 -- not cut (> 128); [2,160,144] -> 256: 2 x 10 x 9 x 2 = 360 = 256 + 104 items cut
+    into 416 blocks: whole and 32-channel blocks in ONE launch, the remainder split over both channel tiles (statistics of
+    a tile folded from both kinds of blocks)."""
+    from det3d_amd import dense_conv as dc
+
+    conv2d_variant(16)
+    for b, h, w in ((2, 96, 112), (3, 112, 176), (2, 160, 144)):
+        g = torch.Generator(device="cuda").manual_seed(b * h)
+        x = torch.randn((b, h, w, 128), device="cuda", generator=g)
+        wt = torch.randn((256, 128, 3, 3), device="cuda", generator=g) * 0.03
+        w_hi, w_lo = dc._packed(torch.nn.Parameter(wt), "fwd", "split")
+        x_hi, x_lo = dc.split_planes(x)
+        y, ws = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, 3, 1, 1, "split", want_stats=True)
+        ref = _ref_conv(x.double(), wt.double(), 1, 1)
+        err, scale = float((y.double() - ref).abs().max()), float(ref.abs().max())
+        assert err <= 3e-5 * scale, (b, h, w, err, scale)
+        yd = y.double().reshape(-1, 256)
+        stats = ws[:512].double()
+        assert torch.allclose(stats[:256], yd.sum(0), rtol=1e-4, atol=1e-3 * yd.shape[0] ** 0.5)
+        assert torch.allclose(stats[256:], (yd * yd).sum(0), rtol=1e-4, atol=1e-3)
+        y2, ws2 = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, 3, 1, 1, "split", want_stats=True)
+        assert torch.equal(y, y2) and torch.equal(ws[:512], ws2[:512])
 
 
 @pytest.mark.parametrize("variant", [16, 17])
@@ -308,9 +348,10 @@ def test_halo_patch_kernel_on_the_benched_map_repeats_bit_for_bit(variant, conv2
         assert torch.equal(y, y2) and torch.equal(ws[:256], ws2[:256])
 
 
+@pytest.mark.parametrize("tail", [0, 1])
 @pytest.mark.parametrize("variant", [None, 16, 17])
 @pytest.mark.parametrize("mode", ["bf16", "split"])
-def test_data_gradient_epilogue_reduces_the_previous_batchnorm_backward_sums(mode, variant, conv2d_variant):
+def test_data_gradient_epilogue_reduces_the_previous_batchnorm_backward_sums(mode, variant, tail, conv2d_variant, conv2d_tail):
     """bn_backward: the dgrad launch's rows are dL/dz of the BatchNorm + ReLU in front of the convolution; its epilogue
     must leave what d3d_bn_bwd_reduce computes from the same rows (sum dz * xhat | sum dz), bit-reproducibly."""
     from det3d_amd import _lib
@@ -320,6 +361,9 @@ def test_data_gradient_epilogue_reduces_the_previous_batchnorm_backward_sums(mod
         if mode != "split":
             pytest.skip("the halo-patch kernel serves the split mode")
         conv2d_variant(variant)
+        conv2d_tail(tail)
+    elif tail == 0:
+        pytest.skip("knob 9 only concerns the halo-patch kernel")
     L = _lib.lib()
     b, h, w, c = 2, 30, 26, 128
     g = torch.Generator(device="cuda").manual_seed(5)
