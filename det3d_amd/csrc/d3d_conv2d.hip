@@ -743,8 +743,8 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
   int variant = g_c2_variant >= 0 ? g_c2_variant : (split ? (ksz == 3 && stride == 1 ? 16 : 9) : 8);
   // 16 / 17: the halo-patch kernel (d3d_conv2d_halo.h; 3x3 stride-1 layers in split mode), with / without the staggered
   // wave groups; other layers under these settings take the round-3 default
-  const bool halo = (variant == 16 || variant == 17) && split && ksz == 3 && stride == 1;
-  if ((variant == 16 || variant == 17) && !halo) variant = split ? 9 : 8;
+  const bool halo = (variant >= 16 && variant <= 18) && split && ksz == 3 && stride == 1;  // 18: requests inside the MFMA part
+  if ((variant >= 16 && variant <= 18) && !halo) variant = split ? 9 : 8;
   if (halo) {
     const C2hPlan hp = c2h_plan(batch, G.ho, G.wo, cout);
     Conv2dEpi eh = {};
@@ -780,8 +780,9 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
   } while (0)
 #define C2_HALO_CASE(CIN)                        \
   if (cin == CIN) {                              \
-    if (variant == 16) C2_HALO(CIN, true);       \
-    else C2_HALO(CIN, false);                    \
+    if (variant == 16) C2_HALO(CIN, 1);          \
+    else if (variant == 18) C2_HALO(CIN, 2);     \
+    else C2_HALO(CIN, 0);                        \
   }
     C2_HALO_CASE(64)
     C2_HALO_CASE(128)
@@ -899,7 +900,7 @@ extern "C" int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const v
   const size_t need = d3d_conv2d_wgrad_workspace_bytes(batch, G.ho, G.wo, cin, cout, ksz);
   if (!workspace || workspace_bytes < need)
     return d3d_set_error(D3D_ECAPACITY, "d3d_conv2d_nhwc_wgrad: workspace %zu B < %zu B", workspace_bytes, need);
-  if (split && ksz == 3 && stride == 1 && (g_c2_wgrad_waves == 16 || g_c2_wgrad_waves == 17)) {
+  if (split && ksz == 3 && stride == 1 && g_c2_wgrad_waves >= 16 && g_c2_wgrad_waves <= 18) {
     // second generation (d3d_conv2d_wgrad3.h): a block per (segment range, kernel row, weight tile), three taps each
     const int total_segs = batch * G.ho * ((G.wo + 31) / 32);
     const int wtiles = (cout / 128) * (cin / 128);
@@ -915,7 +916,7 @@ extern "C" int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const v
     hipLaunchKernelGGL((conv2d_wgrad3_kernel<STG>), grid3, dim3(512), lds3, stream, g_hi, g_lo, x_hi, x_lo,      \
                        (float *)workspace, G, cin, sps, ns);                                                     \
   } while (0)
-    if (g_c2_wgrad_waves == 16) C2_WG3(true); else C2_WG3(false);
+    if (g_c2_wgrad_waves == 16) C2_WG3(1); else if (g_c2_wgrad_waves == 18) C2_WG3(2); else C2_WG3(0);
 #undef C2_WG3
     D3D_LAUNCH_TRY("conv2d_wgrad3_kernel");
     const int64_t n4 = (int64_t)9 * cout * cin / 4;

@@ -48,9 +48,13 @@ struct C2hGrid {
   int n_items;           // patches * ctiles
 };
 
-// PH x PW = 256 output pixels per block; STAGGER: the two wave groups run one barrier apart (else: one barrier per K step)
+// PH x PW = 256 output pixels per block.  SCHED 0: one barrier per K step; 1: the two wave groups run one barrier
+// apart; 2: as 1, and the LDS-DMA requests are issued INSIDE the MFMA part (after the 8th and the 16th MFMA, where an
+// LDS-DMA costs the issuing wave ~60 cycles instead of 100-185 next to the fragment reads: MI355X_MICROARCH.md) --
+// the load part is then fragment reads + waits only.  A request of M(t) is waited for (vmcnt(0)) at the end of
+// L(t+1) and read from L(t+2) on: the RAW / WAR argument above holds with the requests half a step later.
 // WCO waves along cout, NI 32-channel tiles per wave: (2, 2) = 128 output channels per block, (1, 1) = 32
-template <int CIN, int PH, int PW, bool STAGGER, int WCO, int NI>
+template <int CIN, int PH, int PW, int SCHED, int WCO, int NI>
 __device__ __forceinline__ void c2h_body(const void *__restrict__ x_hi, const void *__restrict__ x_lo,
                                          const void *__restrict__ w_hi, const void *__restrict__ w_lo,
                                          float *__restrict__ y, const Conv2dGeom &G, const Conv2dEpi &ep,
@@ -129,13 +133,18 @@ __device__ __forceinline__ void c2h_body(const void *__restrict__ x_hi, const vo
     r0[j] = (q / PW) * HWID + (q % PW);
   }
 
-  c2_f32x16 acc[NI][NJ];  // [cout tile][pixel tile]
+  // [substep chain][cout tile][pixel tile]; a wave with ONE tile keeps two accumulator chains (substep 0 / substep 1):
+  // six back-to-back MFMAs on one accumulator would each wait for the previous one's result
+  constexpr int KA = NI * NJ == 1 ? 2 : 1;
+  c2_f32x16 accs[KA][NI][NJ];
 #pragma unroll
-  for (int i = 0; i < NI; ++i)
+  for (int a = 0; a < KA; ++a)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[a][i][j][r] = 0.f;
 
   // ---- prologue: the whole patch of chunk 0, the weight tiles of K steps 0 and 1
 #pragma unroll
@@ -149,6 +158,7 @@ __device__ __forceinline__ void c2h_body(const void *__restrict__ x_hi, const vo
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  constexpr bool STAGGER = SCHED >= 1, LATE = SCHED == 2;
   if (STAGGER && grp == 1) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -183,15 +193,19 @@ __device__ __forceinline__ void c2h_body(const void *__restrict__ x_hi, const vo
         }
       // requests: one plane of one patch instruction of the NEXT chunk (taps 0-5), the weight tile of K step t + 2
       const bool do_x = tap < 6 && next_chunk && (wave + 8 * (tap >> 1) < XI);
-      if (do_x) stage_x(tap >> 1, tap & 1, kc + 1);
       const int tap2 = (tap + 2) % 9, kc2 = kc + (tap + 2) / 9;
       const bool do_w = kc2 < KC;
-      if (do_w) stage_w(kc2, tap2, (tap + 2) % 3);
-      // everything this wave requested BEFORE this load part has landed (the tiles of K step t + 1 among them)
-      if (do_w && w_mine) {
-        if (do_x) c2h_wait_vm<3>(); else c2h_wait_vm<2>();
+      if constexpr (!LATE) {
+        if (do_x) stage_x(tap >> 1, tap & 1, kc + 1);
+        if (do_w) stage_w(kc2, tap2, (tap + 2) % 3);
+        // everything this wave requested BEFORE this load part has landed (the tiles of K step t + 1 among them)
+        if (do_w && w_mine) {
+          if (do_x) c2h_wait_vm<3>(); else c2h_wait_vm<2>();
+        } else {
+          if (do_x) c2h_wait_vm<1>(); else c2h_wait_vm<0>();
+        }
       } else {
-        if (do_x) c2h_wait_vm<1>(); else c2h_wait_vm<0>();
+        c2h_wait_vm<0>();  // the requests of M(t - 1) and earlier: issued at least half a K step ago
       }
       // my fragment reads are complete: the MFMA part starts without an LDS wait, and nobody overwrites what I read
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -203,6 +217,7 @@ __device__ __forceinline__ void c2h_body(const void *__restrict__ x_hi, const vo
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
+        auto &acc = accs[kk % KA];
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -213,6 +228,16 @@ __device__ __forceinline__ void c2h_body(const void *__restrict__ x_hi, const vo
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[kk][i][0], xf[kk][j][1], acc[i][j], 0, 0, 0);
+        if constexpr (LATE) {
+          // after two thirds of substep 0: the patch request; after two thirds of substep 1: the weight requests
+          __builtin_amdgcn_sched_barrier(0);
+          if (kk == 0) {
+            if (do_x) stage_x(tap >> 1, tap & 1, kc + 1);
+          } else {
+            if (do_w) stage_w(kc2, tap2, (tap + 2) % 3);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -231,6 +256,11 @@ __device__ __forceinline__ void c2h_body(const void *__restrict__ x_hi, const vo
   if (STAGGER && grp == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's last barrier
 
   // ---- epilogue.  C/D of 32x32: col (pixel) = lane & 31, row (cout) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  auto &acc = accs[0];
+  if constexpr (KA == 2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] += accs[1][0][0][r];
+  }
   const bool want_stats = ep.stats != nullptr;
   const bool want_bnb = want_stats && ep.bn_x != nullptr;
   float s1[NI][16], s2[NI][16];
@@ -348,7 +378,7 @@ __device__ __forceinline__ void c2h_body(const void *__restrict__ x_hi, const vo
   }
 }
 
-template <int CIN, int PH, int PW, bool STAGGER>
+template <int CIN, int PH, int PW, int SCHED>
 __global__ void __launch_bounds__(512, 2)
     conv2d_halo_kernel(const void *__restrict__ x_hi, const void *__restrict__ x_lo, const void *__restrict__ w_hi,
                        const void *__restrict__ w_lo, float *__restrict__ y, Conv2dGeom G, Conv2dEpi ep, C2hGrid Q) {
@@ -362,14 +392,14 @@ __global__ void __launch_bounds__(512, 2)
     const int item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     const int tile = item / Q.ctiles, ct = item - tile * Q.ctiles;
     const int rem_ct = rem > ct ? (rem - ct + Q.ctiles - 1) / Q.ctiles : 0;
-    c2h_body<CIN, PH, PW, STAGGER, 2, 2>(x_hi, x_lo, w_hi, w_lo, y, G, ep, Q, tile, ct, ct * 128, tile, fold_full + 4 * rem_ct,
+    c2h_body<CIN, PH, PW, SCHED, 2, 2>(x_hi, x_lo, w_hi, w_lo, y, G, ep, Q, tile, ct, ct * 128, tile, fold_full + 4 * rem_ct,
                                          smem);
   } else {
     const int j = (bid - Q.n_full) >> 2, quarter = (bid - Q.n_full) & 3;
     const int item = Q.n_full + j;
     const int tile = item / Q.ctiles, ct = item - tile * Q.ctiles;  // == j % ctiles: n_full is a multiple of ctiles
     const int rem_ct = (rem - ct + Q.ctiles - 1) / Q.ctiles;
-    c2h_body<CIN, PH, PW, STAGGER, 1, 1>(x_hi, x_lo, w_hi, w_lo, y, G, ep, Q, tile, ct, ct * 128 + quarter * 32,
+    c2h_body<CIN, PH, PW, SCHED, 1, 1>(x_hi, x_lo, w_hi, w_lo, y, G, ep, Q, tile, ct, ct * 128 + quarter * 32,
                                          fold_full + (j / Q.ctiles) * 4 + quarter, fold_full + 4 * rem_ct, smem);
   }
 }

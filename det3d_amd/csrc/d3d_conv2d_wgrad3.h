@@ -18,11 +18,14 @@
 // One partial [3][128][128] slab per block; conv2d_wgrad_reduce_kernel sums the slabs in split order.
 #pragma once
 
-template <bool STAGGER>
+// SCHED: 0 one barrier per K step, 1 staggered wave groups, 2 staggered + the LDS-DMA requests inside the MFMA part
+// (d3d_conv2d_halo.h)
+template <int SCHED>
 __global__ void __launch_bounds__(512, 2)
     conv2d_wgrad3_kernel(const void *__restrict__ g_hi, const void *__restrict__ g_lo, const void *__restrict__ x_hi,
                          const void *__restrict__ x_lo, float *__restrict__ part, Conv2dGeom G, int cin,
                          int segs_per_split, int nsplit) {
+  constexpr bool STAGGER = SCHED >= 1, LATE = SCHED == 2;
   constexpr int GPLANE = 32 * 256, XPLANE = 36 * 256;
   constexpr int STAGE = 2 * GPLANE + 2 * XPLANE;  // g hi | g lo | x hi | x lo
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [3][STAGE]
@@ -163,14 +166,14 @@ __global__ void __launch_bounds__(512, 2)
           for (int t = 0; t < 3; ++t) xr[kk][t][p][h] = tr_read(xbase + (uint32_t)(p * XPLANE + kk * 4096 + h * 1024) + fo_x[t]);
         }
     const bool more = ks + 2 < nks;
-    if (more) {
-      int nb3 = buf + 2;
-      if (nb3 >= 3) nb3 -= 3;
+    int nb3 = buf + 2;
+    if (nb3 >= 3) nb3 -= 3;
+    if (more && !LATE) {
       stage(nb3);
       if (wave < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LATE: the requests of M(ks - 1), half a K step old
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // tie every fragment register to the wait (the compiler does not see the asm reads' latency)
@@ -215,6 +218,13 @@ __global__ void __launch_bounds__(512, 2)
       for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[i][0], xb[t][1], acc[t][i], 0, 0, 0);
+      if constexpr (LATE) {
+        if (kk == 0) {  // after a third of the step's MFMAs: the requests of K step ks + 2
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) stage(nb3);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll

@@ -1033,6 +1033,23 @@ static int sparse_conv_fwd_impl(const void *feat, const void *wpack, const float
     FWD32_VAR(55, 1, 16, 1)
 #undef FWD32_VAR
   }
+  if (fwd_variant >= 60 && fwd_variant < 80 && dtype == D3D_F32) {  // f32 tilings of the 128-channel layers (CBGS)
+#define FWD32_WIDE(V, CI, CO, MT, WV, DP)       \
+    if (fwd_variant == V && cin == CI && cout == CO) \
+      return launch_fwd<CI, CO, MT, WV, DP, false>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    FWD32_WIDE(60, 128, 128, 2, 8, 1)
+    FWD32_WIDE(61, 128, 128, 1, 8, 2)
+    FWD32_WIDE(62, 128, 128, 1, 16, 2)
+    FWD32_WIDE(60, 64, 128, 2, 8, 1)
+    FWD32_WIDE(61, 64, 128, 1, 8, 2)
+    FWD32_WIDE(62, 64, 128, 1, 16, 2)
+    FWD32_WIDE(63, 64, 128, 2, 8, 2)
+    FWD32_WIDE(60, 128, 64, 2, 8, 1)
+    FWD32_WIDE(61, 128, 64, 1, 8, 2)
+    FWD32_WIDE(62, 128, 64, 1, 16, 2)
+    FWD32_WIDE(63, 128, 64, 2, 8, 2)
+#undef FWD32_WIDE
+  }
   FWD_CASE(16, 16, 2, 8, 5, 4)
   FWD_CASE(16, 32, 2, 8, 5, 4)
   FWD_CASE(32, 16, 2, 8, 5, 3)

@@ -136,7 +136,7 @@ def test_weight_gradient(geom, mode):
     assert err <= (1e-5 if mode == "bf16" else 3e-5) * scale + 1e-6, (err, scale)
 
 
-@pytest.mark.parametrize("waves", [16, 17])
+@pytest.mark.parametrize("waves", [16, 17, 18])
 @pytest.mark.parametrize("geom", [g for g in HALO_GEOMS if g[3] % 128 == 0] + [(4, 40, 44, 128, 128, 3, 1, 1),
                                                                              (2, 7, 70, 128, 256, 3, 1, 1)])
 def test_weight_gradient_three_taps_per_block(geom, waves):
@@ -257,7 +257,7 @@ def conv2d_tail():
 
 
 @pytest.mark.parametrize("tail", [0, 1])
-@pytest.mark.parametrize("variant", [16, 17])
+@pytest.mark.parametrize("variant", [16, 17, 18])
 @pytest.mark.parametrize("geom", HALO_GEOMS)
 def test_halo_patch_forward_matches_conv2d(geom, variant, tail, conv2d_variant, conv2d_tail):
     """the second-generation 3x3 kernel (halo patch in LDS, staggered wave groups = 16 / one barrier per K step = 17):
@@ -303,8 +303,8 @@ def test_halo_patch_tail_blocks_with_two_channel_tiles(conv2d_variant):
     a tile folded from both kinds of blocks)."""
     from det3d_amd import dense_conv as dc
 
-    conv2d_variant(16)
-    for b, h, w in ((2, 96, 112), (3, 112, 176), (2, 160, 144)):
+    for (b, h, w), variant in zip(((2, 96, 112), (3, 112, 176), (2, 160, 144), (2, 160, 144)), (16, 16, 16, 18)):
+        conv2d_variant(variant)
         g = torch.Generator(device="cuda").manual_seed(b * h)
         x = torch.randn((b, h, w, 128), device="cuda", generator=g)
         wt = torch.randn((256, 128, 3, 3), device="cuda", generator=g) * 0.03
@@ -322,7 +322,7 @@ def test_halo_patch_tail_blocks_with_two_channel_tiles(conv2d_variant):
         assert torch.equal(y, y2) and torch.equal(ws[:512], ws2[:512])
 
 
-@pytest.mark.parametrize("variant", [16, 17])
+@pytest.mark.parametrize("variant", [16, 17, 18])
 def test_halo_patch_kernel_on_the_benched_map_repeats_bit_for_bit(variant, conv2d_variant):
     """[4,200,176,128] -> 128: 572 patches on 256 CUs (several rounds of blocks, every XCD range, partial patches on
     the lower edge), sampled against float64 and repeated: LDS-DMA hand-offs that are only ALMOST ordered show up as
@@ -349,7 +349,7 @@ def test_halo_patch_kernel_on_the_benched_map_repeats_bit_for_bit(variant, conv2
 
 
 @pytest.mark.parametrize("tail", [0, 1])
-@pytest.mark.parametrize("variant", [None, 16, 17])
+@pytest.mark.parametrize("variant", [None, 16, 17, 18])
 @pytest.mark.parametrize("mode", ["bf16", "split"])
 def test_data_gradient_epilogue_reduces_the_previous_batchnorm_backward_sums(mode, variant, tail, conv2d_variant, conv2d_tail):
     """bn_backward: the dgrad launch's rows are dL/dz of the BatchNorm + ReLU in front of the convolution; its epilogue

@@ -47,13 +47,16 @@ def main():
             else:
                 (x_hi, x_lo), (g_hi, g_lo) = dc.split_planes(x), dc.split_planes(gy)
             for v in variants:
-                _lib.lib().d3d_set_tuning(7, v)
-                t = timeit(lambda: dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, mode))
-                ts = timeit(lambda: dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, mode, want_stats=True))
-                tag = mode + "_v%d" % v
-                row[tag + "_fwd_us"] = round(t, 1)
-                row[tag + "_fwd_stats_us"] = round(ts, 1)
-                row[tag + "_fwd_TF"] = round(flop / t / 1e6, 1)
+                for tail in [int(t) for t in os.environ.get("TAILS", "1").split(",")]:
+                    _lib.lib().d3d_set_tuning(7, v)
+                    _lib.lib().d3d_set_tuning(9, tail)
+                    t = timeit(lambda: dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, mode))
+                    ts = timeit(lambda: dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, mode, want_stats=True))
+                    tag = mode + "_v%d" % v + ("" if tail else "_whole")
+                    row[tag + "_fwd_us"] = round(t, 1)
+                    row[tag + "_fwd_stats_us"] = round(ts, 1)
+                    row[tag + "_fwd_TF"] = round(flop / t / 1e6, 1)
+            _lib.lib().d3d_set_tuning(9, 1)
             _lib.lib().d3d_set_tuning(7, variants[0])
             if cin % 128 == 0:
                 for wv in [int(v) for v in os.environ.get("WGRAD_WAVES", "8").split(",")]:
