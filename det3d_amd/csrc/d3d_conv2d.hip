@@ -738,9 +738,15 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
   if (rc) return rc;
   // measured on the [4,200,176,128] map (profiles/round3_conv2d_variants.txt): bf16 62.3 (8) / 70.7 (9) / 66.6 (0) us,
   // split 145.6 (8) / 138.7 (9) / 146.9 (0) us
-  // defaults (profiles/round4_conv2d_variants.txt, [4,200,176,128] -> 128, split): 9 = 157 us, 17 = 138 us, 16 = 131 us
-  // (with the statistics epilogue 173 / 148 / 139); [4,128,128,256] -> 256: 232 / 182 / 174 us
+  // defaults (profiles/round4_conv2d_variants.txt, split).  [4,200,176,128] -> 128 (572 items: the last round is cut
+  // into 32-channel blocks): 9 = 157 us, 17 = 138, 16 = 125, 18 = 117 (with the statistics epilogue 173 / 148 / 145 /
+  // 128); [4,128,128,256] -> 256 (512 items, whole blocks only): 232 / 182 / 169 / 174.  So: 18 where the launch has
+  // short blocks, 16 where it has not.
   int variant = g_c2_variant >= 0 ? g_c2_variant : (split ? (ksz == 3 && stride == 1 ? 16 : 9) : 8);
+  if (g_c2_variant < 0 && variant == 16) {
+    const C2hPlan hp0 = c2h_plan(batch, G.ho, G.wo, cout);
+    if (hp0.q.n_full != hp0.q.n_items) variant = 18;
+  }
   // 16 / 17: the halo-patch kernel (d3d_conv2d_halo.h; 3x3 stride-1 layers in split mode), with / without the staggered
   // wave groups; other layers under these settings take the round-3 default
   const bool halo = (variant >= 16 && variant <= 18) && split && ksz == 3 && stride == 1;  // 18: requests inside the MFMA part

@@ -1060,6 +1060,16 @@ static int sparse_conv_fwd_impl(const void *feat, const void *wpack, const float
   if (cin == 64 && cout == 64 && dtype == D3D_BF16 && (fwd_variant == 0 || fwd_variant >= 50))
     return launch_fwd_group<64, 64, 2, 8, 2>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
   FWD_CASE(64, 64, 2, 8, 3, 1)
+  // the 128-channel layers of the CBGS backbones in f32 (profiles/round4_tune_fwd_wide.txt, 264k-site rulebook):
+  // 128->128 two tiles per wave on 8 waves 610 us against 748 (each weight fragment read from LDS feeds six MFMAs
+  // instead of three: the 16-wave tiling kept the LDS pipe 2/3 busy); 64->128 one tile on 8 waves, depth 2: 294 us
+  // submanifold / 302 us strided against 310 / 337; 128->64 stays (440 us, 0.69 of the roofline)
+  if (dtype == D3D_F32 && !g_f32_wide) {
+    if (cin == 128 && cout == 128)
+      return launch_fwd<128, 128, 2, 8, 1, false>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    if (cin == 64 && cout == 128)
+      return launch_fwd<64, 128, 1, 8, 2, false>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+  }
   FWD_CASE(64, 128, 1, 16, 3, 1)
   FWD_CASE(128, 64, 1, 16, 3, 1)
   FWD_CASE(128, 128, 1, 16, 2, 1)
