@@ -54,6 +54,9 @@ SIGNATURES = {
     "d3d_bn_apply_split": (i32, [vp, i32, i32, vp, vp, vp, vp, f32, f32, i32, i32, vp, i32, vp, vp, vp, vp, vp]),
     "d3d_bn_bwd_dx_split": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
     "d3d_bn_bwd_reduce": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]),
+    "d3d_bn_apply_residual": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, f32, f32, i32, i32, vp, i32, vp, vp, vp, vp]),
+    "d3d_bn_bwd_reduce_residual": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]),
+    "d3d_bn_bwd_dx_residual": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
     "d3d_bn_bwd_dx": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]),
     "d3d_conv2d_supported": (i32, [i32, i32, i32, i32]),
     "d3d_conv2d_stats_ws_floats": (sz, [i32, i32, i32, i32]),
@@ -97,7 +100,7 @@ SIGNATURES = {
     "d3d_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
 }
 
-ABI_VERSION = 6  # include/d3d.h D3D_ABI_VERSION
+ABI_VERSION = 7  # include/d3d.h D3D_ABI_VERSION
 D3D_F32 = 0
 D3D_BF16 = 1
 D3D_CONV_BF16, D3D_CONV_SPLIT = 0, 1
@@ -113,7 +116,7 @@ class D3dError(RuntimeError):
 class ConvEpilogue(ctypes.Structure):
     """D3dConvEpilogue of include/d3d.h (device pointers as integers)"""
     _fields_ = [("stats", vp), ("bn_x", vp), ("bn_mean", vp), ("bn_invstd", vp), ("bn_gamma", vp),
-                ("bn_beta", vp), ("bn_relu", i32), ("bn_partial", vp), ("ws_floats", i32)]
+                ("bn_beta", vp), ("bn_relu", i32), ("bn_partial", vp), ("ws_floats", i32), ("addend", vp)]
 
 
 class DenseBnBackward(ctypes.Structure):

@@ -61,6 +61,11 @@ class SparseBasicBlock(spconv.SparseModule):
         return [self.conv1, self.conv2]
 
     def forward(self, x):
+        from . import sparse_block
+
+        rb = sparse_block.rulebook_of(spconv, self, x)
+        if rb is not None:  # the whole block as one autograd node, residual add + ReLU inside the BatchNorm sweeps
+            return sparse_block.run(spconv, self, x, rb)
         identity = x
         n = x.indices.shape[0]
         if spconv.FUSE_BN_RELU and n != 0 and spconv._fusable_bn(self.bn1, x.features, channels=self.conv1.out_channels):

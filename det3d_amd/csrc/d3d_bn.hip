@@ -176,7 +176,9 @@ __global__ void __launch_bounds__(256)
                     const float *__restrict__ beta, float *running_mean, float *running_var,
                     float momentum, float eps, int training, int relu,
                     const float *__restrict__ stats, int copies, void *__restrict__ y, float *save_mean,
-                    float *save_invstd, void *__restrict__ y_lo) {
+                    float *save_invstd, void *__restrict__ y_lo, const void *__restrict__ res) {
+  // res (optional): a second [n, c] matrix added BEFORE the ReLU -- y = relu(bn(x) + res), the tail of a residual
+  // block (SparseBasicBlock, det3d/models/backbones/scn.py:84-87: out += identity; relu)
   constexpr int EPV = BnVec<BF16>::EPV;
   __shared__ float scale[BN_MAXC], shift[BN_MAXC];
   for (int ch = threadIdx.x; ch < c; ch += 256) {
@@ -222,22 +224,35 @@ __global__ void __launch_bounds__(256)
     float v[4][EPV];
 #pragma unroll
     for (int u = 0; u < 4; ++u) BnVec<BF16>::load(x, (r + u * step) * segs + seg, v[u]);
+    if (res) {
+      float a[4][EPV];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) BnVec<BF16>::load(res, (r + u * step) * segs + seg, a[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) v[u][j] = fmaf(v[u][j], sc[j], sh[j]) + a[u][j];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) v[u][j] = fmaf(v[u][j], sc[j], sh[j]);
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
 #pragma unroll
-      for (int j = 0; j < EPV; ++j) {
-        float z = fmaf(v[u][j], sc[j], sh[j]);
-        v[u][j] = relu ? fmaxf(z, 0.f) : z;
-      }
+      for (int j = 0; j < EPV; ++j) v[u][j] = relu ? fmaxf(v[u][j], 0.f) : v[u][j];
       bn_store<BF16>(y, y_lo, (r + u * step) * segs + seg, v[u]);
     }
   }
   for (; r < n; r += step) {
-    float v[EPV];
+    float v[EPV], a[EPV];
     BnVec<BF16>::load(x, r * segs + seg, v);
+    if (res) BnVec<BF16>::load(res, r * segs + seg, a);
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
       float z = fmaf(v[j], sc[j], sh[j]);
+      if (res) z += a[j];
       v[j] = relu ? fmaxf(z, 0.f) : z;
     }
     bn_store<BF16>(y, y_lo, r * segs + seg, v);
@@ -250,7 +265,9 @@ __global__ void __launch_bounds__(NT)
     bn_bwd_reduce_kernel(const void *__restrict__ x, const void *__restrict__ dy, int n, int c,
                          const float *__restrict__ gamma, const float *__restrict__ beta,
                          const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
-                         float *__restrict__ partial, unsigned *__restrict__ counters, int fold_g) {
+                         float *__restrict__ partial, unsigned *__restrict__ counters, int fold_g,
+                         const void *__restrict__ res) {
+  // res (optional): the matrix that was added in front of the ReLU (bn_apply_kernel): the mask is [z + res > 0]
   constexpr int EPV = BnVec<BF16>::EPV;
   constexpr int UR = U / 2;  // rows in flight: each row is two loads (x, dy)
   __shared__ float rows[NT / 64][2 * BN_MAXC];
@@ -272,34 +289,41 @@ __global__ void __launch_bounds__(NT)
   }
   const int64_t step = (int64_t)gridDim.x * rp;
   int64_t r = (int64_t)blockIdx.x * rp + rl;
-  const uint4 *xv = (const uint4 *)x, *dv = (const uint4 *)dy;
+  const uint4 *xv = (const uint4 *)x, *dv = (const uint4 *)dy, *av = (const uint4 *)res;
   for (; r + (UR - 1) * step < n; r += UR * step) {
-    uint4 rx[UR], rd[UR];
+    uint4 rx[UR], rd[UR], ra[UR];
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
       rx[u] = xv[(r + u * step) * segs + seg];
       rd[u] = dv[(r + u * step) * segs + seg];
+      if (res) ra[u] = av[(r + u * step) * segs + seg];
     }
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
-      float v[EPV], d[EPV];
+      float v[EPV], d[EPV], a[EPV];
       bn_unpack<BF16>(rx[u], v);
       bn_unpack<BF16>(rd[u], d);
+      if (res) bn_unpack<BF16>(ra[u], a);
 #pragma unroll
       for (int j = 0; j < EPV; ++j) {
-        float dz = (relu && fmaf(v[j], zs[j], zb[j]) <= 0.f) ? 0.f : d[j];
+        float z = fmaf(v[j], zs[j], zb[j]);
+        if (res) z += a[j];
+        float dz = (relu && z <= 0.f) ? 0.f : d[j];
         sb[j] += dz;
         sg[j] = fmaf(dz, fmaf(v[j], is[j], mi[j]), sg[j]);
       }
     }
   }
   for (; r < n; r += step) {
-    float v[EPV], d[EPV];
+    float v[EPV], d[EPV], a[EPV];
     bn_unpack<BF16>(xv[r * segs + seg], v);
     bn_unpack<BF16>(dv[r * segs + seg], d);
+    if (res) bn_unpack<BF16>(av[r * segs + seg], a);
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
-      float dz = (relu && fmaf(v[j], zs[j], zb[j]) <= 0.f) ? 0.f : d[j];
+      float z = fmaf(v[j], zs[j], zb[j]);
+      if (res) z += a[j];
+      float dz = (relu && z <= 0.f) ? 0.f : d[j];
       sb[j] += dz;
       sg[j] = fmaf(dz, fmaf(v[j], is[j], mi[j]), sg[j]);
     }
@@ -314,7 +338,9 @@ __global__ void __launch_bounds__(256)
                      const float *__restrict__ gamma, const float *__restrict__ beta,
                      const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
                      const float *__restrict__ partial, int copies, float *__restrict__ dgamma,
-                     float *__restrict__ dbeta, void *__restrict__ dx, void *__restrict__ dx_lo) {
+                     float *__restrict__ dbeta, void *__restrict__ dx, void *__restrict__ dx_lo,
+                     const void *__restrict__ res, void *__restrict__ dres) {
+  // res / dres (optional, together): the matrix added in front of the ReLU and its gradient dz = dy * [z + res > 0]
   constexpr int EPV = BnVec<BF16>::EPV;
   __shared__ float tot[2 * BN_MAXC];
   for (int i = threadIdx.x; i < 2 * c; i += 256) {  // fold the replicated partial sums
@@ -345,37 +371,48 @@ __global__ void __launch_bounds__(256)
   }
   const int64_t step = (int64_t)gridDim.x * rp;
   int64_t r = (int64_t)blockIdx.x * rp + rl;
-  const uint4 *xv = (const uint4 *)x, *dv = (const uint4 *)dy;
+  const uint4 *xv = (const uint4 *)x, *dv = (const uint4 *)dy, *av = (const uint4 *)res;
   for (; r + (UR - 1) * step < n; r += UR * step) {
-    uint4 rx[UR], rd[UR];
+    uint4 rx[UR], rd[UR], ra[UR];
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
       rx[u] = xv[(r + u * step) * segs + seg];
       rd[u] = dv[(r + u * step) * segs + seg];
+      if (res) ra[u] = av[(r + u * step) * segs + seg];
     }
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
-      float v[EPV], d[EPV];
+      float v[EPV], d[EPV], a[EPV];
       bn_unpack<BF16>(rx[u], v);
       bn_unpack<BF16>(rd[u], d);
+      if (res) bn_unpack<BF16>(ra[u], a);
 #pragma unroll
       for (int j = 0; j < EPV; ++j) {
-        float dz = (relu && fmaf(v[j], zs[j], zb[j]) <= 0.f) ? 0.f : d[j];
+        float z = fmaf(v[j], zs[j], zb[j]);
+        if (res) z += a[j];
+        float dz = (relu && z <= 0.f) ? 0.f : d[j];
         v[j] = fmaf(A[j], dz, fmaf(P[j], v[j], Q[j]));
+        d[j] = dz;
       }
       bn_store<BF16>(dx, dx_lo, (r + u * step) * segs + seg, v);
+      if (dres) bn_store<BF16>(dres, nullptr, (r + u * step) * segs + seg, d);
     }
   }
   for (; r < n; r += step) {
-    float v[EPV], d[EPV];
+    float v[EPV], d[EPV], a[EPV];
     bn_unpack<BF16>(xv[r * segs + seg], v);
     bn_unpack<BF16>(dv[r * segs + seg], d);
+    if (res) bn_unpack<BF16>(av[r * segs + seg], a);
 #pragma unroll
     for (int j = 0; j < EPV; ++j) {
-      float dz = (relu && fmaf(v[j], zs[j], zb[j]) <= 0.f) ? 0.f : d[j];
+      float z = fmaf(v[j], zs[j], zb[j]);
+      if (res) z += a[j];
+      float dz = (relu && z <= 0.f) ? 0.f : d[j];
       v[j] = fmaf(A[j], dz, fmaf(P[j], v[j], Q[j]));
+      d[j] = dz;
     }
     bn_store<BF16>(dx, dx_lo, r * segs + seg, v);
+    if (dres) bn_store<BF16>(dres, nullptr, r * segs + seg, d);
   }
 }
 
@@ -494,7 +531,16 @@ extern "C" int d3d_bn_stats(const void *x, int n, int c, int dtype, float *stats
 static int bn_apply_impl(const void *x, int n, int c, int dtype, const float *gamma, const float *beta,
                          float *running_mean, float *running_var, float momentum, float eps, int training,
                          int relu, const float *stats_ws, int copies, void *y, void *y_lo, float *save_mean,
-                         float *save_invstd, d3d_stream_t stream_);
+                         float *save_invstd, d3d_stream_t stream_, const void *res = nullptr);
+// y = relu?(bn(x) + residual): the tail of a residual block in one sweep
+extern "C" int d3d_bn_apply_residual(const void *x, const void *residual, int n, int c, int dtype, const float *gamma,
+                                     const float *beta, float *running_mean, float *running_var, float momentum,
+                                     float eps, int training, int relu, const float *stats_ws, int copies, void *y,
+                                     float *save_mean, float *save_invstd, d3d_stream_t stream_) {
+  D3D_REQUIRE(residual, "d3d_bn_apply_residual: null residual");
+  return bn_apply_impl(x, n, c, dtype, gamma, beta, running_mean, running_var, momentum, eps, training, relu, stats_ws,
+                       copies, y, nullptr, save_mean, save_invstd, stream_, residual);
+}
 extern "C" int d3d_bn_apply(const void *x, int n, int c, int dtype, const float *gamma, const float *beta,
                             float *running_mean, float *running_var, float momentum, float eps, int training,
                             int relu, const float *stats_ws, int copies, void *y, float *save_mean,
@@ -514,7 +560,7 @@ extern "C" int d3d_bn_apply_split(const float *x, int n, int c, const float *gam
 static int bn_apply_impl(const void *x, int n, int c, int dtype, const float *gamma, const float *beta,
                          float *running_mean, float *running_var, float momentum, float eps, int training,
                          int relu, const float *stats_ws, int copies, void *y, void *y_lo, float *save_mean,
-                         float *save_invstd, d3d_stream_t stream_) {
+                         float *save_invstd, d3d_stream_t stream_, const void *res) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = bn_check(n, c, dtype, "d3d_bn_apply");
   if (rc) return rc;
@@ -526,33 +572,55 @@ static int bn_apply_impl(const void *x, int n, int c, int dtype, const float *ga
   if (dtype == D3D_BF16)
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(nb), dim3(256), 0, stream, x, n, c, gamma, beta,
                        running_mean, running_var, momentum, eps, training, relu, stats_ws, copies, y,
-                       save_mean, save_invstd, y_lo);
+                       save_mean, save_invstd, y_lo, res);
   else
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(nb), dim3(256), 0, stream, x, n, c, gamma, beta,
                        running_mean, running_var, momentum, eps, training, relu, stats_ws, copies, y,
-                       save_mean, save_invstd, y_lo);
+                       save_mean, save_invstd, y_lo, res);
   D3D_LAUNCH_TRY("bn_apply_kernel");
   return D3D_OK;
 }
 
-extern "C" int d3d_bn_bwd_reduce(const void *x, const void *dy, int n, int c, int dtype, const float *gamma,
-                                 const float *beta, const float *save_mean, const float *save_invstd, int relu,
-                                 float *partial_ws, d3d_stream_t stream_) {
+static int bn_bwd_reduce_impl(const void *x, const void *res, const void *dy, int n, int c, int dtype,
+                              const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
+                              int relu, float *partial_ws, d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = bn_check(n, c, dtype, "d3d_bn_bwd_reduce");
   if (rc) return rc;
   D3D_REQUIRE(x && dy && save_mean && save_invstd && partial_ws, "d3d_bn_bwd_reduce: null pointer");
   const int nb = bn_grid(n, c, dtype);
   BN_LAUNCH_REDUCE(bn_bwd_reduce_kernel, x, dy, n, c, gamma, beta, save_mean, save_invstd, relu, partial_ws,
-                   counters, fold_g);
+                   counters, fold_g, res);
   D3D_LAUNCH_TRY("bn_bwd_reduce_kernel");
   return D3D_OK;
+}
+extern "C" int d3d_bn_bwd_reduce(const void *x, const void *dy, int n, int c, int dtype, const float *gamma,
+                                 const float *beta, const float *save_mean, const float *save_invstd, int relu,
+                                 float *partial_ws, d3d_stream_t stream_) {
+  return bn_bwd_reduce_impl(x, nullptr, dy, n, c, dtype, gamma, beta, save_mean, save_invstd, relu, partial_ws, stream_);
+}
+// backward of y = relu?(bn(x) + residual): the ReLU mask is [bn(x) + residual > 0]
+extern "C" int d3d_bn_bwd_reduce_residual(const void *x, const void *residual, const void *dy, int n, int c, int dtype,
+                                          const float *gamma, const float *beta, const float *save_mean,
+                                          const float *save_invstd, int relu, float *partial_ws,
+                                          d3d_stream_t stream_) {
+  D3D_REQUIRE(residual, "d3d_bn_bwd_reduce_residual: null residual");
+  return bn_bwd_reduce_impl(x, residual, dy, n, c, dtype, gamma, beta, save_mean, save_invstd, relu, partial_ws, stream_);
 }
 
 static int bn_bwd_dx_impl(const void *x, const void *dy, int n, int c, int dtype, const float *gamma,
                           const float *beta, const float *save_mean, const float *save_invstd, int relu,
                           const float *partial_ws, int copies, void *dx, void *dx_lo, float *dgamma, float *dbeta,
-                          d3d_stream_t stream_);
+                          d3d_stream_t stream_, const void *res = nullptr, void *dres = nullptr);
+// ... and its data gradients: dx as d3d_bn_bwd_dx, dresidual = dy * [bn(x) + residual > 0]
+extern "C" int d3d_bn_bwd_dx_residual(const void *x, const void *residual, const void *dy, int n, int c, int dtype,
+                                      const float *gamma, const float *beta, const float *save_mean,
+                                      const float *save_invstd, int relu, const float *partial_ws, int copies,
+                                      void *dx, void *dresidual, float *dgamma, float *dbeta, d3d_stream_t stream_) {
+  D3D_REQUIRE(residual && dresidual, "d3d_bn_bwd_dx_residual: null residual / dresidual");
+  return bn_bwd_dx_impl(x, dy, n, c, dtype, gamma, beta, save_mean, save_invstd, relu, partial_ws, copies, dx, nullptr,
+                        dgamma, dbeta, stream_, residual, dresidual);
+}
 extern "C" int d3d_bn_bwd_dx(const void *x, const void *dy, int n, int c, int dtype, const float *gamma,
                              const float *beta, const float *save_mean, const float *save_invstd, int relu,
                              const float *partial_ws, int copies, void *dx, float *dgamma, float *dbeta,
@@ -572,7 +640,7 @@ extern "C" int d3d_bn_bwd_dx_split(const float *x, const float *dy, int n, int c
 static int bn_bwd_dx_impl(const void *x, const void *dy, int n, int c, int dtype, const float *gamma,
                           const float *beta, const float *save_mean, const float *save_invstd, int relu,
                           const float *partial_ws, int copies, void *dx, void *dx_lo, float *dgamma, float *dbeta,
-                          d3d_stream_t stream_) {
+                          d3d_stream_t stream_, const void *res, void *dres) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = bn_check(n, c, dtype, "d3d_bn_bwd_dx");
   if (rc) return rc;
@@ -582,7 +650,7 @@ static int bn_bwd_dx_impl(const void *x, const void *dy, int n, int c, int dtype
   const int nb = bn_stream_grid(n, c, dtype);
 #define BN_DX(BF, UR)                                                                                        \
   hipLaunchKernelGGL((bn_bwd_dx_kernel<BF, UR>), dim3(nb), dim3(256), 0, stream, x, dy, n, c, gamma, beta,   \
-                     save_mean, save_invstd, relu, partial_ws, copies, dgamma, dbeta, dx, dx_lo)
+                     save_mean, save_invstd, relu, partial_ws, copies, dgamma, dbeta, dx, dx_lo, res, dres)
   const int ur = g_bn_dx_rows >= 4 ? 4 : (g_bn_dx_rows <= 1 ? 1 : 2);
   if (dtype == D3D_BF16) {
     if (ur == 4) BN_DX(true, 4); else if (ur == 2) BN_DX(true, 2); else BN_DX(true, 1);

@@ -158,6 +158,16 @@ __device__ __forceinline__ void spconv_fwd_epilogue(f32x4_t (&acc)[MT][COUT / 16
         v[2] += bias[co + 2];
         v[3] += bias[co + 3];
       }
+      if (ep.addend) {  // accumulating launch (residual blocks): out = conv + addend
+        if constexpr (BF16) {
+          const uint2 ar = *(const uint2 *)((const uint16_t *)ep.addend + (int64_t)site[m] * COUT + co);
+          v[0] += bf16_to_f32((uint16_t)(ar.x & 0xffffu)); v[1] += bf16_to_f32((uint16_t)(ar.x >> 16));
+          v[2] += bf16_to_f32((uint16_t)(ar.y & 0xffffu)); v[3] += bf16_to_f32((uint16_t)(ar.y >> 16));
+        } else {
+          const float4 ar = *(const float4 *)((const float *)ep.addend + (int64_t)site[m] * COUT + co);
+          v[0] += ar.x; v[1] += ar.y; v[2] += ar.z; v[3] += ar.w;
+        }
+      }
       float w[4];  // the values as stored (rounded to the feature dtype): what the next pass will read
       if constexpr (BF16) {
         uint16_t *o = (uint16_t *)out_ + (int64_t)site[m] * COUT + co;
@@ -952,9 +962,9 @@ static int sparse_conv_fwd_impl(const void *feat, const void *wpack, const float
   D3D_REQUIRE(!(ep.stats && ep.bn_partial), "d3d_sparse_conv_fwd_ex: one reduction per launch (stats or bn_partial)");
   D3D_REQUIRE(!ep.bn_partial || (ep.bn_x && ep.bn_mean && ep.bn_invstd),
               "d3d_sparse_conv_fwd_ex: bn_partial needs bn_x, bn_mean, bn_invstd");
-  D3D_REQUIRE(!(ep.stats || ep.bn_partial) || d3d_sparse_conv_has_epilogue(cin, cout, dtype),
-              "d3d_sparse_conv_fwd_ex: the fused reductions exist on the MFMA tiles only, channels %d -> %d have "
-              "none (ask d3d_sparse_conv_has_epilogue)", cin, cout);
+  D3D_REQUIRE(!(ep.stats || ep.bn_partial || ep.addend) || d3d_sparse_conv_has_epilogue(cin, cout, dtype),
+              "d3d_sparse_conv_fwd_ex: the fused reductions / the addend exist on the MFMA tiles only, channels %d -> %d "
+              "have none (ask d3d_sparse_conv_has_epilogue)", cin, cout);
   D3D_REQUIRE(dtype == D3D_F32 || dtype == D3D_BF16, "d3d_sparse_conv_fwd: dtype %d", dtype);
   D3D_REQUIRE(n_out >= 0 && n_out <= cap && kvol >= 1 && cin >= 1 && cout >= 1,
               "d3d_sparse_conv_fwd: n_out=%d cap=%d kvol=%d cin=%d cout=%d", n_out, cap, kvol, cin,

@@ -1,0 +1,215 @@
+"""SparseBasicBlock (det3d/models/backbones/scn.py:46-89) as ONE autograd node.
+
+    out = relu(bn1(conv1(x)));  out = bn2(conv2(out));  out += identity;  out = relu(out)
+
+The per-layer path ran the residual tail as PyTorch element-wise ops: an add and a clamp in the forward, a
+threshold_backward and the gradient accumulation `d(identity) + d(conv1 input)` in the backward -- 33 adds and 9 clamps
+per nuScenes-CBGS step, 6 % of it (profiles/round3_kernel_stats_c4.txt) -- plus two `gout.sum(0)` reductions per block
+for the conv biases.  Here the block is a plain loop over C-ABI calls inside one `torch.autograd.Function`:
+
+  forward   conv1 (+BN statistics epilogue) -> bn_apply(ReLU) -> conv2 (+statistics) -> bn_apply_residual(x, ReLU)
+  backward  bn_bwd_reduce_residual -> bn_bwd_dx_residual (dx and d(identity) = dy * mask in one sweep)
+            -> conv2 wgrad, conv2 dgrad (+bn1's backward sums in its epilogue) -> bn_bwd_dx -> conv1 wgrad
+            -> conv1 dgrad with D3dConvEpilogue.addend = d(identity): the block's input gradient leaves the kernel
+               already summed over both branches
+
+no element-wise PyTorch kernel, no per-layer autograd bookkeeping.  The gradients of the two conv biases are returned
+as exact zeros: each bias feeds a train-mode BatchNorm, whose batch mean removes it -- dL/db = sum_i dL/d(conv out)_i
+= 0 identically (a BatchNorm's input gradient sums to zero over the batch); what the per-layer path (and the
+reference) compute there is the rounding noise of that sum.
+
+D3D_FUSE_BLOCK=0 keeps the per-layer path; eval mode, cross-rank BatchNorm, a downsample branch and channel counts
+without an MFMA tiling keep it as well.
+"""
+import ctypes
+import os
+
+import torch
+from torch import nn
+
+from . import _lib
+
+FUSE_BLOCK = os.environ.get("D3D_FUSE_BLOCK", "1") != "0"
+
+
+def _plain_bn(bn, c):
+    if type(bn) is not nn.BatchNorm1d or not bn.training or bn.momentum is None or not bn.track_running_stats:
+        return False
+    if bn.weight is None or bn.num_features != c:
+        return False
+    return all(t is None or t.dtype == torch.float32 for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+
+
+def rulebook_of(sp, block, x):
+    """the submanifold rulebook both convs of `block` share, if the block can run fused on `x`; else None"""
+    if not (FUSE_BLOCK and sp.FUSE_BN_RELU and sp.FUSE_BN_STATS) or block.downsample is not None:
+        return None
+    c1, c2 = block.conv1, block.conv2
+    feats = x.features
+    if not (feats.is_cuda and feats.dtype in sp._DT and feats.dim() == 2 and feats.shape[0] > 1):
+        return None
+    c = c1.in_channels
+    if not (c1.subm and c2.subm and c1.out_channels == c and c2.in_channels == c and c2.out_channels == c):
+        return None
+    if c1._rulebook_key() != c2._rulebook_key() or feats.shape[1] != c:
+        return None
+    for conv in (c1, c2):
+        if conv.weight.dtype != torch.float32 or (conv.bias is not None and conv.bias.dtype != torch.float32):
+            return None
+    if not (sp.has_epilogue(c, c, feats.dtype) and _plain_bn(block.bn1, c) and _plain_bn(block.bn2, c)):
+        return None
+    epv = 8 if feats.dtype == torch.bfloat16 else 4
+    if c % epv or 256 % (c // epv):
+        return None
+    rb = x.indice_dict.get(c1._rulebook_key())
+    if rb is None or not rb.subm or rb.n_in != feats.shape[0] or rb.n_out != rb.n_in:
+        return None
+    return rb
+
+
+class _BlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, block, rb, sp, *params):
+        L = _lib.lib()
+        dev, dtype = feats.device, feats.dtype
+        dt = sp._DT[dtype]
+        st = _lib.stream_ptr(dev)
+        conv1, bn1, conv2, bn2 = block.conv1, block.bn1, block.conv2, block.bn2
+        x = feats.contiguous()
+        n, c = rb.n_out, conv1.in_channels
+        sp.check_gather_source(x, "the feature matrix")
+        need_in_grad = ctx.needs_input_grad[0]
+        wp1, wd1 = sp._packed_weights(conv1.weight, rb.kvol, c, c, dtype, True, need_in_grad, c)
+        wp2, wd2 = sp._packed_weights(conv2.weight, rb.kvol, c, c, dtype, True, True, c)
+
+        def conv(src, wpack, bias):
+            out = torch.empty((n, c), dtype=dtype, device=dev)
+            stats = sp.epilogue_ws(dev, n, c)
+            ep = _lib.ConvEpilogue(stats=stats.data_ptr(), ws_floats=stats.numel())
+            b = bias.detach() if bias is not None else None
+            rc = sp._timed("fwd", c, c, n, rb, dev, lambda: L.d3d_sparse_conv_fwd_ex(
+                src.data_ptr(), wpack.data_ptr(), _lib.ptr(b), rb.nbr_out.data_ptr(), rb.cap_out, n, rb.kvol, c, c, dt,
+                out.data_ptr(), ctypes.byref(ep), st))
+            _lib.check(rc, "d3d_sparse_conv_fwd")
+            return out, stats
+
+        out1, stats1 = conv(x, wp1, conv1.bias)
+        y1 = torch.empty_like(out1)
+        save1 = torch.empty((2, c), dtype=torch.float32, device=dev)
+        rc = L.d3d_bn_apply(out1.data_ptr(), n, c, dt, bn1.weight.data_ptr(), _lib.ptr(bn1.bias),
+                            bn1.running_mean.data_ptr(), bn1.running_var.data_ptr(), float(bn1.momentum), float(bn1.eps),
+                            1, 1, stats1.data_ptr(), 1, y1.data_ptr(), save1[0].data_ptr(), save1[1].data_ptr(), st)
+        _lib.check(rc, "d3d_bn_apply")
+        partial1 = sp.epilogue_ws(dev, n, c)  # conv2's dgrad launch reduces bn1's backward sums into this
+        sp.check_gather_source(y1, "the feature matrix")
+        out2, stats2 = conv(y1, wp2, conv2.bias)
+        y = torch.empty_like(out2)
+        save2 = torch.empty((2, c), dtype=torch.float32, device=dev)
+        rc = L.d3d_bn_apply_residual(out2.data_ptr(), x.data_ptr(), n, c, dt, bn2.weight.data_ptr(), _lib.ptr(bn2.bias),
+                                     bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(), float(bn2.momentum),
+                                     float(bn2.eps), 1, 1, stats2.data_ptr(), 1, y.data_ptr(), save2[0].data_ptr(),
+                                     save2[1].data_ptr(), st)
+        _lib.check(rc, "d3d_bn_apply_residual")
+        ctx.block, ctx.rb, ctx.sp = block, rb, sp
+        ctx.rec = (x, out1, y1, out2, save1, save2, wd1, wd2, partial1)
+        ctx.generation = sp.ARENA.generation
+        ctx.dtype = dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        sp, block, rb = ctx.sp, ctx.block, ctx.rb
+        conv1, bn1, conv2, bn2 = block.conv1, block.bn1, block.conv2, block.bn2
+        x, out1, y1, out2, save1, save2, wd1, wd2, partial1 = ctx.rec
+        dtype = ctx.dtype
+        dt = sp._DT[dtype]
+        dev = g.device
+        st = _lib.stream_ptr(dev)
+        n, c = rb.n_out, conv1.in_channels
+        dy = g.contiguous()
+        if dy.dtype != dtype:
+            dy = dy.to(dtype)
+        # ---- relu(bn2(.) + x): the mask needs the residual; d(identity) comes out of the same sweep as dx
+        partial2 = sp.reduce_ws(dev, n, c, dtype)
+        rc = L.d3d_bn_bwd_reduce_residual(out2.data_ptr(), x.data_ptr(), dy.data_ptr(), n, c, dt, bn2.weight.data_ptr(),
+                                          _lib.ptr(bn2.bias), save2[0].data_ptr(), save2[1].data_ptr(), 1,
+                                          partial2.data_ptr(), st)
+        _lib.check(rc, "d3d_bn_bwd_reduce_residual")
+        gout2 = torch.empty_like(out2)
+        dres = torch.empty_like(x)
+        gbn2 = torch.empty((2, c), dtype=torch.float32, device=dev)
+        rc = L.d3d_bn_bwd_dx_residual(out2.data_ptr(), x.data_ptr(), dy.data_ptr(), n, c, dt, bn2.weight.data_ptr(),
+                                      _lib.ptr(bn2.bias), save2[0].data_ptr(), save2[1].data_ptr(), 1,
+                                      partial2.data_ptr(), 1, gout2.data_ptr(), dres.data_ptr(), gbn2[0].data_ptr(),
+                                      gbn2[1].data_ptr(), st)
+        _lib.check(rc, "d3d_bn_bwd_dx_residual")
+        sp.check_gather_source(gout2, "the output gradient")
+
+        def wgrad(src, gout):
+            gw = torch.empty((rb.kvol, c, c), dtype=torch.float32, device=dev)
+            wsb = L.d3d_sparse_conv_wgrad_workspace_bytes(n, rb.kvol, c, c, dt)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+            rc = sp._timed("wgrad", c, c, n, rb, dev, lambda: L.d3d_sparse_conv_wgrad(
+                src.data_ptr(), gout.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, n, rb.kvol, c, c, dt, gw.data_ptr(),
+                ws.data_ptr(), wsb, st))
+            _lib.check(rc, "d3d_sparse_conv_wgrad")
+            return gw
+
+        # ---- conv2: data gradient (reducing bn1's backward sums while the arena slice is still this pass's), weights
+        gy1 = torch.empty((n, c), dtype=dtype, device=dev)
+        fused = sp.ARENA.generation == ctx.generation
+        ep = None
+        if fused:
+            ep = _lib.ConvEpilogue(bn_x=out1.data_ptr(), bn_mean=save1[0].data_ptr(), bn_invstd=save1[1].data_ptr(),
+                                   bn_gamma=bn1.weight.data_ptr(), bn_beta=_lib.ptr(bn1.bias), bn_relu=1,
+                                   bn_partial=partial1.data_ptr(), ws_floats=partial1.numel())
+        sp.launch_dgrad(rb, gout2, wd2, c, c, gy1, ep, st)
+        gw2 = wgrad(y1, gout2)
+        if not fused:
+            partial1 = sp.reduce_ws(dev, n, c, dtype)
+            rc = L.d3d_bn_bwd_reduce(out1.data_ptr(), gy1.data_ptr(), n, c, dt, bn1.weight.data_ptr(), _lib.ptr(bn1.bias),
+                                     save1[0].data_ptr(), save1[1].data_ptr(), 1, partial1.data_ptr(), st)
+            _lib.check(rc, "d3d_bn_bwd_reduce")
+        gout1 = torch.empty_like(out1)
+        gbn1 = torch.empty((2, c), dtype=torch.float32, device=dev)
+        rc = L.d3d_bn_bwd_dx(out1.data_ptr(), gy1.data_ptr(), n, c, dt, bn1.weight.data_ptr(), _lib.ptr(bn1.bias),
+                             save1[0].data_ptr(), save1[1].data_ptr(), 1, partial1.data_ptr(), 1, gout1.data_ptr(),
+                             gbn1[0].data_ptr(), gbn1[1].data_ptr(), st)
+        _lib.check(rc, "d3d_bn_bwd_dx")
+        sp.check_gather_source(gout1, "the output gradient")
+        gw1 = wgrad(x, gout1)
+        gin = None
+        if ctx.needs_input_grad[0]:
+            gin = torch.empty((n, c), dtype=dtype, device=dev)
+            ep = _lib.ConvEpilogue(addend=dres.data_ptr())  # + the gradient that arrived through the identity branch
+            sp.launch_dgrad(rb, gout1, wd1, c, c, gin, ep, st)
+        zero = lambda p: torch.zeros_like(p)  # the batch mean removes a bias in front of a train-mode BatchNorm
+        grads = []
+        for conv, bn, gw, gbn in ((conv1, bn1, gw1, gbn1), (conv2, bn2, gw2, gbn2)):
+            grads.append(gw.reshape(conv.weight.shape))
+            if conv.bias is not None:
+                grads.append(zero(conv.bias))
+            grads.append(gbn[0])
+            if bn.bias is not None:
+                grads.append(gbn[1])
+        return (gin, None, None, None) + tuple(grads)
+
+
+def _params(block):
+    out = []
+    for conv, bn in ((block.conv1, block.bn1), (block.conv2, block.bn2)):
+        out.append(conv.weight)
+        if conv.bias is not None:
+            out.append(conv.bias)
+        out.append(bn.weight)
+        if bn.bias is not None:
+            out.append(bn.bias)
+    return out
+
+
+def run(sp, block, x, rb):
+    feats = _BlockFn.apply(x.features, block, rb, sp, *_params(block))
+    out = sp.SparseConvTensor(feats, x.indices, x.spatial_shape, x.batch_size, x.grid)
+    out.indice_dict = x.indice_dict
+    return out

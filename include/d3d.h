@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 6 /* 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv; 5: planned strided data gradient, d3d_adam_step; 6: deterministic PillarFeatureNet sums (workspace arguments) */
+#define D3D_ABI_VERSION 7 /* 7: residual forms of the BatchNorm sweeps, D3dConvEpilogue.addend; 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv; 5: planned strided data gradient, d3d_adam_step; 6: deterministic PillarFeatureNet sums (workspace arguments) */
 
 #define D3D_OK 0
 #define D3D_EINVAL -1    /* bad argument / unsupported shape           */
@@ -158,6 +158,10 @@ typedef struct D3dConvEpilogue {
   int bn_relu;
   float *bn_partial;
   int ws_floats; /* capacity of the stats / bn_partial buffer in floats */
+  /* ABI 7: a [n_out, cout] matrix of the feature dtype added to the rows before they are stored (and before any of the
+   * reductions above sees them) -- the accumulating data gradient of a residual block: gin = dgrad(gout) + addend,
+   * where addend is the gradient that reached the block's input through the identity branch (scn.py:84-87) */
+  const void *addend;
 } D3dConvEpilogue;
 int d3d_sparse_conv_has_epilogue(int cin, int cout, int dtype);
 size_t d3d_conv_epilogue_ws_floats(int n_out, int cout);
@@ -272,6 +276,21 @@ int d3d_bn_bwd_reduce(const void *x, const void *dy, int n, int c, int dtype, co
 int d3d_bn_bwd_dx(const void *x, const void *dy, int n, int c, int dtype, const float *gamma, const float *beta,
                   const float *save_mean, const float *save_invstd, int relu, const float *partial_ws, int copies,
                   void *dx, float *dgamma, float *dbeta, d3d_stream_t stream);
+/* Residual forms (ABI 7; SparseBasicBlock, det3d/models/backbones/scn.py:46-89: out = relu(bn2(conv2(.)) + identity)):
+ *  y = relu?(bn(x) + residual) in one sweep; in the backward the ReLU mask is [bn(x) + residual > 0], and
+ *  d3d_bn_bwd_dx_residual also writes dresidual = dy * mask (the gradient of the identity branch).  residual /
+ *  dresidual: dev [n, c] of `dtype`; everything else as in d3d_bn_apply / d3d_bn_bwd_reduce / d3d_bn_bwd_dx. */
+int d3d_bn_apply_residual(const void *x, const void *residual, int n, int c, int dtype, const float *gamma,
+                          const float *beta, float *running_mean, float *running_var, float momentum, float eps,
+                          int training, int relu, const float *stats_ws, int copies, void *y, float *save_mean,
+                          float *save_invstd, d3d_stream_t stream);
+int d3d_bn_bwd_reduce_residual(const void *x, const void *residual, const void *dy, int n, int c, int dtype,
+                               const float *gamma, const float *beta, const float *save_mean,
+                               const float *save_invstd, int relu, float *partial_ws, d3d_stream_t stream);
+int d3d_bn_bwd_dx_residual(const void *x, const void *residual, const void *dy, int n, int c, int dtype,
+                           const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
+                           int relu, const float *partial_ws, int copies, void *dx, void *dresidual, float *dgamma,
+                           float *dbeta, d3d_stream_t stream);
 /* The same two sweeps on f32 rows with the result in the split format of the dense conv kernels (two bf16 planes
  * hi = bf16(v), lo = bf16(v - hi); d3d_conv2d_nhwc_fwd, D3D_CONV_SPLIT): the BatchNorm2d + ReLU between two RPN
  * convolutions writes the next convolution's operand directly (rpn.py:124-142). */

@@ -245,6 +245,65 @@ def test_resnet_fhd_backbone_runs_and_is_self_consistent():
     assert worst[0][0] > 0.99, worst[:5]
 
 
+@pytest.mark.parametrize("channels", [16, 64, 128])
+def test_fused_basic_block_equals_the_per_layer_block(channels):
+    """sparse_block._BlockFn (SparseBasicBlock as one autograd node: residual add + ReLU inside the BatchNorm sweeps,
+    d(identity) out of bn_bwd_dx_residual, conv1's data gradient accumulating it through D3dConvEpilogue.addend)
+    against the per-layer path (the same kernels with PyTorch's add / clamp / gradient accumulation in between),
+    f32: the forward bit for bit, running statistics bit for bit, every gradient to rounding (the backward's ReLU mask
+    is recomputed from the pre-activation in one, read from the output in the other), two identical runs bit-equal."""
+    import copy
+
+    from det3d_amd import sparse_block, spconv
+    from det3d_amd.backbones import SparseBasicBlock
+
+    torch.manual_seed(channels)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(1)
+    cells = np.unique(rng.integers(0, [2, 12, 40, 40], size=(9000, 4)), axis=0).astype(np.int32)
+    idx = torch.from_numpy(cells).to(dev)
+    blk = SparseBasicBlock(channels, channels, indice_key="res").to(dev).train()
+    with torch.no_grad():
+        for bn in (blk.bn1, blk.bn2):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.3)
+    ref = copy.deepcopy(blk)
+    twin = copy.deepcopy(blk)
+    feats0 = torch.randn((len(cells), channels), device=dev)
+    w = torch.randn((len(cells), channels), device=dev)
+
+    def run(m, fused):
+        prev = sparse_block.FUSE_BLOCK
+        sparse_block.FUSE_BLOCK = fused
+        try:
+            f = feats0.clone().requires_grad_(True)
+            x = spconv.SparseConvTensor(f, idx, [12, 40, 40], 2)
+            spconv.SparseSequential(m).plan(x)
+            spconv.ARENA.reset(dev)
+            y = m(x).features
+            (y * w).sum().backward()
+            return y.detach(), f.grad, {k: p.grad.clone() for k, p in m.named_parameters()}
+        finally:
+            sparse_block.FUSE_BLOCK = prev
+
+    ya, ga, pa = run(blk, True)
+    yb, gb, pb = run(ref, False)
+    yc, gc, pc = run(twin, True)
+    assert torch.equal(ya, yc) and torch.equal(ga, gc) and all(torch.equal(pa[k], pc[k]) for k in pa)
+    assert torch.equal(ya, yb)
+    for k in ("running_mean", "running_var"):
+        assert torch.equal(getattr(blk.bn1, k), getattr(ref.bn1, k)) and torch.equal(getattr(blk.bn2, k), getattr(ref.bn2, k))
+    rel = lambda a, b: float((a - b).norm()) / (float(b.norm()) + 1e-30)
+    assert rel(ga, gb) < 1e-5, rel(ga, gb)
+    gmax = max(float(v.abs().max()) for v in pb.values())
+    for k in pa:
+        if k.endswith("conv1.bias") or k.endswith("conv2.bias"):
+            # exactly zero here, summation noise there: the batch mean of the BatchNorm behind it removes the bias
+            assert float(pa[k].abs().max()) == 0.0 and float(pb[k].abs().max()) < 1e-3 * gmax, k
+        else:
+            assert rel(pa[k], pb[k]) < 1e-5, (k, rel(pa[k], pb[k]))
+
+
 def _nusc_example(cfg, batch, n_points, seed, dev):
     """voxelized synthetic nuScenes-like cloud + device-assigned targets for every task group of `cfg`."""
     from det3d_amd import synthetic
