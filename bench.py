@@ -509,20 +509,20 @@ def roofline_object(groups, key, dtype):
 def attach_pmc_traffic(roof, wl):
     """HBM traffic needs PMC passes (rocprofv3 --pmc cannot run inside this process): take the committed
     measurement (tools/pmc_spconv.sh) only if it was taken on THIS kernel source and workload."""
-    path = os.path.join(ROOT, "profiles", "round3_pmc_spconv.json")
+    path = os.path.join(ROOT, "profiles", "round4_pmc_spconv.json")
     src = os.path.join(ROOT, "det3d_amd", "csrc", "d3d_spconv.hip")
     try:
         pmc = json.load(open(path))
         sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
         w = pmc["workload"]
         if pmc.get("kernel_source_sha16") != sha:
-            roof["traffic_source"] = "profiles/round3_pmc_spconv.json is stale (kernel source changed): not used"
+            roof["traffic_source"] = "profiles/round4_pmc_spconv.json is stale (kernel source changed): not used"
             return
         if (w["name"], w["frames_per_gpu"], w["points_per_frame"], w["dtype"]) != (wl.name, wl.batch, wl.points, wl.dtype):
             return
         roof["traffic"] = pmc["traffic_bytes_per_launch"]
         roof["traffic_measured_in_run"] = False
-        roof["traffic_source"] = "profiles/round3_pmc_spconv.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " \
+        roof["traffic_source"] = "profiles/round4_pmc_spconv.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " \
                                  "tools/pmc_spconv.sh; kernel source sha %s)" % sha
         if roof.get("avg_launch_us"):
             roof["hbm_frac_true"] = round(pmc["traffic_bytes_per_launch"] / (roof["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)

@@ -9,6 +9,7 @@
 #   multirank        VERDICT r3 item 1: torchrun x2 over gloo on the one GPU (c2 / c3 / c4), 1-rank RCCL bench, and the
 #                    per-rank host budget (taskset to cores/8)
 #   prof[:<workload>]  rocprofv3 --kernel-trace --stats of the bench step -> kernel + gap tables
+#   pmc              separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES) -> <tag>/pmc/round4_pmc_*
 #   wl:<workload>    bench.py --workload c4|c5|c3|c2-60k, no extras
 #   conv2d           tools/bench_conv2d.py (dense conv kernel variants)
 #   py:<script> ...  python <script> (rest of the line), log to <tag>/<script>.log
@@ -115,6 +116,8 @@ PY
       env $R1 MASTER_PORT=$(port) D3D_DIST_NOCOLL=1 bash tools/profile_step.sh $O/kernel_stats_nocoll.txt > $O/prof_nocoll.log 2>&1
       bash tools/profile_step.sh $O/kernel_stats_plain.txt > $O/prof_plain.log 2>&1
       head -5 $O/kernel_stats_nocoll.txt | cut -c1-200 ;;
+    pmc)
+      bash tools/pmc_spconv.sh $O/pmc > $O/pmc.log 2>&1; tail -30 $O/pmc.log | cut -c1-200 ;;
     wl:*)
       w=${st#wl:}
       timeout 600 python bench.py --gpus 1 --steps 10 --warmup 3 --burn-in 0.5 --workload $w --no-cpu-baseline --no-extras > $O/wl_$w.json 2> $O/wl_$w.err; echo "workload $w rc=$?"
