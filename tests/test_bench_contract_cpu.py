@@ -35,7 +35,8 @@ def test_driver_flags_parse(monkeypatch):
     assert a.gpus == 1 and a.steps >= 10 and a.warmup >= 1 and not a.no_gc_freeze
 
 
-@pytest.mark.parametrize("name", ["round1_bench_v5.json", "round2_bench_final.json", "round3_bench_driver_flags.json"])
+@pytest.mark.parametrize("name", ["round1_bench_v5.json", "round2_bench_final.json", "round3_bench_driver_flags.json",
+                                  "round4_bench_driver_flags.json"])
 def test_recorded_bench_line_has_the_contract_fields(name):
     d = json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -49,6 +50,19 @@ def test_recorded_bench_line_has_the_contract_fields(name):
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["value"] - d["config"]["frames_per_gpu"] * d["n_gpus"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-2
+    if name.startswith("round4"):
+        import math
+
+        # round 4: the dense 3x3 layers on the halo-patch / three-taps kernels, distinct clouds for four batches, the
+        # first loss next to the final one, >= 5 timed CPU steps at the best thread count
+        assert d["dtype"].startswith("f32") and d["precision"]["fp32_within_tolerance"] is True and d["value"] > 540
+        c = d["config"]
+        assert math.isfinite(c["first_loss"]) and c["final_loss"] < c["first_loss"] and c["steps_before_final_loss"] >= 25
+        assert d["rpn_mfma"]["frac"] > 0.38 and d["rpn_mfma"]["gflop_per_step_left_on_miopen"] == 0.0
+        best = d["cpu_baseline"]["runs"][str(d["cpu_baseline"]["cores"])]
+        assert best["steps"] >= 5
+        for w in ("c2-60k", "c4", "c5", "c3"):
+            assert d["workloads"][w]["value"] > 0 and d["workloads"][w]["final_loss"] < d["workloads"][w]["first_loss"]
     if name.startswith("round3"):
         import math
 

@@ -494,6 +494,9 @@ def test_detector_matches_reference_detector_golden_fp32(name):
               name, dev_hip["norm"], norm_hip, dev_hip["element"], dev_hip["one_minus_cos"], dev_o32["norm"],
               dev_o32["element"], dev_o32["one_minus_cos"], norm_hip / dev_o32["norm"],
               dev_hip["element"] / dev_o32["element"], dev_hip["one_minus_cos"] / dev_o32["one_minus_cos"]))
+    # measured (profiles/round4_tests_figures.txt): HIP / f32-oracle ratios of the norm deviation 43 (KITTI SECOND: the
+    # oracle's own 1.6e-4 is the smallest), 10, 4.6, 8.6; of the element deviation 26, 5.2, 4.7, 1.8; of 1 - cos 502,
+    # 54, 56, 11 -- against the allowance of 2^7 (2^14 for 1 - cos)
     K = 2.0 ** 7  # ratio of the unit roundoffs of the two product formats, see above
     assert norm_hip <= K * dev_o32["norm"] and dev_hip["element"] <= K * dev_o32["element"]
     assert dev_hip["one_minus_cos"] <= K * K * dev_o32["one_minus_cos"]  # 1 - cos is quadratic in the relative error
