@@ -138,9 +138,11 @@ def _head_conv_ok(x, convs):
             return False
     elif x.dtype != torch.bfloat16:
         return False
-    if x.shape[1] == 1 or not x.is_contiguous(memory_format=torch.channels_last):
+    if x.shape[1] == 1 or not x.is_contiguous(memory_format=torch.channels_last) or x.data_ptr() % 16:
         return False
     for c in convs:
+        if c.weight.data_ptr() % 16:  # the kernels stage weights and rows with 16-byte loads
+            return False
         if type(c) is not nn.Conv2d or c.kernel_size != (1, 1) or c.stride != (1, 1) or c.padding != (0, 0) or \
                 c.groups != 1 or c.weight.dtype != torch.float32 or (c.bias is not None and c.bias.dtype != torch.float32):
             return False
@@ -204,7 +206,10 @@ class _HeadConvFn(torch.autograd.Function):
         ws = torch.empty((nws,), dtype=torch.float32, device=dev)
         rc = L.d3d_head_conv_wgrad(x.data_ptr(), garr, narr, count, m, cin, dt, ws.data_ptr(), nws, st)
         _lib.check(rc, "d3d_head_conv_wgrad")
-        dw, db = ws[: 32 * cin].view(32, cin), ws[32 * cin: 32 * cin + 32]
+        # the result in a tensor of its own: views into `ws` would keep the whole slab workspace (~8 MB) alive as
+        # p.grad and alias every head parameter's gradient to one buffer
+        res = ws[: 33 * cin + 32].clone() if nws > 33 * cin + 32 else ws
+        dw, db = res[: 32 * cin].view(32, cin), res[32 * cin: 32 * cin + 32]
         grads, first = [], 0
         for k in range(count):
             grads.append(dw[first: first + n[k]].reshape(n[k], cin, 1, 1))

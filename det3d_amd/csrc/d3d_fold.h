@@ -22,6 +22,13 @@
 #pragma once
 #include "d3d_common.h"
 
+// The slab hand-off below (write-through stores + vmcnt(0) + relaxed ticket, no release fence) relies on gfx942 / gfx950
+// behaviour: sc1 stores leave the XCD's L2 before the counter increment is visible.  Any other target must use the
+// release / acquire form of cdna_hip_programming.md 6 Guideline 16.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "d3d_fold.h: the fence-free slab hand-off is only valid on gfx942 / gfx950"
+#endif
+
 #define D3D_FOLD_MAX_BLOCKS 8192
 
 struct D3dFoldPlan {

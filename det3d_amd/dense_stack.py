@@ -86,6 +86,8 @@ def collect(mods, i, x):
     layers = []
     c = x.shape[1]
     training = None
+    L = _lib.lib()
+    bsz, hh, ww = int(x.shape[0]), int(x.shape[2]), int(x.shape[3])  # the map entering the next layer
     while i < len(mods):
         j, extra = i, 0
         if type(mods[j]) is nn.ZeroPad2d:
@@ -103,6 +105,14 @@ def collect(mods, i, x):
             training = bn.training
         if bn.training != training:
             break
+        # what the kernels would refuse later must end the run HERE (the caller then takes the module path): an
+        # output map of 2 GB or more, or more pixel tiles than the statistics fold handles
+        ho, wo = hh + 2 * pad - conv.kernel_size[0] + 1, ww + 2 * pad - conv.kernel_size[1] + 1
+        if ho < 1 or wo < 1 or bsz * ho * wo * conv.out_channels * 2 >= (1 << 31) - 16:
+            break
+        if L.d3d_conv2d_stats_ws_floats(bsz, ho, wo, conv.out_channels) == 0:
+            break
+        hh, ww = ho, wo
         relu = j + 2 < len(mods) and type(mods[j + 2]) is nn.ReLU
         layers.append(_Layer(conv, bn, relu, pad))
         c = conv.out_channels

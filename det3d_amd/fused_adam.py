@@ -86,6 +86,7 @@ class FusedAdam:
             if p.data_ptr() != self._table_ptrs[i]:   # storage replaced (.to(), load through .data =): re-point the table
                 self._upload_table()
         self.step_count += 1
+        self.last_lr, self.last_beta1 = float(lr), float(beta1)  # what state_dict() reports in its param_group
         hp = _lib.AdamHyper(lr=lr, beta1=beta1, beta2=self.beta2, eps=self.eps, decay=decay,
                             max_norm=float(max_norm) if max_norm is not None else 0.0, grad_scale=grad_scale,
                             step=self.step_count)
@@ -97,7 +98,7 @@ class FusedAdam:
         # `_version` -- the packed-weight caches of the conv layers, autograd's saved-tensor checks -- keeps serving
         # the values of the previous step
         torch.autograd.graph.increment_version(self.params)
-        return self._norm[0]
+        return self._norm[0].clone()  # (`_norm` is rewritten by the next step: hand out a value, not a view of it)
 
     # ---- torch.optim.Adam's checkpoint layout
     def state_dict(self):
@@ -106,7 +107,7 @@ class FusedAdam:
             for i, (m, v) in enumerate(zip(self._m, self._v)):
                 state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=m.clone().view(self.params[i].shape),
                                 exp_avg_sq=v.clone().view(self.params[i].shape))
-        group = dict(lr=0.0, betas=(0.9, self.beta2), eps=self.eps, weight_decay=0.0, amsgrad=False, maximize=False,
+        group = dict(lr=getattr(self, "last_lr", 0.0), betas=(getattr(self, "last_beta1", 0.9), self.beta2), eps=self.eps, weight_decay=0.0, amsgrad=False, maximize=False,
                      foreach=None, capturable=False, differentiable=False, fused=True, decoupled_weight_decay=False,
                      params=list(range(len(self.params))))
         return dict(state=state, param_groups=[group])
