@@ -141,10 +141,10 @@ def _head_conv_ok(x, convs):
     if x.shape[1] == 1 or not x.is_contiguous(memory_format=torch.channels_last) or x.data_ptr() % 16:
         return False
     for c in convs:
-        if c.weight.data_ptr() % 16:  # the kernels stage weights and rows with 16-byte loads
-            return False
         if type(c) is not nn.Conv2d or c.kernel_size != (1, 1) or c.stride != (1, 1) or c.padding != (0, 0) or \
                 c.groups != 1 or c.weight.dtype != torch.float32 or (c.bias is not None and c.bias.dtype != torch.float32):
+            return False
+        if c.weight.data_ptr() % 16:  # the kernels stage weights and rows with 16-byte loads
             return False
     from . import _lib
 
