@@ -839,6 +839,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the det3d_amd hot path has no CPU fallback")
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
+    # the geometry stream first: which hardware queue a stream lands on depends on what was created before it
+    # (det3d_amd/prefetch.reserve_stream; D.init_dist has already done this when there is a process group)
+    from det3d_amd import prefetch as _prefetch
+
+    _prefetch.reserve_stream(dev)
     # MIOpen immediate mode for the dense RPN convs.  Find mode (D3D_MIOPEN_FIND=1, torch.backends.cudnn.benchmark)
     # ranks its candidate solvers by ONE timing each, so what it settles on differs from run to run: 16 find-mode
     # runs of this step landed between 558 and 749 frames/s (mean 657; the slow ones picked the assembly igemm

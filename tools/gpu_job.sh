@@ -110,6 +110,25 @@ for f in sorted(glob.glob(os.path.join(O, "p_*.json")), key=os.path.getmtime):
         print("%-26s FAILED" % os.path.basename(f))
 PY
       ;;
+    graphab)
+      # hipGraph tail (neck + head + loss) against the eager tail, both precisions (profiles/round4_graph_ab.txt)
+      B="--steps 40 --warmup 3 --no-cpu-baseline --no-extras"
+      for dt in fp32 bf16; do for g in 0 1; do
+        D3D_GRAPH_TAIL=$g timeout 300 python bench.py --gpus 1 $B --dtype $dt > $O/g_${dt}_$g.json 2> $O/g_${dt}_$g.err
+      done; done
+      python - "$O" <<'PY' | tee $O/graph_ab.txt
+import json, sys, os
+O = sys.argv[1]
+for dt in ("fp32", "bf16"):
+    for g in (0, 1):
+        try:
+            d = json.loads([l for l in open(os.path.join(O, "g_%s_%d.json" % (dt, g))) if l.startswith("{")][-1])
+            print("%-5s graph_tail=%d (captured %s) %8.1f frames/s %7.3f ms/step  host %s" % (
+                dt, g, d["config"]["graphed_tail"], d["value"], d["ms_per_step"], d["config"]["host_ms_per_step"]))
+        except Exception as e:
+            print(dt, g, "FAILED", e)
+PY
+      ;;
     mrprof)
       export D3D_PROFILE_TIMELINE=1
       R1="D3D_DIST_SINGLE=1 D3D_DIST_BACKEND=nccl RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1"
