@@ -624,6 +624,7 @@ def rpn_mfma_probe(wl, dev, dtype):
                 c, h, w = m.out_channels, ho, wo
         return (b, c, h, w)
 
+    mode = "bf16" if dtype == "bf16" else "split"
     neck = wl.model.neck
     if "s" in neck_in and hasattr(neck, "blocks"):
         cur = neck_in["s"]
@@ -632,8 +633,6 @@ def rpn_mfma_probe(wl, dev, dtype):
             j = i - neck._upsample_start_idx
             if j >= 0:
                 walk(neck.deblocks[j], cur)
-    mode = "bf16" if dtype == "bf16" else "split"
-
     def ev_time(fn, reps=5):
         for _ in range(2):
             fn()
@@ -657,9 +656,9 @@ def rpn_mfma_probe(wl, dev, dtype):
             flops = 2.0 * ishape[0] * ishape[1] * oshape[1] * kk * ishape[2] * ishape[3]
         else:
             flops = 2.0 * oshape[0] * oshape[1] * ishape[1] * kk * oshape[2] * oshape[3]
-        pad = dense_stack._conv_ok(m, 0) if isinstance(m, nn.Conv2d) else None
+        pad = dense_stack._conv_ok(m, 0, mode == "split") if isinstance(m, nn.Conv2d) else None
         if pad is None and isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.padding == (0, 0):
-            pad = dense_stack._conv_ok(m, 1)  # the stage's first conv sits behind a ZeroPad2d(1): folded into padding
+            pad = dense_stack._conv_ok(m, 1, mode == "split")  # behind a ZeroPad2d(1): folded into the padding
             if pad is not None:
                 ishape = (ishape[0], ishape[1], ishape[2] - 2, ishape[3] - 2)
         if pad is None:

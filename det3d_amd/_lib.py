@@ -59,6 +59,7 @@ SIGNATURES = {
     "d3d_bn_bwd_dx_residual": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
     "d3d_bn_bwd_dx": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]),
     "d3d_conv2d_supported": (i32, [i32, i32, i32, i32]),
+    "d3d_conv2d_supported_split3x3": (i32, [i32, i32]),
     "d3d_conv2d_stats_ws_floats": (sz, [i32, i32, i32, i32]),
     "d3d_conv2d_nhwc_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
     "d3d_conv2d_pack_weights": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp]),

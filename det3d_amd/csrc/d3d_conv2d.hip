@@ -662,7 +662,9 @@ static int c2_check(const char *who, int batch, int h, int w, int cin, int cout,
   D3D_REQUIRE(mode == D3D_CONV_BF16 || mode == D3D_CONV_SPLIT, "%s: mode %d", who, mode);
   D3D_REQUIRE(batch >= 1 && h >= 1 && w >= 1, "%s: map %d x %d x %d", who, batch, h, w);
   D3D_REQUIRE(cin == 64 || cin == 128 || cin == 256, "%s: cin=%d (64, 128, 256)", who, cin);
-  D3D_REQUIRE(cout >= 128 && cout % 128 == 0, "%s: cout=%d (multiples of 128)", who, cout);
+  // (64 output channels: the 3x3 stride-1 layers in split mode only -- conv2d_halo_kernel's 64-channel block shape)
+  D3D_REQUIRE((cout >= 128 && cout % 128 == 0) || (cout == 64 && ksz == 3 && stride == 1 && mode == D3D_CONV_SPLIT),
+              "%s: cout=%d (multiples of 128; 64 for split 3x3 stride-1 layers)", who, cout);
   D3D_REQUIRE(ksz >= 1 && ksz <= 3 && stride >= 1 && stride <= 2 && pad >= 0 && pad < ksz,
               "%s: kernel %d stride %d pad %d", who, ksz, stride, pad);
   D3D_REQUIRE((int64_t)batch * h * w * cin * 2 < (int64_t)D3D_RSRC_BYTES, "%s: the input map exceeds 2 GB", who);
@@ -672,6 +674,10 @@ static int c2_check(const char *who, int batch, int h, int w, int cin, int cout,
 extern "C" int d3d_conv2d_supported(int cin, int cout, int ksz, int stride) {
   return (cin == 64 || cin == 128 || cin == 256) && cout >= 128 && cout % 128 == 0 && ksz >= 1 && ksz <= 3 &&
          (stride == 1 || stride == 2);
+}
+// 3x3 stride-1 layers in split mode also come with 64 output channels (conv2d_halo_kernel; forward and data gradient)
+extern "C" int d3d_conv2d_supported_split3x3(int cin, int cout) {
+  return (cin == 64 || cin == 128 || cin == 256) && (cout == 64 || (cout >= 128 && cout % 128 == 0));
 }
 
 // conv2d_halo_kernel's grid (d3d_conv2d_halo.h): items = 16 x 16 patches x 128-channel tiles; the items past the last
@@ -687,19 +693,26 @@ static C2hPlan c2h_plan(int batch, int ho, int wo, int cout) {
   C2hPlan p;
   p.q.tiles_x = (wo + 15) / 16;
   p.q.tiles_y = (ho + 15) / 16;
-  p.q.ctiles = cout / 128;
+  p.q.ct_full = cout % 128 == 0 ? 128 : 64;
+  p.q.cut = p.q.ct_full / 32;
+  p.q.ctiles = cout / p.q.ct_full;
   p.q.n_items = batch * p.q.tiles_x * p.q.tiles_y * p.q.ctiles;
   const int rem = p.q.n_items % 256;
   const bool cut = g_c2_tail && rem > 0 && rem <= 128;
   p.q.n_full = cut ? p.q.n_items - rem : p.q.n_items;
-  p.blocks = p.q.n_full + 4 * (p.q.n_items - p.q.n_full);
+  p.blocks = p.q.n_full + p.q.cut * (p.q.n_items - p.q.n_full);
   const int rem_items = p.q.n_items - p.q.n_full;
-  p.fold_nb = p.q.n_full / p.q.ctiles + 4 * ((rem_items + p.q.ctiles - 1) / p.q.ctiles);
+  p.fold_nb = p.q.n_full / p.q.ctiles + p.q.cut * ((rem_items + p.q.ctiles - 1) / p.q.ctiles);
   return p;
 }
 
 extern "C" size_t d3d_conv2d_stats_ws_floats(int batch, int ho, int wo, int cout) {
   const int64_t m = (int64_t)batch * ho * wo;
+  if (m >= 1 && cout == 64) {  // 64-channel layers: the halo-patch kernel only (one 64-channel tile, 128-wide slabs)
+    const C2hPlan hp = c2h_plan(batch, ho, wo, cout);
+    if (hp.fold_nb > D3D_FOLD_MAX_BLOCKS) return 0;
+    return 2 * (size_t)cout + d3d_fold_ws_floats(hp.fold_nb, 256);
+  }
   if (m < 1 || cout < 128 || cout % 128) return 0;
   const int64_t nb = (m + 127) / 128;
   if (nb > D3D_FOLD_MAX_BLOCKS) return 0;
@@ -751,6 +764,7 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
   // wave groups; other layers under these settings take the round-3 default
   const bool halo = (variant >= 16 && variant <= 18) && split && ksz == 3 && stride == 1;  // 18: requests inside the MFMA part
   if ((variant >= 16 && variant <= 18) && !halo) variant = split ? 9 : 8;
+  D3D_REQUIRE(halo || cout % 128 == 0, "d3d_conv2d_nhwc_fwd: 64 output channels need the halo-patch kernel (variant %d)", variant);
   if (halo) {
     const C2hPlan hp = c2h_plan(batch, G.ho, G.wo, cout);
     Conv2dEpi eh = {};

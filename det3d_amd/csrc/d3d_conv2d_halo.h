@@ -43,9 +43,11 @@ template <int N> __device__ __forceinline__ void c2h_wait_vm() {
 // how a launch's items map to blocks (host: c2h_plan; device: conv2d_halo_kernel)
 struct C2hGrid {
   int tiles_x, tiles_y;  // patches per image
-  int ctiles;            // 128-channel output tiles
-  int n_full;            // items [0, n_full) are whole blocks; item n_full + j is blocks n_full + 4 j .. + 3
+  int ctiles;            // output-channel tiles of ct_full channels
+  int n_full;            // items [0, n_full) are whole blocks; item n_full + j is blocks n_full + cut j .. + cut - 1
   int n_items;           // patches * ctiles
+  int ct_full;           // output channels of a whole block: 128, or 64 for 64-channel layers (PointPillars block 0)
+  int cut;               // 32-channel blocks per cut item: ct_full / 32
 };
 
 // PH x PW = 256 output pixels per block.  SCHED 0: one barrier per K step; 1: the two wave groups run one barrier
@@ -53,7 +55,7 @@ struct C2hGrid {
 // LDS-DMA costs the issuing wave ~60 cycles instead of 100-185 next to the fragment reads: MI355X_MICROARCH.md) --
 // the load part is then fragment reads + waits only.  A request of M(t) is waited for (vmcnt(0)) at the end of
 // L(t+1) and read from L(t+2) on: the RAW / WAR argument above holds with the requests half a step later.
-// WCO waves along cout, NI 32-channel tiles per wave: (2, 2) = 128 output channels per block, (1, 1) = 32
+// WCO waves along cout, NI 32-channel tiles per wave: (2, 2) = 128 output channels per block, (2, 1) = 64, (1, 1) = 32
 template <int CIN, int PH, int PW, int SCHED, int WCO, int NI>
 __device__ __forceinline__ void c2h_body(const void *__restrict__ x_hi, const void *__restrict__ x_lo,
                                          const void *__restrict__ w_hi, const void *__restrict__ w_lo,
@@ -352,7 +354,7 @@ __device__ __forceinline__ void c2h_body(const void *__restrict__ x_hi, const vo
         vals[k] = keep + __shfl_xor(send, d, 64);
       }
     }
-    const int c_in_tile = n0 - ct * 128;  // first channel of this block inside its 128-channel tile
+    const int c_in_tile = n0 - ct * Q.ct_full;  // first channel of this block inside its channel tile
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
       const int v = (lane & 31) * NK + k;
@@ -373,7 +375,7 @@ __device__ __forceinline__ void c2h_body(const void *__restrict__ x_hi, const vo
     if (d3d_fold_block_at<512>(tot, 256, ws, ep.counters + ct * ep.ctr_stride, ep.fold_g, (int *)(tot + 256), fold_b,
                                fold_nb)) {
       const int i = threadIdx.x;
-      if (i < 256) ep.stats[(i >> 7) * G.cout + ct * 128 + (i & 127)] = ws[i];
+      if (i < 256 && (i & 127) < Q.ct_full) ep.stats[(i >> 7) * G.cout + ct * Q.ct_full + (i & 127)] = ws[i];
     }
   }
 }
@@ -392,14 +394,18 @@ __global__ void __launch_bounds__(512, 2)
     const int item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     const int tile = item / Q.ctiles, ct = item - tile * Q.ctiles;
     const int rem_ct = rem > ct ? (rem - ct + Q.ctiles - 1) / Q.ctiles : 0;
-    c2h_body<CIN, PH, PW, SCHED, 2, 2>(x_hi, x_lo, w_hi, w_lo, y, G, ep, Q, tile, ct, ct * 128, tile, fold_full + 4 * rem_ct,
-                                         smem);
+    if (Q.ct_full == 128)
+      c2h_body<CIN, PH, PW, SCHED, 2, 2>(x_hi, x_lo, w_hi, w_lo, y, G, ep, Q, tile, ct, ct * 128, tile,
+                                         fold_full + Q.cut * rem_ct, smem);
+    else
+      c2h_body<CIN, PH, PW, SCHED, 2, 1>(x_hi, x_lo, w_hi, w_lo, y, G, ep, Q, tile, ct, ct * 64, tile,
+                                         fold_full + Q.cut * rem_ct, smem);
   } else {
-    const int j = (bid - Q.n_full) >> 2, quarter = (bid - Q.n_full) & 3;
+    const int j = (bid - Q.n_full) / Q.cut, part = (bid - Q.n_full) - j * Q.cut;
     const int item = Q.n_full + j;
     const int tile = item / Q.ctiles, ct = item - tile * Q.ctiles;  // == j % ctiles: n_full is a multiple of ctiles
     const int rem_ct = (rem - ct + Q.ctiles - 1) / Q.ctiles;
-    c2h_body<CIN, PH, PW, SCHED, 1, 1>(x_hi, x_lo, w_hi, w_lo, y, G, ep, Q, tile, ct, ct * 128 + quarter * 32,
-                                         fold_full + (j / Q.ctiles) * 4 + quarter, fold_full + 4 * rem_ct, smem);
+    c2h_body<CIN, PH, PW, SCHED, 1, 1>(x_hi, x_lo, w_hi, w_lo, y, G, ep, Q, tile, ct, ct * Q.ct_full + part * 32,
+                                       fold_full + (j / Q.ctiles) * Q.cut + part, fold_full + Q.cut * rem_ct, smem);
   }
 }

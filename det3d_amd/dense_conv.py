@@ -86,8 +86,13 @@ def _packed(weight, kind, mode):
     return out[kind]
 
 
-def supported(cin, cout, ksz, stride):
-    return bool(_lib.lib().d3d_conv2d_supported(int(cin), int(cout), int(ksz), int(stride)))
+def supported(cin, cout, ksz, stride, mode=None):
+    """channel pairs / geometries with a library kernel.  mode "split": the 3x3 stride-1 layers also come with 64 output
+    channels (conv2d_halo_kernel); their weight gradient then takes wgrad_raw's fallback"""
+    L = _lib.lib()
+    if mode == "split" and int(ksz) == 3 and int(stride) == 1:
+        return bool(L.d3d_conv2d_supported_split3x3(int(cin), int(cout)))
+    return bool(L.d3d_conv2d_supported(int(cin), int(cout), int(ksz), int(stride)))
 
 
 def _out_hw(h, w, ksz, stride, pad):
@@ -134,6 +139,15 @@ def wgrad_raw(g_hi, g_lo, x_hi, x_lo, ksz, stride, pad, mode):
     ho, wo = _out_hw(h, w, ksz, stride, pad)
     assert tuple(g_hi.shape[:3]) == (b, ho, wo)
     dev = x_hi.device
+    if cin % 128 or cout % 128:
+        # 64-channel layers (the first block of the PointPillars necks): no library weight-gradient kernel yet -- the
+        # f32 values back from their planes, MIOpen's weight gradient on channels-last views of them
+        if mode == "split":
+            xf, gf = join_planes(x_hi, x_lo), join_planes(g_hi, g_lo)
+        else:
+            xf, gf = x_hi.float(), g_hi.float()
+        return torch.nn.grad.conv2d_weight(xf.permute(0, 3, 1, 2), (cout, cin, ksz, ksz), gf.permute(0, 3, 1, 2),
+                                           stride, pad).contiguous()
     dw = torch.empty((cout, cin, ksz, ksz), dtype=torch.float32, device=dev)
     nb = L.d3d_conv2d_wgrad_workspace_bytes(b, ho, wo, cin, cout, ksz)
     ws = torch.empty((nb,), dtype=torch.uint8, device=dev)

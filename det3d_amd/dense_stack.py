@@ -45,7 +45,7 @@ class _Layer:
         self.cin, self.cout = conv.in_channels, conv.out_channels
 
 
-def _conv_ok(conv, extra_pad):
+def _conv_ok(conv, extra_pad, split=False):
     if type(conv) is not nn.Conv2d or conv.bias is not None or conv.groups != 1 or conv.weight.dtype != torch.float32:
         return None
     k = conv.kernel_size
@@ -57,6 +57,9 @@ def _conv_ok(conv, extra_pad):
     if pad >= k[0] or 2 * pad != k[0] - 1:  # "same" convolutions: the data gradient is the mirrored forward
         return None
     cin, cout = conv.in_channels, conv.out_channels
+    if split and k[0] == 3 and cin in (64, 128, 256) and cout in (64, 128, 256):
+        # the halo-patch kernel: 64-channel layers too (forward and data gradient; weight gradient: dc.wgrad_raw)
+        return pad if dc.supported(cin, cout, 3, 1, "split") else None
     if cin not in (128, 256) or cout not in (128, 256) or not dc.supported(cin, cout, k[0], 1):
         return None
     return pad
@@ -97,7 +100,7 @@ def collect(mods, i, x):
                 break
             extra, j = p[0], j + 1
         conv = mods[j]
-        pad = _conv_ok(conv, extra)
+        pad = _conv_ok(conv, extra, x.dtype == torch.float32)
         if pad is None or conv.in_channels != c or j + 1 >= len(mods) or not _bn_ok(mods[j + 1], conv.out_channels):
             break
         bn = mods[j + 1]

@@ -346,6 +346,10 @@ typedef struct D3dDenseBnBackward {
   int relu;
 } D3dDenseBnBackward;
 int d3d_conv2d_supported(int cin, int cout, int ksz, int stride);
+/* ABI 7: the 3x3 / stride-1 layers in D3D_CONV_SPLIT mode also exist with 64 output channels (the first block of the
+ * PointPillars necks, det3d/models/necks/rpn.py:80-110 with ds_num_filters[0] = 64): forward and data gradient through
+ * d3d_conv2d_nhwc_fwd; their weight gradient is not covered by d3d_conv2d_nhwc_wgrad (multiples of 128 only). */
+int d3d_conv2d_supported_split3x3(int cin, int cout);
 size_t d3d_conv2d_stats_ws_floats(int batch, int ho, int wo, int cout);
 int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo, void *y, int batch,
                         int h, int w, int cin, int cout, int ksz, int stride, int pad, int mode, float *stats_ws,

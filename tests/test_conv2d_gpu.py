@@ -28,6 +28,8 @@ HALO_GEOMS = [  # 3x3 stride-1 layers for the halo-patch kernel (csrc/d3d_conv2d
     (2, 16, 32, 64, 128, 3, 1, 1),       # two chunks, whole patches only
     (1, 20, 22, 128, 128, 3, 1, 0),      # no padding: 18 x 20 output
     (1, 14, 18, 128, 128, 3, 1, 2),      # full padding: 16 x 20 output (the data gradient of a pad-0 layer)
+    (2, 40, 36, 64, 64, 3, 1, 1),        # PointPillars block 0: 64 -> 64 (the 64-channel block shape)
+    (1, 20, 24, 128, 64, 3, 1, 1),       # ... and a 64-channel output behind four chunks
 ]
 
 
@@ -182,8 +184,9 @@ def _rpn_like(cin, widths):
     return seq
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_dense_stack_is_the_torch_module_stack(dtype):
+@pytest.mark.parametrize("dtype,cin,widths", [(torch.float32, 256, [128, 128, 128]), (torch.bfloat16, 256, [128, 128, 128]),
+                                              (torch.float32, 64, [64, 64, 128])])
+def test_dense_stack_is_the_torch_module_stack(dtype, cin, widths):
     """nn_utils.Sequential routes [pad] conv -> BN -> ReLU runs to dense_stack: same activations, gradients and running
     statistics as the plain torch modules in float64 (split mode: 1e-4 relative; bf16: bf16-class tolerances)."""
     import copy
@@ -191,14 +194,14 @@ def test_dense_stack_is_the_torch_module_stack(dtype):
     from det3d_amd import dense_stack
 
     torch.manual_seed(3)
-    seq = _rpn_like(256, [128, 128, 128]).cuda().train()
+    seq = _rpn_like(cin, widths).cuda().train()  # (64-channel layers: PointPillars block 0, split mode only)
     for m in seq.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
             torch.nn.init.uniform_(m.weight, 0.5, 1.5)
             torch.nn.init.normal_(m.bias, 0, 0.3)
     ref = copy.deepcopy(seq).double()
-    x = torch.randn(2, 256, 20, 24, device="cuda").contiguous(memory_format=torch.channels_last)
-    gy = torch.randn(2, 128, 20, 24, device="cuda").contiguous(memory_format=torch.channels_last)
+    x = torch.randn(2, cin, 20, 24, device="cuda").contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(2, widths[-1], 20, 24, device="cuda").contiguous(memory_format=torch.channels_last)
     xa = x.detach().clone().to(dtype).requires_grad_(True)
     calls = []
     orig = dense_stack.run
@@ -276,15 +279,17 @@ def test_halo_patch_forward_matches_conv2d(geom, variant, tail, conv2d_variant, 
     w_hi, w_lo = dc._packed(weight, "fwd", "split")
     x_hi, x_lo = dc.split_planes(x)
     conv2d_tail(tail)
-    conv2d_variant(9)
-    y_old, _ = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, "split", want_stats=True)
+    y_old = None
+    if cout % 128 == 0:  # (the round-3 kernel has no 64-channel shape)
+        conv2d_variant(9)
+        y_old, _ = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, "split", want_stats=True)
     conv2d_variant(variant)
     y, ws = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, s, p, "split", want_stats=True)
     ref = _ref_conv(x.double(), wt.double(), s, p)
     assert y.shape == ref.shape
     err, scale = float((y.double() - ref).abs().max()), float(ref.abs().max())
     assert err <= 3e-5 * scale, (err, scale)
-    assert float((y - y_old).abs().max()) <= 3e-6 * scale  # same products, another summation order
+    assert y_old is None or float((y - y_old).abs().max()) <= 3e-6 * scale  # same products, another summation order
     yd = y.double().reshape(-1, cout)
     stats = ws[:2 * cout].double()
     assert torch.allclose(stats[:cout], yd.sum(0), rtol=1e-4, atol=1e-3 * yd.shape[0] ** 0.5)
