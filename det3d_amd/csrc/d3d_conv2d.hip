@@ -786,7 +786,7 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
       eh.fold_g = fp.g;
       eh.ws_stride = (int)d3d_fold_ws_floats(hp.fold_nb, 256);
       eh.ctr_stride = d3d_fold_counter_words(fp);
-      eh.counters = d3d_fold_counters(eh.ctr_stride * (cout / 128));
+      eh.counters = d3d_fold_counters(eh.ctr_stride * hp.q.ctiles);
       if (!eh.counters) return D3D_EHIP;
     }
     constexpr int HALO_XI = (18 * 18 + 15) / 16;
