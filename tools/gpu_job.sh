@@ -29,6 +29,9 @@ while [ $# -gt 0 ]; do
       timeout 1500 python -m pytest tests/ -x -q -m gpu -rP > $O/tests.log 2>&1; echo "pytest rc=$?"; tail -3 $O/tests.log
       grep -h "vs float64\|max |pred - reference|\|worst gradient-norm\|ResNetFHD" $O/tests.log | cut -c1-400 > $O/tests_figures.txt; cat $O/tests_figures.txt
       timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 ;;
+    testsall:*)
+      timeout 1500 python -m pytest tests/ -q -m gpu -k "${st#testsall:}" > $O/tests_all.log 2>&1; echo "pytest rc=$?"
+      grep -n "^FAILED\|^E  .*Error\|passed\|failed" $O/tests_all.log | cut -c1-260 | head -60 ;;
     tests:*)
       timeout 1500 python -m pytest tests/ -x -q -m gpu -k "${st#tests:}" > $O/tests_k.log 2>&1; echo "pytest rc=$?"; tail -15 $O/tests_k.log ;;
     bench)
