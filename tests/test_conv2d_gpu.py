@@ -327,6 +327,28 @@ def test_halo_patch_tail_blocks_with_two_channel_tiles(conv2d_variant):
         assert torch.equal(y, y2) and torch.equal(ws[:512], ws2[:512])
 
 
+@pytest.mark.parametrize("variant", [16, 18])
+@pytest.mark.parametrize("geom", [g for g in HALO_GEOMS if g[7] == 1])
+def test_halo_patch_data_gradient_matches_conv2d_input(geom, variant, conv2d_variant):
+    """the data gradient of a 3x3 "same" layer = the halo-patch kernel on the output gradient with the [mirrored tap]
+    [cin][cout] weights, for every channel pair incl. the 64-channel ones, against torch.nn.grad.conv2d_input in float64"""
+    from det3d_amd import dense_conv as dc
+
+    b, h, w, cin, cout, k, s, p = geom
+    g = torch.Generator(device="cuda").manual_seed(17)
+    wt = torch.randn((cout, cin, k, k), device="cuda", generator=g) * (1.0 / (cout * k * k) ** 0.5)
+    wt[:, :, 0, 1] *= 1.7
+    gy = torch.randn((b, h, w, cout), device="cuda", generator=g)
+    w_hi, w_lo = dc._packed(torch.nn.Parameter(wt), "dgrad", "split")
+    g_hi, g_lo = dc.split_planes(gy)
+    conv2d_variant(variant)
+    dx, _ = dc.conv2d_raw(g_hi, g_lo, w_hi, w_lo, k, 1, k - 1 - p, "split")
+    ref = torch.nn.grad.conv2d_input((b, cin, h, w), wt.double(), gy.double().permute(0, 3, 1, 2), 1, p).permute(0, 2, 3, 1)
+    assert dx.shape == ref.shape
+    err, scale = float((dx.double() - ref).abs().max()), float(ref.abs().max())
+    assert err <= 3e-5 * scale, (err, scale)
+
+
 @pytest.mark.parametrize("variant", [16, 17, 18])
 def test_halo_patch_kernel_on_the_benched_map_repeats_bit_for_bit(variant, conv2d_variant):
     """[4,200,176,128] -> 128: 572 patches on 256 CUs (several rounds of blocks, every XCD range, partial patches on
