@@ -224,8 +224,16 @@ def test_dense_stack_is_the_torch_module_stack(dtype, cin, widths):
     tol = 2e-4 if dtype == torch.float32 else 6e-2
 
     def close(a, b, what, t=tol):
-        err, scale = float((a.double() - b).abs().max()), float(b.abs().max())
-        assert err <= t * scale, (what, err, scale)
+        d = (a.double() - b).abs()
+        err, scale = float(d.max()), float(b.abs().max())
+        bad = d > t * scale
+        where = ""
+        if bad.any() and d.dim() == 4:  # how the excess is distributed: a flipped ReLU mask is local, a wrong kernel is not
+            px = bad.any(1).nonzero()
+            where = "%d elements over the bound in %d pixels, rows %d-%d cols %d-%d, rel L2 %.2e" % (
+                int(bad.sum()), len(px), int(px[:, 1].min()), int(px[:, 1].max()), int(px[:, 2].min()), int(px[:, 2].max()),
+                float((a.double() - b).norm() / b.norm()))
+        assert err <= t * scale, (what, err, scale, where)
 
     close(y, yr, "output")
     close(xa.grad, xr.grad, "input gradient", tol * 3)
