@@ -297,6 +297,9 @@ class MultiGroupHead(nn.Module):
                     nn.init.constant_(m.bias, 0)
 
     def forward(self, x):
+        convs = _fused_heads_convs(self, x)
+        if convs is not None:  # every task's 1x1 convolutions as one stacked convolution on the library's kernels
+            return _run_fused_heads(self, x, convs)
         return [task(x) for task in self.tasks]
 
     # ------------------------------------------------------------------- loss
@@ -543,3 +546,115 @@ class MultiGroupHead(nn.Module):
             inside = ((boxes[:, :3] >= lim[:3]) & (boxes[:, :3] <= lim[3:])).all(dim=1)
             boxes, scores, labels = boxes[inside], scores[inside], labels[inside]
         return boxes.reshape(-1, self.anchor_dim), scores, labels
+
+
+# ------------------------------------------------------------------------------------------------ fused task heads
+# The multi-task configs (nuScenes: 6 task groups, Lyft: 5; det3d/models/bbox_heads/mg_head.py:193-232, :453-470) run
+# 12-18 1x1 convolutions with 2-40 output channels each on the SAME 384 / 512-channel map.  As separate MIOpen calls
+# (exact-f32 igemm at the f32 MFMA rate, a zero-fill launch in front of every weight / data gradient) they were 12 %
+# of the nuScenes-PointPillars step and 5 % of the CBGS step.  Here they are ONE 1x1 convolution whose output channels
+# are the task heads' rows stacked (zero rows up to a multiple of 128) on the library's NHWC implicit-GEMM kernels in
+# split arithmetic: forward, data gradient (the transposed stack) and weight gradient are one launch each, the
+# per-head tensors are slices of the result.
+FUSE_HEADS = os.environ.get("D3D_FUSE_HEADS", "1") != "0"
+
+
+def _fused_heads_convs(head, x):
+    """[(conv, ...)] of every task in forward order if `head`'s tasks can run as one stacked 1x1 convolution on x"""
+    from . import dense_conv as dc
+
+    if not (FUSE_HEADS and torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32):
+        return None
+    if torch.is_autocast_enabled("cuda") or x.shape[1] not in (256, 384, 512):
+        return None
+    if not x.is_contiguous(memory_format=torch.channels_last) or x.numel() * 2 >= (1 << 31) - 16:
+        return None
+    convs = []
+    for task in head.tasks:
+        if type(task) is not Head:
+            return None
+        cs = [task.conv_box, task.conv_cls] + ([task.conv_dir] if task.use_dir else [])
+        for c in cs:
+            if type(c) is not nn.Conv2d or c.kernel_size != (1, 1) or c.stride != (1, 1) or c.padding != (0, 0) or \
+                    c.groups != 1 or c.weight.dtype != torch.float32 or c.bias is None or c.bias.dtype != torch.float32:
+                return None
+        convs.append(cs)
+    total = sum(c.out_channels for cs in convs for c in cs)
+    if len(convs) < 2 or total > 256 or not dc.supported(256, 128, 1, 1):
+        return None
+    return convs
+
+
+class _FusedHeadsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sizes, *params):
+        from . import _lib
+        from . import dense_conv as dc
+
+        L = _lib.lib()
+        dev = x.device
+        b, cin, h, w = x.shape
+        weights, biases = params[0::2], params[1::2]
+        total = sum(sizes)
+        npad = 128 if total <= 128 else 256
+        rows = x.permute(0, 2, 3, 1)
+        if not rows.is_contiguous():
+            rows = rows.contiguous()
+        x_hi, x_lo = dc.split_planes(rows)
+        w_all = torch.zeros((npad, cin), dtype=torch.float32, device=dev)
+        torch.cat([wt.detach().reshape(wt.shape[0], cin) for wt in weights], 0, out=w_all[:total])
+        f_hi = torch.empty((1, npad, cin), dtype=torch.bfloat16, device=dev)
+        f_lo = torch.empty_like(f_hi)
+        d_hi = torch.empty((1, cin, npad), dtype=torch.bfloat16, device=dev)
+        d_lo = torch.empty_like(d_hi)
+        rc = L.d3d_conv2d_pack_weights(w_all.data_ptr(), npad, cin, 1, f_hi.data_ptr(), f_lo.data_ptr(), d_hi.data_ptr(),
+                                       d_lo.data_ptr(), _lib.stream_ptr(dev))
+        _lib.check(rc, "d3d_conv2d_pack_weights")
+        y_all, _ = dc.conv2d_raw(x_hi, x_lo, f_hi, f_lo, 1, 1, 0, "split")  # [B, H, W, npad] f32
+        outs, off = [], 0
+        for n, bias in zip(sizes, biases):
+            outs.append(y_all[..., off: off + n] + bias.detach())  # contiguous [B, H, W, n]
+            off += n
+        ctx.save_for_backward(x_hi, x_lo, d_hi, d_lo)
+        ctx.meta = (tuple(sizes), npad, (b, cin, h, w))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        from . import dense_conv as dc
+
+        x_hi, x_lo, d_hi, d_lo = ctx.saved_tensors
+        sizes, npad, (b, cin, h, w) = ctx.meta
+        dev = x_hi.device
+        total = sum(sizes)
+        parts = [(g if g is not None else torch.zeros((b, h, w, n), dtype=torch.float32, device=dev)).float()
+                 for g, n in zip(gouts, sizes)]
+        if npad > total:
+            parts.append(torch.zeros((b, h, w, npad - total), dtype=torch.float32, device=dev))
+        g_all = torch.cat(parts, -1)                         # [B, H, W, npad]
+        db_all = g_all.sum((0, 1, 2))                        # bias gradients of every head at once
+        g_hi, g_lo = dc.split_planes(g_all)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxr, _ = dc.conv2d_raw(g_hi, g_lo, d_hi, d_lo, 1, 1, 0, "split")  # [B, H, W, cin]
+            dx = dxr.permute(0, 3, 1, 2)
+        dw_all = dc.wgrad_raw(g_hi, g_lo, x_hi, x_lo, 1, 1, 0, "split")       # [npad, cin, 1, 1]
+        grads, off = [], 0
+        for n in sizes:
+            grads.append(dw_all[off: off + n].clone())
+            grads.append(db_all[off: off + n].clone())
+            off += n
+        return (dx, None) + tuple(grads)
+
+
+def _run_fused_heads(head, x, convs):
+    flat = [c for cs in convs for c in cs]
+    outs = _FusedHeadsFn.apply(x, [c.out_channels for c in flat], *[t for c in flat for t in (c.weight, c.bias)])
+    rets, i = [], 0
+    for task, cs in zip(head.tasks, convs):
+        ret = {"box_preds": outs[i], "cls_preds": outs[i + 1]}
+        if task.use_dir:
+            ret["dir_cls_preds"] = outs[i + 2]
+        rets.append(ret)
+        i += len(cs)
+    return rets

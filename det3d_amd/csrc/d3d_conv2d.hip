@@ -661,7 +661,8 @@ static int c2_check(const char *who, int batch, int h, int w, int cin, int cout,
                     int mode) {
   D3D_REQUIRE(mode == D3D_CONV_BF16 || mode == D3D_CONV_SPLIT, "%s: mode %d", who, mode);
   D3D_REQUIRE(batch >= 1 && h >= 1 && w >= 1, "%s: map %d x %d x %d", who, batch, h, w);
-  D3D_REQUIRE(cin == 64 || cin == 128 || cin == 256, "%s: cin=%d (64, 128, 256)", who, cin);
+  D3D_REQUIRE(cin == 64 || cin == 128 || cin == 256 || ((cin == 384 || cin == 512) && ksz == 1),
+              "%s: cin=%d (64, 128, 256; 384 / 512 for 1x1 layers)", who, cin);
   // (64 output channels: the 3x3 stride-1 layers in split mode only -- conv2d_halo_kernel's 64-channel block shape)
   D3D_REQUIRE((cout >= 128 && cout % 128 == 0) || (cout == 64 && ksz == 3 && stride == 1 && mode == D3D_CONV_SPLIT),
               "%s: cout=%d (multiples of 128; 64 for split 3x3 stride-1 layers)", who, cout);
@@ -812,6 +813,7 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
     D3D_LAUNCH_TRY("conv2d_halo_kernel");
     return D3D_OK;
   }
+  if (cin > 256) variant = split ? 9 : 8;  // (384 / 512 input channels exist in the default tilings only)
   const bool w8 = variant == 8 || variant == 9;  // 128-pixel tiles on 8 waves
   const int wpx = ((variant & 2) || w8) ? 4 : 2;
   const int bm = w8 ? 128 : 64 * wpx;
@@ -866,6 +868,16 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
   C2_CASE(64)
   C2_CASE(128)
   C2_CASE(256)
+  // 384 / 512 input channels: the concatenated neck outputs in front of the multi-group heads (1x1 convolutions; the
+  // default tilings only)
+#define C2_WIDE(CIN)                                         \
+  if (cin == CIN) {                                          \
+    if (split) C2_LAUNCH(CIN, true, 4, true, false, 1);      \
+    else C2_LAUNCH(CIN, false, 4, false, false, 1);          \
+  }
+  C2_WIDE(384)
+  C2_WIDE(512)
+#undef C2_WIDE
 #undef C2_CASE
 #undef C2_VARIANTS
 #undef C2_LAUNCH
@@ -905,8 +917,8 @@ extern "C" int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const v
                                      d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   D3D_REQUIRE(mode == D3D_CONV_BF16 || mode == D3D_CONV_SPLIT, "d3d_conv2d_nhwc_wgrad: mode %d", mode);
-  D3D_REQUIRE(cin % 128 == 0 && cout % 128 == 0 && cin >= 128 && cout >= 128 && cin <= 256 && cout <= 256,
-              "d3d_conv2d_nhwc_wgrad: channels %d -> %d (multiples of 128 up to 256)", cin, cout);
+  D3D_REQUIRE(cin % 128 == 0 && cout % 128 == 0 && cin >= 128 && cout >= 128 && cin <= 512 && cout <= 512,
+              "d3d_conv2d_nhwc_wgrad: channels %d -> %d (multiples of 128 up to 512)", cin, cout);
   D3D_REQUIRE(ksz >= 1 && ksz <= 3 && stride >= 1 && stride <= 2 && pad >= 0 && pad < ksz,
               "d3d_conv2d_nhwc_wgrad: kernel %d stride %d pad %d", ksz, stride, pad);
   const bool split = mode == D3D_CONV_SPLIT;

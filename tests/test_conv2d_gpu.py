@@ -481,3 +481,59 @@ def test_head_convolutions_in_one_launch(dtype, use_dir):
     torch.autograd.backward([outs2[k] for k in keys], gs)
     assert all(torch.equal(outs[k], outs2[k]) for k in keys) and torch.equal(xa.grad, xb.grad)
     assert all(torch.equal(g1[k], p.grad) for k, p in head.named_parameters())
+
+
+@pytest.mark.parametrize("cin,use_dir", [(384, False), (512, True), (256, True)])
+def test_task_heads_as_one_stacked_convolution(cin, use_dir):
+    """bbox_heads._FusedHeadsFn: the 1x1 prediction convolutions of ALL task groups (nuScenes: 6, Lyft: 5;
+    mg_head.py:453-470 builds one Head per task on the same map) as one convolution with stacked output rows on the
+    library's kernels -- outputs, input gradient, every weight and bias gradient against the per-task nn.Conv2d
+    modules in float64."""
+    import copy
+
+    from det3d_amd import bbox_heads
+
+    torch.manual_seed(cin)
+    sizes = [(18, 2), (36, 4), (36, 4), (18, 2), (36, 4), (36, 4)] if cin != 256 else [(14, 2), (28, 4), (14, 2)]
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.tasks = torch.nn.ModuleList(
+                [bbox_heads.Head(cin, nb, nc, use_dir=use_dir, num_dir=(nc if use_dir else 0)) for nb, nc in sizes])
+
+    h = Holder().cuda()
+    with torch.no_grad():
+        for p in h.parameters():
+            p.normal_(0, 0.05)
+    ref = copy.deepcopy(h).double()
+    x = torch.randn(2, cin, 24, 20, device="cuda").contiguous(memory_format=torch.channels_last)
+    xa = x.clone().requires_grad_(True)
+    convs = bbox_heads._fused_heads_convs(h, xa)
+    assert convs is not None and len(convs) == len(sizes)
+    outs = bbox_heads._run_fused_heads(h, xa, convs)
+    xr = x.double().requires_grad_(True)
+    prev = bbox_heads.FUSE_HEADS
+    bbox_heads.FUSE_HEADS = False
+    try:
+        outs_r = [t(xr) for t in ref.tasks]
+    finally:
+        bbox_heads.FUSE_HEADS = prev
+    loss = loss_r = 0.0
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for o, orf in zip(outs, outs_r):
+        assert o.keys() == orf.keys()
+        for k in o:
+            assert o[k].shape == orf[k].shape and o[k].is_contiguous()
+            err, scale = float((o[k].double() - orf[k]).abs().max()), float(orf[k].abs().max())
+            assert err <= 3e-5 * scale + 1e-6, (k, err, scale)
+            wgt = torch.randn(o[k].shape, device="cuda", generator=g)
+            loss = loss + (o[k] * wgt).sum()
+            loss_r = loss_r + (orf[k] * wgt.double()).sum()
+    loss.backward()
+    loss_r.backward()
+    close = lambda a, b, what: None if float((a.double() - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-6 else \
+        pytest.fail("%s: %g vs scale %g" % (what, float((a.double() - b).abs().max()), float(b.abs().max())))
+    close(xa.grad, xr.grad, "input gradient")
+    for (k, p), (_, q) in zip(h.named_parameters(), ref.named_parameters()):
+        close(p.grad, q.grad, k)
