@@ -233,7 +233,9 @@ def test_dense_stack_is_the_torch_module_stack(dtype, cin, widths):
         # the forward effect is nil, the backward mask differs at ONE (pixel, channel) and every gradient downstream of
         # it differs inside that site's receptive field (measured: 1259 elements in one 5 x 5 window, rel L2 1.9e-3).
         # Accept at most two such windows (7 x 7 pixels each); a wrong kernel spreads over the map.
-        assert d.dim() == 4, (what, err, scale)
+        if d.dim() != 4:  # a per-channel sum (BatchNorm gamma / beta gradient) contains the flipped site once
+            assert err <= 5e-3 * scale, (what, err, scale)
+            return
         px = bad.any(1).nonzero()[:, 1:].tolist()
         windows = 0
         while px:
