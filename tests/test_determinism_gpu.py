@@ -107,6 +107,27 @@ def test_two_identical_training_steps_are_bit_equal(dtype):
     assert not bad, "not bit-equal across two steps of one model: %s" % bad[:6]
 
 
+@pytest.mark.parametrize("config", ["nusc_cbgs.py", "lyft_cbgs.py", "nusc_point_pillars.py"])
+def test_two_identical_steps_of_the_multi_task_configs_are_bit_equal(config):
+    """The same for the CBGS (SpMiddleResNetFHD: fused residual blocks, 128-channel sparse layers; rpn2 neck; 5-6 task
+    groups as one stacked head convolution) and the PointPillars configs (PillarFeatureNet, 64-channel dense layers):
+    two copies of the model on one batch, f32 / split arithmetic.  The strided and transposed convolutions of the
+    necks are still MIOpen's -- asked for their deterministic solvers."""
+    from det3d_amd import synthetic
+
+    cfg, a = _model(config)
+    b = copy.deepcopy(a)
+    dev = torch.device("cuda", 0)
+    ds = synthetic.TaskGroupSynthetic(cfg, n_points=30000, n_seeds=2)
+    ex = ds.make_example(ds.device_batch(0, 2, dev))
+    with torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=True):
+        la, ga = _step(a, ex, None)
+        lb, gb = _step(b, ex, None)
+    assert la == lb and ga.keys() == gb.keys()
+    bad = [k for k in ga if not torch.equal(ga[k], gb[k])]
+    assert not bad, "not bit-equal across two copies: %s" % bad[:6]
+
+
 def test_conv_epilogue_reduction_refuses_a_channel_pair_without_mfma_tiles():
     """(128, 16), (48, 48) ... pass the old `% 16` test but have no MFMA tiling; the fused reduction
     must be refused loudly (and Python must not ask for it) instead of leaving all-zero statistics behind."""
