@@ -139,7 +139,7 @@ def test_weight_gradient(geom, mode):
 
 
 @pytest.mark.parametrize("waves", [16, 17, 18])
-@pytest.mark.parametrize("geom", [g for g in HALO_GEOMS if g[3] % 128 == 0] + [(4, 40, 44, 128, 128, 3, 1, 1),
+@pytest.mark.parametrize("geom", [g for g in HALO_GEOMS if g[3] % 128 == 0 and g[4] % 128 == 0] + [(4, 40, 44, 128, 128, 3, 1, 1),
                                                                              (2, 7, 70, 128, 256, 3, 1, 1)])
 def test_weight_gradient_three_taps_per_block(geom, waves):
     """conv2d_wgrad3_kernel (csrc/d3d_conv2d_wgrad3.h; knob 8 = 16 staggered wave groups / 17 one barrier per K step):
