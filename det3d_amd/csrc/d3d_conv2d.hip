@@ -900,9 +900,18 @@ static int c2_wgrad3_splits(int total_segs, int wtiles) {
   if (s > total_segs) s = total_segs;
   return s < 1 ? 1 : s;
 }
+// conv2d_wgrad3n_kernel (64 x 64 weights, 3x3 stride 1, split mode): ~3 four-wave blocks per CU over (splits x 3 rows)
+static int c2_wgrad3n_splits(int total_segs) {
+  int s = 256;
+  if (s > total_segs) s = total_segs;
+  return s < 1 ? 1 : s;
+}
 extern "C" size_t d3d_conv2d_wgrad_workspace_bytes(int batch, int ho, int wo, int cin, int cout, int ksz) {
   const int64_t m = (int64_t)batch * ho * wo;
   if (m < 1) return 0;
+  if (cin == 64 && cout == 64 && ksz == 3)
+    return (size_t)c2_wgrad3n_splits(batch * ho * ((wo + 31) / 32)) * 9 * 64 * 64 * sizeof(float);
+  if (cin < 128 || cout < 128) return 0;
   size_t s = (size_t)c2_wgrad_splits((int)m, ksz * ksz * (cin / 128) * (cout / 128));
   if (ksz == 3 && cin >= 128 && cout >= 128) {
     const size_t s3 = (size_t)c2_wgrad3_splits(batch * ho * ((wo + 31) / 32), (cin / 128) * (cout / 128));
@@ -917,8 +926,10 @@ extern "C" int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const v
                                      d3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   D3D_REQUIRE(mode == D3D_CONV_BF16 || mode == D3D_CONV_SPLIT, "d3d_conv2d_nhwc_wgrad: mode %d", mode);
-  D3D_REQUIRE(cin % 128 == 0 && cout % 128 == 0 && cin >= 128 && cout >= 128 && cin <= 512 && cout <= 512,
-              "d3d_conv2d_nhwc_wgrad: channels %d -> %d (multiples of 128 up to 512)", cin, cout);
+  const bool narrow = cin == 64 && cout == 64 && ksz == 3 && stride == 1 && mode == D3D_CONV_SPLIT;
+  D3D_REQUIRE(narrow || (cin % 128 == 0 && cout % 128 == 0 && cin >= 128 && cout >= 128 && cin <= 512 && cout <= 512),
+              "d3d_conv2d_nhwc_wgrad: channels %d -> %d (multiples of 128 up to 512; 64 -> 64 for split 3x3 stride-1 layers)",
+              cin, cout);
   D3D_REQUIRE(ksz >= 1 && ksz <= 3 && stride >= 1 && stride <= 2 && pad >= 0 && pad < ksz,
               "d3d_conv2d_nhwc_wgrad: kernel %d stride %d pad %d", ksz, stride, pad);
   const bool split = mode == D3D_CONV_SPLIT;
@@ -928,6 +939,25 @@ extern "C" int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const v
   if (rc) return rc;
   D3D_REQUIRE((int64_t)batch * h * w * cin * 2 < (int64_t)D3D_RSRC_BYTES, "d3d_conv2d_nhwc_wgrad: the input map exceeds 2 GB");
   G.w_bytes = (int)((int64_t)G.m * cout * 2);  // the descriptor of g
+  if (narrow) {
+    const int total_segs = batch * G.ho * ((G.wo + 31) / 32);
+    int ns = c2_wgrad3n_splits(total_segs);
+    const int sps = (total_segs + ns - 1) / ns;
+    ns = (total_segs + sps - 1) / sps;
+    const size_t needn = (size_t)c2_wgrad3n_splits(total_segs) * 9 * 64 * 64 * sizeof(float);
+    if (!workspace || workspace_bytes < needn)
+      return d3d_set_error(D3D_ECAPACITY, "d3d_conv2d_nhwc_wgrad: workspace %zu B < %zu B", workspace_bytes, needn);
+    const size_t ldsn = 3 * (size_t)(2 * 32 * 128 + 2 * 40 * 128);
+    D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_wgrad3n_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn));
+    hipLaunchKernelGGL(conv2d_wgrad3n_kernel, dim3(ns * 3), dim3(256), ldsn, stream, g_hi, g_lo, x_hi, x_lo,
+                       (float *)workspace, G, sps, ns);
+    D3D_LAUNCH_TRY("conv2d_wgrad3n_kernel");
+    const int64_t n4 = (int64_t)9 * 64 * 64 / 4;
+    hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, stream,
+                       (const float4 *)workspace, ns, 9, 64, 64, dw);
+    D3D_LAUNCH_TRY("conv2d_wgrad_reduce_kernel");
+    return D3D_OK;
+  }
   const int splits = c2_wgrad_splits(G.m, ksz * ksz * (cin / 128) * (cout / 128));
   const size_t need = d3d_conv2d_wgrad_workspace_bytes(batch, G.ho, G.wo, cin, cout, ksz);
   if (!workspace || workspace_bytes < need)

@@ -254,3 +254,199 @@ __global__ void __launch_bounds__(512, 2)
       }
   }
 }
+
+// ---- 64 x 64 weight tiles: the 64-channel 3x3 layers of the PointPillars necks' first block (rpn.py:80-110 with
+// ds_num_filters[0] = 64).  The same construction on 128-byte rows: a block of FOUR waves owns one kernel row of the whole
+// 64 x 64 weight matrix and a range of 32-pixel segments; wave (wco, wci) holds a 32 x 32 tile for the three taps.  LDS-DMA
+// instructions cover 8 rows of 128 B; chunk c of row r sits at c ^ (((r >> 1) & 3) << 1): the four pixel rows of a
+// transposing read are then 64 B apart within the two 256-byte bank lines they share, and the 32-byte piece a lane
+// group reads stays contiguous.  18 KB per stage, ring of three, one barrier per K step, two to three blocks per CU
+// (the blocks overlap each other's load and MFMA parts; no stagger inside a block).  18 MFMAs per wave and K step.
+__global__ void __launch_bounds__(256, 2)
+    conv2d_wgrad3n_kernel(const void *__restrict__ g_hi, const void *__restrict__ g_lo, const void *__restrict__ x_hi,
+                          const void *__restrict__ x_lo, float *__restrict__ part, Conv2dGeom G, int segs_per_split,
+                          int nsplit) {
+  constexpr int GPLANE = 32 * 128, XPLANE = 40 * 128;
+  constexpr int STAGE = 2 * GPLANE + 2 * XPLANE;  // g hi | g lo | x hi | x lo = 18432 B
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [3][STAGE]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wco = wave >> 1, wci = wave & 1;
+  int logical;
+  {
+    const int nb = (int)gridDim.x, q = nb >> 3, r = nb & 7, xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int ky = logical % 3;
+  const int split = logical / 3;
+  const int segs = (G.wo + 31) >> 5;
+  const int total = G.batch * G.ho * segs;
+  const int q_begin = split * segs_per_split;
+  int q_end = q_begin + segs_per_split;
+  if (q_end > total) q_end = total;
+  const int nks = q_end > q_begin ? q_end - q_begin : 0;
+
+  const __amdgpu_buffer_rsrc_t gr_hi = __builtin_amdgcn_make_buffer_rsrc((void *)g_hi, 0, G.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t gr_lo = __builtin_amdgcn_make_buffer_rsrc((void *)g_lo, 0, G.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr_hi = __builtin_amdgcn_make_buffer_rsrc((void *)x_hi, 0, G.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr_lo = __builtin_amdgcn_make_buffer_rsrc((void *)x_lo, 0, G.x_bytes, 0x00020000);
+
+  // staging: this wave's instructions = rows 8 wave .. 8 wave + 7 of the g tile and of the input run (both planes); rows
+  // 32 .. 39 of the run (36 used): plane hi by wave 0, plane lo by wave 1
+  auto swz = [](int r) { return ((r >> 1) & 3) << 1; };
+  const int srow = 8 * wave + (lane >> 3), srow8 = 32 + (lane >> 3);
+  const uint32_t schunk = (uint32_t)(((lane & 7) ^ swz(srow)) * 16);  // swz(srow8) == swz(srow): 32 = 0 mod 8
+  int s_seg, s_y, s_b;
+  {
+    const int ry = q_begin / segs;
+    s_seg = q_begin - ry * segs;
+    s_b = ry / G.ho;
+    s_y = ry - s_b * G.ho;
+  }
+  auto stage = [&](int buf) {
+    unsigned char *sg = smem + buf * STAGE, *sx = sg + 2 * GPLANE;
+    const int x0 = s_seg << 5;
+    const int iy = s_y - G.pad + ky;
+    const bool row_ok = iy >= 0 && iy < G.h;
+    {
+      const int ox = x0 + srow;
+      const uint32_t goff = ox < G.wo ? (uint32_t)(((s_b * G.ho + s_y) * G.wo + ox) * 128) + schunk : D3D_OOB_OFFSET;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(gr_hi, (c2_lds_void *)(sg + wave * 1024), 16, (int)goff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(gr_lo, (c2_lds_void *)(sg + GPLANE + wave * 1024), 16, (int)goff, 0, 0, 0);
+    }
+    {
+      const int ix = x0 - G.pad + srow;
+      const uint32_t xoff = (row_ok && ix >= 0 && ix < G.w) ? (uint32_t)(((s_b * G.h + iy) * G.w + ix) * 128) + schunk
+                                                            : D3D_OOB_OFFSET;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr_hi, (c2_lds_void *)(sx + wave * 1024), 16, (int)xoff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr_lo, (c2_lds_void *)(sx + XPLANE + wave * 1024), 16, (int)xoff, 0, 0, 0);
+    }
+    if (wave < 2) {
+      const int ix = x0 - G.pad + srow8;
+      const uint32_t xoff = (row_ok && ix >= 0 && ix < G.w) ? (uint32_t)(((s_b * G.h + iy) * G.w + ix) * 128) + schunk
+                                                            : D3D_OOB_OFFSET;
+      if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr_hi, (c2_lds_void *)(sx + 4 * 1024), 16, (int)xoff, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(xr_lo, (c2_lds_void *)(sx + XPLANE + 4 * 1024), 16, (int)xoff, 0, 0, 0);
+    }
+    if (++s_seg == segs) {
+      s_seg = 0;
+      if (++s_y == G.ho) {
+        s_y = 0;
+        ++s_b;
+      }
+    }
+  };
+
+  c2_f32x16 acc[3];  // [kx]
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+  const int i16 = lane & 15;
+  const int prow = ((lane >> 5) << 3) + (i16 >> 2);
+  const int chan = (((lane >> 4) & 1) << 4) + ((i16 & 3) << 2);
+  // (row + 4 changes the swizzle, row + 16 does not: one address per (tile | tap, first / second read))
+  uint32_t fo_g[2], fo_x[3][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    {
+      const int ch = wco * 32 + chan, row = prow + 4 * h;
+      fo_g[h] = (uint32_t)(row * 128 + ((((ch * 2) >> 4) ^ swz(row)) << 4) + ((ch * 2) & 15));
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int ch = wci * 32 + chan, row = prow + 4 * h + t;
+      fo_x[t][h] = (uint32_t)(row * 128 + ((((ch * 2) >> 4) ^ swz(row)) << 4) + ((ch * 2) & 15));
+    }
+  }
+  auto tr_read = [&](uint32_t addr) -> u2 {
+    u2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+  };
+
+  if (nks > 0) stage(0);
+  if (nks > 1) stage(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+#pragma unroll 1
+  for (int ks = 0; ks < nks; ++ks) {
+    const int buf = ks % 3;
+    const uint32_t gbase = lds_base + (uint32_t)(buf * STAGE);
+    const uint32_t xbase = gbase + (uint32_t)(2 * GPLANE);
+    u2 gr[2][2][2], xr[2][3][2][2];  // [substep][tap][plane][first / second read]
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          gr[kk][p][h] = tr_read(gbase + (uint32_t)(p * GPLANE + kk * 2048) + fo_g[h]);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) xr[kk][t][p][h] = tr_read(xbase + (uint32_t)(p * XPLANE + kk * 2048) + fo_x[t][h]);
+        }
+    if (ks + 2 < nks) {
+      int nb3 = buf + 2;
+      if (nb3 >= 3) nb3 -= 3;
+      stage(nb3);
+      if (wave < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          asm volatile("" : "+v"(gr[kk][p][h]));
+#pragma unroll
+          for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(xr[kk][t][p][h]));
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      c2_bf16x8 ga[2], xb[3][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const u4 v = {gr[kk][p][0][0], gr[kk][p][0][1], gr[kk][p][1][0], gr[kk][p][1][1]};
+        ga[p] = __builtin_bit_cast(c2_bf16x8, v);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const u4 u = {xr[kk][t][p][0][0], xr[kk][t][p][0][1], xr[kk][t][p][1][0], xr[kk][t][p][1][1]};
+          xb[t][p] = __builtin_bit_cast(c2_bf16x8, u);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], xb[t][0], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], xb[t][1], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], xb[t][0], acc[t], 0, 0, 0);
+    }
+  }
+
+  // partial slabs: part[split][tap = 3 ky + kx][co][ci] with cout = cin = 64
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float *dst = part + ((int64_t)split * 9 + (ky * 3 + t)) * (64 * 64);
+    const int ci = wci * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      dst[co * 64 + ci] = acc[t][r];
+    }
+  }
+}

@@ -139,9 +139,10 @@ def wgrad_raw(g_hi, g_lo, x_hi, x_lo, ksz, stride, pad, mode):
     ho, wo = _out_hw(h, w, ksz, stride, pad)
     assert tuple(g_hi.shape[:3]) == (b, ho, wo)
     dev = x_hi.device
-    if cin % 128 or cout % 128:
-        # 64-channel layers (the first block of the PointPillars necks): no library weight-gradient kernel yet -- the
-        # f32 values back from their planes, MIOpen's weight gradient on channels-last views of them
+    narrow = cin == 64 and cout == 64 and ksz == 3 and stride == 1 and mode == "split"  # conv2d_wgrad3n_kernel
+    if (cin % 128 or cout % 128) and not narrow:
+        # other 64-channel pairs (64 -> 128 with stride 1 does not occur in the shipped necks): the f32 values back from
+        # their planes, MIOpen's weight gradient on channels-last views of them
         if mode == "split":
             xf, gf = join_planes(x_hi, x_lo), join_planes(g_hi, g_lo)
         else:
