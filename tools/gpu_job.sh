@@ -132,6 +132,15 @@ for dt in ("fp32", "bf16"):
             print(dt, g, "FAILED", e)
 PY
       ;;
+    alloc)
+      # caching-allocator growth inside the timed window, with and without size rounding
+      B="--steps 20 --warmup 3 --no-cpu-baseline --no-extras"
+      for v in none "roundup_power2_divisions:4" "roundup_power2_divisions:8" "expandable_segments:True"; do
+        n=$(echo $v | tr -c 'a-zA-Z0-9' '_')
+        if [ "$v" = none ]; then timeout 300 python bench.py --gpus 1 $B > $O/a_$n.json 2> $O/a_$n.err
+        else PYTORCH_HIP_ALLOC_CONF=$v PYTORCH_CUDA_ALLOC_CONF=$v timeout 300 python bench.py --gpus 1 $B > $O/a_$n.json 2> $O/a_$n.err; fi
+        echo "$v: $(grep -h 'timed region done' $O/a_$n.err | cut -c1-220)"; show $O/a_$n.json 1
+      done ;;
     mrprof)
       export D3D_PROFILE_TIMELINE=1
       R1="D3D_DIST_SINGLE=1 D3D_DIST_BACKEND=nccl RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1"
