@@ -58,6 +58,7 @@ SIGNATURES = {
     "d3d_bn_bwd_reduce_residual": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]),
     "d3d_bn_bwd_dx_residual": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
     "d3d_bn_bwd_dx": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]),
+    "d3d_pack_all": (i32, [vp, i32, vp]),
     "d3d_conv2d_supported": (i32, [i32, i32, i32, i32]),
     "d3d_conv2d_supported_split3x3": (i32, [i32, i32]),
     "d3d_conv2d_stats_ws_floats": (sz, [i32, i32, i32, i32]),
@@ -118,6 +119,12 @@ class ConvEpilogue(ctypes.Structure):
     """D3dConvEpilogue of include/d3d.h (device pointers as integers)"""
     _fields_ = [("stats", vp), ("bn_x", vp), ("bn_mean", vp), ("bn_invstd", vp), ("bn_gamma", vp),
                 ("bn_beta", vp), ("bn_relu", i32), ("bn_partial", vp), ("ws_floats", i32), ("addend", vp)]
+
+
+class PackDesc(ctypes.Structure):
+    """D3dPackDesc of include/d3d.h"""
+    _fields_ = [("weight", vp), ("fwd", vp), ("fwd_lo", vp), ("dgrad", vp), ("dgrad_lo", vp), ("kind", i32), ("a", i32),
+                ("b", i32), ("c", i32), ("flip", i32), ("dtype", i32)]
 
 
 class DenseBnBackward(ctypes.Structure):

@@ -133,3 +133,108 @@ extern "C" int d3d_adam_step(const int64_t *tensors, int n_tensors, const int32_
   }
   return D3D_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ d3d_pack_all
+// The conv kernels read their weights in packed operand forms (sparse: [kvol][cout][cin] / [kvol][cin][cout] with
+// mirrored offsets, bf16 or hi / lo planes; dense: [tap][cout][cin] / [mirrored tap][cin][cout]).  An optimizer step
+// changes every weight, so every layer repacked in front of its first launch of the next step: 21 small launches inside
+// the host-bound forward phase of the KITTI step.  d3d_pack_all rewrites ALL packed forms in one launch behind the
+// optimizer: descriptors travel as kernel arguments (<= D3D_PACK_MAX per launch), a block finds its tensor by its first
+// block index.  Same element arithmetic as spconv_pack_weights_kernel / conv2d_pack_kernel.
+#define PACK_ELEMS_PER_BLOCK 2048
+struct PackDescDev {
+  const float *w;
+  void *fwd, *fwd_lo, *dgrad, *dgrad_lo;
+  int kind, a, b, c;      // sparse (0): kvol, cin, cout; dense (1): cout, cin, taps
+  int flip, mode_fwd, mode_dgrad;
+  int block_begin;
+};
+struct PackAllArgs {
+  PackDescDev d[D3D_PACK_MAX];
+  int n;
+};
+
+__device__ __forceinline__ uint16_t pk_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+__global__ void __launch_bounds__(256) pack_all_kernel(PackAllArgs A) {
+  int ti = 0;
+  for (int i = 1; i < A.n; ++i) ti = (int)blockIdx.x >= A.d[i].block_begin ? i : ti;  // wave-uniform
+  const PackDescDev &D = A.d[ti];
+  const int total = D.a * D.b * D.c;
+  const int first = ((int)blockIdx.x - D.block_begin) * PACK_ELEMS_PER_BLOCK;
+  for (int t = first + (int)threadIdx.x; t < first + PACK_ELEMS_PER_BLOCK && t < total; t += 256) {
+    const float v = D.w[t];
+    const uint16_t h = pk_bf16(v);
+    const uint16_t l = pk_bf16(v - __uint_as_float((uint32_t)h << 16));
+    if (D.kind == 0) {
+      const int kvol = D.a, cin = D.b, cout = D.c;
+      const int per_k = cin * cout;
+      const int k = t / per_k, rem = t - k * per_k;
+      const int ci = rem / cout, co = rem - ci * cout;
+      const int kd = D.flip ? kvol - 1 - k : k;
+      if (D.fwd) {
+        if (D.mode_fwd == 0) ((float *)D.fwd)[(k * cout + co) * cin + ci] = v;
+        else if (D.mode_fwd == 1) ((uint16_t *)D.fwd)[(k * cout + co) * cin + ci] = h;
+        else {
+          ((uint16_t *)D.fwd)[((k * 2 + 0) * cout + co) * cin + ci] = h;
+          ((uint16_t *)D.fwd)[((k * 2 + 1) * cout + co) * cin + ci] = l;
+        }
+      }
+      if (D.dgrad) {
+        if (D.mode_dgrad == 0) ((float *)D.dgrad)[(kd * cin + ci) * cout + co] = v;
+        else if (D.mode_dgrad == 1) ((uint16_t *)D.dgrad)[(kd * cin + ci) * cout + co] = h;
+        else {
+          ((uint16_t *)D.dgrad)[((kd * 2 + 0) * cin + ci) * cout + co] = h;
+          ((uint16_t *)D.dgrad)[((kd * 2 + 1) * cin + ci) * cout + co] = l;
+        }
+      }
+    } else {
+      const int cout = D.a, cin = D.b, taps = D.c;
+      const int tap = t % taps, ci = (t / taps) % cin, co = t / (taps * cin);
+      const int fi = (tap * cout + co) * cin + ci;
+      const int di = ((taps - 1 - tap) * cin + ci) * cout + co;
+      if (D.fwd) ((uint16_t *)D.fwd)[fi] = h;
+      if (D.fwd_lo) ((uint16_t *)D.fwd_lo)[fi] = l;
+      if (D.dgrad) ((uint16_t *)D.dgrad)[di] = h;
+      if (D.dgrad_lo) ((uint16_t *)D.dgrad_lo)[di] = l;
+    }
+  }
+}
+
+extern "C" int d3d_sparse_conv_has_epilogue(int cin, int cout, int dtype);
+
+extern "C" int d3d_pack_all(const D3dPackDesc *descs, int n, d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  D3D_REQUIRE(descs && n >= 0, "d3d_pack_all: arguments");
+  for (int base = 0; base < n; base += D3D_PACK_MAX) {
+    PackAllArgs A;
+    A.n = n - base < D3D_PACK_MAX ? n - base : D3D_PACK_MAX;
+    int blocks = 0;
+    for (int i = 0; i < A.n; ++i) {
+      const D3dPackDesc &s = descs[base + i];
+      D3D_REQUIRE(s.weight && (s.fwd || s.dgrad) && s.a >= 1 && s.b >= 1 && s.c >= 1 && (s.kind == 0 || s.kind == 1),
+                  "d3d_pack_all: descriptor %d", base + i);
+      D3D_REQUIRE((int64_t)s.a * s.b * s.c < ((int64_t)1 << 30), "d3d_pack_all: tensor %d too large", base + i);
+      PackDescDev &d = A.d[i];
+      d.w = s.weight; d.fwd = s.fwd; d.fwd_lo = s.fwd_lo; d.dgrad = s.dgrad; d.dgrad_lo = s.dgrad_lo;
+      d.kind = s.kind; d.a = s.a; d.b = s.b; d.c = s.c; d.flip = s.flip;
+      d.mode_fwd = d.mode_dgrad = 1;
+      if (s.kind == 0) {  // as d3d_pack_conv_weights: f32 features -> hi / lo planes where an MFMA tiling exists
+        D3D_REQUIRE(s.dtype == D3D_F32 || s.dtype == D3D_BF16, "d3d_pack_all: dtype %d", s.dtype);
+        d.mode_fwd = s.dtype == D3D_BF16 ? 1 : (d3d_sparse_conv_has_epilogue(s.b, s.c, s.dtype) ? 2 : 0);
+        d.mode_dgrad = s.dtype == D3D_BF16 ? 1 : (d3d_sparse_conv_has_epilogue(s.c, s.b, s.dtype) ? 2 : 0);
+      }
+      d.block_begin = blocks;
+      blocks += (s.a * s.b * s.c + PACK_ELEMS_PER_BLOCK - 1) / PACK_ELEMS_PER_BLOCK;
+    }
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL(pack_all_kernel, dim3(blocks), dim3(256), 0, stream, A);
+    D3D_LAUNCH_TRY("pack_all_kernel");
+  }
+  return D3D_OK;
+}

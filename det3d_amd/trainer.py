@@ -80,6 +80,9 @@ class TrainStep:
 
             self.fused = FusedAdam(self.params, beta2=0.99)
             self.opt = None
+            from .repack import Repacker
+
+            self.repacker = Repacker(self.params)  # every packed conv operand in one launch behind the optimizer
         else:
             try:
                 self.opt = torch.optim.Adam(self.params, fused=dev.type == "cuda", **kw)
@@ -120,6 +123,7 @@ class TrainStep:
                 self.bucket.allreduce_mean()
                 scale = 1.0
             gnorm = self.fused.step(lr, mom, decay=1.0 - self.wd * lr, max_norm=self.grad_clip, grad_scale=scale)
+            self.repacker.run()
         else:
             for g in self.opt.param_groups:
                 g["lr"] = lr

@@ -235,6 +235,23 @@ int d3d_adam_step(const int64_t *tensors, int n_tensors, const int32_t *chunks, 
                   const int32_t *tensor_chunk_start, const uint64_t *grads_host, const D3dAdamHyper *hyper,
                   float *partial, float *grad_norm, d3d_stream_t stream);
 
+/* Every packed conv operand rewritten in ONE launch behind the optimizer step (ABI 7; csrc/d3d_optim.hip).  The conv
+ * layers read their weights in packed forms -- d3d_pack_conv_weights (sparse) / d3d_conv2d_pack_weights (dense) -- and
+ * an optimizer step invalidates all of them: d3d_pack_all takes one descriptor per weight tensor (HOST array) and does
+ * what n calls of those two functions would, same bytes.
+ *  kind 0 (sparse): weight dev f32 [a = kvol][b = cin][c = cout]; fwd / dgrad as d3d_pack_conv_weights' wpack_fwd /
+ *                   wpack_dgrad (either may be NULL), flip = its flip_dgrad, dtype = the feature dtype;
+ *  kind 1 (dense):  weight dev f32 [a = cout][b = cin][c = k*k]; fwd, fwd_lo, dgrad, dgrad_lo as d3d_conv2d_pack_weights'
+ *                   fwd_hi / fwd_lo / dgrad_hi / dgrad_lo (NULL = not wanted). */
+#define D3D_PACK_MAX 40
+typedef struct D3dPackDesc {
+  const float *weight;
+  void *fwd, *fwd_lo, *dgrad, *dgrad_lo;
+  int kind, a, b, c;
+  int flip, dtype;
+} D3dPackDesc;
+int d3d_pack_all(const D3dPackDesc *descs, int n, d3d_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * BatchNorm1d (+ReLU) over the active sites: replaces the nn.BatchNorm1d / nn.ReLU module
  * pairs that spconv.SparseSequential applies to `.features` after every sparse conv
