@@ -159,3 +159,48 @@ def test_training_steps_with_the_fused_optimizer_follow_the_torch_sequence(monke
     for x, y in zip(pa, pb):
         assert float((x - y).abs().max()) <= 1e-7 + 1e-5 * float(y.abs().max())
     assert max(float(y.abs().max()) for y in pb) > 1e-4
+
+
+def test_pack_all_rewrites_every_cached_operand_like_the_per_layer_packs():
+    """d3d_pack_all / repack.Repacker: after the parameters changed, ONE launch must leave every cached packed operand
+    (sparse [kvol][cout][cin] / mirrored dgrad form in hi / lo planes or bf16, dense [tap][cout][cin] planes) bit-equal
+    to what the per-layer pack launches produce from the same weights, and stamp the caches with the new versions."""
+    from det3d_amd import dense_conv, spconv
+    from det3d_amd.repack import Repacker
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    sparse = [torch.nn.Parameter(torch.randn(3, 3, 3, ci, co, device=dev) * 0.1) for ci, co in ((16, 16), (32, 64), (64, 64), (128, 128))]
+    sparse.append(torch.nn.Parameter(torch.randn(3, 1, 1, 64, 64, device=dev) * 0.1))
+    dense = [torch.nn.Parameter(torch.randn(co, ci, k, k, device=dev) * 0.1) for co, ci, k in ((128, 128, 3), (256, 128, 3), (128, 256, 1), (64, 64, 3))]
+    subm = [True, False, True, True, False]
+    dts = [torch.float32, torch.float32, torch.bfloat16, torch.float32, torch.float32]
+
+    def pack_now():
+        out = []
+        for p, sm, dt in zip(sparse, subm, dts):
+            kvol = p.numel() // (p.shape[-2] * p.shape[-1])
+            out.append(spconv._packed_weights(p, kvol, p.shape[-2], p.shape[-1], dt, sm, True, p.shape[-2]))
+        for p in dense:
+            out.append((dense_conv._packed(p, "fwd", "split"), dense_conv._packed(p, "dgrad", "split")))
+        out.append((dense_conv._packed(dense[0], "fwd", "bf16"), dense_conv._packed(dense[0], "dgrad", "bf16")))
+        return out
+
+    first = pack_now()
+    rp = Repacker(sparse + dense)
+    with torch.no_grad():
+        for p in sparse + dense:
+            p.add_(torch.randn_like(p) * 0.05)  # bumps ._version, like an optimizer step
+    n = rp.run()
+    assert n == len(sparse) + len(dense) + 1
+    flat = lambda o: [t for t in (o if isinstance(o, (list, tuple)) else [o]) for t in (flat(t) if isinstance(t, (list, tuple)) else [t])]
+    got = [t.clone() if t is not None else None for t in flat(first)]          # the SAME buffers, rewritten in place
+    again = pack_now()                                                          # cache hits: no new pack launches
+    for a, b in zip(flat(first), flat(again)):
+        assert (a is None and b is None) or a.data_ptr() == b.data_ptr()
+    spconv._PACK_CACHE.clear()
+    dense_conv._PACK.clear()
+    ref = pack_now()                                                            # fresh per-layer packs of the new weights
+    for a, b in zip(got, flat(ref)):
+        assert (a is None and b is None) or torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a,
+                                                        b.view(torch.int16) if b.dtype == torch.bfloat16 else b)
