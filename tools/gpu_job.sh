@@ -141,6 +141,13 @@ PY
         else PYTORCH_HIP_ALLOC_CONF=$v PYTORCH_CUDA_ALLOC_CONF=$v timeout 300 python bench.py --gpus 1 $B > $O/a_$n.json 2> $O/a_$n.err; fi
         echo "$v: $(grep -h 'timed region done' $O/a_$n.err | cut -c1-220)"; show $O/a_$n.json 1
       done ;;
+    ab:*)
+      # bench.py with an environment switch off and on, twice each, same box:  ab:D3D_PACK_ALL
+      v=${st#ab:}
+      for rep in 1 2; do for val in 0 1; do
+        env $v=$val timeout 300 python bench.py --gpus 1 --steps 60 --warmup 3 --no-cpu-baseline --no-extras > $O/ab_${v}_${val}_$rep.json 2> $O/ab_${v}_${val}_$rep.err
+        echo "$v=$val: $(show $O/ab_${v}_${val}_$rep.json 2 | tr '\n' ' ' | cut -c1-200)"
+      done; done ;;
     mrprof)
       export D3D_PROFILE_TIMELINE=1
       R1="D3D_DIST_SINGLE=1 D3D_DIST_BACKEND=nccl RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1"
