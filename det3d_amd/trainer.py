@@ -105,12 +105,17 @@ class TrainStep:
             return contextlib.nullcontext()
         return torch.autocast(device_type="cuda", dtype=self.autocast_dtype)
 
-    def __call__(self, example):
+    def __call__(self, example, after_forward=None):
+        """one optimizer step on `example`.  after_forward: called between the forward and the backward enqueue -- the
+        place to start host work for a LATER step (the next geometry build on its worker thread): the forward phase is
+        the host-bound part of the step, the backward's large dense kernels leave the host time to spare."""
         lr, mom = self.sched.at(self.global_step)
         self.bucket.zero()
         with self._ctx():
             losses = self.model(example, return_loss=True)
         loss = sum(losses["loss"])
+        if after_forward is not None:
+            after_forward()
         loss.backward()
         if self.fused is not None:
             # the exchanged sums (or the local gradients) as they are: mean over ranks, clipping, true weight decay
