@@ -72,3 +72,30 @@ for key, cin, cout in (("subm", 128, 128), ("subm", 64, 128), ("subm", 128, 64),
         print("  variant %2d %-20s rc %d  %7.1f us  %6.1f GB/s alg = %.3f of 8 TB/s  identical %s" % (
             v, names[v], rc, t, balg / t / 1e3, balg / t / 1e3 / 8000, same), flush=True)
     L.d3d_set_tuning(0, 0)
+
+# ---- weight gradient of the same layers: target block count (d3d_set_tuning knob 1; default one block per CU).  The kernel
+# launches (offset groups x splits) blocks with splits rounded to a multiple of 8: 128x128 (9 groups) gets 216 blocks at
+# the default -- 40 CUs idle
+print("\nweight gradient, f32 (split): us per launch by target block count", flush=True)
+for key, cin, cout in (("subm", 128, 128), ("subm", 64, 64), ("subm", 32, 32), ("down", 64, 128)):
+    rb = x.indice_dict[key]
+    n_in, n, P = rb.n_in, rb.n_out, rb.pairs()
+    f = torch.randn(n_in, cin, device=dev)
+    g = torch.randn(n, cout, device=dev)
+    dw = torch.empty((rb.kvol, cin, cout), device=dev)
+    row = []
+    ref = None
+    for blocks in (0, 288, 384, 512, 768, 1024):
+        L.d3d_set_tuning(1, blocks)
+        wsb = L.d3d_sparse_conv_wgrad_workspace_bytes(n, rb.kvol, cin, cout, _lib.D3D_F32)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        call = lambda: L.d3d_sparse_conv_wgrad(f.data_ptr(), g.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, n, rb.kvol, cin,
+                                               cout, _lib.D3D_F32, dw.data_ptr(), ws.data_ptr(), wsb, st)
+        rc = call()
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = dw.clone()
+        close = float((dw - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+        row.append("%s %.0f%s" % ("default" if blocks == 0 else blocks, timed(call, 10), "" if (rc == 0 and close) else " (rc %d, mismatch)" % rc))
+    L.d3d_set_tuning(1, 0)
+    print("  %s %d x %d (%d pairs, B_alg %.0f MB): %s" % (key, cin, cout, P, P * (cin + cout) * 4 / 1e6, " | ".join(row)), flush=True)
