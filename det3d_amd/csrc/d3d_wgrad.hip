@@ -301,10 +301,14 @@ struct WgPlan {
   int kg, step, csplit, splits, rows_per_split;
 };
 
-static int wg_target_blocks() {
-  static const int v = getenv("D3D_WGRAD_BLOCKS") ? atoi(getenv("D3D_WGRAD_BLOCKS")) : 256;  // one per CU
+// Blocks to aim for.  One per CU by default; the f32 layers that take three offsets per block (nine offset groups: 64->128
+// and 128x128) get two rounds -- 24 splits x 9 = 216 blocks left 40 CUs idle, 56 x 9 = 504 fills two rounds (measured on the
+// CBGS rulebooks: 1049 -> 850 us and 514 -> 472 us per launch; the nine-offset layers are flat or slower with more splits)
+static int wg_target_blocks(int kg, int dtype) {
+  static const int v = getenv("D3D_WGRAD_BLOCKS") ? atoi(getenv("D3D_WGRAD_BLOCKS")) : 0;
   if (g_d3d_wgrad_blocks > 0) return g_d3d_wgrad_blocks;
-  return v < 1 ? 256 : v;
+  if (v >= 1) return v;
+  return (dtype == D3D_F32 && kg == 3) ? 512 : 256;
 }
 
 // offsets per block: the accumulators of a wave are 4 * KG * TPW registers
@@ -330,7 +334,7 @@ static WgPlan wg_plan(int n_out, int kvol, int cin, int cout, int dtype) {
   p.csplit = wg_csplit(cin, cout, dtype);
   const int kgroups = kvol / p.kg;
   const int tiles = (n_out + p.step - 1) / p.step;
-  int splits = (wg_target_blocks() + kgroups - 1) / kgroups;
+  int splits = (wg_target_blocks(p.kg, dtype) + kgroups - 1) / kgroups;
   int max_splits = (tiles + 1) / 2;  // >= 2 tiles per block
   if (max_splits < 1) max_splits = 1;
   if (splits > max_splits) splits = max_splits;
