@@ -72,7 +72,10 @@ static int wg_csplit(int cin, int cout, int dtype) {
 //         64 us in bf16): the f32 rows are split where they are written to LDS -- hi = bf16(v), lo = bf16(v - hi)
 //         into two planes of the same [16 sites][16 ch] tiles -- and every product is three bf16 MFMAs
 //         (hi*hi + hi*lo + lo*hi), f32 accumulation: relative error ~2^-16 of the products
-template <int CIN, int COUT, int KG, int DEPTH, bool BF16>
+// BREG (round 4): the dout fragments of a tile do not depend on the kernel offset -- a wave reads ITS fragments (one cout
+// tile, its k-steps, hi / lo) once per tile into registers instead of once per stage: half of the transposing LDS reads
+// of a stage gone (64 x 64 f32: 16 -> 8 per wave), for QN * NPL * 4 registers
+template <int CIN, int COUT, int KG, int DEPTH, bool BF16, bool BREG = false>
 __global__ void __launch_bounds__(WG_THREADS)
     spconv_wgrad_tile_kernel(const void *__restrict__ feat_, const void *__restrict__ dout_,
                              const int32_t *__restrict__ nbr, int cap, int n_out, int rows_per_split,
@@ -179,6 +182,9 @@ __global__ void __launch_bounds__(WG_THREADS)
   // indices of the stage DEPTH after that one.  DEPTH divides KG, so inside the unrolled tile body the slot of
   // offset kk is the compile-time constant kk % DEPTH.
   static_assert(KG % DEPTH == 0, "prefetch depth must divide the offset group");
+  constexpr int QN = KSTEPS / CSPLIT;  // k-steps of a stage per wave
+  static_assert(!BREG || (16 % COT == 0 || COT % 16 == 0), "BREG: the tiles of a wave share one cout tile");
+  wg_bf16x8_t breg[BREG ? QN : 1][NPL];
   uint4 fr[DEPTH];
   int ix[DEPTH];
   if (ntiles > 0) {
@@ -219,30 +225,59 @@ __global__ void __launch_bounds__(WG_THREADS)
       fr[d] = load_feat(ix[d], tile + (kk + DEPTH) / KG);
       ix[d] = load_index(tile + (kk + 2 * DEPTH) / KG, (kk + 2 * DEPTH) % KG);
       if (kk == 0) load_dout(tile + 1);
-#pragma unroll 4
-      for (int q = 0; q < (my_part < CSPLIT ? KSTEPS / CSPLIT : 0); ++q) {
-        const int ks = q * CSPLIT + my_part;  // this wave's k-steps of the stage
+      // 32 sites = LDS chunks 2*ks and 2*ks+1.  Each lane passes the address of ITS 8 bytes in the
+      // row-major 4x16 block of sites [lg*4, lg*4+4); the hardware returns the transposed column lr.
+      // A and B use the same site order, so any consistent k labelling is a valid sum.
+      auto operand = [&](const unsigned char *plane, int ctiles, int ct, int ks) -> wg_bf16x8_t {
+        const uint16_t *p16 = (const uint16_t *)plane;
+        wg_s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) wg_s16x4_t *)(p16 + ((2 * ks) * ctiles + ct) * 256 + lg * 64 + lr * 4));
+        wg_s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) wg_s16x4_t *)(p16 + ((2 * ks + 1) * ctiles + ct) * 256 + lg * 64 + lr * 4));
+        return __builtin_bit_cast(wg_bf16x8_t, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+      };
+      if constexpr (BREG) {
+        if (kk == 0 && my_part < CSPLIT) {  // this tile's dout fragments: once for the KG stages
+          const int cot0 = my_tile % COT;
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-          const int tl = my_tile + t * WG_WAVES;
-          const int cit = tl / COT, cot = tl - cit * COT;
-          // 32 sites = LDS chunks 2*ks and 2*ks+1.  Each lane passes the address of ITS 8 bytes in the
-          // row-major 4x16 block of sites [lg*4, lg*4+4); the hardware returns the transposed column lr.
-          // A and B use the same site order, so any consistent k labelling is a valid sum.
-          auto operand = [&](const unsigned char *plane, int ctiles, int ct) -> wg_bf16x8_t {
-            const uint16_t *p16 = (const uint16_t *)plane;
-            wg_s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) wg_s16x4_t *)(p16 + ((2 * ks) * ctiles + ct) * 256 + lg * 64 + lr * 4));
-            wg_s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) wg_s16x4_t *)(p16 + ((2 * ks + 1) * ctiles + ct) * 256 + lg * 64 + lr * 4));
-            return __builtin_bit_cast(wg_bf16x8_t, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
-          };
-          const wg_bf16x8_t ah = operand(bf, CIT, cit), bh = operand(bd, COT, cot);
-          acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[kk][t], 0, 0, 0);
-          if constexpr (!BF16) {
-            const wg_bf16x8_t al = operand(bf + FBUF * 2, CIT, cit), bl = operand(bd + DBUF * 2, COT, cot);
-            acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[kk][t], 0, 0, 0);
-            acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[kk][t], 0, 0, 0);
+          for (int q = 0; q < QN; ++q) {
+            breg[q][0] = operand(bd, COT, cot0, q * CSPLIT + my_part);
+            if constexpr (!BF16) breg[q][1] = operand(bd + DBUF * 2, COT, cot0, q * CSPLIT + my_part);
+          }
+        }
+        if (my_part < CSPLIT) {
+#pragma unroll
+          for (int q = 0; q < QN; ++q) {
+            const int ks = q * CSPLIT + my_part;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+              const int tl = my_tile + t * WG_WAVES;
+              const int cit = tl / COT;
+              const wg_bf16x8_t ah = operand(bf, CIT, cit, ks);
+              acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, breg[q][0], acc[kk][t], 0, 0, 0);
+              if constexpr (!BF16) {
+                const wg_bf16x8_t al = operand(bf + FBUF * 2, CIT, cit, ks);
+                acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, breg[q][1], acc[kk][t], 0, 0, 0);
+                acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, breg[q][0], acc[kk][t], 0, 0, 0);
+              }
+            }
+          }
+        }
+      } else {
+#pragma unroll 4
+        for (int q = 0; q < (my_part < CSPLIT ? KSTEPS / CSPLIT : 0); ++q) {
+          const int ks = q * CSPLIT + my_part;  // this wave's k-steps of the stage
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) {
+            const int tl = my_tile + t * WG_WAVES;
+            const int cit = tl / COT, cot = tl - cit * COT;
+            const wg_bf16x8_t ah = operand(bf, CIT, cit, ks), bh = operand(bd, COT, cot, ks);
+            acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[kk][t], 0, 0, 0);
+            if constexpr (!BF16) {
+              const wg_bf16x8_t al = operand(bf + FBUF * 2, CIT, cit, ks), bl = operand(bd + DBUF * 2, COT, cot, ks);
+              acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[kk][t], 0, 0, 0);
+              acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[kk][t], 0, 0, 0);
+            }
           }
         }
       }
@@ -304,9 +339,10 @@ struct WgPlan {
 // Blocks to aim for.  One per CU by default; the f32 layers that take three offsets per block (nine offset groups: 64->128
 // and 128x128) get two rounds -- 24 splits x 9 = 216 blocks left 40 CUs idle, 56 x 9 = 504 fills two rounds (measured on the
 // CBGS rulebooks: 1049 -> 850 us and 514 -> 472 us per launch; the nine-offset layers are flat or slower with more splits)
+// (tuning knob 1 carries two numbers: value % 100000 = blocks, value / 100000 = kernel variant, see wg_variant)
 static int wg_target_blocks(int kg, int dtype) {
   static const int v = getenv("D3D_WGRAD_BLOCKS") ? atoi(getenv("D3D_WGRAD_BLOCKS")) : 0;
-  if (g_d3d_wgrad_blocks > 0) return g_d3d_wgrad_blocks;
+  if (g_d3d_wgrad_blocks > 0 && g_d3d_wgrad_blocks % 100000 > 0) return g_d3d_wgrad_blocks % 100000;
   if (v >= 1) return v;
   return (dtype == D3D_F32 && kg == 3) ? 512 : 256;
 }
@@ -353,11 +389,18 @@ extern "C" size_t d3d_sparse_conv_wgrad_workspace_bytes(int n_out, int kvol, int
   return (size_t)p.splits * p.csplit * kvol * cin * cout * sizeof(float) + 256;
 }
 
-template <int CI, int CO, int KG, int DEPTH, bool BF16>
+// kernel variant: 0 = the shape's default, 1 = dout fragments re-read from LDS every stage (round 3), 2 = dout fragments
+// in registers (BREG) at the shape's prefetch depth, 3 = BREG at depth 3
+static int wg_variant() {
+  static const int v = getenv("D3D_WGRAD_VARIANT") ? atoi(getenv("D3D_WGRAD_VARIANT")) : 0;
+  return g_d3d_wgrad_blocks >= 100000 ? g_d3d_wgrad_blocks / 100000 : v;
+}
+
+template <int CI, int CO, int KG, int DEPTH, bool BF16, bool BREG = false>
 static int wg_launch(const void *feat, const void *dout, const int32_t *nbr, int cap, int n_out, int kvol,
                      const WgPlan &p, float *part, hipStream_t stream) {
   const int remap = g_xcd_remap && ((kvol / KG) * p.splits) % 8 == 0 && p.splits >= 8;
-  hipLaunchKernelGGL((spconv_wgrad_tile_kernel<CI, CO, KG, DEPTH, BF16>), dim3(kvol / KG, p.splits),
+  hipLaunchKernelGGL((spconv_wgrad_tile_kernel<CI, CO, KG, DEPTH, BF16, BREG>), dim3(kvol / KG, p.splits),
                      dim3(WG_THREADS), 0, stream, feat, dout, nbr, cap, n_out, p.rows_per_split, kvol, part, remap);
   D3D_LAUNCH_TRY("spconv_wgrad_tile_kernel");
   return D3D_OK;
@@ -373,6 +416,8 @@ static int wg_launch(const void *feat, const void *dout, const int32_t *nbr, int
       if (p.kg == 3) return wg_launch<CI, CO, 3, 3, true>(WG_ARGS);                                    \
       if (p.kg == 1) return wg_launch<CI, CO, 1, 1, true>(WG_ARGS);                                    \
     } else {                                                                                           \
+      if (p.kg == KGMAIN && wg_variant() == 2) return wg_launch<CI, CO, KGMAIN, DF32, false, true>(WG_ARGS); \
+      if (p.kg == KGMAIN && wg_variant() == 3) return wg_launch<CI, CO, KGMAIN, 3, false, true>(WG_ARGS);    \
       if (p.kg == KGMAIN) return wg_launch<CI, CO, KGMAIN, DF32, false>(WG_ARGS);                      \
       if (p.kg == 3) return wg_launch<CI, CO, 3, 3, false>(WG_ARGS);                                   \
       if (p.kg == 1) return wg_launch<CI, CO, 1, 1, false>(WG_ARGS);                                   \
