@@ -100,26 +100,28 @@ for key, cin, cout in (("subm", 128, 128), ("subm", 64, 64), ("subm", 32, 32), (
     L.d3d_set_tuning(1, 0)
     print("  %s %d x %d (%d pairs, B_alg %.0f MB): %s" % (key, cin, cout, P, P * (cin + cout) * 4 / 1e6, " | ".join(row)), flush=True)
 
-# ---- dout fragments in registers (knob 1 value = 100000 * variant + blocks): 0 default, 2 BREG, 3 BREG at prefetch depth 3
-print("\nweight gradient, f32 (split): us per launch by kernel variant (default | dout fragments in registers | same, depth 3)", flush=True)
-for key, cin, cout in (("subm", 128, 128), ("subm", 64, 64), ("subm", 32, 32), ("subm", 16, 16), ("down", 64, 128), ("down", 32, 64)):
-    rb = x.indice_dict[key]
-    n_in, n, P = rb.n_in, rb.n_out, rb.pairs()
-    f = torch.randn(n_in, cin, device=dev)
-    g = torch.randn(n, cout, device=dev)
-    dw = torch.empty((rb.kvol, cin, cout), device=dev)
-    row = []
-    ref = None
-    for variant in (0, 2, 3):
-        L.d3d_set_tuning(1, 100000 * variant)
-        wsb = L.d3d_sparse_conv_wgrad_workspace_bytes(n, rb.kvol, cin, cout, _lib.D3D_F32)
-        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
-        call = lambda: L.d3d_sparse_conv_wgrad(f.data_ptr(), g.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, n, rb.kvol, cin,
-                                               cout, _lib.D3D_F32, dw.data_ptr(), ws.data_ptr(), wsb, st)
-        rc = call()
-        torch.cuda.synchronize()
-        if ref is None:
-            ref = dw.clone()
-        row.append("%d: %.0f%s" % (variant, timed(call, 10), "" if (rc == 0 and torch.equal(dw, ref)) else " (rc %d, DIFFERENT)" % rc))
-    L.d3d_set_tuning(1, 0)
-    print("  %s %d x %d (%d pairs): %s" % (key, cin, cout, P, " | ".join(row)), flush=True)
+# ---- dout fragments in registers (knob 1 value = 100000 * variant + blocks): 0 = default (f32: in registers, bf16: re-read
+# from LDS), 1 = re-read every stage (round 3), 2 = in registers at the round-3 prefetch depth
+print("\nweight gradient: us per launch by kernel variant (0 default | 1 dout re-read per stage | 2 dout fragments in registers)", flush=True)
+for tdt, ddt, name in ((torch.float32, _lib.D3D_F32, "f32"), (torch.bfloat16, _lib.D3D_BF16, "bf16")):
+    for key, cin, cout in (("subm", 128, 128), ("subm", 64, 64), ("subm", 32, 32), ("subm", 16, 16), ("down", 64, 128), ("down", 32, 64)):
+        rb = x.indice_dict[key]
+        n_in, n, P = rb.n_in, rb.n_out, rb.pairs()
+        f = torch.randn(n_in, cin, device=dev).to(tdt)
+        g = torch.randn(n, cout, device=dev).to(tdt)
+        dw = torch.empty((rb.kvol, cin, cout), device=dev)
+        row = []
+        ref = None
+        for variant in (0, 1, 2):
+            L.d3d_set_tuning(1, 100000 * variant)
+            wsb = L.d3d_sparse_conv_wgrad_workspace_bytes(n, rb.kvol, cin, cout, ddt)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+            call = lambda: L.d3d_sparse_conv_wgrad(f.data_ptr(), g.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, n, rb.kvol, cin,
+                                                   cout, ddt, dw.data_ptr(), ws.data_ptr(), wsb, st)
+            rc = call()
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = dw.clone()
+            row.append("%d: %.0f%s" % (variant, timed(call, 10), "" if (rc == 0 and torch.equal(dw, ref)) else " (rc %d, DIFFERENT)" % rc))
+        L.d3d_set_tuning(1, 0)
+        print("  %s %s %d x %d (%d pairs): %s" % (name, key, cin, cout, P, " | ".join(row)), flush=True)
