@@ -389,7 +389,7 @@ extern "C" size_t d3d_sparse_conv_wgrad_workspace_bytes(int n_out, int kvol, int
   return (size_t)p.splits * p.csplit * kvol * cin * cout * sizeof(float) + 256;
 }
 
-// kernel variant: 0 = the shape's default (f32: BREG, 64 x 64 at prefetch depth 3; bf16: round 3's), 1 = dout fragments
+// kernel variant: 0 = the shape's default (BREG except bf16 64 x 128; f32 64 x 64 at prefetch depth 3), 1 = dout fragments
 // re-read from LDS every stage (round 3), 2 = dout fragments in registers (BREG) at the round-3 prefetch depth
 static int wg_variant() {
   static const int v = getenv("D3D_WGRAD_VARIANT") ? atoi(getenv("D3D_WGRAD_VARIANT")) : 0;
@@ -409,11 +409,12 @@ static int wg_launch(const void *feat, const void *dout, const int32_t *nbr, int
 #define WG_ARGS feat, dout, nbr, cap, n_out, kvol, p, part, stream
 // (channels) -> the offset group wg_kgroup() picks for a 27-offset kernel with its prefetch depth, plus the
 // 3-offset ((3,1,1) kernels) and 1-offset fallbacks
-#define WG_CASE(CI, CO, KGMAIN, DMAIN, DF32, DBREG)                                                       \
+#define WG_CASE(CI, CO, KGMAIN, DMAIN, DF32, DBREG, B16)                                                     \
   if (cin == CI && cout == CO) {                                                                       \
     const int var = wg_variant();                                                                      \
     if (bf16) {                                                                                        \
-      if (p.kg == KGMAIN && var == 2) return wg_launch<CI, CO, KGMAIN, DMAIN, true, true>(WG_ARGS);    \
+      if (p.kg == KGMAIN && (var == 2 || (var == 0 && B16)))                                           \
+        return wg_launch<CI, CO, KGMAIN, DMAIN, true, true>(WG_ARGS);                                  \
       if (p.kg == KGMAIN) return wg_launch<CI, CO, KGMAIN, DMAIN, true>(WG_ARGS);                      \
       if (p.kg == 3) return wg_launch<CI, CO, 3, 3, true>(WG_ARGS);                                    \
       if (p.kg == 1) return wg_launch<CI, CO, 1, 1, true>(WG_ARGS);                                    \
@@ -433,13 +434,15 @@ static int wg_dispatch(const void *feat, const void *dout, const int32_t *nbr, i
   // 16-wave block leaves each lane (accumulators: 4 * KG * TPW)
   // f32: the dout fragments of a tile live in registers (BREG; tools/tune_fwd_wide.py on a 264k-site rulebook, bit-identical
   // sums: 64 x 64 332 -> 263 us at depth 3, 32 x 64 156 -> 124, 32 x 32 105 -> 95, 128 x 128 810 -> 770)
-  WG_CASE(16, 16, 9, 3, 3, 3)
-  WG_CASE(16, 32, 9, 3, 3, 3)
-  WG_CASE(32, 32, 9, 3, 3, 3)
-  WG_CASE(32, 64, 9, 3, 3, 3)
-  WG_CASE(64, 64, 9, 9, 9, 3)
-  WG_CASE(64, 128, 9, 3, 3, 3)
-  WG_CASE(128, 128, 3, 3, 3, 3)
+  // bf16: 64 x 64 158 -> 135, 128 x 128 452 -> 427, 32 x 64 83 -> 71; not 64 x 128 (nine offsets x two tiles: the extra
+  // registers spill, 229 -> 340 us)
+  WG_CASE(16, 16, 9, 3, 3, 3, true)
+  WG_CASE(16, 32, 9, 3, 3, 3, true)
+  WG_CASE(32, 32, 9, 3, 3, 3, true)
+  WG_CASE(32, 64, 9, 3, 3, 3, true)
+  WG_CASE(64, 64, 9, 9, 9, 3, true)
+  WG_CASE(64, 128, 9, 3, 3, 3, false)
+  WG_CASE(128, 128, 3, 3, 3, 3, true)
   return d3d_set_error(D3D_EINVAL, "wgrad tile kernel: unsupported channels %d -> %d (kg %d)", cin, cout, p.kg);
 }
 
