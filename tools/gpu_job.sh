@@ -4,6 +4,7 @@
 # by hand afterwards.  Stages:
 #   tests            the driver's round-end sequence: pytest -m gpu -x, smoke()
 #   tests:<expr>     pytest -m gpu -k <expr>
+#   env:<VAR=VAL[,..]> one 60-step bench.py run under these environment variables
 #   bench            bench.py at the driver's flags (--gpus 1 --steps 20 --warmup 5)
 #   bench300         300 timed steps, no extras
 #   multirank        VERDICT r3 item 1: torchrun x2 over gloo on the one GPU (c2 / c3 / c4), 1-rank RCCL bench, and the
@@ -148,6 +149,11 @@ PY
         env $v=$val timeout 300 python bench.py --gpus 1 --steps 60 --warmup 3 --no-cpu-baseline --no-extras > $O/ab_${v}_${val}_$rep.json 2> $O/ab_${v}_${val}_$rep.err
         echo "$v=$val: $(show $O/ab_${v}_${val}_$rep.json 2 | tr '\n' ' ' | cut -c1-200)"
       done; done ;;
+    env:*)
+      # one 60-step bench.py run under VAR=VALUE (comma-separated list):  env:D3D_BN_STREAM_BLOCKS=1024
+      v=${st#env:}
+      env ${v//,/ } timeout 300 python bench.py --gpus 1 --steps 60 --warmup 3 --no-cpu-baseline --no-extras > $O/env_${v//[^A-Za-z0-9_=]/_}.json 2> $O/env_${v//[^A-Za-z0-9_=]/_}.err
+      echo "$v: $(show $O/env_${v//[^A-Za-z0-9_=]/_}.json 2 | tr '\n' ' ' | cut -c1-200)" ;;
     mrprof)
       export D3D_PROFILE_TIMELINE=1
       R1="D3D_DIST_SINGLE=1 D3D_DIST_BACKEND=nccl RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1"
