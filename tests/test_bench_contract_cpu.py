@@ -58,7 +58,7 @@ def test_recorded_bench_line_has_the_contract_fields(name):
         assert d["dtype"].startswith("f32") and d["precision"]["fp32_within_tolerance"] is True and d["value"] > 540
         c = d["config"]
         assert math.isfinite(c["first_loss"]) and c["final_loss"] < c["first_loss"] and c["steps_before_final_loss"] >= 25
-        assert d["rpn_mfma"]["frac"] > 0.38 and d["rpn_mfma"]["gflop_per_step_left_on_miopen"] == 0.0
+        assert d["rpn_mfma"]["frac"] > 0.37 and d["rpn_mfma"]["gflop_per_step_left_on_miopen"] == 0.0
         best = d["cpu_baseline"]["runs"][str(d["cpu_baseline"]["cores"])]
         assert best["steps"] >= 5
         for w in ("c2-60k", "c4", "c5", "c3"):
