@@ -45,22 +45,22 @@ __device__ __forceinline__ void wg_split2(float a, float b, uint32_t &hi, uint32
 #define WG_THREADS (WG_WAVES * 64)
 
 // compile-time geometry shared by the kernel and the host-side planner
-template <int CIN, int COUT, bool BF16> struct WgGeom {
+template <int CIN, int COUT, bool BF16, int WAVES = WG_WAVES> struct WgGeom {
   static constexpr int EPV = BF16 ? 8 : 4;                       // elements per 16-byte vector
   static constexpr int CIT = CIN / 16, COT = COUT / 16, TILES = CIT * COT;
   static constexpr int FSEG = CIN / EPV, DSEG = COUT / EPV;      // 16-byte segments per row
-  static constexpr int STEP = WG_THREADS / FSEG;                 // sites per stage (1 vector / thread)
+  static constexpr int STEP = WAVES * 64 / FSEG;                 // sites per stage (1 vector / thread)
   static constexpr int KSTEPS = STEP / 32;                       // MFMA k-steps (32 sites each) per stage
-  static constexpr int TPW = TILES >= WG_WAVES ? TILES / WG_WAVES : 1;     // MFMA tiles per wave
-  static constexpr int CSPLIT_ = TILES >= WG_WAVES ? 1 : WG_WAVES / TILES;
+  static constexpr int TPW = TILES >= WAVES ? TILES / WAVES : 1;     // MFMA tiles per wave
+  static constexpr int CSPLIT_ = TILES >= WAVES ? 1 : WAVES / TILES;
   static constexpr int CSPLIT = CSPLIT_ < KSTEPS ? CSPLIT_ : KSTEPS;       // waves sharing one tile: they
   //   split the sites of a stage and each keeps its own partial sum -> CSPLIT partial slabs per block (f32 rows of
   //   16 channels give 8 k-steps per stage: 8 of the 16 waves multiply, all 16 load)
 };
-static int wg_csplit(int cin, int cout, int dtype) {
+static int wg_csplit(int cin, int cout, int dtype, int waves) {
   const int tiles = (cin / 16) * (cout / 16);
-  const int step = WG_THREADS / (cin / (dtype == D3D_BF16 ? 8 : 4));
-  int cs = tiles >= WG_WAVES ? 1 : WG_WAVES / tiles;
+  const int step = waves * 64 / (cin / (dtype == D3D_BF16 ? 8 : 4));
+  int cs = tiles >= waves ? 1 : waves / tiles;
   if (cs > step / 32) cs = step / 32;
   return cs < 1 ? 1 : cs;
 }
@@ -75,16 +75,18 @@ static int wg_csplit(int cin, int cout, int dtype) {
 // BREG (round 4): the dout fragments of a tile do not depend on the kernel offset -- a wave reads ITS fragments (one cout
 // tile, its k-steps, hi / lo) once per tile into registers instead of once per stage: half of the transposing LDS reads
 // of a stage gone (64 x 64 f32: 16 -> 8 per wave), for QN * NPL * 4 registers
-template <int CIN, int COUT, int KG, int DEPTH, bool BF16, bool BREG = false>
-__global__ void __launch_bounds__(WG_THREADS)
+// WAVES: 16 (one block per CU) or 8 (two per CU, half the sites per stage, twice the MFMA tiles per wave)
+template <int CIN, int COUT, int KG, int DEPTH, bool BF16, bool BREG = false, int WAVES = WG_WAVES>
+__global__ void __launch_bounds__(WAVES * 64, WAVES == 16 ? 1 : 4)
     spconv_wgrad_tile_kernel(const void *__restrict__ feat_, const void *__restrict__ dout_,
                              const int32_t *__restrict__ nbr, int cap, int n_out, int rows_per_split,
                              int kvol, float *__restrict__ part, int xcd_remap) {
-  using G = WgGeom<CIN, COUT, BF16>;
+  using G = WgGeom<CIN, COUT, BF16, WAVES>;
+  constexpr int NTH = WAVES * 64;
   constexpr int CIT = G::CIT, COT = G::COT, TILES = G::TILES, TPW = G::TPW, CSPLIT = G::CSPLIT;
   constexpr int FSEG = G::FSEG, DSEG = G::DSEG, STEP = G::STEP, EPV = G::EPV;
   constexpr int DN = STEP * DSEG;
-  constexpr int DV = (DN + WG_THREADS - 1) / WG_THREADS;  // dout vectors per thread and tile
+  constexpr int DV = (DN + NTH - 1) / NTH;  // dout vectors per thread and tile
   // one plane: [chunk of 16 sites][ch tile][16 sites][16 ch] bf16; f32 inputs fill two planes (hi, lo)
   constexpr int NPL = BF16 ? 1 : 2;
   constexpr int FBUF = STEP * CIN, DBUF = STEP * COUT;  // elements per plane
@@ -152,8 +154,8 @@ __global__ void __launch_bounds__(WG_THREADS)
     const int base = s0 + tile * STEP;
 #pragma unroll
     for (int j = 0; j < DV; ++j) {
-      const int e = threadIdx.x + j * WG_THREADS;
-      const int ec = (DN % WG_THREADS != 0 && e >= DN) ? DN - 1 : e;
+      const int e = threadIdx.x + j * NTH;
+      const int ec = (DN % NTH != 0 && e >= DN) ? DN - 1 : e;
       const int r = ec / DSEG, seg = ec - r * DSEG;
       const int site = base + r;
       const uint32_t off = site < s1 ? (uint32_t)site * (uint32_t)(COUT * ESZ) + (uint32_t)(seg * 16) : D3D_OOB_OFFSET;
@@ -213,8 +215,8 @@ __global__ void __launch_bounds__(WG_THREADS)
       if (kk == 0) {
 #pragma unroll
         for (int j = 0; j < DV; ++j) {
-          const int e = threadIdx.x + j * WG_THREADS;
-          if (DN % WG_THREADS != 0 && e >= DN) break;
+          const int e = threadIdx.x + j * NTH;
+          if (DN % NTH != 0 && e >= DN) break;
           const int r = e / DSEG, seg = e - r * DSEG;
           put(bd, DBUF, lds_off(r, seg, COT), dr[j]);
         }
@@ -251,7 +253,7 @@ __global__ void __launch_bounds__(WG_THREADS)
             const int ks = q * CSPLIT + my_part;
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
-              const int tl = my_tile + t * WG_WAVES;
+              const int tl = my_tile + t * WAVES;
               const int cit = tl / COT;
               const wg_bf16x8_t ah = operand(bf, CIT, cit, ks);
               acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, breg[q][0], acc[kk][t], 0, 0, 0);
@@ -269,7 +271,7 @@ __global__ void __launch_bounds__(WG_THREADS)
           const int ks = q * CSPLIT + my_part;  // this wave's k-steps of the stage
 #pragma unroll
           for (int t = 0; t < TPW; ++t) {
-            const int tl = my_tile + t * WG_WAVES;
+            const int tl = my_tile + t * WAVES;
             const int cit = tl / COT, cot = tl - cit * COT;
             const wg_bf16x8_t ah = operand(bf, CIT, cit, ks), bh = operand(bd, COT, cot, ks);
             acc[kk][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[kk][t], 0, 0, 0);
@@ -291,7 +293,7 @@ __global__ void __launch_bounds__(WG_THREADS)
   for (int a = 0; a < KG; ++a) {
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-      const int tl = my_tile + t * WG_WAVES;
+      const int tl = my_tile + t * WAVES;
       const int cit = tl / COT, cot = tl - cit * COT;
       float *o = pbase + ((int64_t)(k0 + a) * CIN + cit * 16 + lg * 4) * COUT + cot * 16 + lr;
 #pragma unroll
@@ -333,8 +335,23 @@ __global__ void __launch_bounds__(256)
 }
 
 struct WgPlan {
-  int kg, step, csplit, splits, rows_per_split;
+  int kg, step, csplit, splits, rows_per_split, waves;
 };
+
+// kernel variant: 0 = the shape's default (BREG except bf16 64 x 128; f32 64 x 64 at prefetch depth 3), 1 = dout fragments
+// re-read from LDS every stage (round 3), 2 = dout fragments in registers (BREG) at the round-3 prefetch depth, 3 = 8-wave
+// blocks (two independent blocks per CU: one writes its stage while the other multiplies) where instantiated
+static int wg_variant() {
+  static const int v = getenv("D3D_WGRAD_VARIANT") ? atoi(getenv("D3D_WGRAD_VARIANT")) : 0;
+  return g_d3d_wgrad_blocks >= 100000 ? g_d3d_wgrad_blocks / 100000 : v;
+}
+
+// waves per block
+static int wg_waves(int kvol, int cin, int cout, int dtype) {
+  const bool has8 = dtype == D3D_F32 && kvol % 9 == 0 &&
+                    ((cin == 64 && (cout == 64 || cout == 128)) || (cin == 32 && (cout == 32 || cout == 64)));
+  return (has8 && wg_variant() == 3) ? 8 : WG_WAVES;
+}
 
 // Blocks to aim for.  One per CU by default; the f32 layers that take three offsets per block (nine offset groups: 64->128
 // and 128x128) get two rounds -- 24 splits x 9 = 216 blocks left 40 CUs idle, 56 x 9 = 504 fills two rounds (measured on the
@@ -366,11 +383,12 @@ static WgPlan wg_plan(int n_out, int kvol, int cin, int cout, int dtype) {
   const int epv = dtype == D3D_BF16 ? 8 : 4;
   const int tiles_mfma = (cin / 16) * (cout / 16);
   p.kg = wg_kgroup(kvol, cin, cout, dtype);
-  p.step = WG_THREADS / (cin / epv);
-  p.csplit = wg_csplit(cin, cout, dtype);
+  p.waves = wg_waves(kvol, cin, cout, dtype);
+  p.step = p.waves * 64 / (cin / epv);
+  p.csplit = wg_csplit(cin, cout, dtype, p.waves);
   const int kgroups = kvol / p.kg;
   const int tiles = (n_out + p.step - 1) / p.step;
-  int splits = (wg_target_blocks(p.kg, dtype) + kgroups - 1) / kgroups;
+  int splits = (wg_target_blocks(p.kg, dtype) * (WG_WAVES / p.waves) + kgroups - 1) / kgroups;
   int max_splits = (tiles + 1) / 2;  // >= 2 tiles per block
   if (max_splits < 1) max_splits = 1;
   if (splits > max_splits) splits = max_splits;
@@ -389,19 +407,12 @@ extern "C" size_t d3d_sparse_conv_wgrad_workspace_bytes(int n_out, int kvol, int
   return (size_t)p.splits * p.csplit * kvol * cin * cout * sizeof(float) + 256;
 }
 
-// kernel variant: 0 = the shape's default (BREG except bf16 64 x 128; f32 64 x 64 at prefetch depth 3), 1 = dout fragments
-// re-read from LDS every stage (round 3), 2 = dout fragments in registers (BREG) at the round-3 prefetch depth
-static int wg_variant() {
-  static const int v = getenv("D3D_WGRAD_VARIANT") ? atoi(getenv("D3D_WGRAD_VARIANT")) : 0;
-  return g_d3d_wgrad_blocks >= 100000 ? g_d3d_wgrad_blocks / 100000 : v;
-}
-
-template <int CI, int CO, int KG, int DEPTH, bool BF16, bool BREG = false>
+template <int CI, int CO, int KG, int DEPTH, bool BF16, bool BREG = false, int WAVES = WG_WAVES>
 static int wg_launch(const void *feat, const void *dout, const int32_t *nbr, int cap, int n_out, int kvol,
                      const WgPlan &p, float *part, hipStream_t stream) {
   const int remap = g_xcd_remap && ((kvol / KG) * p.splits) % 8 == 0 && p.splits >= 8;
-  hipLaunchKernelGGL((spconv_wgrad_tile_kernel<CI, CO, KG, DEPTH, BF16, BREG>), dim3(kvol / KG, p.splits),
-                     dim3(WG_THREADS), 0, stream, feat, dout, nbr, cap, n_out, p.rows_per_split, kvol, part, remap);
+  hipLaunchKernelGGL((spconv_wgrad_tile_kernel<CI, CO, KG, DEPTH, BF16, BREG, WAVES>), dim3(kvol / KG, p.splits),
+                     dim3(WAVES * 64), 0, stream, feat, dout, nbr, cap, n_out, p.rows_per_split, kvol, part, remap);
   D3D_LAUNCH_TRY("spconv_wgrad_tile_kernel");
   return D3D_OK;
 }
@@ -436,6 +447,14 @@ static int wg_dispatch(const void *feat, const void *dout, const int32_t *nbr, i
   // sums: 64 x 64 332 -> 263 us at depth 3, 32 x 64 156 -> 124, 32 x 32 105 -> 95, 128 x 128 810 -> 770)
   // bf16: 64 x 64 158 -> 135, 128 x 128 452 -> 427, 32 x 64 83 -> 71; not 64 x 128 (nine offsets x two tiles: the extra
   // registers spill, 229 -> 340 us)
+#define WG_CASE8(CI, CO, KG8)                                                                           \
+  if (cin == CI && cout == CO && !bf16 && p.waves == 8 && p.kg == KG8)                                  \
+    return wg_launch<CI, CO, KG8, 3, false, true, 8>(WG_ARGS);
+  WG_CASE8(32, 32, 9)
+  WG_CASE8(32, 64, 9)
+  WG_CASE8(64, 64, 9)
+  WG_CASE8(64, 128, 3)
+  if (p.waves != WG_WAVES) return d3d_set_error(D3D_EINVAL, "wgrad tile kernel: no 8-wave kernel for %d -> %d (kg %d)", cin, cout, p.kg);
   WG_CASE(16, 16, 9, 3, 3, 3, true)
   WG_CASE(16, 32, 9, 3, 3, 3, true)
   WG_CASE(32, 32, 9, 3, 3, 3, true)

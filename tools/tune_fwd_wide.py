@@ -101,8 +101,9 @@ for key, cin, cout in (("subm", 128, 128), ("subm", 64, 64), ("subm", 32, 32), (
     print("  %s %d x %d (%d pairs, B_alg %.0f MB): %s" % (key, cin, cout, P, P * (cin + cout) * 4 / 1e6, " | ".join(row)), flush=True)
 
 # ---- dout fragments in registers (knob 1 value = 100000 * variant + blocks): 0 = default (f32: in registers, bf16: re-read
-# from LDS), 1 = re-read every stage (round 3), 2 = in registers at the round-3 prefetch depth
-print("\nweight gradient: us per launch by kernel variant (0 default | 1 dout re-read per stage | 2 dout fragments in registers)", flush=True)
+# from LDS), 1 = re-read every stage (round 3), 2 = in registers at the round-3 prefetch depth, 3 = 8-wave blocks (another
+# split of the sites: compared with a tolerance instead of bit for bit)
+print("\nweight gradient: us per launch by kernel variant (0 default | 1 dout re-read per stage | 2 dout fragments in registers | 3 8-wave blocks)", flush=True)
 for tdt, ddt, name in ((torch.float32, _lib.D3D_F32, "f32"), (torch.bfloat16, _lib.D3D_BF16, "bf16")):
     for key, cin, cout in (("subm", 128, 128), ("subm", 64, 64), ("subm", 32, 32), ("subm", 16, 16), ("down", 64, 128), ("down", 32, 64)):
         rb = x.indice_dict[key]
@@ -112,7 +113,7 @@ for tdt, ddt, name in ((torch.float32, _lib.D3D_F32, "f32"), (torch.bfloat16, _l
         dw = torch.empty((rb.kvol, cin, cout), device=dev)
         row = []
         ref = None
-        for variant in (0, 1, 2):
+        for variant in (0, 1, 2, 3):
             L.d3d_set_tuning(1, 100000 * variant)
             wsb = L.d3d_sparse_conv_wgrad_workspace_bytes(n, rb.kvol, cin, cout, ddt)
             ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
@@ -122,6 +123,7 @@ for tdt, ddt, name in ((torch.float32, _lib.D3D_F32, "f32"), (torch.bfloat16, _l
             torch.cuda.synchronize()
             if ref is None:
                 ref = dw.clone()
-            row.append("%d: %.0f%s" % (variant, timed(call, 10), "" if (rc == 0 and torch.equal(dw, ref)) else " (rc %d, DIFFERENT)" % rc))
+            same = torch.equal(dw, ref) if variant != 3 else float((dw - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+            row.append("%d: %.0f%s" % (variant, timed(call, 10), "" if (rc == 0 and same) else " (rc %d, DIFFERENT)" % rc))
         L.d3d_set_tuning(1, 0)
         print("  %s %s %d x %d (%d pairs): %s" % (name, key, cin, cout, P, " | ".join(row)), flush=True)
