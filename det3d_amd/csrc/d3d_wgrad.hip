@@ -339,8 +339,9 @@ struct WgPlan {
 };
 
 // kernel variant: 0 = the shape's default (BREG except bf16 64 x 128; f32 64 x 64 at prefetch depth 3), 1 = dout fragments
-// re-read from LDS every stage (round 3), 2 = dout fragments in registers (BREG) at the round-3 prefetch depth, 3 = 8-wave
-// blocks (two independent blocks per CU: one writes its stage while the other multiplies) where instantiated
+// re-read from LDS every stage (round 3), 2 = dout fragments in registers (BREG) on 16 waves at the round-3 prefetch depth, 3 = as 0.
+// 0 also picks 8-wave blocks (two independent blocks per CU: one writes its stage while the other multiplies) for the f32
+// shapes that have them
 static int wg_variant() {
   static const int v = getenv("D3D_WGRAD_VARIANT") ? atoi(getenv("D3D_WGRAD_VARIANT")) : 0;
   return g_d3d_wgrad_blocks >= 100000 ? g_d3d_wgrad_blocks / 100000 : v;
@@ -350,7 +351,10 @@ static int wg_variant() {
 static int wg_waves(int kvol, int cin, int cout, int dtype) {
   const bool has8 = dtype == D3D_F32 && kvol % 9 == 0 &&
                     ((cin == 64 && (cout == 64 || cout == 128)) || (cin == 32 && (cout == 32 || cout == 64)));
-  return (has8 && wg_variant() == 3) ? 8 : WG_WAVES;
+  // default where instantiated (f32, tools/tune_fwd_wide.py: 64 x 64 262 -> 251 us, 32 x 64 127 -> 117, 32 x 32 95 -> 89,
+  // 64 -> 128 448 -> 416); variants 1 / 2 keep the 16-wave kernels
+  const int var = wg_variant();
+  return (has8 && (var == 0 || var == 3)) ? 8 : WG_WAVES;
 }
 
 // Blocks to aim for.  One per CU by default; the f32 layers that take three offsets per block (nine offset groups: 64->128
