@@ -156,3 +156,157 @@ def wgrad_raw(g_hi, g_lo, x_hi, x_lo, ksz, stride, pad, mode):
                                  w, cin, cout, ksz, stride, pad, _MODES[mode], ws.data_ptr(), nb, _lib.stream_ptr(dev))
     _lib.check(rc, "d3d_conv2d_nhwc_wgrad")
     return dw
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# kernel == stride layers of the necks' deblocks (det3d/models/necks/rpn.py:83-100): ConvTranspose2d(k = s) for the
+# up-sampling strides, Conv2d(k = s) for the fractional ones.  Neither mixes neighbouring pixels: after a space-to-depth
+# (Conv2d) / before a depth-to-space (ConvTranspose2d) re-arrangement they are 1x1 convolutions -- the library's per-pixel
+# GEMM kernels with s*s*C channels on one side -- so the reference's cuDNN deconvolution needs no kernel of its own.
+KS_CONV = __import__("os").environ.get("D3D_KS_CONV", "1") != "0"
+_KS_MAX_C = 512  # widest channel count of the 1x1 kernels (conv2d_nhwc_kernel<512>, conv2d_wgrad_kernel)
+
+
+def _pack_now(w2d, mode="split"):
+    """packed forward / data-gradient planes of a [cout, cin] matrix used as a 1x1 convolution (no cache: the matrix is a
+    per-step re-arrangement of the layer's parameter)"""
+    co, ci = w2d.shape
+    dev = w2d.device
+    w = w2d.contiguous()
+    f_hi = torch.empty((1, co, ci), dtype=torch.bfloat16, device=dev)
+    d_hi = torch.empty((1, ci, co), dtype=torch.bfloat16, device=dev)
+    f_lo, d_lo = (torch.empty_like(f_hi), torch.empty_like(d_hi)) if mode == "split" else (None, None)
+    rc = _lib.lib().d3d_conv2d_pack_weights(w.data_ptr(), co, ci, 1, f_hi.data_ptr(), _lib.ptr(f_lo), d_hi.data_ptr(),
+                                            _lib.ptr(d_lo), _lib.stream_ptr(dev))
+    _lib.check(rc, "d3d_conv2d_pack_weights")
+    return (f_hi, f_lo), (d_hi, d_lo)
+
+
+def _ks_groups(s, cout):
+    """ConvTranspose2d(k = s): how many of the s output-row phases one 1x1 launch covers (its s * cout channels per
+    phase must stay within the widest kernel)"""
+    ga = max(1, min(s, _KS_MAX_C // (s * cout)))
+    while s % ga:
+        ga -= 1
+    return ga
+
+
+def ks_eligible(m, x):
+    """Conv2d / ConvTranspose2d with kernel == stride on a channels-last f32 CUDA map, with channel counts the 1x1 kernels
+    take on both sides"""
+    if not KS_CONV or type(m) not in (torch.nn.Conv2d, torch.nn.ConvTranspose2d):
+        return False
+    if not (torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32) or torch.is_autocast_enabled("cuda"):
+        return False
+    k, s = m.kernel_size, m.stride
+    if k[0] != k[1] or s != k or k[0] < 2 or k[0] > 4 or m.bias is not None or m.groups != 1 or m.dilation != (1, 1):
+        return False
+    if m.padding != (0, 0) or m.weight.dtype != torch.float32 or not x.is_contiguous(memory_format=torch.channels_last):
+        return False
+    if type(m) is torch.nn.ConvTranspose2d and m.output_padding != (0, 0):
+        return False
+    b, c, h, w = x.shape
+    s = s[0]
+    cin, cout = m.in_channels, m.out_channels
+    if c != cin:
+        return False
+    if type(m) is torch.nn.Conv2d:
+        if h % s or w % s:
+            return False
+        wide, narrow, pixels = s * s * cin, cout, b * (h // s) * (w // s)
+    else:
+        wide, narrow, pixels = _ks_groups(s, cout) * s * cout, cin, b * h * w
+    # both sides are the input channels of one launch (forward / data gradient) and the output channels of the other:
+    # 128, 256, 384, 512 (d3d_conv2d_nhwc_fwd's 1x1 layers, d3d_conv2d_nhwc_wgrad)
+    ok = lambda ch: ch in (128, 256, 384, 512)
+    return ok(wide) and ok(narrow) and pixels * s * s * max(cin, cout) * 2 < (1 << 31) - 16
+
+
+def _s2d(rows, s):
+    """[B, H, W, C] -> [B, H/s, W/s, (a, b, C)] (a, b = row / column phase)"""
+    b, h, w, c = rows.shape
+    return rows.reshape(b, h // s, s, w // s, s, c).permute(0, 1, 3, 2, 4, 5).reshape(b, h // s, w // s, s * s * c)
+
+
+def _d2s(rows, s):
+    """inverse of _s2d"""
+    b, h, w, cc = rows.shape
+    c = cc // (s * s)
+    return rows.reshape(b, h, w, s, s, c).permute(0, 1, 3, 2, 4, 5).reshape(b, h * s, w * s, c)
+
+
+class _KsConvFn(torch.autograd.Function):
+    """y = Conv2d(k = s)(x) or ConvTranspose2d(k = s)(x) on [B, C, H, W] channels-last f32 maps, split arithmetic"""
+
+    @staticmethod
+    def forward(ctx, x, weight, transposed, s):
+        rows = x.permute(0, 2, 3, 1)
+        if not rows.is_contiguous():
+            rows = rows.contiguous()
+        b, h, w, cin = rows.shape
+        ctx.transposed, ctx.s, ctx.in_shape = transposed, s, (b, h, w, cin)
+        ctx.need_in_grad = ctx.needs_input_grad[0]
+        wt = weight.detach()
+        if not transposed:
+            cout = wt.shape[0]
+            xs = _s2d(rows, s)
+            x_hi, x_lo = split_planes(xs)
+            w2 = wt.permute(0, 2, 3, 1).reshape(cout, s * s * cin)  # [cout, (a, b, ci)]
+            fwd, dgr = _pack_now(w2)
+            y, _ = conv2d_raw(x_hi, x_lo, fwd[0], fwd[1], 1, 1, 0, "split")
+            ctx.save_for_backward(x_hi, x_lo, dgr[0], dgr[1])
+            return y.permute(0, 3, 1, 2)
+        cout = wt.shape[1]
+        ga = _ks_groups(s, cout)
+        x_hi, x_lo = split_planes(rows)
+        y = torch.empty((b, h, s, w, s, cout), dtype=torch.float32, device=x.device)  # = [B, H*s, W*s, cout]
+        saved = [x_hi, x_lo]
+        for a0 in range(0, s, ga):
+            w2 = wt[:, :, a0:a0 + ga, :].permute(2, 3, 1, 0).reshape(ga * s * cout, cin)  # [(a, b, co), ci]
+            fwd, dgr = _pack_now(w2)
+            o, _ = conv2d_raw(x_hi, x_lo, fwd[0], fwd[1], 1, 1, 0, "split")  # [B, H, W, (a, b, co)]
+            y[:, :, a0:a0 + ga] = o.reshape(b, h, w, ga, s, cout).permute(0, 1, 3, 2, 4, 5)
+            saved += [dgr[0], dgr[1]]
+        ctx.save_for_backward(*saved)
+        return y.reshape(b, h * s, w * s, cout).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        s = ctx.s
+        b, h, w, cin = ctx.in_shape
+        grow = g.permute(0, 2, 3, 1)
+        if grow.dtype != torch.float32:
+            grow = grow.float()
+        if not ctx.transposed:
+            x_hi, x_lo, d_hi, d_lo = ctx.saved_tensors
+            cout = grow.shape[3]
+            g_hi, g_lo = split_planes(grow.contiguous())
+            dw2 = wgrad_raw(g_hi, g_lo, x_hi, x_lo, 1, 1, 0, "split")  # [cout, (a, b, ci), 1, 1]
+            dw = dw2.reshape(cout, s, s, cin).permute(0, 3, 1, 2).contiguous()
+            dx = None
+            if ctx.need_in_grad:
+                dxs, _ = conv2d_raw(g_hi, g_lo, d_hi, d_lo, 1, 1, 0, "split")  # [B, H/s, W/s, (a, b, ci)]
+                dx = _d2s(dxs, s).permute(0, 3, 1, 2)
+            return dx, dw, None, None
+        saved = ctx.saved_tensors
+        x_hi, x_lo = saved[0], saved[1]
+        cout = grow.shape[3]
+        ga = _ks_groups(s, cout)
+        g6 = grow.reshape(b, h, s, w, s, cout)
+        dw = torch.empty((cin, cout, s, s), dtype=torch.float32, device=g.device)
+        dx = None
+        for gi, a0 in enumerate(range(0, s, ga)):
+            gg = g6[:, :, a0:a0 + ga].permute(0, 1, 3, 2, 4, 5).reshape(b, h, w, ga * s * cout)  # [B, H, W, (a, b, co)]
+            g_hi, g_lo = split_planes(gg.contiguous())
+            dw2 = wgrad_raw(g_hi, g_lo, x_hi, x_lo, 1, 1, 0, "split")  # [(a, b, co), ci, 1, 1]
+            dw[:, :, a0:a0 + ga, :] = dw2.reshape(ga, s, cout, cin).permute(3, 2, 0, 1)
+            if ctx.need_in_grad:
+                d_hi, d_lo = saved[2 + 2 * gi], saved[3 + 2 * gi]
+                part, _ = conv2d_raw(g_hi, g_lo, d_hi, d_lo, 1, 1, 0, "split")  # [B, H, W, ci]
+                dx = part if dx is None else dx.add_(part)
+        return (dx.permute(0, 3, 1, 2) if dx is not None else None), dw, None, None
+
+
+def ks_conv(m, x):
+    """the module's forward on the library's 1x1 kernels (call only when ks_eligible(m, x))"""
+    return _KsConvFn.apply(x, m.weight, type(m) is torch.nn.ConvTranspose2d, int(m.stride[0]))

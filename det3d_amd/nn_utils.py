@@ -117,6 +117,14 @@ class Sequential(nn.Module):
                     input = spconv.bn_relu_2d(m, input, relu)
                     i += 2 if relu else 1
                     continue
+            if type(m) in (nn.Conv2d, nn.ConvTranspose2d) and m.kernel_size == m.stride and m.kernel_size[0] > 1 and \
+                    torch.is_tensor(input) and input.is_cuda:
+                from . import dense_conv  # the deblocks' kernel == stride layers as 1x1 convolutions (dense_conv.ks_conv)
+
+                if dense_conv.ks_eligible(m, input):
+                    input = dense_conv.ks_conv(m, input)
+                    i += 1
+                    continue
             input = m(input)
             i += 1
         return input

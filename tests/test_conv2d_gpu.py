@@ -562,3 +562,47 @@ def test_weight_gradient_of_the_64_channel_layers(geom):
     ref = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (cout, cin, k, k), gy.double().permute(0, 3, 1, 2), s, p)
     err, scale = float((dw.double() - ref).abs().max()), float(ref.abs().max())
     assert err <= 3e-5 * scale + 1e-6, (err, scale)
+
+
+@pytest.mark.parametrize("kind,cin,cout,s,hw", [("conv", 64, 128, 2, (48, 40)), ("deconv", 256, 128, 2, (24, 20)),
+                                                ("deconv", 256, 256, 2, (16, 24)), ("deconv", 128, 128, 2, (10, 12)),
+                                                ("deconv", 256, 128, 4, (8, 6)), ("deconv", 128, 256, 2, (9, 7))])
+def test_kernel_equals_stride_layers_as_one_by_one_convolutions(kind, cin, cout, s, hw):
+    """dense_conv.ks_conv: the deblocks' Conv2d(k = s) / ConvTranspose2d(k = s) (det3d/models/necks/rpn.py:83-100) as 1x1
+    convolutions around a space-to-depth / depth-to-space re-arrangement, against the nn modules in float64: output,
+    input gradient, weight gradient; and through nn_utils.Sequential, which must route the module there."""
+    import copy
+
+    from det3d_amd import dense_conv as dc
+    from det3d_amd import nn_utils
+
+    torch.manual_seed(cin + cout + s)
+    m = (torch.nn.Conv2d if kind == "conv" else torch.nn.ConvTranspose2d)(cin, cout, s, stride=s, bias=False).cuda()
+    with torch.no_grad():
+        m.weight.normal_(0, 0.05)
+    ref = copy.deepcopy(m).double()
+    x = torch.randn(2, cin, hw[0], hw[1], device="cuda").contiguous(memory_format=torch.channels_last)
+    xa = x.clone().requires_grad_(True)
+    assert dc.ks_eligible(m, xa)
+    y = dc.ks_conv(m, xa)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    assert y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last)
+    err, scale = float((y.double() - yr).abs().max()), float(yr.abs().max())
+    assert err <= 3e-5 * scale, (err, scale)
+    wgt = torch.randn(y.shape, device="cuda").contiguous(memory_format=torch.channels_last)
+    (y * wgt).sum().backward()
+    (yr * wgt.double()).sum().backward()
+    for a, b, what in ((xa.grad, xr.grad, "input gradient"), (m.weight.grad, ref.weight.grad, "weight gradient")):
+        assert a.shape == b.shape
+        err, scale = float((a.double() - b).abs().max()), float(b.abs().max())
+        assert err <= 1e-4 * scale, (what, err, scale)
+    assert m.weight.grad.is_contiguous()
+    # the container hands the module to the same function (bit-equal), and leaves other layers alone
+    seq = nn_utils.Sequential(m)
+    xb = x.clone().requires_grad_(True)
+    y2 = seq(xb)
+    assert torch.equal(y2, y)
+    odd = torch.nn.ConvTranspose2d(96, 128, 2, stride=2, bias=False).cuda()
+    assert not dc.ks_eligible(odd, torch.randn(1, 96, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last))
+    assert not dc.ks_eligible(m, x.contiguous())  # NCHW-contiguous map: the module path
