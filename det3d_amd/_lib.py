@@ -63,6 +63,7 @@ SIGNATURES = {
     "d3d_conv2d_supported_split3x3": (i32, [i32, i32]),
     "d3d_conv2d_stats_ws_floats": (sz, [i32, i32, i32, i32]),
     "d3d_conv2d_nhwc_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
+    "d3d_conv2d_nhwc_dgrad_s2": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "d3d_conv2d_pack_weights": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "d3d_split_planes": (i32, [vp, i64, vp, vp, vp]),
     "d3d_conv2d_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
@@ -102,7 +103,7 @@ SIGNATURES = {
     "d3d_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
 }
 
-ABI_VERSION = 7  # include/d3d.h D3D_ABI_VERSION
+ABI_VERSION = 8  # include/d3d.h D3D_ABI_VERSION
 D3D_F32 = 0
 D3D_BF16 = 1
 D3D_CONV_BF16, D3D_CONV_SPLIT = 0, 1

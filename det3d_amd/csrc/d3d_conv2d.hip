@@ -52,6 +52,17 @@ struct Conv2dEpi {
   int bn_relu;
 };
 
+// TR launches (the data gradient of a stride-2 layer, round 4): the rows of a block are the pixels of ONE parity class
+// (iy & 1, ix & 1) of the gradient map dx -- a pixel of class (py, px) only receives the kernel taps with
+// (py + pad - ky) and (px + pad - kx) even, 1 / 2 / 2 / 4 of the nine for a 3x3 layer, and its sources are the pixels
+// (i + dy, j + dx) of g with i = iy >> 1, j = ix >> 1, dy = (py + pad - ky) / 2 in {-1, 0, 1}: a stride-1 problem per class
+struct Conv2dTr {
+  int tiles_end[4];   // cumulative pixel tiles of the classes (py * 2 + px) in launch order
+  int hc[4], wc[4];   // class grids: rows / columns of dx with that parity
+  int ntap[4];
+  unsigned taps[4];   // 8 bits per tap: (dy + 1) | (dx + 1) << 2 | weight slot << 4
+};
+
 __device__ __forceinline__ uint16_t c2_f32_to_bf16(float f) {
   uint32_t u = __float_as_uint(f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
@@ -80,10 +91,10 @@ template <int BK> struct C2Tile {
 //      two -- more waves to cover the wait + barrier at the top of every K step, at twice the barriers per FLOP
 //  PXT: 32-pixel MFMA tiles per wave (2 -> 64 x 64 wave tiles; 1 -> 64 x 32: with WPX = 4 the same 128-pixel block on 8
 //      waves, twice the waves per CU to cover the waits of the two-stage loop, 1.5x the LDS fragment reads)
-template <int CIN, bool SPLIT, bool OUT_F32, int WPX, bool ILV, bool HB = false, int PXT = 2>
+template <int CIN, bool SPLIT, bool OUT_F32, int WPX, bool ILV, bool HB = false, int PXT = 2, bool TR = false>
 __global__ void __launch_bounds__(128 * WPX, (WPX * PXT == 4 ? (HB ? 4 : 2) : (HB ? 2 : 1)))
     conv2d_nhwc_kernel(const void *__restrict__ x_hi, const void *__restrict__ x_lo, const void *__restrict__ w_hi,
-                       const void *__restrict__ w_lo, void *__restrict__ y, Conv2dGeom G, Conv2dEpi ep) {
+                       const void *__restrict__ w_lo, void *__restrict__ y, Conv2dGeom G, Conv2dEpi ep, Conv2dTr R) {
   constexpr int BK = (SPLIT ? 32 : 64) / (HB ? 2 : 1);
   using T = C2Tile<BK>;
   constexpr int WAVES = 2 * WPX, NTH = WAVES * 64, BM = 32 * PXT * WPX;
@@ -106,6 +117,15 @@ __global__ void __launch_bounds__(128 * WPX, (WPX * PXT == 4 ? (HB ? 4 : 2) : (H
     const int nb = (int)gridDim.x, q = nb >> 3, r = nb & 7, xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  // TR: the block's parity class (uniform), its grid and its first pixel within the class
+  int cls = 0, cls_h = 1, cls_w = 1, cls_m = 0;
+  if constexpr (TR) {
+    cls = (tile >= R.tiles_end[0] ? 1 : 0) + (tile >= R.tiles_end[1] ? 1 : 0) + (tile >= R.tiles_end[2] ? 1 : 0);
+    tile -= cls ? R.tiles_end[cls - 1] : 0;
+    cls_h = R.hc[cls];
+    cls_w = R.wc[cls];
+    cls_m = G.batch * cls_h * cls_w;
+  }
   const int m0 = tile * BM;
   const int n0 = (int)blockIdx.y * 128;
 
@@ -119,6 +139,23 @@ __global__ void __launch_bounds__(128 * WPX, (WPX * PXT == 4 ? (HB ? 4 : 2) : (H
     const int row = idx / T::CPR, cp = idx % T::CPR;
     const int c = cp ^ T::swz(row);
     const int m = m0 + row;
+    if constexpr (TR) {
+      // row = pixel (b, i, jj) of the class grid; slot k of the masks = source row / column i + k - 1 of g
+      const int mm = m < cls_m ? m : cls_m - 1;
+      const int b = mm / (cls_h * cls_w), rem = mm - b * (cls_h * cls_w);
+      const int i = rem / cls_w, jj = rem - i * cls_w;
+      uint32_t vy = 0, vx = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        vy |= (uint32_t)((i + k - 1 >= 0 && i + k - 1 < G.h) ? 1 : 0) << k;
+        vx |= (uint32_t)((jj + k - 1 >= 0 && jj + k - 1 < G.w) ? 1 : 0) << k;
+      }
+      if (m >= cls_m) vy = vx = 0;
+      a_vy[j] = vy;
+      a_vx[j] = vx;
+      a_off[j] = (uint32_t)(((b * G.h + i) * G.w + jj) * (CIN * 2) + c * 16);
+      continue;
+    }
     const int mm = m < G.m ? m : G.m - 1;
     const int b = mm / (G.ho * G.wo), rem = mm - b * (G.ho * G.wo);
     const int oy = rem / G.wo, ox = rem - oy * G.wo;
@@ -145,14 +182,21 @@ __global__ void __launch_bounds__(128 * WPX, (WPX * PXT == 4 ? (HB ? 4 : 2) : (H
   const __amdgpu_buffer_rsrc_t xr_lo = __builtin_amdgcn_make_buffer_rsrc((void *)(SPLIT ? x_lo : x_hi), 0, G.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr_lo = __builtin_amdgcn_make_buffer_rsrc((void *)(SPLIT ? w_lo : w_hi), 0, G.w_bytes, 0x00020000);
 
-  const int nks = G.ksz * G.ksz * KC;
+  const int nks = (TR ? R.ntap[cls] : G.ksz * G.ksz) * KC;
   // stage the slots with (slot % PARTS) == part of K step `ks` (tap = ks / KC, channel block = ks % KC) into LDS
   // stage `buf`; slots 0 .. AI-1 are activation rows, AI .. AI+BI-1 weight rows
   auto stage = [&](int ks, int buf, int part, int parts) {
     const int tap = ks / KC, kc = ks - tap * KC;
-    const int ky = tap / G.ksz, kx = tap - ky * G.ksz;
-    const uint32_t tap_off = (uint32_t)((ky * G.w + kx) * (CIN * 2) + kc * (BK * 2));
-    const uint32_t w_tap_off = (uint32_t)(tap * G.cout * (CIN * 2) + kc * (BK * 2));
+    int ky = tap / G.ksz, kx = tap - ky * G.ksz, wslot = tap;
+    if constexpr (TR) {  // (ky, kx) = mask slots of the tap's source offset (dy + 1, dx + 1)
+      const unsigned code = (R.taps[cls] >> (8 * tap)) & 0xffu;
+      ky = (int)(code & 3u);
+      kx = (int)((code >> 2) & 3u);
+      wslot = (int)(code >> 4);
+    }
+    const uint32_t tap_off = TR ? (uint32_t)(((ky - 1) * G.w + (kx - 1)) * (CIN * 2) + kc * (BK * 2))
+                                : (uint32_t)((ky * G.w + kx) * (CIN * 2) + kc * (BK * 2));
+    const uint32_t w_tap_off = (uint32_t)(wslot * G.cout * (CIN * 2) + kc * (BK * 2));
     unsigned char *sa = smem + buf * STAGE, *sb = sa + NP * APLANE;
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
@@ -269,8 +313,15 @@ __global__ void __launch_bounds__(128 * WPX, (WPX * PXT == 4 ? (HB ? 4 : 2) : (H
       }
 #pragma unroll
       for (int j = 0; j < PXT; ++j) {
-        const int m = m0 + wpx * (32 * PXT) + j * 32 + (lane & 31);
-        const bool live = m < G.m;
+        int m = m0 + wpx * (32 * PXT) + j * 32 + (lane & 31);
+        bool live = m < G.m;
+        if constexpr (TR) {  // class pixel -> row of dx
+          live = m < cls_m;
+          const int mm = live ? m : 0;
+          const int b = mm / (cls_h * cls_w), rem = mm - b * (cls_h * cls_w);
+          const int ii = rem / cls_w, jj = rem - ii * cls_w;
+          m = (b * G.ho + 2 * ii + (cls >> 1)) * G.wo + 2 * jj + (cls & 1);
+        }
         float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
         float x[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (OUT_F32) {
@@ -848,7 +899,7 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
     D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_nhwc_kernel<CIN, SPLIT, SPLIT, WPX, ILV, HB, PXT>,     \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
     hipLaunchKernelGGL((conv2d_nhwc_kernel<CIN, SPLIT, SPLIT, WPX, ILV, HB, PXT>), dim3(nb, cout / 128),        \
-                       dim3(128 * WPX), lds, stream, x_hi, x_lo, w_hi, w_lo, y, G, ep);                         \
+                       dim3(128 * WPX), lds, stream, x_hi, x_lo, w_hi, w_lo, y, G, ep, Conv2dTr{});             \
   } while (0)
 #define C2_VARIANTS(CIN, SPLIT)                                         \
   do {                                                                  \
@@ -882,6 +933,80 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
 #undef C2_VARIANTS
 #undef C2_LAUNCH
   D3D_LAUNCH_TRY("conv2d_nhwc_kernel");
+  return D3D_OK;
+}
+
+// data gradient of a stride-2 3x3 layer (ABI 8): g = dL/dy [batch, ho, wo, cout] -> dx [batch, h, w, cin] of the layer
+// y = conv(x, w, stride 2, pad); w_hi / w_lo = the layer's data-gradient planes of d3d_conv2d_pack_weights
+// ([mirrored tap][cin][cout]).  conv2d_nhwc_kernel in TR mode: one block = 128 pixels of one parity class of dx.
+extern "C" int d3d_conv2d_nhwc_dgrad_s2(const void *g_hi, const void *g_lo, const void *w_hi, const void *w_lo, void *dx,
+                                        int batch, int h, int w, int cin, int cout, int ksz, int pad, int mode,
+                                        d3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  D3D_REQUIRE(mode == D3D_CONV_BF16 || mode == D3D_CONV_SPLIT, "d3d_conv2d_nhwc_dgrad_s2: mode %d", mode);
+  const bool split = mode == D3D_CONV_SPLIT;
+  D3D_REQUIRE(g_hi && w_hi && dx && (!split || (g_lo && w_lo)), "d3d_conv2d_nhwc_dgrad_s2: null pointer");
+  D3D_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && ksz == 3 && pad >= 0 && pad < ksz, "d3d_conv2d_nhwc_dgrad_s2: map %d x %d x %d, kernel %d pad %d (3x3 layers)", batch, h, w, ksz, pad);
+  D3D_REQUIRE((cout == 128 || cout == 256) && cin >= 128 && cin % 128 == 0,
+              "d3d_conv2d_nhwc_dgrad_s2: channels %d -> %d (cout 128 | 256, cin a multiple of 128)", cin, cout);
+  const int ho = (h + 2 * pad - ksz) / 2 + 1, wo = (w + 2 * pad - ksz) / 2 + 1;
+  D3D_REQUIRE(ho >= 1 && wo >= 1, "d3d_conv2d_nhwc_dgrad_s2: empty output map");
+  D3D_REQUIRE((int64_t)batch * ho * wo * cout * 2 < (int64_t)D3D_RSRC_BYTES && (int64_t)batch * h * w * cin * 4 < ((int64_t)1 << 33),
+              "d3d_conv2d_nhwc_dgrad_s2: map too large");
+  // the kernel's input map is g, its output map dx
+  Conv2dGeom G = {};
+  G.batch = batch; G.h = ho; G.w = wo; G.ho = h; G.wo = w;
+  G.cout = cin; G.ksz = ksz; G.stride = 1; G.pad = pad;
+  G.m = batch * h * w;
+  G.x_bytes = (int)((int64_t)batch * ho * wo * cout * 2);
+  G.w_bytes = (int)((int64_t)ksz * ksz * cin * cout * 2);
+  Conv2dTr T = {};
+  const int bm = 128;
+  int tiles = 0;
+  for (int c = 0; c < 4; ++c) {
+    const int py = c >> 1, px = c & 1;
+    T.hc[c] = (h - py + 1) / 2;
+    T.wc[c] = (w - px + 1) / 2;
+    if (T.hc[c] < 0) T.hc[c] = 0;
+    if (T.wc[c] < 0) T.wc[c] = 0;
+    tiles += (batch * T.hc[c] * T.wc[c] + bm - 1) / bm;
+    T.tiles_end[c] = tiles;
+    int n = 0;
+    unsigned code = 0;
+    for (int ky = 0; ky < ksz; ++ky) {
+      if ((py + pad - ky) & 1) continue;
+      const int dy = (py + pad - ky) / 2;  // even numerator: exact, also when negative
+      for (int kx = 0; kx < ksz; ++kx) {
+        if ((px + pad - kx) & 1) continue;
+        const int dxx = (px + pad - kx) / 2;
+        const int wslot = ksz * ksz - 1 - (ky * ksz + kx);  // the pack's mirrored order holds tap (ky, kx) there
+        code |= (unsigned)((dy + 1) | ((dxx + 1) << 2) | (wslot << 4)) << (8 * n);
+        ++n;
+      }
+    }
+    D3D_REQUIRE(n >= 1 && n <= 4, "d3d_conv2d_nhwc_dgrad_s2: %d taps in class %d", n, c);
+    T.ntap[c] = n;
+    T.taps[c] = code;
+  }
+  Conv2dEpi ep = {};
+  ep.fold_g = 16;
+  const size_t lds = 2 * (size_t)((split ? 2 : 1) * (bm + 128) * (split ? 64 : 128));
+#define C2_TR(CIN, SPLIT)                                                                                          \
+  do {                                                                                                             \
+    D3D_HIP_TRY(hipFuncSetAttribute((const void *)conv2d_nhwc_kernel<CIN, SPLIT, SPLIT, 4, true, false, 1, true>,  \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+    hipLaunchKernelGGL((conv2d_nhwc_kernel<CIN, SPLIT, SPLIT, 4, true, false, 1, true>), dim3(tiles, cin / 128),   \
+                       dim3(512), lds, stream, g_hi, g_lo, w_hi, w_lo, dx, G, ep, T);                              \
+  } while (0)
+  if (cout == 128) {
+    if (split) C2_TR(128, true);
+    else C2_TR(128, false);
+  } else {
+    if (split) C2_TR(256, true);
+    else C2_TR(256, false);
+  }
+#undef C2_TR
+  D3D_LAUNCH_TRY("conv2d_nhwc_kernel (strided data gradient)");
   return D3D_OK;
 }
 

@@ -131,6 +131,25 @@ def conv2d_raw(x_hi, x_lo, w_hi, w_lo, ksz, stride, pad, mode, want_stats=False,
     return y, ws
 
 
+def dgrad_s2_supported(cin, cout, ksz):
+    """stride-2 layers whose data gradient d3d_conv2d_nhwc_dgrad_s2 takes"""
+    return int(ksz) == 3 and int(cout) in (128, 256) and int(cin) >= 128 and int(cin) % 128 == 0
+
+
+def conv2d_dgrad_s2(g_hi, g_lo, wd_hi, wd_lo, h, w, ksz, pad, mode):
+    """data gradient of y = conv(x [B,h,w,Cin], stride 2, pad): g_* [B,Ho,Wo,Cout] in the operand format, wd_* = the
+    layer's 'dgrad' planes ([mirrored tap][Cin][Cout]); returns dx [B,h,w,Cin] f32 (split) | bf16"""
+    L = _lib.lib()
+    b, ho, wo, cout = g_hi.shape
+    cin = wd_hi.shape[1]
+    assert (ho, wo) == _out_hw(h, w, ksz, 2, pad) and wd_hi.shape[2] == cout
+    dx = torch.empty((b, h, w, cin), dtype=torch.float32 if mode == "split" else torch.bfloat16, device=g_hi.device)
+    rc = L.d3d_conv2d_nhwc_dgrad_s2(g_hi.data_ptr(), _lib.ptr(g_lo), wd_hi.data_ptr(), _lib.ptr(wd_lo), dx.data_ptr(), b, h,
+                                    w, cin, cout, ksz, pad, _MODES[mode], _lib.stream_ptr(g_hi.device))
+    _lib.check(rc, "d3d_conv2d_nhwc_dgrad_s2")
+    return dx
+
+
 def wgrad_raw(g_hi, g_lo, x_hi, x_lo, ksz, stride, pad, mode):
     """dw [Cout, Cin, ksz, ksz] f32 (nn.Conv2d's layout) from g = dL/dy [B,Ho,Wo,Cout] and the layer input x"""
     L = _lib.lib()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 7 /* 7: residual forms of the BatchNorm sweeps, D3dConvEpilogue.addend; 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv; 5: planned strided data gradient, d3d_adam_step; 6: deterministic PillarFeatureNet sums (workspace arguments) */
+#define D3D_ABI_VERSION 8 /* 8: d3d_conv2d_nhwc_dgrad_s2; 7: residual forms of the BatchNorm sweeps, D3dConvEpilogue.addend; 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv; 5: planned strided data gradient, d3d_adam_step; 6: deterministic PillarFeatureNet sums (workspace arguments) */
 
 #define D3D_OK 0
 #define D3D_EINVAL -1    /* bad argument / unsupported shape           */
@@ -371,6 +371,13 @@ size_t d3d_conv2d_stats_ws_floats(int batch, int ho, int wo, int cout);
 int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const void *w_hi, const void *w_lo, void *y, int batch,
                         int h, int w, int cin, int cout, int ksz, int stride, int pad, int mode, float *stats_ws,
                         size_t stats_ws_floats, const D3dDenseBnBackward *bn, d3d_stream_t stream);
+/* ABI 8: the data gradient of a STRIDE-2 3x3 layer (the first convolution of an RPN block, det3d/models/necks/rpn.py:64-68
+ * ZeroPad2d(1) + Conv2d(3, stride 2); the reference gets it from cuDNN through autograd).  g = dL/dy [batch, ho, wo, cout]
+ * in the operand format of `mode`, w_hi / w_lo = the layer's dgrad planes of d3d_conv2d_pack_weights, dx [batch, h, w, cin]
+ * f32 (split) or bf16.  cout 128 | 256, cin a multiple of 128, ksz 3, pad 0..2.  (Stride-1 layers: d3d_conv2d_nhwc_fwd on
+ * g with the dgrad planes and pad' = ksz - 1 - pad.) */
+int d3d_conv2d_nhwc_dgrad_s2(const void *g_hi, const void *g_lo, const void *w_hi, const void *w_lo, void *dx, int batch,
+                             int h, int w, int cin, int cout, int ksz, int pad, int mode, d3d_stream_t stream);
 int d3d_conv2d_pack_weights(const float *weight, int cout, int cin, int ksz, void *fwd_hi, void *fwd_lo,
                             void *dgrad_hi, void *dgrad_lo, d3d_stream_t stream);
 int d3d_split_planes(const float *x, int64_t n, void *hi, void *lo, d3d_stream_t stream);

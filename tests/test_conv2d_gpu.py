@@ -606,3 +606,36 @@ def test_kernel_equals_stride_layers_as_one_by_one_convolutions(kind, cin, cout,
     odd = torch.nn.ConvTranspose2d(96, 128, 2, stride=2, bias=False).cuda()
     assert not dc.ks_eligible(odd, torch.randn(1, 96, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last))
     assert not dc.ks_eligible(m, x.contiguous())  # NCHW-contiguous map: the module path
+
+
+@pytest.mark.parametrize("mode", ["split", "bf16"])
+@pytest.mark.parametrize("geom", [(2, 12, 12, 128, 256, 1), (1, 17, 23, 128, 128, 1), (2, 16, 20, 256, 256, 1), (1, 9, 9, 128, 256, 0),
+                                  (1, 14, 10, 256, 128, 2), (3, 33, 40, 128, 256, 1), (1, 1, 1, 128, 128, 1), (4, 64, 64, 128, 256, 1)])
+def test_stride_two_data_gradient_in_parity_classes(geom, mode):
+    """d3d_conv2d_nhwc_dgrad_s2 (conv2d_nhwc_kernel in TR mode): the data gradient of a 3x3 stride-2 layer -- each block
+    walks the pixels of one parity class of dx and only the 1 / 2 / 2 / 4 kernel taps that reach it -- against
+    torch.nn.grad.conv2d_input in float64 on the format-rounded operands; odd and even map sizes, pad 0 / 1 / 2."""
+    from det3d_amd import dense_conv as dc
+
+    b, h, w, cin, cout, p = geom
+    k = 3
+    ho, wo = dc._out_hw(h, w, k, 2, p)
+    g = torch.Generator(device="cuda").manual_seed(h * 31 + w)
+    wt = torch.randn((cout, cin, k, k), device="cuda", generator=g) * (1.0 / (cout * k * k) ** 0.5)
+    weight = torch.nn.Parameter(wt)
+    gy = torch.randn((b, ho, wo, cout), device="cuda", generator=g)
+    w_hi, w_lo = dc._packed(weight, "dgrad", mode)
+    if mode == "bf16":
+        g_hi, g_lo = gy.to(torch.bfloat16), None
+        gr, wr = g_hi.double(), wt.to(torch.bfloat16).double()
+    else:
+        g_hi, g_lo = dc.split_planes(gy)
+        gr, wr = gy.double(), wt.double()
+    assert dc.dgrad_s2_supported(cin, cout, k)
+    dx = dc.conv2d_dgrad_s2(g_hi, g_lo, w_hi, w_lo, h, w, k, p, mode)
+    dx2 = dc.conv2d_dgrad_s2(g_hi, g_lo, w_hi, w_lo, h, w, k, p, mode)
+    assert torch.equal(dx, dx2)
+    ref = torch.nn.grad.conv2d_input((b, cin, h, w), wr, gr.permute(0, 3, 1, 2), 2, p).permute(0, 2, 3, 1)
+    assert dx.shape == ref.shape
+    err, scale = float((dx.double() - ref).abs().max()), float(ref.abs().max())
+    assert err <= (2.0 ** -8 if mode == "bf16" else 3e-5) * scale + 1e-7, (err, scale)
