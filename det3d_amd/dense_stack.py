@@ -1,8 +1,8 @@
 """Runs of `[ZeroPad2d] -> Conv2d -> BatchNorm2d [-> ReLU]` on a channels-last map as ONE autograd node on the
 library's own kernels (csrc/d3d_conv2d.hip + the BatchNorm sweeps of csrc/d3d_bn.hip).
 
-Reference: the RPN blocks and deblocks, det3d/models/necks/rpn.py:58-100 (`Sequential(ZeroPad2d(1), Conv2d(3x3),
-BN, ReLU, [Conv2d(3x3, padding=1), BN, ReLU] * n)`), cuDNN kernels behind nn.Conv2d / nn.BatchNorm2d.  Per layer:
+Reference: the RPN blocks and deblocks, det3d/models/necks/rpn.py:58-100 (`Sequential(ZeroPad2d(1), Conv2d(3x3, stride
+1 | 2), BN, ReLU, [Conv2d(3x3, padding=1), BN, ReLU] * n)`), cuDNN kernels behind nn.Conv2d / nn.BatchNorm2d.  Per layer:
 
   forward   conv (BN statistics in its epilogue)  ->  bn_apply (+ReLU), written in the next conv's operand format
   backward  bn_bwd_dx (written in the conv operand format) -> wgrad (two-pass) -> dgrad (= the forward kernel on the
@@ -36,12 +36,13 @@ STATS_EPILOGUE_BF16 = os.environ.get("D3D_DENSE_STATS_EPILOGUE_BF16", "1") == "1
 
 
 class _Layer:
-    __slots__ = ("conv", "bn", "relu", "ksz", "pad", "cin", "cout")
+    __slots__ = ("conv", "bn", "relu", "ksz", "pad", "stride", "cin", "cout")
 
     def __init__(self, conv, bn, relu, pad):
         self.conv, self.bn, self.relu = conv, bn, relu
         self.ksz = conv.kernel_size[0]
         self.pad = pad
+        self.stride = conv.stride[0]
         self.cin, self.cout = conv.in_channels, conv.out_channels
 
 
@@ -49,14 +50,20 @@ def _conv_ok(conv, extra_pad, split=False):
     if type(conv) is not nn.Conv2d or conv.bias is not None or conv.groups != 1 or conv.weight.dtype != torch.float32:
         return None
     k = conv.kernel_size
-    if k[0] != k[1] or conv.stride != (1, 1) or conv.dilation != (1, 1) or conv.padding_mode != "zeros":
+    if k[0] != k[1] or conv.stride not in ((1, 1), (2, 2)) or conv.dilation != (1, 1) or conv.padding_mode != "zeros":
         return None
     if not isinstance(conv.padding, tuple) or conv.padding[0] != conv.padding[1]:
         return None
     pad = conv.padding[0] + extra_pad
+    cin, cout = conv.in_channels, conv.out_channels
+    if conv.stride == (2, 2):
+        # the first convolution of an RPN block (rpn.py:64-68: ZeroPad2d(1) + Conv2d(3, stride 2)): forward and weight
+        # gradient on the strided implicit GEMM, data gradient in parity classes (d3d_conv2d_nhwc_dgrad_s2)
+        if k[0] != 3 or pad >= 3 or cin not in (128, 256) or cout not in (128, 256):
+            return None
+        return pad if dc.supported(cin, cout, 3, 2) and dc.dgrad_s2_supported(cin, cout, 3) else None
     if pad >= k[0] or 2 * pad != k[0] - 1:  # "same" convolutions: the data gradient is the mirrored forward
         return None
-    cin, cout = conv.in_channels, conv.out_channels
     if split and k[0] == 3 and cin in (64, 128, 256) and cout in (64, 128, 256):
         # the halo-patch kernel: 64-channel layers too (forward and data gradient; weight gradient: dc.wgrad_raw)
         return pad if dc.supported(cin, cout, 3, 1, "split") else None
@@ -110,7 +117,8 @@ def collect(mods, i, x):
             break
         # what the kernels would refuse later must end the run HERE (the caller then takes the module path): an
         # output map of 2 GB or more, or more pixel tiles than the statistics fold handles
-        ho, wo = hh + 2 * pad - conv.kernel_size[0] + 1, ww + 2 * pad - conv.kernel_size[1] + 1
+        st = conv.stride[0]
+        ho, wo = (hh + 2 * pad - conv.kernel_size[0]) // st + 1, (ww + 2 * pad - conv.kernel_size[1]) // st + 1
         if ho < 1 or wo < 1 or bsz * ho * wo * conv.out_channels * 2 >= (1 << 31) - 16:
             break
         if L.d3d_conv2d_stats_ws_floats(bsz, ho, wo, conv.out_channels) == 0:
@@ -156,7 +164,7 @@ class _DenseStackFn(torch.autograd.Function):
             # faster with the epilogue (789 vs 717 frames/s, gpurun_out r3j17 / r3j18): 7 launches and 7 allocations
             # less on a step whose host side is 70 % of its wall time
             epi = training and (split or STATS_EPILOGUE_BF16)
-            y, ws = dc.conv2d_raw(a_hi, a_lo, w_hi, w_lo, ly.ksz, 1, ly.pad, mode, want_stats=epi)
+            y, ws = dc.conv2d_raw(a_hi, a_lo, w_hi, w_lo, ly.ksz, ly.stride, ly.pad, mode, want_stats=epi)
             n = y.shape[0] * y.shape[1] * y.shape[2]
             cout = ly.cout
             if training and not epi:
@@ -235,18 +243,21 @@ class _DenseStackFn(torch.autograd.Function):
                                      save[0].data_ptr(), save[1].data_ptr(), int(ly.relu), partial.data_ptr(), 1,
                                      g_hi.data_ptr(), gbn[0].data_ptr(), gbn[1].data_ptr(), st)
                 _lib.check(rc, "d3d_bn_bwd_dx")
-            gw = dc.wgrad_raw(g_hi, g_lo, a_hi, a_lo, ly.ksz, 1, ly.pad, mode)
+            gw = dc.wgrad_raw(g_hi, g_lo, a_hi, a_lo, ly.ksz, ly.stride, ly.pad, mode)
             partial = None
             if li > 0 or ctx.need_in_grad:
                 wd_hi, wd_lo = dc._packed(ly.conv.weight, "dgrad", mode)
-                bnb = None
-                if li > 0 and FUSE_BN_BACKWARD:
-                    # the rows this launch produces are dL/dz of layer li - 1's BatchNorm + ReLU: reduce its sums here
-                    pl = layers[li - 1]
-                    _, _, py, psave = rec[li - 1]
-                    bnb = (py, psave[0], psave[1], pl.bn.weight, pl.bn.bias, pl.relu)
-                dy, partial = dc.conv2d_raw(g_hi, g_lo, wd_hi, wd_lo, ly.ksz, 1, ly.ksz - 1 - ly.pad, mode,
-                                            bn_backward=bnb)
+                if ly.stride == 2:  # the taps that reach each parity class of the input map (no epilogue)
+                    dy = dc.conv2d_dgrad_s2(g_hi, g_lo, wd_hi, wd_lo, a_hi.shape[1], a_hi.shape[2], ly.ksz, ly.pad, mode)
+                else:
+                    bnb = None
+                    if li > 0 and FUSE_BN_BACKWARD:
+                        # the rows this launch produces are dL/dz of layer li - 1's BatchNorm + ReLU: reduce its sums here
+                        pl = layers[li - 1]
+                        _, _, py, psave = rec[li - 1]
+                        bnb = (py, psave[0], psave[1], pl.bn.weight, pl.bn.bias, pl.relu)
+                    dy, partial = dc.conv2d_raw(g_hi, g_lo, wd_hi, wd_lo, ly.ksz, 1, ly.ksz - 1 - ly.pad, mode,
+                                                bn_backward=bnb)
             else:
                 dy = None
             grads.append([gw, gbn[0], gbn[1]])
