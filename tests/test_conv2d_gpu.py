@@ -205,8 +205,8 @@ def test_dense_stack_is_the_torch_module_stack(dtype, cin, widths, stride):
             # the ReLU mask itself is exercised by the two 128 / 256-channel cases)
             torch.nn.init.normal_(m.bias, 2.5 if cin == 64 else 0.0, 0.3)
     ref = copy.deepcopy(seq).double()
-    x = torch.randn(2, cin, 20, 24, device="cuda").contiguous(memory_format=torch.channels_last)
-    gy = torch.randn(2, widths[-1], 20 // stride, 24 // stride, device="cuda").contiguous(memory_format=torch.channels_last)
+    x = torch.randn(2, cin, 20 * stride, 24 * stride, device="cuda").contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(2, widths[-1], 20, 24, device="cuda").contiguous(memory_format=torch.channels_last)
     xa = x.detach().clone().to(dtype).requires_grad_(True)
     calls = []
     orig = dense_stack.run
