@@ -256,7 +256,9 @@ def test_dense_stack_is_the_torch_module_stack(dtype, cin, widths, stride):
         close(p.grad, q.grad, k, tol * 3)
     for (k, p), (_, q) in zip(seq.named_buffers(), ref.named_buffers()):
         if k.endswith("running_mean") or k.endswith("running_var"):
-            assert torch.allclose(p.double(), q, rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=1e-5), k
+            # (bf16: a channel mean near zero carries the rounding of its 960 summands, not 2 % of itself)
+            atol = 1e-5 if dtype == torch.float32 else 2e-2 * float(q.abs().max())
+            assert torch.allclose(p.double(), q, rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=atol), k
     # eval mode: running statistics, no autograd bookkeeping
     seq.eval()
     ref.eval()
