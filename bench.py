@@ -680,9 +680,13 @@ def rpn_mfma_probe(wl, dev, dtype):
             (x_hi, x_lo), (g_hi, g_lo) = dc.split_planes(x), dc.split_planes(gy)
         w_hi, w_lo = dc._packed(m.weight, "fwd", mode)
         d_hi, d_lo = dc._packed(m.weight, "dgrad", mode)
-        t_f = ev_time(lambda: dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, 1, pad, mode, want_stats=True))
-        t_d = ev_time(lambda: dc.conv2d_raw(g_hi, g_lo, d_hi, d_lo, k, 1, k - 1 - pad, mode))
-        t_w = ev_time(lambda: dc.wgrad_raw(g_hi, g_lo, x_hi, x_lo, k, 1, pad, mode))
+        st = m.stride[0]  # 2: the first convolution of a CBGS / PointPillars block (data gradient in parity classes)
+        t_f = ev_time(lambda: dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, k, st, pad, mode, want_stats=True))
+        if st == 2:
+            t_d = ev_time(lambda: dc.conv2d_dgrad_s2(g_hi, g_lo, d_hi, d_lo, h, w, k, pad, mode))
+        else:
+            t_d = ev_time(lambda: dc.conv2d_raw(g_hi, g_lo, d_hi, d_lo, k, 1, k - 1 - pad, mode))
+        t_w = ev_time(lambda: dc.wgrad_raw(g_hi, g_lo, x_hi, x_lo, k, st, pad, mode))
         own_flops += 3 * flops
         own_ms += t_f + t_d + t_w
         layers.append(dict(shape=[b, h, w, cin, oshape[1], k], fwd_us=round(1e3 * t_f, 1), dgrad_us=round(1e3 * t_d, 1),
