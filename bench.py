@@ -651,7 +651,7 @@ def rpn_mfma_probe(wl, dev, dtype):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    own_flops = own_ms = other_flops = 0.0
+    own_flops = own_ms = other_flops = ks_flops = 0.0
     layers = []
     for m in convs:
         if m not in shapes:
@@ -668,7 +668,10 @@ def rpn_mfma_probe(wl, dev, dtype):
             if pad is not None:
                 ishape = (ishape[0], ishape[1], ishape[2] - 2, ishape[3] - 2)
         if pad is None:
-            other_flops += 3 * flops
+            if dc.KS_CONV and mode == "split" and dc.ks_channels_ok(m):
+                ks_flops += 3 * flops  # kernel == stride layer: 1x1 launches around a re-arrangement (dense_conv.ks_conv)
+            else:
+                other_flops += 3 * flops
             continue
         b, cin, h, w = ishape
         k = m.kernel_size[0]
@@ -696,7 +699,8 @@ def rpn_mfma_probe(wl, dev, dtype):
     return dict(convs_on_library_kernels=len(layers), gflop_per_step=round(own_flops / 1e9, 1),
                 conv_ms_per_step=round(own_ms, 3), achieved_TFLOPs=round(ach, 1), mfma_issued_TFLOPs=round(ach * issue, 1),
                 peak_TFLOPs=MFMA_BF16_PEAK_TFLOPS, frac=round(ach * issue / MFMA_BF16_PEAK_TFLOPS, 4), mode=mode,
-                bound="mfma", gflop_per_step_left_on_miopen=round(other_flops / 1e9, 1), layers=layers[:3],
+                bound="mfma", gflop_per_step_left_on_miopen=round(other_flops / 1e9, 1),
+                gflop_per_step_as_1x1_rearranged=round(ks_flops / 1e9, 1), layers=layers[:3],
                 note="csrc/d3d_conv2d.hip (implicit GEMM, LDS-DMA staging), fwd (BN statistics epilogue on) + dgrad + "
                      "wgrad incl. its reduce pass; `achieved` counts each product once, `mfma_issued` what the matrix "
                      "pipe executes (split mode: three bf16 MFMAs per product); frac = mfma_issued / bf16 peak")

@@ -210,6 +210,19 @@ def _ks_groups(s, cout):
     return ga
 
 
+def ks_channels_ok(m):
+    """the static part of ks_eligible: a kernel == stride layer whose channel counts the 1x1 kernels take on both sides"""
+    if type(m) not in (torch.nn.Conv2d, torch.nn.ConvTranspose2d):
+        return False
+    k, s = m.kernel_size, m.stride
+    if k[0] != k[1] or s != k or k[0] < 2 or k[0] > 4 or m.bias is not None or m.groups != 1 or m.dilation != (1, 1):
+        return False
+    s = s[0]
+    cin, cout = m.in_channels, m.out_channels
+    wide, narrow = (s * s * cin, cout) if type(m) is torch.nn.Conv2d else (_ks_groups(s, cout) * s * cout, cin)
+    return wide in (128, 256, 384, 512) and narrow in (128, 256, 384, 512)
+
+
 def ks_eligible(m, x):
     """Conv2d / ConvTranspose2d with kernel == stride on a channels-last f32 CUDA map, with channel counts the 1x1 kernels
     take on both sides"""
