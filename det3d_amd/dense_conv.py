@@ -225,33 +225,22 @@ def ks_channels_ok(m):
 
 def ks_eligible(m, x):
     """Conv2d / ConvTranspose2d with kernel == stride on a channels-last f32 CUDA map, with channel counts the 1x1 kernels
-    take on both sides"""
-    if not KS_CONV or type(m) not in (torch.nn.Conv2d, torch.nn.ConvTranspose2d):
+    take on both sides (128, 256, 384, 512: each side is the input channels of one launch -- forward or data gradient --
+    and the output channels of the other; d3d_conv2d_nhwc_fwd's 1x1 layers, d3d_conv2d_nhwc_wgrad)"""
+    if not KS_CONV or not ks_channels_ok(m):
         return False
     if not (torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32) or torch.is_autocast_enabled("cuda"):
-        return False
-    k, s = m.kernel_size, m.stride
-    if k[0] != k[1] or s != k or k[0] < 2 or k[0] > 4 or m.bias is not None or m.groups != 1 or m.dilation != (1, 1):
         return False
     if m.padding != (0, 0) or m.weight.dtype != torch.float32 or not x.is_contiguous(memory_format=torch.channels_last):
         return False
     if type(m) is torch.nn.ConvTranspose2d and m.output_padding != (0, 0):
         return False
     b, c, h, w = x.shape
-    s = s[0]
-    cin, cout = m.in_channels, m.out_channels
-    if c != cin:
+    s = m.stride[0]
+    if c != m.in_channels or (type(m) is torch.nn.Conv2d and (h % s or w % s)):
         return False
-    if type(m) is torch.nn.Conv2d:
-        if h % s or w % s:
-            return False
-        wide, narrow, pixels = s * s * cin, cout, b * (h // s) * (w // s)
-    else:
-        wide, narrow, pixels = _ks_groups(s, cout) * s * cout, cin, b * h * w
-    # both sides are the input channels of one launch (forward / data gradient) and the output channels of the other:
-    # 128, 256, 384, 512 (d3d_conv2d_nhwc_fwd's 1x1 layers, d3d_conv2d_nhwc_wgrad)
-    ok = lambda ch: ch in (128, 256, 384, 512)
-    return ok(wide) and ok(narrow) and pixels * s * s * max(cin, cout) * 2 < (1 << 31) - 16
+    pixels = b * (h // s) * (w // s) if type(m) is torch.nn.Conv2d else b * h * w
+    return pixels * s * s * max(m.in_channels, m.out_channels) * 2 < (1 << 31) - 16
 
 
 def _s2d(rows, s):
