@@ -82,7 +82,45 @@ def report(name, nbr):
     print(line)
 
 
+def report_ranges(name, nbr, t=32):
+    """for tiles of `t` consecutive rows and each kz slice (nine offsets), the span of the valid
+    neighbour indices -- the rows a coalesced range load would stage -- against the row requests of the per-offset gather"""
+    v = nbr >= 0
+    n = v.shape[1]
+    nt = (n + t - 1) // t
+    pad = (-n) % t
+    lo = np.where(v, nbr, np.iinfo(np.int64).max)
+    hi = np.where(v, nbr, -1)
+    lo = np.pad(lo, ((0, 0), (0, pad)), constant_values=np.iinfo(np.int64).max).reshape(27, nt, t)
+    hi = np.pad(hi, ((0, 0), (0, pad)), constant_values=-1).reshape(27, nt, t)
+    spans = []
+    for dz in range(3):
+        a = lo[dz * 9:(dz + 1) * 9].min((0, 2))
+        b = hi[dz * 9:(dz + 1) * 9].max((0, 2))
+        spans.append(np.where(b >= 0, b - a + 1, 0))
+    spans = np.stack(spans)  # [3, tiles]
+    valid = v.sum()
+    print("%-34s rows %6d  T%d: span per (tile, kz) median %d  mean %.1f  p90 %d  p99 %d;  <= 48 rows: %.3f  <= 64: %.3f;  "
+          "rows staged / valid row requests %.2f, / all row requests %.2f" % (
+              name, n, t, np.median(spans), spans.mean(), np.percentile(spans, 90), np.percentile(spans, 99),
+              (spans <= 48).mean(), (spans <= 64).mean(), spans.sum() / valid, spans.sum() / (27.0 * n)))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "ranges":
+        c, shape = voxels()
+        geoms = [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1))]
+        print("# tools/tile_occupancy.py ranges: one KITTI-like frame (20k points), rows in the order the rulebooks produce them "
+              "(stage 1: first-point order; later stages: cell order)")
+        for stage, g in enumerate(geoms + [None], 1):
+            report_ranges("stage %d submanifold 3x3x3" % stage, subm_table(c, shape))
+            if stage == 1:  # what cell order would give the first stage
+                o = np.argsort(lin(c, shape))
+                report_ranges("stage 1, rows sorted by cell", subm_table(c[o], shape))
+            if g is None:
+                break
+            c, shape, _ = strided(c, shape, *g)
+        return
     c, shape = voxels()
     geoms = [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)),
              ((3, 1, 1), (2, 1, 1), (0, 0, 0))]
