@@ -135,3 +135,41 @@ def test_host_side_planning_helpers(hip_lib):
     chunk, chunks, start = plan_chunks([40_000_000, 5])
     assert chunk % 256 == 0 and chunk >= 40_000_005 / 4096 and len(chunks) <= 4097 and start[-1] == len(chunks)
     assert all(o % chunk == 0 for _, o in chunks)
+
+
+def test_round4_planners_and_argument_checks_without_gpu(hip_lib):
+    """The host-side planners of the round-4 entry points run before any HIP call: the sparse weight gradient's
+    workspace follows its split plan (and the tuning knob that moves it), the strided data gradient and the stacked
+    conv entry points refuse what they do not implement."""
+    from det3d_amd import _lib
+
+    err = hip_lib.d3d_last_error
+    ws = hip_lib.d3d_sparse_conv_wgrad_workspace_bytes
+    for cin, cout in ((16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128)):
+        slab = 27 * cin * cout * 4
+        for dt in (_lib.D3D_F32, _lib.D3D_BF16):
+            for n in (1, 100, 65083, 1500000):
+                b = ws(n, 27, cin, cout, dt)
+                assert b > 256 and (b - 256) % slab == 0, (cin, cout, dt, n, b)  # whole partial slabs + the header
+            assert ws(100, 27, cin, cout, dt) <= ws(65083, 27, cin, cout, dt) <= ws(1500000, 27, cin, cout, dt)
+    assert ws(1000, 27, 48, 48, _lib.D3D_F32) == 256  # channel pair without a tile kernel: the one-pass fallback
+    # knob 1: value % 100000 = target blocks, value / 100000 = kernel variant (1 = the round-3 kernel on 16 waves)
+    base = ws(126683, 27, 64, 64, _lib.D3D_F32)
+    try:
+        assert hip_lib.d3d_set_tuning(1, 100000) == 0
+        old = ws(126683, 27, 64, 64, _lib.D3D_F32)
+        assert hip_lib.d3d_set_tuning(1, 100000 + 128) == 0
+        few = ws(126683, 27, 64, 64, _lib.D3D_F32)
+    finally:
+        hip_lib.d3d_set_tuning(1, 0)
+    assert few < old <= base and ws(126683, 27, 64, 64, _lib.D3D_F32) == base
+    assert hip_lib.d3d_set_tuning(99, 0) == -1 and b"knob" in err()
+    # the stride-2 data gradient: 3x3 layers, cout 128 | 256, cin a multiple of 128
+    dg = hip_lib.d3d_conv2d_nhwc_dgrad_s2
+    assert dg(1, 1, 1, 1, 1, 2, 16, 16, 128, 256, 3, 1, 7, None) == -1 and b"mode" in err()
+    assert dg(1, 1, 1, 1, 1, 2, 16, 16, 64, 64, 3, 1, _lib.D3D_CONV_SPLIT, None) == -1 and b"channels" in err()
+    assert dg(1, 1, 1, 1, 1, 2, 16, 16, 128, 256, 2, 0, _lib.D3D_CONV_SPLIT, None) == -1 and b"3x3" in err()
+    assert dg(None, None, None, None, None, 2, 16, 16, 128, 256, 3, 1, _lib.D3D_CONV_SPLIT, None) == -1 and b"null" in err()
+    assert hip_lib.d3d_conv2d_supported(128, 256, 3, 2) == 1 and hip_lib.d3d_conv2d_supported(512, 128, 1, 1) == 0
+    assert hip_lib.d3d_conv2d_supported_split3x3(64, 64) == 1 and hip_lib.d3d_conv2d_supported_split3x3(96, 128) == 0
+    assert hip_lib.d3d_pack_all(None, 0, None) in (0, -1)  # nothing to pack: no launch either way
