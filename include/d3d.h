@@ -165,11 +165,15 @@ typedef struct D3dConvEpilogue {
 } D3dConvEpilogue;
 int d3d_sparse_conv_has_epilogue(int cin, int cout, int dtype);
 size_t d3d_conv_epilogue_ws_floats(int n_out, int cout);
-/* tuning hook for tools/tune_fwd.py and tools/bench_bn.py: knob 0 = tiling variant of the forward 64->64 bf16
- * kernel (0 = default), 1 = target block count of the weight-gradient kernel (<= 0 = default, one block per CU),
- * 2 = XCD-aware tile order, 3 = BatchNorm reduction variant for inputs of >= 2^23 elements, 4 = leave the BatchNorm
- * global atomics out (timing diagnosis: wrong sums), 5 = rows in flight in bn_bwd_dx (1, 2, 4), 6 = grid cap of the
- * BatchNorm streaming sweeps (0 = default) */
+/* tuning hook for the tools/tune_*.py, tools/bench_bn.py and tools/bench_conv2d.py sweeps (a process-wide setting, not
+ * part of the product path): knob 0 = tiling variant of the sparse forward kernel (0 = default; 50-55 f32 64->64, 60-63
+ * f32 128-channel layers), 1 = sparse weight gradient: value % 100000 = target block count (0 = default: one block per
+ * CU, two rounds for the three-offset f32 layers), value / 100000 = kernel variant (0 default, 1 = round-3 kernel,
+ * 2 = dout fragments in registers on 16 waves), 2 = XCD-aware tile order, 3 = BatchNorm reduction variant for inputs of
+ * >= 2^23 elements, 4 = ignored (round 2: leave the BatchNorm global atomics out), 5 = rows in flight in bn_bwd_dx
+ * (1, 2, 4), 6 = grid cap of the BatchNorm streaming sweeps (0 = default), 7 = dense conv tiling variant (-1 default),
+ * 8 = dense weight-gradient kernel / waves, 9 = cut the last partial round of the dense 3x3 kernel into 32-channel
+ * blocks (1 default) */
 int d3d_set_tuning(int knob, int value);
 int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const float *bias,
                            const int32_t *nbr, int cap, int n_out, int kvol, int cin, int cout,
