@@ -12,7 +12,10 @@
 // Round 3: the per-channel sums are deterministic.  Every wave leaves ONE slab of partial sums (it walks its pillars in
 // a fixed order) and pfn_fold_kernel adds the slabs in ascending wave order; rounds 1-2 added them with float atomics
 // (2048 waves x 640 same-address atomics made pfn_bwd_weight the slowest launch of the PointPillars step: 620 us).
+// Round 4: 8192 waves (pfn_blocks): the kernels are bound by per-pillar latency, not by bytes.
 // All f32 (the reader runs before any bf16 cast); HBM-bound on reading the voxel rows once per pass.
+#include <stdlib.h>
+
 #include "d3d_common.h"
 #include "d3d_fill.h"
 
@@ -331,7 +334,12 @@ static int pfn_geom(PfnGeom &G, int m, int t, int c, int f, float vx, float vy, 
   } while (0)
 
 static int pfn_blocks(int m) {
-  int waves = m < 2048 ? m : 2048;  // <= 2048 waves (8 per CU), each leaves one slab
+  // waves of a launch (D3D_PFN_WAVES), each leaves one slab.  A wave walks its pillars one after the other with two
+  // dependent passes over a pillar's points, i.e. the kernels are latency-bound and want every wave slot of the chip: 32
+  // per CU (nuScenes PointPillars step, 120k pillars: 2048 waves 505 frames/s, 4096 519, 8192 527, 16384 521)
+  static const int cap = getenv("D3D_PFN_WAVES") ? atoi(getenv("D3D_PFN_WAVES")) : 8192;
+  const int lim = cap < 64 ? 64 : cap;
+  int waves = m < lim ? m : lim;
   int nb = (waves + 3) / 4;
   return nb < 1 ? 1 : nb;
 }
