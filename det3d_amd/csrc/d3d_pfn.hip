@@ -100,14 +100,19 @@ __global__ void __launch_bounds__(256)
 // out[i] = sum over slabs w = 0 .. nslabs-1 (ascending) of slabs[w][i]: 16 waves per block share the slab range, each
 // adds its contiguous share in order, the shares are combined in wave order
 #define PFN_FOLD_WAVES 16
+// blockIdx.y = segment of the slab range (gridDim.y segments of `seg` slabs; the last may be short): segment y writes row y
+// of `out` ([gridDim.y][nval]) -- the first level of a two-level fold -- or, with one segment, the final vectors
 __global__ void __launch_bounds__(64 * PFN_FOLD_WAVES)
     pfn_fold_kernel(const float *__restrict__ slabs, int nslabs, int nval, float *__restrict__ out, int split,
-                    float *__restrict__ out2) {  // values i >= split go to out2[i - split]
+                    float *__restrict__ out2, int seg) {  // values i >= split go to out2[i - split]
   __shared__ float part[PFN_FOLD_WAVES][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = (int)blockIdx.x * 64 + lane;
-  const int per = (nslabs + PFN_FOLD_WAVES - 1) / PFN_FOLD_WAVES;
-  const int w0 = wave * per, w1 = (w0 + per < nslabs) ? w0 + per : nslabs;
+  const int s0 = (int)blockIdx.y * seg;
+  const int s1 = (s0 + seg < nslabs) ? s0 + seg : nslabs;
+  const int per = (s1 - s0 + PFN_FOLD_WAVES - 1) / PFN_FOLD_WAVES;
+  const int w0 = s0 + wave * per, w1 = (w0 + per < s1) ? w0 + per : s1;
+  if (gridDim.y > 1) out += (size_t)blockIdx.y * nval;
   float s = 0.f;
   if (i < nval) {
     int w = w0;
@@ -344,16 +349,34 @@ static int pfn_blocks(int m) {
   return nb < 1 ? 1 : nb;
 }
 
+static size_t pfn_slab(int c, int f) { return (size_t)f * (size_t)(c + 5 > 2 ? c + 5 : 2); }
+
 // floats of the scratch either direction needs: [2f] folded statistics | one slab of max(2f, f (c + 5)) per wave
 extern "C" size_t d3d_pfn_ws_floats(int m, int c, int f) {
   if (m < 1 || c < 3 || c > 5 || f < 1 || f > 64) return 0;
   const size_t slab = (size_t)f * (size_t)(c + 5 > 2 ? c + 5 : 2);
-  return (size_t)2 * f + (size_t)pfn_blocks(m) * 4 * slab;
+  return (size_t)2 * f + ((size_t)pfn_blocks(m) * 4 + 16 /* PFN_FOLD_SEGS rows of the two-level fold */) * slab;
 }
 
-static int pfn_fold(const float *slabs, int nslabs, int nval, float *out, int split, float *out2, hipStream_t stream) {
-  hipLaunchKernelGGL(pfn_fold_kernel, dim3((nval + 63) / 64), dim3(64 * PFN_FOLD_WAVES), 0, stream, slabs, nslabs, nval,
-                     out, split, out2);
+// out = sum of the slabs in ascending order.  More than 1024 slabs: two levels -- PFN_FOLD_SEGS segments in parallel into
+// `tmp` ([PFN_FOLD_SEGS][nval], behind the slabs in the caller's workspace), then those rows (a fixed order again;
+// one block of 16 waves walking 8192 slabs took 35 us, i.e. as long as the kernels it serves)
+#define PFN_FOLD_SEGS 16
+static int pfn_fold(const float *slabs, int nslabs, int nval, float *out, int split, float *out2, float *tmp,
+                    hipStream_t stream) {
+  const dim3 blk(64 * PFN_FOLD_WAVES);
+  if (nslabs > 1024 && tmp) {
+    const int seg = (nslabs + PFN_FOLD_SEGS - 1) / PFN_FOLD_SEGS;
+    const int nseg = (nslabs + seg - 1) / seg;
+    hipLaunchKernelGGL(pfn_fold_kernel, dim3((nval + 63) / 64, nseg), blk, 0, stream, slabs, nslabs, nval, tmp, nval,
+                       nullptr, seg);
+    D3D_LAUNCH_TRY("pfn_fold_kernel");
+    hipLaunchKernelGGL(pfn_fold_kernel, dim3((nval + 63) / 64, 1), blk, 0, stream, (const float *)tmp, nseg, nval, out,
+                       split, out2, nseg);
+  } else {
+    hipLaunchKernelGGL(pfn_fold_kernel, dim3((nval + 63) / 64, 1), blk, 0, stream, slabs, nslabs, nval, out, split, out2,
+                       nslabs);
+  }
   D3D_LAUNCH_TRY("pfn_fold_kernel");
   return D3D_OK;
 }
@@ -379,7 +402,7 @@ extern "C" int d3d_pfn_fwd(const float *voxels, const int32_t *num_points, const
     float *slabs = stats_ws + 2 * f;
     PFN_DISPATCH(pfn_stats_kernel, G, voxels, num_points, (const int4 *)coors, weight, slabs);
     D3D_LAUNCH_TRY("pfn_stats_kernel");
-    if (int frc = pfn_fold(slabs, nb * 4, 2 * f, stats_ws, 2 * f, nullptr, stream)) return frc;
+    if (int frc = pfn_fold(slabs, nb * 4, 2 * f, stats_ws, 2 * f, nullptr, slabs + (size_t)nb * 4 * pfn_slab(c, f), stream)) return frc;
   }
   PFN_DISPATCH(pfn_apply_kernel, G, voxels, num_points, (const int4 *)coors, weight, gamma, beta,
                running_mean, running_var, momentum, eps, training, stats_ws, out, argmax, save_mean,
@@ -409,9 +432,10 @@ extern "C" int d3d_pfn_bwd(const float *voxels, const int32_t *num_points, const
   PFN_DISPATCH(pfn_bwd_reduce_kernel, G, voxels, num_points, (const int4 *)coors, weight, save_mean,
                save_invstd, out, dout, argmax, slabs);
   D3D_LAUNCH_TRY("pfn_bwd_reduce_kernel");
-  if (int frc = pfn_fold(slabs, nb * 4, 2 * f, dgamma, f, dbeta, stream)) return frc;
+  float *tmp = slabs + (size_t)nb * 4 * pfn_slab(c, f);
+  if (int frc = pfn_fold(slabs, nb * 4, 2 * f, dgamma, f, dbeta, tmp, stream)) return frc;
   PFN_DISPATCH(pfn_bwd_weight_kernel, G, voxels, num_points, (const int4 *)coors, weight, gamma,
                save_mean, save_invstd, out, dout, argmax, dgamma, dbeta, slabs);
   D3D_LAUNCH_TRY("pfn_bwd_weight_kernel");
-  return pfn_fold(slabs, nb * 4, f * G.k, dweight, f * G.k, nullptr, stream);
+  return pfn_fold(slabs, nb * 4, f * G.k, dweight, f * G.k, nullptr, tmp, stream);
 }

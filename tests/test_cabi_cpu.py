@@ -124,9 +124,9 @@ def test_host_side_planning_helpers(hip_lib):
     for cin, cout, ok in [(64, 32, 1), (32, 16, 1), (64, 64, 1), (128, 64, 1), (128, 128, 1), (16, 16, 0), (32, 64, 0)]:
         assert L.d3d_sparse_conv_dgrad_plan_supported(cin, cout, _lib.D3D_F32) == ok
         assert L.d3d_sparse_conv_dgrad_plan_supported(cin, cout, _lib.D3D_BF16) == ok
-    # one slab of max(2f, f (c + 5)) floats per wave (<= 8192 waves, rounded to blocks of 4) behind the 2f results
-    assert L.d3d_pfn_ws_floats(100, 4, 64) == 128 + 100 * 64 * 9
-    assert L.d3d_pfn_ws_floats(50000, 5, 64) == 128 + 8192 * 64 * 10
+    # one slab of max(2f, f (c + 5)) floats per wave (<= 8192 waves, rounded to blocks of 4) behind the 2f results, + 16 rows for the two-level fold
+    assert L.d3d_pfn_ws_floats(100, 4, 64) == 128 + (100 + 16) * 64 * 9
+    assert L.d3d_pfn_ws_floats(50000, 5, 64) == 128 + (8192 + 16) * 64 * 10
     assert L.d3d_pfn_ws_floats(10, 6, 64) == 0 and L.d3d_pfn_ws_floats(10, 4, 65) == 0
     assert L.d3d_conv_epilogue_ws_floats(0, 64) == 0 and L.d3d_conv_epilogue_ws_floats(1000, 64) >= 128 * (1 + 16)
     # optimizer chunks: tensor by tensor, multiples of 256 elements, at most ~4096 chunks of >= 4096 elements
