@@ -750,7 +750,9 @@ static C2hPlan c2h_plan(int batch, int ho, int wo, int cout) {
   p.q.ctiles = cout / p.q.ct_full;
   p.q.n_items = batch * p.q.tiles_x * p.q.tiles_y * p.q.ctiles;
   const int rem = p.q.n_items % 256;
-  const bool cut = g_c2_tail && rem > 0 && rem <= 128;
+  // the statistics fold numbers a tile's blocks as (whole blocks) + (cut blocks): that needs the whole blocks to end on a
+  // channel-tile boundary -- always true for 1 / 2 / 4 tiles (256 | n_full), not for cout = 384 / 640 / 768
+  const bool cut = g_c2_tail && rem > 0 && rem <= 128 && (p.q.n_items - rem) % p.q.ctiles == 0;
   p.q.n_full = cut ? p.q.n_items - rem : p.q.n_items;
   p.blocks = p.q.n_full + p.q.cut * (p.q.n_items - p.q.n_full);
   const int rem_items = p.q.n_items - p.q.n_full;

@@ -352,6 +352,33 @@ def test_halo_patch_tail_blocks_with_two_channel_tiles(conv2d_variant):
         assert torch.equal(y, y2) and torch.equal(ws[:512], ws2[:512])
 
 
+def test_halo_patch_statistics_with_three_channel_tiles(conv2d_variant):
+    """cout = 384 (three 128-channel tiles): [1,160,160,128] -> 100 patches x 3 tiles = 300 items = 256 whole
+    blocks + 44 -- the whole blocks do NOT end on a channel-tile boundary (256 % 3 != 0), so the tail must stay whole
+    blocks (cutting it left the last fold ticket undrawn: statistics never written); [2,160,208,128] -> 260 patches = 780
+    items = 768 + 12, 768 % 3 == 0: the cut is legal and the statistics fold sees both block kinds in all three tiles."""
+    from det3d_amd import dense_conv as dc
+
+    for (b, h, w), variant in (((1, 160, 160), 16), ((2, 160, 208), 16), ((1, 160, 160), 18)):
+        conv2d_variant(variant)
+        g = torch.Generator(device="cuda").manual_seed(b * h + w)
+        x = torch.randn((b, h, w, 128), device="cuda", generator=g)
+        wt = torch.randn((384, 128, 3, 3), device="cuda", generator=g) * 0.03
+        w_hi, w_lo = dc._packed(torch.nn.Parameter(wt), "fwd", "split")
+        x_hi, x_lo = dc.split_planes(x)
+        poison = torch.full((1 << 22,), float("nan"), device="cuda")  # what a fold that never completes would leave
+        del poison
+        y, ws2 = dc.conv2d_raw(x_hi, x_lo, w_hi, w_lo, 3, 1, 1, "split", want_stats=True)
+        ref = _ref_conv(x.double(), wt.double(), 1, 1)
+        err, scale = float((y.double() - ref).abs().max()), float(ref.abs().max())
+        assert err <= 3e-5 * scale, (b, h, w, err, scale)
+        yd = y.double().reshape(-1, 384)
+        stats = ws2[:768].double()
+        assert torch.isfinite(stats).all()
+        assert torch.allclose(stats[:384], yd.sum(0), rtol=1e-4, atol=1e-3 * yd.shape[0] ** 0.5)
+        assert torch.allclose(stats[384:], (yd * yd).sum(0), rtol=1e-4, atol=1e-3)
+
+
 @pytest.mark.parametrize("variant", [16, 18])
 @pytest.mark.parametrize("geom", [g for g in HALO_GEOMS if g[7] == 1])
 def test_halo_patch_data_gradient_matches_conv2d_input(geom, variant, conv2d_variant):
