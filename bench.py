@@ -9,8 +9,8 @@
 One step = one pass of the whole hot path over one batch of synthetic clouds that are already resident in
 HBM: device voxelizer + fused mean VFE -> anchor target assignment (HIP) -> sparse backbone (HIP rulebooks,
 sparse conv fwd with the BN statistics in its epilogue) -> RPN (the library's NHWC implicit-GEMM conv kernels,
-BN statistics in their epilogue) -> head 1x1 convs (MIOpen) -> fused loss -> backward (HIP dgrad / two-pass wgrad,
-sparse and dense) -> gradient mean over ranks (RCCL) -> clip -> true-WD Adam.  The input-side geometry of step i+1
+BN statistics in their epilogue) -> head 1x1 convs (the library's d3d_head_conv_* kernels) -> fused loss -> backward
+(HIP dgrad / two-pass wgrad, sparse and dense) -> gradient mean over ranks (RCCL) -> clip -> true-WD Adam.  The input-side geometry of step i+1
 (voxelizer, targets, rulebooks) is built on a second HIP stream while step i runs (det3d_amd/prefetch.py;
 --no-prefetch builds it inline): K timed steps contain K geometry builds.  Rank 0 prints ONE JSON line and refuses
 to if the loss or the gradient norm after the timed region is not finite.
@@ -25,7 +25,9 @@ line) is ~1.5x faster and misses the tolerance by 37x; round 2's headline was th
 Besides the contract fields the line carries
   roofline      the hand-written sparse-conv gather kernel of the dominant 64->64 layers, HIP events on the launch
                 stream inside the timed region (last step); `frac` is the SURVEY.md 8(d) algorithmic-bytes figure
-                against the HBM peak; `traffic` from committed rocprofv3 PMC passes when they match this kernel source
+                against the HBM peak; `sources` lists every duration this run and the committed profile have for that
+                kernel (timed-region events, the extra all-launches step, the rocprofv3 kernel-trace average) with the
+                frac each gives; `traffic` from committed rocprofv3 PMC passes when they match the kernel AND host sources
   bf16 | fp32   the same workload in the other precision
   precision     max |box regression - CPU oracle| of both modes on one frame with O(1)-scale outputs
   rpn_mfma      the dense RPN convolutions alone (the library's kernels: fwd + dgrad + wgrad): useful FLOPs per
@@ -73,6 +75,10 @@ WORKLOADS = {
                note="Lyft CBGS ResNetFHD, 2016x2016x40 grid, samples_per_gpu = 6 as configured"),
     "c3": dict(config="nusc_point_pillars.py", kind="tasks", batch=4, points=250000, beams=32, sweeps=10,
                note="nuScenes PointPillars"),
+    # BASELINE configs[0] on the GPU: examples/point_pillars/configs/kitti_point_pillars_mghead_syncbn.py:192 trains with
+    # samples_per_gpu = 3 (the CPU plumbing figure of `cpu_baseline.c1_plumbing` is its batch-2 CPU twin)
+    "c1": dict(config="kitti_point_pillars.py", kind="kitti", pillars=True, batch=3, points=16384,
+               note="KITTI-car PointPillars, 16k-point clouds, samples_per_gpu = 3 as configured"),
 }
 
 
@@ -112,6 +118,11 @@ def parse():
                     help="do not gc.freeze() after warm-up (shows the cost of full CPython collections)")
     ap.add_argument("--no-channels-last", action="store_true",
                     help="NCHW dense()/RPN activations (default: channels-last, written directly by d3d_dense_scatter)")
+    ap.add_argument("--rank-diagnostics", action="store_true",
+                    help="per-rank medians of step / exchange wait / geometry wait / host enqueue over 8 extra untimed steps "
+                         "(always on with more than one rank)")
+    ap.add_argument("--cpu-steps", type=int, default=20,
+                    help="timed steps of the CPU baseline (after 5 warm-ups; SURVEY.md 8d asks for 20: ~70 s of host time)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -131,12 +142,12 @@ def _cpu_threads(limit=None):
 
 
 # --------------------------------------------------------------------------------------------- CPU baseline
-def cpu_baseline_worker(batch, points):
+def cpu_baseline_worker(batch, points, timed_steps=20):
     """child process (bench.py --cpu-baseline-only): the reference CPU path on the host cores --
     voxelizer = the reference's own C++ point_cloud_ops.h compiled into oracle/_ref (falls back to the oracle's
     C restatement if that module was not built), model = oracle/model_ref (PyTorch-CPU fp32 SECOND
-    fwd/bwd/clip/Adam).  Protocol (bounded to ~30 s): per thread count one warm-up step, then
-    the median of the timed steps; plus the C1 plumbing case (KITTI PointPillars, batch 2, product modules on CPU)."""
+    fwd/bwd/clip/Adam).  Protocol: the thread count from one probing step each, then 5 warm-up steps and
+    the median of `timed_steps` (20) steps; plus the C1 plumbing case (KITTI PointPillars, batch 2, product modules on CPU)."""
     import numpy as np
 
     from det3d_amd import Config, synthetic
@@ -177,29 +188,26 @@ def cpu_baseline_worker(batch, points):
 
     runs = {}
     budget_t0 = time.perf_counter()
-    for cores, n_timed in ((8, 3), (16, 2)):
+    # thread count: one warm-up step (primitive creation / page faults) and one timed step each at 8 and 16 threads
+    for cores in (8, 16):
         cores = _cpu_threads(cores)
         if cores in runs:
             continue
         torch.set_num_threads(cores)
-        one(0, 1)  # primitive creation / page faults, untimed
-        rec = []
-        for i in range(n_timed):
-            rec.append(one(1 + i, batch))
-            if time.perf_counter() - budget_t0 > 40:
-                break
-        med = statistics.median(r["total"] for r in rec)
-        mid = sorted(rec, key=lambda r: r["total"])[len(rec) // 2]
-        runs[cores] = dict(frames_per_s=round(batch / med, 4), median_step_s=round(med, 3), steps=len(rec),
-                           buckets_s={k: round(v, 3) for k, v in mid.items()})
+        one(0, 1)
+        r = one(1, batch)
+        runs[cores] = dict(frames_per_s=round(batch / r["total"], 4), median_step_s=round(r["total"], 3), steps=1,
+                           buckets_s={k: round(v, 3) for k, v in r.items()})
     best = max(runs, key=lambda c: runs[c]["frames_per_s"])
-    # ... then >= 5 timed steps at the best thread count (SURVEY.md 8d asks 20 after 5 warm-ups, which
-    # at ~3.5 s per step does not fit the default run's wall-clock)
+    # 5 warm-up steps, then the median of >= 20 timed steps at the best thread count (VERDICT round 4;
+    # ~2.5-3.5 s per step: the bench's longest leg, bounded by --cpu-steps and a wall-clock cap)
     torch.set_num_threads(best)
+    for i in range(5 if timed_steps >= 20 else 1):
+        one(2 + i, batch)
     rec = []
-    for i in range(5):
+    for i in range(timed_steps):
         rec.append(one(10 + i, batch))
-        if time.perf_counter() - budget_t0 > 90 and len(rec) >= 3:
+        if time.perf_counter() - budget_t0 > 240 and len(rec) >= 5:
             break
     med = statistics.median(r["total"] for r in rec)
     mid = sorted(rec, key=lambda r: r["total"])[len(rec) // 2]
@@ -208,9 +216,10 @@ def cpu_baseline_worker(batch, points):
                       buckets_s={k: round(v, 3) for k, v in mid.items()})
     out = dict(value=runs[best]["frames_per_s"], unit="frames/s", cores=best, kind="port", voxelizer=vox_kind,
                runs={str(c): r for c, r in runs.items()},
-               sample="median of %d training steps of %d frames x %d pts at the best thread count, chosen by 2-3 steps "
-                      "after a warm-up step per thread count (%s): CPU voxelizer (%s) + PyTorch-CPU fp32 SECOND fwd/bwd/clip/Adam; best = %d threads"
-                      % (runs[best]["steps"], batch, points, ", ".join("%s threads" % c for c in runs),
+               sample="median of %d training steps of %d frames x %d pts after %d warm-up steps at the best thread count (one "
+                      "probing step each at %s): CPU voxelizer (%s) + PyTorch-CPU fp32 SECOND fwd/bwd/clip/Adam; best = %d threads"
+                      % (runs[best]["steps"], batch, points, 5 if timed_steps >= 20 else 1,
+                         ", ".join("%s threads" % c for c in runs),
                          "compiled reference point_cloud_ops.h" if vox_kind == "reference" else "oracle C port", best))
     # C1 plumbing (BASELINE configs[0]): KITTI PointPillars on the CPU-only PyTorch path, batch 2, 16k points
     try:
@@ -257,12 +266,12 @@ def cpu_baseline_worker(batch, points):
     print(json.dumps(out))
 
 
-def cpu_baseline(batch, points, budget_s=300):
+def cpu_baseline(batch, points, timed_steps=20, budget_s=600):
     import subprocess
 
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only",
-                            "--batch", str(batch), "--points", str(points)],
+                            "--batch", str(batch), "--points", str(points), "--cpu-steps", str(timed_steps)],
                            capture_output=True, text=True, timeout=budget_s)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode == 0 and line:
@@ -292,14 +301,24 @@ class Workload:
         D.broadcast_params(model)
         self.model = model
         self.cached_targets = args.cached_targets
-        self.augment = bool(getattr(args, "augment", False)) and spec["kind"] == "kitti"
+        self.augment = bool(getattr(args, "augment", False)) and spec["kind"] == "kitti" and not spec.get("pillars")
         import numpy as np
 
         self.aug_rng = np.random.RandomState(1234 + rank)
         # distinct clouds per step -- at least four different batches per rank before a cloud repeats
         # (frames are generated lazily: a rank pays for the 4 x batch seeds it reads out of the job's 4 x batch x world)
         n_seeds = 4 * self.batch * world
-        if spec["kind"] == "kitti":
+        self.pillars = bool(spec.get("pillars"))
+        if self.pillars:
+            # the KITTI generator on the PointPillars geometry (0.16 m pillars, 100 points each, 12000 pillars)
+            vg, gen = cfg.voxel_generator, cfg.assigner.target_assigner.anchor_generators[0]
+            self.vox_cfg = dict(voxel_size=list(vg.voxel_size), pc_range=list(vg.range), max_points=vg.max_points_in_voxel,
+                                max_voxels=vg.max_voxel_num, anchor_ranges=list(gen.anchor_ranges), sizes=list(gen.sizes),
+                                rotations=list(gen.rotations), matched_threshold=gen.matched_threshold,
+                                unmatched_threshold=gen.unmatched_threshold,
+                                out_size_factor=int(cfg.assigner.out_size_factor))
+            self.ds = synthetic.KittiCarSynthetic(n_points=self.points, n_seeds=n_seeds, cfg=self.vox_cfg)
+        elif spec["kind"] == "kitti":
             self.ds = synthetic.KittiCarSynthetic(n_points=self.points, n_seeds=n_seeds)
             self.vox_cfg = synthetic.KITTI_CAR
         else:
@@ -313,10 +332,11 @@ class Workload:
                                  grad_clip=cfg.optimizer_config.grad_clip.max_norm,
                                  autocast_dtype=torch.bfloat16 if dtype == "bf16" else None)
 
-    def example(self, i, targets=True):
+    def example(self, i, targets=True, batch=None):
+        """the collate-style example of resident batch i (or of `batch`, a device_batch dict of any size)"""
         from det3d_amd import synthetic
 
-        b = self.batches[i % self.n_batches]
+        b = self.batches[i % self.n_batches] if batch is None else batch
         if self.augment:
             from det3d_amd import augment
 
@@ -324,6 +344,9 @@ class Workload:
             pts, gt = augment.apply_global_augmentation(b["points"], b["frame_offsets"], b["gt_boxes"], prm)
             b = dict(b, points=augment.shuffle_points(pts, b["frame_offsets"]), gt_boxes=gt)
             return synthetic.make_example(b, self.vox_cfg, fused_mean=True, device_targets=targets)
+        if self.pillars:  # PillarFeatureNet reads the padded [M, T, C] pillars, not the fused mean
+            return synthetic.make_example(b, self.vox_cfg, fused_mean=False, want_voxels=True,
+                                          device_targets=targets and not self.cached_targets)
         if self.spec["kind"] == "kitti":
             return synthetic.make_example(b, self.vox_cfg, fused_mean=True, device_targets=targets and not self.cached_targets)
         return self.ds.make_example(b, targets=targets)
@@ -448,6 +471,48 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
     return float(t.item()), records, loss
 
 
+def rank_diagnostics(wl, dev, rank, world, steps=8):
+    """make the first real multi-GPU run diagnosable.  `steps` extra UNTIMED steps after the
+    region (HIP event pairs perturb the stream, so they stay out of the timed steps), every rank: per-step medians of
+      step_ms            start of step i -> start of step i+1 on the compute stream (the GPU-side cadence)
+      exchange_wait_ms   compute stream: backward enqueued -> gradient all-reduces waited for (TrainStep.probe)
+      geometry_wait_ms   compute stream: end of step i -> the side stream's geometry of step i+1 complete
+      host_enqueue_ms    Python time to enqueue one step
+      host_geometry_ms   Python time blocked on the geometry worker thread
+    gathered to rank 0 (all_gather_object).  Matches what det3d/core/utils/dist_utils.py:31-57 would need timers for."""
+    from det3d_amd import dist as D
+    from det3d_amd.prefetch import GeometryPrefetcher
+
+    pf = GeometryPrefetcher(wl.example, wl.model, dev, enabled=True)
+    ex, nxt = pf.prepare(0), pf.submit(1)
+    wl.step_fn.probe = []
+    host, geo = [], []
+    for i in range(steps + 2):
+        t_a = time.perf_counter()
+        wl.step_fn(ex)
+        t_b = time.perf_counter()
+        g0, g1 = _ev(), _ev()
+        g0.record()
+        ex = nxt.result()
+        g1.record()
+        nxt = pf.submit(i + 2)
+        host.append((t_b - t_a, time.perf_counter() - t_b))
+        geo.append((g0, g1))
+    nxt.result()
+    torch.cuda.synchronize()
+    pf.close()
+    pr, wl.step_fn.probe = wl.step_fn.probe, None
+    med = lambda v: round(statistics.median(v), 3) if v else None
+    k = range(2, len(pr) - 1)  # the first two steps refill pools / caches
+    row = dict(rank=rank, steps=len(k),
+               step_ms=med([pr[i][0].elapsed_time(pr[i + 1][0]) for i in k]),
+               exchange_wait_ms=med([pr[i][1].elapsed_time(pr[i][2]) for i in k if pr[i][1] is not None]),
+               geometry_wait_ms=med([geo[i][0].elapsed_time(geo[i][1]) for i in k]),
+               host_enqueue_ms=med([1e3 * host[i][0] for i in k]), host_geometry_ms=med([1e3 * host[i][1] for i in k]))
+    rows = D.all_gather_objects(row) if world > 1 else [row]
+    return rows
+
+
 def kernel_table(wl, step_index, rank, esz):
     """one extra untimed step with every sparse-conv launch event-timed (rank 0); all ranks run it (collective)."""
     from det3d_amd import spconv
@@ -512,28 +577,67 @@ def roofline_object(groups, key, dtype):
     return out
 
 
+def _stamp():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import stamp
+
+    return stamp.source_sha16()
+
+
 def attach_pmc_traffic(roof, wl):
     """HBM traffic needs PMC passes (rocprofv3 --pmc cannot run inside this process): take the committed
-    measurement (tools/pmc_spconv.sh) only if it was taken on THIS kernel source and workload."""
-    path = os.path.join(ROOT, "profiles", "round4_pmc_spconv.json")
-    src = os.path.join(ROOT, "det3d_amd", "csrc", "d3d_spconv.hip")
+    measurement (tools/pmc_spconv.sh) only if it was taken on THIS kernel source, THESE host files (tools/stamp.py:
+    d3d_spconv.hip, its headers, spconv.py, sparse_stack.py, sparse_block.py) and this workload."""
+    name = "profiles/round5_pmc_spconv.json"
     try:
-        pmc = json.load(open(path))
-        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+        pmc = json.load(open(os.path.join(ROOT, name)))
+        sha = _stamp()
         w = pmc["workload"]
-        if pmc.get("kernel_source_sha16") != sha:
-            roof["traffic_source"] = "profiles/round4_pmc_spconv.json is stale (kernel source changed): not used"
+        if pmc.get("source_sha16") != sha:
+            roof["traffic_source"] = "%s is stale (kernel or launch-side source changed since the counter pass): not used" % name
             return
         if (w["name"], w["frames_per_gpu"], w["points_per_frame"], w["dtype"]) != (wl.name, wl.batch, wl.points, wl.dtype):
             return
         roof["traffic"] = pmc["traffic_bytes_per_launch"]
         roof["traffic_measured_in_run"] = False
-        roof["traffic_source"] = "profiles/round4_pmc_spconv.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " \
-                                 "tools/pmc_spconv.sh; kernel source sha %s)" % sha
+        roof["traffic_source"] = "%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_spconv.sh; source " \
+                                 "stamp %s over kernel + launch-side files)" % (name, sha)
         if roof.get("avg_launch_us"):
             roof["hbm_frac_true"] = round(pmc["traffic_bytes_per_launch"] / (roof["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
     except (OSError, KeyError, ValueError):
         pass
+
+
+def roofline_sources(roof, wl, extra_groups, key):
+    """one kernel, three clocks.  `frac` stays the contract's figure (HIP events on the launch stream
+    inside the timed region); `sources` puts the other two next to it -- the extra all-launches step of the `kernels`
+    table and the committed rocprofv3 kernel-trace average (tools/profile_step.sh -> profiles/round5_rocprof_spconv.json,
+    used only when its source stamp and workload match) -- each with the frac the same algorithmic bytes give."""
+    b = roof["alg_bytes_per_launch"]
+
+    def entry(us, n, what):
+        return dict(avg_launch_us=round(us, 2), launches=n, frac=round(b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), how=what)
+
+    src = {"timed_region_events": entry(roof["avg_launch_us"], roof["launches_timed"],
+                                        "HIP events around the launches of the last timed step (the line's `frac`)")}
+    g = (extra_groups or {}).get(key)
+    if g:
+        src["extra_step_events"] = entry(1e3 * g["ms"] / g["launches"], g["launches"],
+                                         "one untimed step after the region with EVERY sparse launch event-timed "
+                                         "(the `kernels` table); its own bytes: %d per launch" % int(g["bytes"] / g["launches"]))
+    name = "profiles/round5_rocprof_spconv.json"
+    try:
+        rp = json.load(open(os.path.join(ROOT, name)))
+        if rp.get("source_sha16") != _stamp():
+            src["rocprof"] = dict(stale="%s was taken on other sources: not used" % name)
+        elif (rp["workload"], rp["dtype"]) == (wl.name, wl.dtype) and rp.get("avg_launch_us"):
+            src["rocprof"] = entry(rp["avg_launch_us"], rp["launches_per_step"],
+                                   "%s: rocprofv3 --kernel-trace average over the steady-state window of a separate run" % name)
+    except (OSError, KeyError, ValueError):
+        pass
+    roof["sources"] = src
+    fr = [v["frac"] for v in src.values() if "frac" in v]
+    roof["frac_range"] = [min(fr), max(fr)]
 
 
 # --------------------------------------------------------------------------------------------------- probes
@@ -585,7 +689,113 @@ def stage_probe(wl, dev):
                                 achieved_GBs=round(rb_bytes / (ms * 1e-3) / 1e9, 1),
                                 note="all rulebooks of the backbone incl. the one host sync; bytes = coords in + "
                                      "neighbour tables out")
+        # the same builds call by call (exact sizes known now, no sync inside): d3d_subm_rulebook per level,
+        # d3d_conv_rulebook (+ the row plan of its data gradient) per strided layer
+        calls, seen = [], set()
+        idx, shape, n = ex_t["coordinates"], list(st.spatial_shape), int(ex_t["coordinates"].shape[0])
+        for m in bb.middle_conv.conv_layers():
+            key = m._rulebook_key()
+            if key in seen:
+                continue
+            seen.add(key)
+            r = d[key]
+            n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+            if m.subm:
+                fn = lambda: spconv.build_subm_rulebook(idx, n_dev, n, max(n, 1), wl.batch, shape, m.kernel_size)
+                byts = n * 16 + r.kvol * n * 4
+            else:
+                fn = lambda: spconv.build_conv_rulebook(idx, n_dev, n, max(n, 1), wl.batch, shape, m.kernel_size,
+                                                        m.stride, m.padding)
+                byts = n * 16 + r.kvol * r.n_out * 4 + r.n_out * 16 + r.kvol * n * 4
+            for _ in range(2):
+                fn()
+            ea, eb = _ev(), _ev()
+            torch.cuda.synchronize()
+            ea.record()
+            for _ in range(3):
+                fn()
+            eb.record()
+            torch.cuda.synchronize()
+            us = 1e3 * ea.elapsed_time(eb) / 3
+            calls.append(dict(call="d3d_subm_rulebook" if m.subm else "d3d_conv_rulebook+dgrad_plan", sites_in=n,
+                              sites_out=int(r.n_out), kvol=r.kvol, us=round(us, 1), alg_MB=round(byts / 1e6, 2),
+                              achieved_GBs=round(byts / (us * 1e-6) / 1e9, 1)))
+            if not m.subm:
+                idx, shape, n = r.out_indices, list(r.out_shape), int(r.n_out)
+        tot_us = sum(c["us"] for c in calls)
+        out["rulebooks"]["calls"] = calls
+        out["rulebooks"]["gpu_ms_sum_of_calls"] = round(tot_us / 1e3, 4)
+        out["rulebooks"]["achieved_GBs_gpu_only"] = round(rb_bytes / (tot_us * 1e-6) / 1e9, 1) if tot_us else None
+    try:
+        out["batchnorm_sweeps"] = bn_probe(wl, dev, ex_t)
+    except Exception as e:  # a side table: never fail the stage probe over it
+        out["batchnorm_sweeps"] = dict(error=repr(e)[:200])
     return out
+
+
+def bn_probe(wl, dev, ex):
+    """achieved GB/s of the four BatchNorm sweeps (d3d_bn_stats / apply / bwd_reduce / bwd_dx, csrc/d3d_bn.hip) on the
+    workload's two dominant row matrices: the RPN's channels-last map [B*H*W, C] and the largest sparse level [N, C].
+    Buffers rotate through > 512 MB so the Infinity Cache does not serve them; algorithmic bytes: stats N*C*e, apply
+    2*N*C*e, bwd_reduce 2*N*C*e, bwd_dx 3*N*C*e."""
+    from det3d_amd import _lib
+
+    L = _lib.lib()
+    st = _lib.stream_ptr(dev)
+    f32 = wl.dtype != "bf16"
+    dtype, dt, esz = (torch.float32, _lib.D3D_F32, 4) if f32 else (torch.bfloat16, _lib.D3D_BF16, 2)
+    shape = [int(s) for s in ex["shape"][0]]
+    f = int(wl.cfg.assigner.out_size_factor)
+    c_rpn = int(wl.model.neck.blocks[0][1].out_channels) if hasattr(wl.model, "neck") else 128
+    mats = [("rpn map", wl.batch * (shape[1] // f) * (shape[0] // f), c_rpn)]
+    if hasattr(wl.model.backbone, "last_indice_dict"):
+        rbs = sorted({id(r): r for r in wl.model.backbone.last_indice_dict.values()}.values(), key=lambda r: -r.n_out)
+        mats.append(("largest sparse level", int(rbs[0].n_out), 64 if wl.spec["kind"] == "kitti" else 32))
+    rows = []
+    for what, n, c in mats:
+        mb = n * c * esz / 1e6
+        k = max(3, int(512 / (3 * mb)) + 1)
+        g = torch.Generator(device=dev).manual_seed(1)
+        bufs = [((torch.randn((n, c), device=dev, generator=g) * 1.5 + 0.3).to(dtype),
+                 torch.randn((n, c), device=dev, generator=g).to(dtype), torch.empty((n, c), dtype=dtype, device=dev))
+                for _ in range(k)]
+        gamma, beta = torch.linspace(0.5, 1.5, c, device=dev), torch.linspace(-0.5, 0.5, c, device=dev)
+        nws = L.d3d_bn_reduce_ws_floats(n, c, dt)
+        stats, part = torch.empty((nws,), device=dev), torch.empty((nws,), device=dev)
+        save, g2 = torch.empty((2, c), device=dev), torch.empty((2, c), device=dev)
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        fns = {
+            "bn_stats": (1, lambda x, dy, o: L.d3d_bn_stats(x.data_ptr(), n, c, dt, stats.data_ptr(), st)),
+            "bn_apply": (2, lambda x, dy, o: L.d3d_bn_apply(x.data_ptr(), n, c, dt, gamma.data_ptr(), beta.data_ptr(),
+                                                            rm.data_ptr(), rv.data_ptr(), 0.01, 1e-3, 1, 1, stats.data_ptr(), 1,
+                                                            o.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), st)),
+            "bn_bwd_reduce": (2, lambda x, dy, o: L.d3d_bn_bwd_reduce(x.data_ptr(), dy.data_ptr(), n, c, dt, gamma.data_ptr(),
+                                                                      beta.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), 1,
+                                                                      part.data_ptr(), st)),
+            "bn_bwd_dx": (3, lambda x, dy, o: L.d3d_bn_bwd_dx(x.data_ptr(), dy.data_ptr(), n, c, dt, gamma.data_ptr(),
+                                                              beta.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), 1,
+                                                              part.data_ptr(), 1, o.data_ptr(), g2[0].data_ptr(),
+                                                              g2[1].data_ptr(), st)),
+        }
+        row = dict(matrix=what, rows=n, channels=c, dtype="f32" if f32 else "bf16", MB=round(mb, 1))
+        for name, (passes, fn) in fns.items():
+            for i in range(3):
+                _lib.check(fn(*bufs[i % k]), name)
+            ea, eb = _ev(), _ev()
+            torch.cuda.synchronize()
+            ea.record()
+            reps = 12
+            for i in range(reps):
+                fn(*bufs[i % k])
+            eb.record()
+            torch.cuda.synchronize()
+            us = 1e3 * ea.elapsed_time(eb) / reps
+            row[name] = dict(us=round(us, 1), achieved_GBs=round(passes * mb / us * 1e3, 0),
+                             frac_of_hbm_peak=round(passes * mb / us * 1e3 / HBM_PEAK_GBS, 3))
+        rows.append(row)
+        del bufs
+    torch.cuda.empty_cache()
+    return rows
 
 
 def rpn_mfma_probe(wl, dev, dtype):
@@ -760,16 +970,41 @@ def predict_probe(wl, dev, dtype, iters=20):
                     detections_per_frame=round(n_det / (iters * wl.batch), 1), task_groups=len(us["nms"]),
                     decode_filter_topk_us=round(sum(us["decode"]), 1), rotate_nms_batched_us=round(sum(us["nms"]), 1))
 
+    def batch1_latency(frames=60):
+        """the reference's speed test, tools/dist_test.py:145,178-193,217: batch size 1, the clock runs over the middle
+        third of the frames between two synchronisations, `Total time per frame` = elapsed / frames"""
+        singles = [wl.ds.device_batch(i, 1, dev) for i in range(8)]
+        a, b = frames // 3, 2 * frames // 3
+        t0 = t1 = 0.0
+        for i in range(frames):
+            if i == a:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            if i == b:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+            model(wl.example(i, targets=False, batch=singles[i % len(singles)]), return_loss=False)
+        torch.cuda.synchronize()
+        per = (t1 - t0) / (b - a)
+        return dict(ms_per_frame=round(1e3 * per, 3), frames_per_s=round(1.0 / per, 1), frames_timed=b - a,
+                    protocol="tools/dist_test.py --speed_test: batch 1, middle third of %d frames, synchronise at both ends; "
+                             "voxelizer on the device inside the clock (the reference's runs in DataLoader workers outside it)" % frames)
+
     thr = get_thr()
     try:
         with torch.no_grad(), wl.step_fn._ctx():
             configured = measure()
+            try:
+                b1 = batch1_latency()
+            except Exception as e:
+                b1 = dict(error=repr(e)[:200])
             set_thr(0.0)
             saturated = measure()
     finally:
         set_thr(thr)
         model.train()
     out = dict(saturated)
+    out["batch1_latency_as_configured"] = b1
     out.update(dtype=dtype, score_threshold="0 (saturated: full top-k into the NMS)",
                as_configured=dict(configured, score_threshold=thr),
                note="whole batch per call: d3d_decode_filter_topk (2 launches) + d3d_rotate_nms_batched (3 launches) "
@@ -843,7 +1078,7 @@ def child_workload(name, dtype, steps=8, warmup=3, budget_s=200):
 def main():
     args = parse()
     if args.cpu_baseline_only:
-        return cpu_baseline_worker(args.batch or 4, args.points or 20000)
+        return cpu_baseline_worker(args.batch or 4, args.points or 20000, args.cpu_steps)
     from det3d_amd import dist as D
 
     t_start = time.perf_counter()
@@ -877,7 +1112,7 @@ def main():
     esz = 2 if args.dtype == "bf16" else 4
     dominant = (lambda kind, cin, cout: kind != "wgrad" and cin == 64 and cout == 64) if not args.no_launch_log else None
     roof_key = FWD64_BF16 if args.dtype == "bf16" else "spconv_fwd_mfma_kernel<64,64>"
-    if head == "c3":
+    if head in ("c3", "c1"):
         dominant = None  # PointPillars has no sparse convolutions
     elapsed, records, loss = timed_region(wl, args.steps, args.warmup, rank, world, dev, note, dominant,
                                           freeze=not args.no_gc_freeze, burn_in_s=args.burn_in,
@@ -891,7 +1126,7 @@ def main():
                          % (float(loss), gnorm))
     out = {
         "metric": "training frames/sec (%s, voxelize->sparse conv->RPN->head->loss->bwd->step)" % (
-            "KITTI-car SECOND" if wl.spec["kind"] == "kitti" else wl.spec["config"].replace(".py", "")),
+            "KITTI-car SECOND" if wl.spec["kind"] == "kitti" and not wl.pillars else wl.spec["config"].replace(".py", "")),
         "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -923,8 +1158,19 @@ def main():
                                 ms_per_step=round(g["ms"], 4), achieved_GBs=round(g["bytes"] / (g["ms"] * 1e-3) / 1e9, 1),
                                 B_alg_MB_per_launch=round(g["bytes"] / g["launches"] / 1e6, 2))
             out["kernels"] = table
+            if "roofline" in out:
+                roofline_sources(out["roofline"], wl, groups, roof_key)
             out["sparse_conv_ms_per_step"] = round(sum(g["ms"] for g in groups.values()), 3)
 
+    if world > 1 or args.rank_diagnostics:
+        try:
+            rows = rank_diagnostics(wl, dev, rank, world)  # all ranks: the steps have collectives
+            if rank == 0:
+                out["ranks"] = rows
+        except Exception as e:
+            if world > 1:
+                raise  # a rank that leaves the collective sequence must not leave the others hanging silently
+            out["ranks_error"] = repr(e)[:300]
     extras = rank == 0 and world == 1 and not args.no_extras
     if extras:
         try:
@@ -934,7 +1180,7 @@ def main():
             out["predict"] = predict_probe(wl, dev, args.dtype)
         except Exception as e:
             out["probe_error"] = repr(e)[:300]
-    if extras and wl.spec["kind"] == "kitti":
+    if extras and wl.spec["kind"] == "kitti" and not wl.pillars:
         try:
             note("precision probe (both modes vs the CPU oracle) ...")
             out["precision"] = precision_probe(dev)
@@ -965,14 +1211,14 @@ def main():
         # the other single-GPU configurations of BASELINE.json, each in a CHILD process (a fault there must not
         # take the headline line down): by default the capped KITTI cloud and the ResNetFHD model, `--workload all`
         # adds Lyft and nuScenes PointPillars
-        names = ("c2-60k", "c4", "c5", "c3")
+        names = ("c2-60k", "c4", "c5", "c3", "c1")
         out["workloads"] = {}
         for name in names:
             note("workload %s (child process) ..." % name)
             out["workloads"][name] = child_workload(name, args.dtype)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and wl.spec["kind"] == "kitti":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and wl.spec["kind"] == "kitti" and not wl.pillars:
         note("cpu baseline (child process) ...")
-        out["cpu_baseline"] = cpu_baseline(wl.batch, wl.points)
+        out["cpu_baseline"] = cpu_baseline(wl.batch, wl.points, args.cpu_steps)
         if "value" in out["cpu_baseline"]:
             out["config"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
             for k in ("fp32", "bf16"):

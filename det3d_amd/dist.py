@@ -195,6 +195,14 @@ class OverlappedGradBuckets:
         # once.  (Round 3 concatenated into a NEW buffer every step: three allocations that the communication stream
         # then held on to through recordStream -- the caching allocator kept growing, and the 1-rank RCCL step ran 15 %
         # behind the plain one, profiles/round4_multirank.txt.)
+        self._build_flats()
+        self.handles = [None] * len(self.buckets)
+        self.ready = [0] * len(self.buckets)
+        self.next_launch = 0
+        self.armed = False
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _build_flats(self):
         self.flats, self.views = [], []
         for ps in self.buckets:
             offs, n = [], 0
@@ -204,14 +212,15 @@ class OverlappedGradBuckets:
             flat = torch.zeros((n,), dtype=ps[0].dtype, device=ps[0].device)
             self.flats.append(flat)
             self.views.append([flat[o: o + p.numel()].view(p.shape) for o, p in zip(offs, ps)])
-        self.handles = [None] * len(self.buckets)
-        self.ready = [0] * len(self.buckets)
-        self.next_launch = 0
-        self.armed = False
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def zero(self):
         """call before backward: forget the previous step's gradients and arm the hooks"""
+        # the exchange buffers follow the parameters: a model.to(device | dtype) after construction would otherwise leave
+        # p.grad and the all-reduce on the old buffers (build the buckets after the final placement to avoid the rebuild)
+        p0 = self.params[0]
+        if self.flats[0].device != p0.device or self.flats[0].dtype != p0.dtype:
+            assert len({(p.dtype, p.device) for p in self.params}) == 1, "single dtype / device buckets"
+            self._build_flats()
         for p in self.params:
             p.grad = None
         self.handles = [None] * len(self.buckets)

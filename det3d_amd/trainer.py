@@ -90,6 +90,10 @@ class TrainStep:
                 self.opt = torch.optim.Adam(self.params, foreach=True, **kw)
         self.global_step = 0
         self.last = {}
+        # diagnosis (bench.py --gpus N, per-rank medians): a list that receives one tuple of HIP events per step --
+        # (step start, backward enqueued = in front of the wait for the gradient exchange, exchange waited for, step
+        # end), all recorded on the stream the step runs on
+        self.probe = None
 
     # ---- resume (the reference keeps epoch / iter / optimizer in the checkpoint: trainer.py save_checkpoint,
     # resume :470-499); here the schedule position is the global step
@@ -110,6 +114,10 @@ class TrainStep:
         place to start host work for a LATER step (the next geometry build on its worker thread): the forward phase is
         the host-bound part of the step, the backward's large dense kernels leave the host time to spare."""
         lr, mom = self.sched.at(self.global_step)
+        ev = None
+        if self.probe is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
         self.bucket.zero()
         with self._ctx():
             losses = self.model(example, return_loss=True)
@@ -120,6 +128,8 @@ class TrainStep:
         if self.fused is not None:
             # the exchanged sums (or the local gradients) as they are: mean over ranks, clipping, true weight decay
             # and Adam happen inside the two launches
+            if ev is not None:
+                ev[1].record()
             if self.overlap:
                 self.bucket.finish_sums()  # exchanges were started by the hooks during backward
                 scale = 1.0 / d3d_dist.world_size()
@@ -127,6 +137,8 @@ class TrainStep:
                 self.bucket.gather()
                 self.bucket.allreduce_mean()
                 scale = 1.0
+            if ev is not None:
+                ev[2].record()
             gnorm = self.fused.step(lr, mom, decay=1.0 - self.wd * lr, max_norm=self.grad_clip, grad_scale=scale)
             self.repacker.run()
         else:
@@ -143,5 +155,10 @@ class TrainStep:
                 torch._foreach_mul_(self.params, 1.0 - self.wd * lr)  # true weight decay, bn_wd=True
             self.opt.step()
         self.global_step += 1
+        if ev is not None:
+            if self.fused is None:
+                ev[1] = ev[2] = None  # (the unfused optimizer path is not instrumented)
+            ev[3].record()
+            self.probe.append(tuple(ev))
         self.last = dict(loss=loss.detach(), grad_norm=gnorm, lr=lr, losses=losses)
         return loss.detach()

@@ -1,12 +1,14 @@
-"""profiles/round4_pmc_spconv.json from the per-counter summaries of tools/pmc_spconv.sh: HBM traffic per launch of
+"""profiles/round5_pmc_spconv.json from the per-counter summaries of tools/pmc_spconv.sh: HBM traffic per launch of
 the roofline kernel (read side doubled per MI355X_MICROARCH.md: gfx950's FETCH_SIZE tallies 128-B requests at 64 B)
-stamped with the sha of the kernel source, so bench.py can refuse a stale file; MFMA-busy fraction of the dense conv
-kernels.  usage: pmc_json.py <dir with round4_pmc_*.txt>"""
-import hashlib
+stamped with the sha of the kernel source AND the host files that launch it (tools/stamp.py), so bench.py can refuse a stale file; MFMA-busy fraction of the dense conv
+kernels.  usage: pmc_json.py <dir with round5_pmc_*.txt>"""
 import json
 import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import stamp
 
 d = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,7 +35,7 @@ def pick(rs, pat):
     return None
 
 
-fetch, write, mfma = rows("round4_pmc_fetch_size.txt"), rows("round4_pmc_write_size.txt"), rows("round4_pmc_sq_valu_mfma_busy_cycles.txt")
+fetch, write, mfma = rows("round5_pmc_fetch_size.txt"), rows("round5_pmc_write_size.txt"), rows("round5_pmc_sq_valu_mfma_busy_cycles.txt")
 # the roofline kernel of the default (f32, split arithmetic) step; D3D_PMC_DTYPE=bf16 for the autocast step
 DT = os.environ.get("D3D_PMC_DTYPE", "fp32")
 # (the trailing `false` of the mfma kernel = not the planned variant of the strided data gradients)
@@ -43,7 +45,7 @@ f, w = pick(fetch, pat), pick(write, pat)
 out = {"_comment": "separate rocprofv3 --kernel-trace --pmc passes over `bench.py --steps 3 --warmup 3` (tools/pmc_spconv.sh); "
                    "FETCH_SIZE / WRITE_SIZE in KiB per launch, read side x2 (MI355X_MICROARCH.md, gfx950), write side as is",
        "kernel": (re.match(r"(?:void )?(spconv_fwd_\w+)<", f[3]).group(1) + "<64,64>") if f else "spconv_fwd_group_kernel<64,64>",
-       "kernel_source_sha16": hashlib.sha256(open(os.path.join(ROOT, "det3d_amd", "csrc", "d3d_spconv.hip"), "rb").read()).hexdigest()[:16],
+       "source_sha16": stamp.source_sha16(), "source_files": list(stamp.FILES),
        "workload": {"name": "c2-20k", "frames_per_gpu": 4, "points_per_frame": 20000, "dtype": DT}}
 if f and w:
     out.update(fetch_size_kib_per_launch=f[1], write_size_kib_per_launch=w[1], fetch_correction=2.0,
@@ -74,5 +76,5 @@ if mfma:
     wgm = pick(mfma, r"spconv_wgrad_tile_kernel<64, 64, 9")
     if wgm:
         out.setdefault("wgrad_64x64", {})["mfma_busy_frac"] = round(busy_frac(wgm), 4)
-json.dump(out, open(os.path.join(d, "round4_pmc_spconv.json"), "w"), indent=1)
-print("wrote", os.path.join(d, "round4_pmc_spconv.json"))
+json.dump(out, open(os.path.join(d, "round5_pmc_spconv.json"), "w"), indent=1)
+print("wrote", os.path.join(d, "round5_pmc_spconv.json"))

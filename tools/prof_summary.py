@@ -4,6 +4,7 @@ copies back).  usage:
     prof_summary.py gaps <db> <window_ms> <steps> <out.txt>      (appends)
     prof_summary.py pmc <db> <counter> <out.txt>
     prof_summary.py timeline <db> <window_ms> <out.txt>
+    prof_summary.py roofjson <db> <window_ms> <steps> <out.json> <workload> <dtype>
 """
 import sqlite3
 import sys
@@ -91,8 +92,39 @@ def pmc(db, counter, out):
             f.write("%8d %16.1f %10.2f  %s\n" % (r[1], r[2], r[4], r[0][:130]))
 
 
+def roofjson(db, window_ms, steps, out, workload, dtype):
+    """the roofline kernel's launch durations in the steady-state window of a kernel trace -> a small json bench.py
+    attaches to its `roofline.sources` (stamped with tools/stamp.py's source sha)"""
+    import json
+    import os
+    import re
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import stamp
+
+    cur = sqlite3.connect(db).cursor()
+    t1 = cur.execute("select max(end) from kernels").fetchone()[0]
+    w0 = t1 - int(float(window_ms) * 1e6)
+    pat = r"spconv_fwd_mfma_kernel<64, 64, \d+, \d+, \d+, false, (false|true)>" if dtype == "fp32" else \
+        r"spconv_fwd_(group_kernel<64, 64, \d+, \d+, \d+>|mfma_kernel<64, 64, \d+, \d+, \d+, true, (false|true)>)"
+    rows = cur.execute("select name, count(*), sum(end-start)/1e3 from kernels where start > ? group by name", (w0,)).fetchall()
+    mine = [(n, c, us) for n, c, us in rows if re.search(pat, n)]
+    launches = sum(c for _, c, _ in mine)
+    total_us = sum(us for _, _, us in mine)
+    d = {"_comment": "rocprofv3 --kernel-trace --stats of `bench.py --steps N --warmup 5` (tools/profile_step.sh): every forward / "
+                     "data-gradient launch of the 64->64 sparse gather kernel (plain and parity-class-planned variants) in the "
+                     "steady-state window",
+         "workload": workload, "dtype": dtype, "steps": float(steps), "source_sha16": stamp.source_sha16(),
+         "launches_per_step": launches / float(steps), "avg_launch_us": round(total_us / launches, 3) if launches else None,
+         "variants": {n[:100]: {"launches": c, "avg_us": round(us / c, 3)} for n, c, us in mine}}
+    json.dump(d, open(out, "w"), indent=1)
+    print("wrote", out, d["avg_launch_us"])
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "kernels":
+    if sys.argv[1] == "roofjson":
+        roofjson(*sys.argv[2:8])
+    elif sys.argv[1] == "kernels":
         kernels(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6:])
     elif sys.argv[1] == "gaps":
         gaps(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])

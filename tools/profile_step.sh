@@ -16,6 +16,9 @@ DB=$(find /tmp/d3d_prof -name "*.db" | head -1)
 MS=$(python -c "import json,sys; print(json.loads(sys.argv[1])['ms_per_step']*$STEPS)" "$LINE")
 python $TOOLS/prof_summary.py kernels "$DB" "$MS" $STEPS "$OUT" "rocprofv3 --kernel-trace --stats -- $CMD" "bench line under the profiler: $LINE"
 python $TOOLS/prof_summary.py gaps "$DB" "$MS" $STEPS "$OUT"
+WL=$(python -c "import json,sys; c=json.loads(sys.argv[1])['config']; print(c['name'])" "$LINE")
+DT=$(python -c "import json,sys; print('bf16' if json.loads(sys.argv[1])['dtype']=='bf16' else 'fp32')" "$LINE")
+python $TOOLS/prof_summary.py roofjson "$DB" "$MS" $STEPS "${OUT%.txt}_roofline.json" "$WL" "$DT"
 if [ -n "$D3D_PROFILE_TIMELINE" ]; then
   # the last two steps, kernel by kernel
   python $TOOLS/prof_summary.py timeline "$DB" "$(python -c "print($MS / $STEPS * 2.0)")" "${OUT%.txt}_timeline.txt"
