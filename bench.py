@@ -749,8 +749,10 @@ def bn_probe(wl, dev, ex):
     c_rpn = int(wl.model.neck.blocks[0][1].out_channels) if hasattr(wl.model, "neck") else 128
     mats = [("rpn map", wl.batch * (shape[1] // f) * (shape[0] // f), c_rpn)]
     if hasattr(wl.model.backbone, "last_indice_dict"):
-        rbs = sorted({id(r): r for r in wl.model.backbone.last_indice_dict.values()}.values(), key=lambda r: -r.n_out)
-        mats.append(("largest sparse level", int(rbs[0].n_out), 64 if wl.spec["kind"] == "kitti" else 32))
+        d = wl.model.backbone.last_indice_dict
+        lv = max(((int(d[m._rulebook_key()].n_out), int(m.out_channels)) for m in wl.model.backbone.middle_conv.conv_layers()
+                  if m._rulebook_key() in d), key=lambda t: t[0] * t[1])
+        mats.append(("largest sparse feature matrix", lv[0], lv[1]))
     rows = []
     for what, n, c in mats:
         mb = n * c * esz / 1e6

@@ -49,10 +49,16 @@ int g_d3d_wgrad_blocks = -1;  // d3d_wgrad.hip reads these two
 // XCD-aware tile order: measured neutral-to-slightly-negative on MI355X for these gathers (profiles/round2_tune_fwd.txt:
 // 50.6 vs 50.6-54 us on the 126k-site 64->64 layer, 578 vs 566 frames/s end to end), so it is off by default
 int g_xcd_remap = getenv("D3D_XCD_REMAP") ? atoi(getenv("D3D_XCD_REMAP")) : 0;
+// knob 10 (test knob): f32 features on the EXACT-f32 kernels -- every product one fmaf on the VALU
+// (spconv_fwd_generic_kernel for forward and data gradient, spconv_wgrad_generic_kernel with one split per offset, i.e. a
+// deterministic sum) instead of three bf16 MFMAs on hi / lo pairs.  d3d_sparse_conv_has_epilogue and
+// d3d_sparse_conv_dgrad_plan_supported then answer 0 for f32, the packers write plain f32 copies, the host side keeps
+// the per-layer path.  10-50x slower: for "split vs exact f32" comparisons, not for use.
+int g_sp_exact_f32 = getenv("D3D_SPCONV_EXACT_F32") ? atoi(getenv("D3D_SPCONV_EXACT_F32")) : 0;
 extern int g_bn_variant, g_bn_skip_global, g_bn_dx_rows, g_bn_stream_blocks;  // d3d_bn.hip
 extern int g_c2_variant, g_c2_wgrad_waves, g_c2_tail;  // d3d_conv2d.hip
 extern "C" int d3d_set_tuning(int knob, int value) {
-  D3D_REQUIRE(knob >= 0 && knob <= 9, "d3d_set_tuning: unknown knob %d (9 = cut the last partial round of the dense 3x3 kernel into 32-channel blocks, 8 = waves of the dense weight-gradient kernel, 7 = dense conv tiling variant, 0 = forward 64->64 tiling variant, "
+  D3D_REQUIRE(knob >= 0 && knob <= 10, "d3d_set_tuning: unknown knob %d (10 = exact-f32 sparse kernels for f32 features (test knob), 9 = cut the last partial round of the dense 3x3 kernel into 32-channel blocks, 8 = waves of the dense weight-gradient kernel, 7 = dense conv tiling variant, 0 = forward 64->64 tiling variant, "
               "1 = target block count of the weight-gradient kernel, 2 = XCD-aware tile order on/off, 3 = BatchNorm "
               "reduction variant for large inputs, 4 = skip the BatchNorm global atomics (timing diagnosis), 5 = rows "
               "in flight in bn_bwd_dx, 6 = grid cap of the BatchNorm streaming sweeps)", knob);
@@ -65,7 +71,8 @@ extern "C" int d3d_set_tuning(int knob, int value) {
   else if (knob == 6) g_bn_stream_blocks = value;
   else if (knob == 7) g_c2_variant = value;
   else if (knob == 8) g_c2_wgrad_waves = value;
-  else g_c2_tail = value;
+  else if (knob == 9) g_c2_tail = value;
+  else g_sp_exact_f32 = value;
   return D3D_OK;
 }
 
@@ -864,6 +871,21 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+static int launch_fwd_generic(const void *feat, const void *wpack, const float *bias, const int32_t *nbr, int cap,
+                              int n_out, int kvol, int cin, int cout, int dtype, void *out, hipStream_t stream) {
+  int64_t items = (int64_t)n_out * cout;
+  int nb = (int)((items + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  if (dtype == D3D_BF16)
+    hipLaunchKernelGGL(spconv_fwd_generic_kernel<true>, dim3(nb), dim3(256), 0, stream, feat, wpack,
+                       bias, nbr, cap, n_out, kvol, cin, cout, out);
+  else
+    hipLaunchKernelGGL(spconv_fwd_generic_kernel<false>, dim3(nb), dim3(256), 0, stream, feat,
+                       wpack, bias, nbr, cap, n_out, kvol, cin, cout, out);
+  D3D_LAUNCH_TRY("spconv_fwd_generic_kernel");
+  return D3D_OK;
+}
+
 template <int CIN, int COUT, int MT, int WAVES, int DEPTH, bool BF16, bool PLAN = false>
 static int launch_fwd(const void *feat, const void *wpack, const float *bias, const int32_t *nbr,
                       int cap, int n_out, int kvol, void *out, ConvEpiDev ep, hipStream_t stream) {
@@ -896,6 +918,7 @@ static const int g_f32_wide = getenv("D3D_F32_WIDE") ? atoi(getenv("D3D_F32_WIDE
 // channel pairs with an MFMA tiling below (FWD_CASE list): only these can carry the epilogue reductions
 extern "C" int d3d_sparse_conv_has_epilogue(int cin, int cout, int dtype) {
   if (dtype != D3D_F32 && dtype != D3D_BF16) return 0;
+  if (g_sp_exact_f32 && dtype == D3D_F32) return 0;  // knob 10: the VALU kernels carry no epilogue
   static const int pairs[][2] = {{16, 16}, {16, 32}, {32, 16}, {32, 32}, {32, 64}, {64, 32},
                                  {64, 64}, {64, 128}, {128, 64}, {128, 128}};
   for (auto &pr : pairs)
@@ -933,6 +956,7 @@ extern "C" int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const
 // (scn.py:113-150: 16->32, 32->64, 64->64; :347-407: 64->128, 128->128), either precision
 extern "C" int d3d_sparse_conv_dgrad_plan_supported(int cin, int cout, int dtype) {
   if (dtype != D3D_F32 && dtype != D3D_BF16) return 0;
+  if (g_sp_exact_f32 && dtype == D3D_F32) return 0;
   static const int pairs[][2] = {{32, 16}, {64, 32}, {64, 64}, {128, 64}, {128, 128}};
   for (auto &pr : pairs)
     if (pr[0] == cin && pr[1] == cout) return 1;
@@ -978,6 +1002,10 @@ static int sparse_conv_fwd_impl(const void *feat, const void *wpack, const float
   // (Cin, Cout) -> tiles per wave, waves per block, pipeline depth for bf16 / f32.  Depth x gathered bytes per
   // stage is what hides the L2 gather latency; it is bounded by the 128 VGPRs of a 4-waves-per-SIMD block.
   // D3D_FWD_VARIANT (tools/tune_fwd.py) selects alternative 64->64 tilings.
+  if (g_sp_exact_f32 && dtype == D3D_F32) {  // knob 10: exact f32 products (weights packed as plain f32 copies)
+    D3D_REQUIRE(!row_plan, "d3d_sparse_conv_dgrad_planned: not with the exact-f32 test knob");
+    return launch_fwd_generic(feat, wpack, bias, nbr, cap, n_out, kvol, cin, cout, dtype, out, stream);
+  }
   if (row_plan) {
     // three to four stages per block on average: depth 2 (1 where the f32 fragments of two tiles fill the registers).
     // Block shapes from profiles/round3_dgrad_plan.txt: `<64,32>` f32 67.6 us on 16 waves, 55.2 on 8, 59.5 on 4.
@@ -1083,17 +1111,7 @@ static int sparse_conv_fwd_impl(const void *feat, const void *wpack, const float
   FWD_CASE(64, 128, 1, 16, 3, 1)
   FWD_CASE(128, 64, 1, 16, 3, 1)
   FWD_CASE(128, 128, 1, 16, 2, 1)
-  int64_t items = (int64_t)n_out * cout;
-  int nb = (int)((items + 255) / 256);
-  if (nb > 4096) nb = 4096;
-  if (dtype == D3D_BF16)
-    hipLaunchKernelGGL(spconv_fwd_generic_kernel<true>, dim3(nb), dim3(256), 0, stream, feat, wpack,
-                       bias, nbr, cap, n_out, kvol, cin, cout, out);
-  else
-    hipLaunchKernelGGL(spconv_fwd_generic_kernel<false>, dim3(nb), dim3(256), 0, stream, feat,
-                       wpack, bias, nbr, cap, n_out, kvol, cin, cout, out);
-  D3D_LAUNCH_TRY("spconv_fwd_generic_kernel");
-  return D3D_OK;
+  return launch_fwd_generic(feat, wpack, bias, nbr, cap, n_out, kvol, cin, cout, dtype, out, stream);
 }
 
 // ======================================================================= wgrad
@@ -1383,6 +1401,16 @@ int d3d_wgrad_legacy(const void *feat, const void *dout, const int32_t *nbr, int
   // D3D_WGRAD_BLOCKS = target number of blocks per launch
   // defaults from the sweep on a KITTI batch (126k sites, 1.67M pairs, 64x64): KG=1 pipelined
   // 64-site tiles 138 us, KG=3 pipelined 141 us, v1 (unpipelined) 149 us, 128-site tiles 199 us
+  if (g_sp_exact_f32 && dtype == D3D_F32) {
+    // knob 10: one block per kernel offset walks ALL sites with fmaf -- one atomicAdd per element onto the zeroed dw,
+    // i.e. a deterministic, exact-f32 sum in site order
+    const int rows = (n_out + 127) / 128 * 128;
+    const size_t smem = (size_t)32 * (cin + cout) * sizeof(float);
+    hipLaunchKernelGGL(spconv_wgrad_generic_kernel<false>, dim3(kvol, 1), dim3(256), smem, stream, feat, dout, nbr, cap,
+                       n_out, rows, cin, cout, dw);
+    D3D_LAUNCH_TRY("spconv_wgrad_generic_kernel");
+    return D3D_OK;
+  }
   static const int knob_kg = getenv("D3D_WGRAD_KG") ? atoi(getenv("D3D_WGRAD_KG")) : 1;
   static const int knob_blocks = getenv("D3D_WGRAD_LEGACY_BLOCKS") ? atoi(getenv("D3D_WGRAD_LEGACY_BLOCKS")) : 1024;
   static const int variant = getenv("D3D_WGRAD_VARIANT") ? atoi(getenv("D3D_WGRAD_VARIANT")) : 1;

@@ -480,7 +480,8 @@ extern "C" int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const i
   D3D_REQUIRE(dw, "d3d_sparse_conv_wgrad: null dw");
   // D3D_WGRAD_LEGACY=1: the round-1 kernels (one block per offset, float atomics) for A/B timing
   static const int legacy = getenv("D3D_WGRAD_LEGACY") ? atoi(getenv("D3D_WGRAD_LEGACY")) : 0;
-  const bool tile_path = !legacy && wg_supported(cin, cout) && n_out > 0 &&
+  const bool exact = g_sp_exact_f32 && dtype == D3D_F32;  // d3d_set_tuning knob 10 (test knob): VALU f32 kernel
+  const bool tile_path = !legacy && !exact && wg_supported(cin, cout) && n_out > 0 &&
                          (int64_t)n_out * cout * (dtype == D3D_BF16 ? 2 : 4) < (int64_t)D3D_RSRC_BYTES;  // 2 GB descriptors
   if (!tile_path) return d3d_wgrad_legacy(feat, dout, nbr, cap, n_out, kvol, cin, cout, dtype, dw, stream);
   D3D_REQUIRE(feat && dout && nbr, "d3d_sparse_conv_wgrad: null pointer");

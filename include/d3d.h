@@ -173,7 +173,9 @@ size_t d3d_conv_epilogue_ws_floats(int n_out, int cout);
  * >= 2^23 elements, 4 = ignored (round 2: leave the BatchNorm global atomics out), 5 = rows in flight in bn_bwd_dx
  * (1, 2, 4), 6 = grid cap of the BatchNorm streaming sweeps (0 = default), 7 = dense conv tiling variant (-1 default),
  * 8 = dense weight-gradient kernel / waves, 9 = cut the last partial round of the dense 3x3 kernel into 32-channel
- * blocks (1 default) */
+ * blocks (1 default), 10 = TEST knob: f32 sparse features on exact-f32 VALU kernels (one fmaf per product, deterministic
+ * sums) instead of the split-arithmetic MFMA kernels -- d3d_sparse_conv_has_epilogue / _dgrad_plan_supported then answer
+ * 0 for f32 and the packers write plain f32 copies; for "split vs exact" comparisons (det3d_amd/precision.py) */
 int d3d_set_tuning(int knob, int value);
 int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const float *bias,
                            const int32_t *nbr, int cap, int n_out, int kvol, int cin, int cout,

@@ -428,6 +428,22 @@ def fill_deterministic(module, seed=0):
     return module
 
 
+def tame_head(module, box_scale=0.03, cls_scale=0.5, cls_bias=-1.0):
+    """After fill_deterministic: give the prediction convs of every task head the magnitude of a TRAINED head -- box
+    regressions of O(0.1) (fill_deterministic's O(10) size regressions decode to boxes of 1e4 m whose NMS decisions are
+    arbitrary on every implementation), class logits spread around `cls_bias` so that some anchors pass the score
+    threshold and the rotated NMS has real overlaps to resolve.  tests/golden/detectors_sane.pt is made with it."""
+    with torch.no_grad():
+        for name, t in module.state_dict().items():
+            if ".conv_box." in name:
+                t.mul_(box_scale)
+            elif name.endswith("conv_cls.weight"):
+                t.mul_(cls_scale)
+            elif name.endswith("conv_cls.bias"):
+                t.mul_(cls_scale).add_(cls_bias)
+    return module
+
+
 def cpu_example(host_batch, cfg_vox):
     """reference CPU data path: per-frame oracle voxelizer + collate_kitti layout."""
     vox, coors, nums, nv = [], [], [], []

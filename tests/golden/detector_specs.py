@@ -24,6 +24,9 @@ CASES = {
                     voxel=[0.2, 0.2, 8.0], T=8, C=5, points=6000),
 }
 BATCH = 2
+# arguments of oracle.model_ref.tame_head for the sane-head goldens (detectors_sane.pt): head magnitudes like a trained
+# net's -- boxes within metres of their anchors, class scores on both sides of the config's score threshold
+SANE_HEAD = {"kitti_second": dict(box_scale=0.1, cls_scale=0.5, cls_bias=0.5), "nusc_cbgs": {}, "lyft_cbgs": {}, "nusc_pp": {}}
 
 
 def load_cfg(name):

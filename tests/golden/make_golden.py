@@ -898,7 +898,10 @@ pickle.dump(out, open(%r, "wb"))
     subprocess.run([sys.executable, "-c", code], check=True)
 
 
-def detector_cases():
+def detector_cases(sane=False):
+    """sane=True -> detectors_sane.pt: the same detectors with model_ref.tame_head applied (trained-like head magnitudes),
+    eval only: raw predictions and the reference's OWN predict() output, so that the GPU test can compare EVERY
+    detection."""
     import pickle
     import tempfile
 
@@ -936,6 +939,8 @@ def detector_cases():
         torch.manual_seed(0)
         net = dets_mod[kind](train_cfg=None, test_cfg=test_cfg, **m)
         model_ref.fill_deterministic(net)
+        if sane:
+            model_ref.tame_head(net, **S.SANE_HEAD[name])
         code_size = m["bbox_head"]["box_coder"].code_size
         ex, fmap, nv = S.make_example(name, m["bbox_head"]["tasks"], c["n_dim"], code_size)
         anchors, labels, reg_targets = ex["anchors"], ex["labels"], ex["reg_targets"]
@@ -952,6 +957,13 @@ def detector_cases():
             preds = net.bbox_head(net.neck(bev))
             dets = net.bbox_head.predict(ex, preds, test_cfg)
         assert preds[0]["box_preds"].shape[1:3] == fmap, (preds[0]["box_preds"].shape, fmap)
+        if sane:
+            out[name] = dict(preds=[{k: v[:, ::2, 1::2].clone() for k, v in p.items()} for p in preds],
+                             dets=[{k: v.clone() for k, v in d.items() if torch.is_tensor(v)} for d in dets])
+            print("detector (sane head)", name, "dets", [d["scores"].shape[0] for d in dets], "max |box|",
+                  [round(float(d["box3d_lidar"].abs().max()), 2) if d["scores"].shape[0] else 0 for d in dets],
+                  "score range", [(round(float(d["scores"].min()), 3), round(float(d["scores"].max()), 3)) if d["scores"].shape[0] else 0 for d in dets])
+            continue
         # ---- train: loss per task group, all gradients (norms) + a few whole gradient tensors
         net.train()
         losses = net(ex, return_loss=True)
@@ -975,7 +987,7 @@ def detector_cases():
             loss=[l.detach().clone() for l in losses["loss"]], grad_norms=gnorm, grads=small)
         print("detector", name, "voxels", nv, "bev", tuple(bev.shape), "loss", [round(float(l), 4) for l in losses["loss"]],
               "dets", [d["scores"].shape[0] for d in dets], "small grads", len(small))
-    torch.save(out, os.path.join(HERE, "detectors.pt"))
+    torch.save(out, os.path.join(HERE, "detectors_sane.pt" if sane else "detectors.pt"))
 
 
 def nms_gpu_cases():
@@ -1029,7 +1041,7 @@ def nms_gpu_cases():
 
 def main():
     ref_loader.install()
-    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "objnoise", "gtsampler", "loading", "annotations", "preprocess", "sampler", "collate", "pipeline", "rangefilter", "nmsgpu", "detectors"]
+    which = sys.argv[1:] or ["voxel", "iou", "ioueval", "vfe", "rpn", "head", "anchors", "tasks", "augment", "objnoise", "gtsampler", "loading", "annotations", "preprocess", "sampler", "collate", "pipeline", "rangefilter", "nmsgpu", "detectors", "detectors_sane"]
     if "anchors" in which:
         anchors_targets()
     if "tasks" in which:
@@ -1070,6 +1082,8 @@ def main():
         nms_gpu_cases()
     if "detectors" in which:
         detector_cases()
+    if "detectors_sane" in which:
+        detector_cases(sane=True)
 
 
 if __name__ == "__main__":

@@ -525,6 +525,48 @@ def test_detector_matches_reference_detector_golden_fp32(name):
     assert worst_n < 3e-2 and worst_t < 1e-1 and worst_c < 2e-3
 
 
+@pytest.mark.parametrize("name", ["kitti_second", "nusc_cbgs", "lyft_cbgs", "nusc_pp"])
+def test_every_detection_matches_the_reference_detector_with_a_sane_head(name):
+    """tests/golden/detectors_sane.pt: the reference's own detectors with trained-like head magnitudes
+    (oracle.model_ref.tame_head: boxes within metres of their anchors, scores on both sides of the threshold) and the
+    reference's OWN predict().  Every reference detection must have its GPU twin: same count per frame, same label,
+    box within 1e-3 (relative above 1 m / rad), score within 1e-4 -- no 90 % allowance."""
+    from det3d_amd import build_detector
+    from oracle import model_ref as M
+
+    S, g, cfg, ex = _golden_case(name)
+    gs = torch.load(os.path.join(ROOT, "tests", "golden", "detectors_sane.pt"), weights_only=False)[name]
+    m = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg)
+    M.fill_deterministic(m)
+    M.tame_head(m, **S.SANE_HEAD[name])
+    m = m.cuda().eval()
+    exg = _to_gpu(ex)
+    with torch.no_grad():
+        data = dict(features=exg["voxels"], num_voxels=exg["num_points"], coors=exg["coordinates"],
+                    batch_size=S.BATCH, input_shape=exg["shape"][0])
+        preds = m.bbox_head(m.extract_feat(data))
+        dets = m.bbox_head.predict(exg, preds, m.test_cfg)
+    worst = max(float((p[k][:, ::2, 1::2].float().cpu() - gp[k]).abs().max()) for p, gp in zip(preds, gs["preds"]) for k in gp)
+    assert worst < 1e-3, worst
+    total = 0
+    for f, (d, gd) in enumerate(zip(dets, gs["dets"])):
+        a, b = d["box3d_lidar"].cpu(), gd["box3d_lidar"]
+        sa, sb = d["scores"].cpu(), gd["scores"]
+        la, lb = d["label_preds"].cpu(), gd["label_preds"]
+        assert float(b.abs().max()) < 200  # the golden really is sane
+        assert a.shape == b.shape, (name, f, a.shape, b.shape)
+        # twin = the GPU detection of the same label closest in (x, y, z, w, l, h)
+        dist = torch.cdist(b[:, :6], a[:, :6]) + 1e3 * (lb[:, None] != la[None, :]).float()
+        nn = dist.argmin(1)
+        assert len(set(nn.tolist())) == len(nn), (name, f, "two reference detections share one GPU twin")
+        err = ((b - a[nn]).abs() / b.abs().clamp(min=1.0)).max(1)[0]
+        assert bool((lb == la[nn]).all()), (name, f)
+        assert float(err.max()) < 1e-3, (name, f, float(err.max()))
+        assert float((sb - sa[nn]).abs().max()) < 1e-4, (name, f)
+        total += len(b)
+    print("%s: %d of %d reference detections matched (sane head), max |pred - reference| = %.2e" % (name, total, total, worst))
+
+
 @pytest.mark.parametrize("name", ["nusc_cbgs", "lyft_cbgs"])
 def test_resnet_fhd_backbone_vs_oracle_on_a_larger_cloud(name):
     """SpMiddleResNetFHD alone, 3x the golden's voxel count: HIP fp32 vs oracle/model_ref.SpMiddleResNetFHDRef

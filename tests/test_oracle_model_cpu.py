@@ -138,6 +138,34 @@ def test_oracle_detector_vs_reference_detector_golden(name):
     _compare_with_detector_golden(g, preds, dets, losses, dict(zip(params, grads)))
 
 
+@pytest.mark.parametrize("name", ["kitti_second", "nusc_cbgs", "lyft_cbgs", "nusc_pp"])
+def test_oracle_detector_vs_reference_detector_golden_with_a_sane_head(name):
+    """detectors_sane.pt (the reference's detectors after model_ref.tame_head: trained-like head magnitudes, boxes within
+    metres of their anchors): the oracle reproduces the reference's raw predictions and EVERY detection of its predict()."""
+    S, g, cfg, ex = _detector_case(name)
+    gs = _load("detectors_sane.pt")[name]
+    m = M.DetectorRef(cfg)
+    M.fill_deterministic(m)
+    M.tame_head(m, **S.SANE_HEAD[name])
+    m.eval()
+    with torch.no_grad():
+        x = m.features(ex)
+        preds = [t(x) for t in m.bbox_head.tasks]
+        dets = m.predict(ex, preds)
+    for p, gp in zip(preds, gs["preds"]):
+        for k in gp:
+            assert float((p[k][:, ::2, 1::2] - gp[k]).abs().max()) < 1e-4, k
+    n = 0
+    for d, gd in zip(dets, gs["dets"]):
+        assert float(gd["box3d_lidar"].abs().max()) < 200 and gd["scores"].shape[0] > 0
+        assert d["box3d_lidar"].shape == gd["box3d_lidar"].shape
+        assert torch.equal(d["label_preds"], gd["label_preds"])
+        assert float((d["box3d_lidar"] - gd["box3d_lidar"]).abs().max()) < 1e-3
+        assert float((d["scores"] - gd["scores"]).abs().max()) < 1e-4
+        n += gd["scores"].shape[0]
+    assert n >= 40
+
+
 def test_product_point_pillars_cpu_path_vs_reference_detector_golden():
     """BASELINE configs[0]/[2] plumbing: the product's PyTorch-op PointPillars path on the CPU against the
     reference's PointPillars detector (nuScenes 6-group head)."""
