@@ -118,6 +118,11 @@ def parse():
                     help="do not gc.freeze() after warm-up (shows the cost of full CPython collections)")
     ap.add_argument("--no-channels-last", action="store_true",
                     help="NCHW dense()/RPN activations (default: channels-last, written directly by d3d_dense_scatter)")
+    ap.add_argument("--syncbn", action="store_true",
+                    help="norm_cfg = dict(type='SyncBN', eps=1e-3, momentum=0.01) as in the reference's commented switch "
+                         "(BASELINE configs[2..4] are 'DDP + SyncBN'): cross-rank BatchNorm statistics, one packed all-reduce "
+                         "per layer and direction inside the fused conv nodes; needs a process group (several ranks, or "
+                         "D3D_DIST_SINGLE=1 for a 1-rank RCCL communicator)")
     ap.add_argument("--rank-diagnostics", action="store_true",
                     help="per-rank medians of step / exchange wait / geometry wait / host enqueue over 8 extra untimed steps "
                          "(always on with more than one rank)")
@@ -295,6 +300,13 @@ class Workload:
         self.batch = batch or spec["batch"]
         self.points = points or spec["points"]
         self.cfg = cfg = Config.fromfile(os.path.join(ROOT, "det3d_amd", "configs", spec["config"]))
+        self.syncbn = bool(getattr(args, "syncbn", False))
+        if self.syncbn:
+            # the switch the reference's "_syncbn" configs carry as a comment (examples/cbgs/configs/lyft_all_...py:7 ->
+            # det3d/models/utils/norm.py:60-68): every BatchNorm of reader / backbone / neck becomes DistributedSyncBN
+            for part in ("reader", "backbone", "neck", "bbox_head"):
+                if part in cfg.model:
+                    cfg.model[part]["norm_cfg"] = dict(type="SyncBN", eps=1e-3, momentum=0.01)
         torch.manual_seed(0)
         model = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).to(dev).train()
         model.backbone.dense_channels_last = not args.no_channels_last
@@ -1142,6 +1154,9 @@ def main():
                    "timed_region_s": round(elapsed, 3),
                    "burn_in_steps": getattr(wl, "burn_in_steps", 0),
                    "graphed_tail": bool(wl.model.__dict__.get("_graph_tails")),
+                   "norm": "SyncBN (DistributedSyncBN, statistics exchanged %s)" % (
+                       "over the process group" if D.exchanging() else "NOT exchanged: no process group, falls back to "
+                       "plain batch norm like the reference's else-branch") if wl.syncbn else "BN (the configs' default)",
                    "geometry_prefetch": not args.no_prefetch,
                    "geometry_thread": not (args.no_prefetch or args.no_prefetch_thread), "augment": bool(args.augment),
                    "host_ms_per_step": getattr(wl, "host_ms", None)},

@@ -42,6 +42,9 @@ SIGNATURES = {
     "d3d_dgrad_plan_ints": (sz, [i32]),
     "d3d_dgrad_plan_supported": (i32, [vp, vp]),
     "d3d_dgrad_plan_build": (i32, [vp, vp, i32, vp, vp, vp, vp, sz, vp]),
+    "d3d_conv_rulebook_chain_workspace_bytes": (sz, [i32, i32, vp]),
+    "d3d_conv_rulebook_chain": (i32, [i32, vp, i32, vp, vp, i32, vp, sz, vp]),
+    "d3d_subm_rulebook_ranked": (i32, [vp, vp, i32, i32, _i32p, _i32p, vp, vp, vp, vp, vp]),
     "d3d_sparse_conv_dgrad_plan_supported": (i32, [i32, i32, i32]),
     "d3d_sparse_conv_dgrad_planned": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "d3d_adam_step": (i32, [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
@@ -103,7 +106,7 @@ SIGNATURES = {
     "d3d_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
 }
 
-ABI_VERSION = 8  # include/d3d.h D3D_ABI_VERSION
+ABI_VERSION = 9  # include/d3d.h D3D_ABI_VERSION
 D3D_F32 = 0
 D3D_BF16 = 1
 D3D_CONV_BF16, D3D_CONV_SPLIT = 0, 1
@@ -126,6 +129,14 @@ class PackDesc(ctypes.Structure):
     """D3dPackDesc of include/d3d.h"""
     _fields_ = [("weight", vp), ("fwd", vp), ("fwd_lo", vp), ("dgrad", vp), ("dgrad_lo", vp), ("kind", i32), ("a", i32),
                 ("b", i32), ("c", i32), ("flip", i32), ("dtype", i32)]
+
+
+class ChainLayer(ctypes.Structure):
+    """D3dChainLayer of include/d3d.h"""
+    _i3 = ctypes.c_int32 * 3
+    _fields_ = [("in_shape", _i3), ("ksize", _i3), ("stride", _i3), ("padding", _i3), ("out_shape", _i3),
+                ("cap_out", ctypes.c_int32), ("coords_out", vp), ("n_out_dev", vp), ("nbr_out", vp), ("nbr_in", vp),
+                ("pair_count", vp), ("plan", vp), ("plan_ints", ctypes.c_uint64), ("rank_bitmap", vp), ("rank_prefix", vp)]
 
 
 class DenseBnBackward(ctypes.Structure):

@@ -19,6 +19,7 @@ SOURCES = [
     "d3d_core.hip",
     "d3d_voxelize.hip",
     "d3d_rulebook.hip",
+    "d3d_rbchain.hip",
     "d3d_spconv.hip",
     "d3d_wgrad.hip",
     "d3d_bn.hip",

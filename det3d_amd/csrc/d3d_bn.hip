@@ -183,7 +183,12 @@ __global__ void __launch_bounds__(256)
   __shared__ float scale[BN_MAXC], shift[BN_MAXC];
   for (int ch = threadIdx.x; ch < c; ch += 256) {
     float mean, var;
-    if (training) {
+    if (training == 2) {
+      // cross-rank statistics (DistributedSyncBN, det3d/ops/syncbn/syncbn.py:39-52): the caller has all-reduced the
+      // per-rank moments and hands in the finished mean | variance; the running statistics are the caller's too
+      mean = stats[ch];
+      var = stats[c + ch];
+    } else if (training) {
       float s1 = 0.f, s2 = 0.f;
       for (int k = 0; k < copies; ++k) {
         s1 += stats[(size_t)k * 2 * c + ch];
@@ -202,7 +207,7 @@ __global__ void __launch_bounds__(256)
     if (blockIdx.x == 0) {
       if (save_mean) save_mean[ch] = mean;
       if (save_invstd) save_invstd[ch] = invstd;
-      if (training && running_mean) {
+      if (training == 1 && running_mean) {
         float unbiased = n > 1 ? var * ((float)n / (float)(n - 1)) : var;
         running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * mean;
         running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;

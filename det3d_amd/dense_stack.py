@@ -22,7 +22,7 @@ import os
 import torch
 from torch import nn
 
-from . import _lib
+from . import _lib, syncbn
 from . import dense_conv as dc
 
 ENABLED = os.environ.get("D3D_DENSE_CONV", "1") != "0"
@@ -73,7 +73,11 @@ def _conv_ok(conv, extra_pad, split=False):
 
 
 def _bn_ok(bn, c):
-    if type(bn) is not nn.BatchNorm2d or bn.momentum is None or not bn.track_running_stats or bn.weight is None:
+    # nn.BatchNorm2d, or the cross-rank DistributedSyncBN while it exchanges statistics (the same kernels around one packed
+    # all-reduce per direction: syncbn.exchange_moments / exchange_backward_sums)
+    if type(bn) is not nn.BatchNorm2d and not syncbn.fused_sync(bn):
+        return False
+    if bn.momentum is None or not bn.track_running_stats or bn.weight is None:
         return False
     if any(t is not None and t.dtype != torch.float32 for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)):
         return False
@@ -173,8 +177,12 @@ class _DenseStackFn(torch.autograd.Function):
             save = torch.empty((2, cout), dtype=torch.float32, device=dev) if training else None
             last = li + 1 == len(layers)
             common = (n, cout)
+            bn_mode, cf = int(training), None
+            if training and type(bn) is not nn.BatchNorm2d:  # DistributedSyncBN: moments through one packed all-reduce
+                ws, cf = syncbn.exchange_moments(bn, ws, n)
+                bn_mode = 2
             tail = (bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-                    float(bn.momentum), float(bn.eps), int(training), int(ly.relu), _lib.ptr(ws), 1)
+                    float(bn.momentum), float(bn.eps), bn_mode, int(ly.relu), _lib.ptr(ws), 1)
             if split and not last:
                 z_hi = torch.empty(y.shape, dtype=torch.bfloat16, device=dev)
                 z_lo = torch.empty_like(z_hi)
@@ -192,7 +200,7 @@ class _DenseStackFn(torch.autograd.Function):
                 nxt = (z, None)
                 if last:
                     out = z
-            rec.append((a_hi, a_lo, y, save))
+            rec.append((a_hi, a_lo, y, save, cf))
             a_hi, a_lo = nxt
         ctx.layers, ctx.rec, ctx.mode, ctx.training = layers, rec, mode, training
         ctx.in_dtype = x.dtype
@@ -220,7 +228,7 @@ class _DenseStackFn(torch.autograd.Function):
         for li in range(len(layers) - 1, -1, -1):
             ly = layers[li]
             bn = ly.bn
-            a_hi, a_lo, y, save = rec[li]
+            a_hi, a_lo, y, save, cf = rec[li]
             n, cout = y.shape[0] * y.shape[1] * y.shape[2], ly.cout
             if partial is None:
                 partial = torch.empty((L.d3d_bn_reduce_ws_floats(n, cout, dt),), dtype=torch.float32, device=dev)
@@ -228,6 +236,10 @@ class _DenseStackFn(torch.autograd.Function):
                                          bn.bias.data_ptr(), save[0].data_ptr(), save[1].data_ptr(), int(ly.relu),
                                          partial.data_ptr(), st)
                 _lib.check(rc, "d3d_bn_bwd_reduce")
+            sync = None
+            if cf is not None:  # cross-rank BN: the sums over ranks; the dx sweep takes their rank means
+                partial, gg, gb = syncbn.exchange_backward_sums(bn, partial, cf, save[1])
+                sync = (gg, gb)
             gbn = torch.empty((2, cout), dtype=torch.float32, device=dev)
             if split:
                 g_hi = torch.empty(y.shape, dtype=torch.bfloat16, device=dev)
@@ -254,12 +266,14 @@ class _DenseStackFn(torch.autograd.Function):
                     if li > 0 and FUSE_BN_BACKWARD:
                         # the rows this launch produces are dL/dz of layer li - 1's BatchNorm + ReLU: reduce its sums here
                         pl = layers[li - 1]
-                        _, _, py, psave = rec[li - 1]
+                        _, _, py, psave, _ = rec[li - 1]
                         bnb = (py, psave[0], psave[1], pl.bn.weight, pl.bn.bias, pl.relu)
                     dy, partial = dc.conv2d_raw(g_hi, g_lo, wd_hi, wd_lo, ly.ksz, 1, ly.ksz - 1 - ly.pad, mode,
                                                 bn_backward=bnb)
             else:
                 dy = None
+            if sync is not None:
+                gbn = sync  # grad_gamma / grad_beta summed over ranks (syncbn.py:99-103)
             grads.append([gw, gbn[0], gbn[1]])
         gin = None
         if dy is not None:

@@ -117,6 +117,17 @@ class Sequential(nn.Module):
                     input = spconv.bn_relu_2d(m, input, relu)
                     i += 2 if relu else 1
                     continue
+            if type(m).__name__ == "DistributedSyncBN" and torch.is_tensor(input) and input.is_cuda and input.dim() == 4:
+                # a cross-rank BN outside a conv run (behind a deblock's kernel == stride layer): the HIP sweeps split at
+                # its packed all-reduce, the ReLU that follows folded in
+                from .syncbn import sync_bn_relu
+
+                relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+                y = sync_bn_relu(m, input, relu)
+                if y is not None:
+                    input = y
+                    i += 2 if relu else 1
+                    continue
             if type(m) in (nn.Conv2d, nn.ConvTranspose2d) and m.kernel_size == m.stride and m.kernel_size[0] > 1 and \
                     torch.is_tensor(input) and input.is_cuda:
                 from . import dense_conv  # the deblocks' kernel == stride layers as 1x1 convolutions (dense_conv.ks_conv)

@@ -27,13 +27,17 @@ import os
 import torch
 from torch import nn
 
-from . import _lib
+from . import _lib, syncbn
 
 FUSE_BLOCK = os.environ.get("D3D_FUSE_BLOCK", "1") != "0"
 
 
 def _plain_bn(bn, c):
-    if type(bn) is not nn.BatchNorm1d or not bn.training or bn.momentum is None or not bn.track_running_stats:
+    """nn.BatchNorm1d in training mode -- or the cross-rank DistributedSyncBN while it exchanges statistics: the node
+    then runs the same kernels around syncbn.exchange_moments / exchange_backward_sums"""
+    if type(bn) is not nn.BatchNorm1d and not syncbn.fused_sync(bn):
+        return False
+    if not bn.training or bn.momentum is None or not bn.track_running_stats:
         return False
     if bn.weight is None or bn.num_features != c:
         return False
@@ -93,24 +97,35 @@ class _BlockFn(torch.autograd.Function):
             _lib.check(rc, "d3d_sparse_conv_fwd")
             return out, stats
 
+        def moments(bn, stats):
+            """(training argument of d3d_bn_apply, its statistics, cf): local sums as they are, or -- cross-rank BN --
+            the finished mean | variance behind one packed all-reduce"""
+            if type(bn) is nn.BatchNorm1d:
+                return 1, stats, None
+            mv, cf = syncbn.exchange_moments(bn, stats, n)
+            return 2, mv, cf
+
         out1, stats1 = conv(x, wp1, conv1.bias)
         y1 = torch.empty_like(out1)
         save1 = torch.empty((2, c), dtype=torch.float32, device=dev)
+        mode1, stats1, cf1 = moments(bn1, stats1)
         rc = L.d3d_bn_apply(out1.data_ptr(), n, c, dt, bn1.weight.data_ptr(), _lib.ptr(bn1.bias),
                             bn1.running_mean.data_ptr(), bn1.running_var.data_ptr(), float(bn1.momentum), float(bn1.eps),
-                            1, 1, stats1.data_ptr(), 1, y1.data_ptr(), save1[0].data_ptr(), save1[1].data_ptr(), st)
+                            mode1, 1, stats1.data_ptr(), 1, y1.data_ptr(), save1[0].data_ptr(), save1[1].data_ptr(), st)
         _lib.check(rc, "d3d_bn_apply")
         partial1 = sp.epilogue_ws(dev, n, c)  # conv2's dgrad launch reduces bn1's backward sums into this
         sp.check_gather_source(y1, "the feature matrix")
         out2, stats2 = conv(y1, wp2, conv2.bias)
         y = torch.empty_like(out2)
         save2 = torch.empty((2, c), dtype=torch.float32, device=dev)
+        mode2, stats2, cf2 = moments(bn2, stats2)
         rc = L.d3d_bn_apply_residual(out2.data_ptr(), x.data_ptr(), n, c, dt, bn2.weight.data_ptr(), _lib.ptr(bn2.bias),
                                      bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(), float(bn2.momentum),
-                                     float(bn2.eps), 1, 1, stats2.data_ptr(), 1, y.data_ptr(), save2[0].data_ptr(),
+                                     float(bn2.eps), mode2, 1, stats2.data_ptr(), 1, y.data_ptr(), save2[0].data_ptr(),
                                      save2[1].data_ptr(), st)
         _lib.check(rc, "d3d_bn_apply_residual")
         ctx.block, ctx.rb, ctx.sp = block, rb, sp
+        ctx.cf = (cf1, cf2)
         ctx.rec = (x, out1, y1, out2, save1, save2, wd1, wd2, partial1)
         ctx.generation = sp.ARENA.generation
         ctx.dtype = dtype
@@ -136,6 +151,11 @@ class _BlockFn(torch.autograd.Function):
                                           _lib.ptr(bn2.bias), save2[0].data_ptr(), save2[1].data_ptr(), 1,
                                           partial2.data_ptr(), st)
         _lib.check(rc, "d3d_bn_bwd_reduce_residual")
+        cf1, cf2 = ctx.cf
+        sync1 = sync2 = None
+        if cf2 is not None:  # cross-rank BN: the sums over ranks; d3d_bn_bwd_dx takes their rank means
+            partial2, gg, gb = syncbn.exchange_backward_sums(bn2, partial2, cf2, save2[1])
+            sync2 = (gg, gb)
         gout2 = torch.empty_like(out2)
         dres = torch.empty_like(x)
         gbn2 = torch.empty((2, c), dtype=torch.float32, device=dev)
@@ -171,6 +191,9 @@ class _BlockFn(torch.autograd.Function):
             rc = L.d3d_bn_bwd_reduce(out1.data_ptr(), gy1.data_ptr(), n, c, dt, bn1.weight.data_ptr(), _lib.ptr(bn1.bias),
                                      save1[0].data_ptr(), save1[1].data_ptr(), 1, partial1.data_ptr(), st)
             _lib.check(rc, "d3d_bn_bwd_reduce")
+        if cf1 is not None:
+            partial1, gg, gb = syncbn.exchange_backward_sums(bn1, partial1, cf1, save1[1])
+            sync1 = (gg, gb)
         gout1 = torch.empty_like(out1)
         gbn1 = torch.empty((2, c), dtype=torch.float32, device=dev)
         rc = L.d3d_bn_bwd_dx(out1.data_ptr(), gy1.data_ptr(), n, c, dt, bn1.weight.data_ptr(), _lib.ptr(bn1.bias),
@@ -186,7 +209,7 @@ class _BlockFn(torch.autograd.Function):
             sp.launch_dgrad(rb, gout1, wd1, c, c, gin, ep, st)
         zero = lambda p: torch.zeros_like(p)  # the batch mean removes a bias in front of a train-mode BatchNorm
         grads = []
-        for conv, bn, gw, gbn in ((conv1, bn1, gw1, gbn1), (conv2, bn2, gw2, gbn2)):
+        for conv, bn, gw, gbn in ((conv1, bn1, gw1, sync1 or gbn1), (conv2, bn2, gw2, sync2 or gbn2)):
             grads.append(gw.reshape(conv.weight.shape))
             if conv.bias is not None:
                 grads.append(zero(conv.bias))

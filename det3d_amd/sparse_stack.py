@@ -19,7 +19,7 @@ import os
 import torch
 from torch import nn
 
-from . import _lib
+from . import _lib, syncbn
 
 FUSE_STACK = os.environ.get("D3D_FUSE_STACK", "1") != "0"
 
@@ -42,7 +42,9 @@ def _eligible(sp, conv, bn, feats_dtype, rb):
         return False  # VALU fallback kernels have no epilogues
     if rb is None or rb.subm != conv.subm or rb.n_out <= 1 or rb.n_in <= 0:
         return False
-    if type(bn) is not nn.BatchNorm1d or not bn.training or bn.momentum is None or not bn.track_running_stats:
+    if type(bn) is not nn.BatchNorm1d and not syncbn.fused_sync(bn):  # (cross-rank BN: the same kernels around two
+        return False                                                  # packed all-reduces, syncbn.exchange_*)
+    if not bn.training or bn.momentum is None or not bn.track_running_stats:
         return False
     if bn.weight is None or bn.num_features != cout:
         return False
@@ -103,14 +105,18 @@ class _StackFn(torch.autograd.Function):
             _lib.check(rc, "d3d_sparse_conv_fwd")
             y = torch.empty_like(out)
             save = torch.empty((2, cout), dtype=torch.float32, device=dev)
+            mode, cf = 1, None
+            if type(bn) is not nn.BatchNorm1d:  # DistributedSyncBN: the moments travel through one packed all-reduce
+                stats, cf = syncbn.exchange_moments(bn, stats, rb.n_out)
+                mode = 2
             rc = L.d3d_bn_apply(out.data_ptr(), rb.n_out, cout, dt, bn.weight.data_ptr(), _lib.ptr(bn.bias),
                                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum),
-                                float(bn.eps), 1, int(ly.relu), stats.data_ptr(), 1, y.data_ptr(),
+                                float(bn.eps), mode, int(ly.relu), stats.data_ptr(), 1, y.data_ptr(),
                                 save[0].data_ptr(), save[1].data_ptr(), st)
             _lib.check(rc, "d3d_bn_apply")
             # the conv behind this layer reduces this BatchNorm's backward sums in its dgrad epilogue
             partial = sp.epilogue_ws(dev, rb.n_out, cout) if li + 1 < len(layers) else None
-            rec.append((x, out, save, wd, partial))
+            rec.append((x, out, save, wd, partial, cf))
             x = y
         ctx.layers, ctx.rec, ctx.sp = layers, rec, sp
         ctx.generation = arena.generation
@@ -133,7 +139,7 @@ class _StackFn(torch.autograd.Function):
             ly = layers[li]
             rb, conv, bn = ly.rb, ly.conv, ly.bn
             cin, cout, pad_cin = ly.cin, ly.cout, ly.pad_cin
-            x, out, save, wd, partial = rec[li]
+            x, out, save, wd, partial, cf = rec[li]
             dy = g.contiguous()
             if dy.dtype != dtype:
                 dy = dy.to(dtype)
@@ -143,6 +149,10 @@ class _StackFn(torch.autograd.Function):
                                          _lib.ptr(bn.bias), save[0].data_ptr(), save[1].data_ptr(), int(ly.relu),
                                          partial.data_ptr(), st)
                 _lib.check(rc, "d3d_bn_bwd_reduce")
+            sync = None
+            if cf is not None:  # cross-rank BN: sum the two vectors over ranks, hand d3d_bn_bwd_dx the rank means
+                partial, g_gamma, g_beta = syncbn.exchange_backward_sums(bn, partial, cf, save[1])
+                sync = (g_gamma, g_beta)
             gout = torch.empty_like(out)
             sp.check_gather_source(gout, "the output gradient")
             gbn = torch.empty((2, cout), dtype=torch.float32, device=dev)
@@ -158,7 +168,7 @@ class _StackFn(torch.autograd.Function):
                 ep = None
                 if li > 0 and fused and pad_cin == cin and sp.has_epilogue(cout, pad_cin, dtype):
                     pl = layers[li - 1]
-                    _, pout, psave, _, ppartial = rec[li - 1]
+                    _, pout, psave, _, ppartial, _ = rec[li - 1]
                     ep = _lib.ConvEpilogue(bn_x=pout.data_ptr(), bn_mean=psave[0].data_ptr(),
                                            bn_invstd=psave[1].data_ptr(), bn_gamma=pl.bn.weight.data_ptr(),
                                            bn_beta=_lib.ptr(pl.bn.bias), bn_relu=int(pl.relu),
@@ -179,6 +189,8 @@ class _StackFn(torch.autograd.Function):
             lg = [gw.reshape(conv.weight.shape)]
             if conv.bias is not None:
                 lg.append(gout.float().sum(0))
+            if sync is not None:
+                gbn = sync  # grad_gamma / grad_beta summed over ranks (syncbn.py:99-103)
             lg.append(gbn[0])
             if bn.bias is not None:
                 lg.append(gbn[1])

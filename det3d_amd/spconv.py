@@ -284,6 +284,70 @@ def build_conv_rulebook(indices, n_dev, n, cap_in, batch, in_shape, ksize, strid
     return rb, n_out_dev
 
 
+RB_CHAIN = os.environ.get("D3D_RB_CHAIN", "1") != "0"  # SparseSequential.plan(): all strided layers in one chain call
+
+
+def build_conv_rulebook_chain(indices, n_dev, cap0, batch, in_shape, convs):
+    """Enqueue d3d_conv_rulebook_chain for the strided layers `convs` (in execution order; the first one reads
+    `indices` / `n_dev` / `cap0`).  Returns ([(rulebook, n_out_dev)] as build_conv_rulebook would per layer, the row
+    plans included; [(bitmap pointer, prefix pointer)] per produced level for build_subm_rulebook_ranked; the
+    workspace tensor those pointers live in -- keep it until the ranked builds are enqueued)."""
+    L = _lib.lib()
+    dev = indices.device
+    arr = (_lib.ChainLayer * len(convs))()
+    out, cap_in, shape = [], int(cap0), list(in_shape)
+    for j, m in enumerate(convs):
+        ksize, stride, padding = m.kernel_size, m.stride, m.padding
+        out_shape = conv_out_shape(shape, ksize, stride, padding)
+        kvol = ksize[0] * ksize[1] * ksize[2]
+        fan = 1
+        for a in range(3):
+            fan *= -(-ksize[a] // stride[a])
+        cells = batch * out_shape[0] * out_shape[1] * out_shape[2]
+        cap_out = int(max(1, min(cap_in * fan, cells)))
+        coords_out = torch.empty((cap_out, 4), dtype=torch.int32, device=dev)
+        n_out_dev = torch.empty((1,), dtype=torch.int32, device=dev)
+        nbr_out = torch.empty((kvol * cap_out,), dtype=torch.int32, device=dev)
+        nbr_in = torch.empty((kvol * cap_in,), dtype=torch.int32, device=dev)
+        plan = None
+        if DGRAD_PLAN and L.d3d_dgrad_plan_supported(_lib.i32_array(ksize), _lib.i32_array(stride)):
+            plan = torch.empty((L.d3d_dgrad_plan_ints(cap_in),), dtype=torch.int32, device=dev)
+        y = arr[j]
+        for a in range(3):
+            y.in_shape[a], y.ksize[a], y.stride[a], y.padding[a], y.out_shape[a] = shape[a], ksize[a], stride[a], padding[a], out_shape[a]
+        y.cap_out = cap_out
+        y.coords_out, y.n_out_dev, y.nbr_out, y.nbr_in = coords_out.data_ptr(), n_out_dev.data_ptr(), nbr_out.data_ptr(), nbr_in.data_ptr()
+        y.pair_count = None
+        y.plan, y.plan_ints = (plan.data_ptr(), plan.numel()) if plan is not None else (None, 0)
+        rb = Rulebook(kvol, cap_in, cap_out, nbr_out, nbr_in, None, None, None, coords_out, out_shape, False)
+        rb.dgrad_plan = plan
+        out.append((rb, n_out_dev))
+        cap_in, shape = cap_out, out_shape
+    wsb = L.d3d_conv_rulebook_chain_workspace_bytes(len(convs), batch, ctypes.cast(arr, ctypes.c_void_p))
+    if wsb == 0:
+        raise _lib.D3dError("d3d_conv_rulebook_chain: unsupported chain of %d layers" % len(convs))
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    rc = L.d3d_conv_rulebook_chain(len(convs), ctypes.cast(arr, ctypes.c_void_p), batch, indices.data_ptr(),
+                                   n_dev.data_ptr(), int(cap0), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
+    _lib.check(rc, "d3d_conv_rulebook_chain")
+    ranks = [(arr[j].rank_bitmap, arr[j].rank_prefix) for j in range(len(convs))]
+    return out, ranks, ws
+
+
+def build_subm_rulebook_ranked(indices, n_dev, n, batch, spatial_shape, ksize, rank):
+    """submanifold table of a level produced by a chain layer (rows in ascending cell order): d3d_subm_rulebook_ranked
+    on that layer's rank structure `rank` = (bitmap pointer, prefix pointer).  Exact-size table ([kvol * n])."""
+    L = _lib.lib()
+    dev = indices.device
+    kvol = ksize[0] * ksize[1] * ksize[2]
+    cap = max(int(n), 1)
+    nbr = torch.empty((kvol * cap,), dtype=torch.int32, device=dev)
+    rc = L.d3d_subm_rulebook_ranked(indices.data_ptr(), n_dev.data_ptr(), cap, batch, _lib.i32_array(spatial_shape),
+                                    _lib.i32_array(ksize), rank[0], rank[1], nbr.data_ptr(), None, _lib.stream_ptr(dev))
+    _lib.check(rc, "d3d_subm_rulebook_ranked")
+    return Rulebook(kvol, cap, cap, nbr, None, None, n, n, indices, list(spatial_shape), True)
+
+
 def finalize_conv_rulebook(rb, n_in, n_out):
     if n_out > rb.cap_out:
         raise _lib.D3dError("conv rulebook overflow: %d outputs > capacity %d" % (n_out, rb.cap_out))
@@ -844,14 +908,21 @@ class SparseSequential(SparseModule):
         cur_idx, cur_n_dev, cur_cap, cur_shape = x.indices, _count_tensor(n0, dev), max(n0, 1), list(x.spatial_shape)
         chain = []  # (layer, rb, n_out_dev, level_before)
         levels = [dict(indices=cur_idx, n_dev=cur_n_dev, cap=cur_cap, shape=cur_shape)]
-        for m in layers:
-            if m.subm:
-                continue
-            rb, n_out_dev = build_conv_rulebook(cur_idx, cur_n_dev, None, cur_cap, x.batch_size,
-                                                cur_shape, m.kernel_size, m.stride, m.padding)
-            chain.append((m, rb, n_out_dev))
-            cur_idx, cur_n_dev, cur_cap, cur_shape = rb.out_indices, n_out_dev, rb.cap_out, rb.out_shape
-            levels.append(dict(indices=cur_idx, n_dev=cur_n_dev, cap=cur_cap, shape=cur_shape))
+        strided = [m for m in layers if not m.subm]
+        ranks = None  # per level >= 1: (bitmap, prefix) pointers of the chain's rank structure, kept alive by `chain_ws`
+        if RB_CHAIN and 1 <= len(strided) <= 8:
+            # every strided layer in ONE C call: 1 + 4 launches per layer, the row plans included (csrc/d3d_rbchain.hip)
+            built, ranks, chain_ws = build_conv_rulebook_chain(cur_idx, cur_n_dev, cur_cap, x.batch_size, cur_shape, strided)
+            for m, (rb, n_out_dev) in zip(strided, built):
+                chain.append((m, rb, n_out_dev))
+                levels.append(dict(indices=rb.out_indices, n_dev=n_out_dev, cap=rb.cap_out, shape=rb.out_shape))
+        else:
+            for m in strided:
+                rb, n_out_dev = build_conv_rulebook(cur_idx, cur_n_dev, None, cur_cap, x.batch_size,
+                                                    cur_shape, m.kernel_size, m.stride, m.padding)
+                chain.append((m, rb, n_out_dev))
+                cur_idx, cur_n_dev, cur_cap, cur_shape = rb.out_indices, n_out_dev, rb.cap_out, rb.out_shape
+                levels.append(dict(indices=cur_idx, n_dev=cur_n_dev, cap=cur_cap, shape=cur_shape))
         # ---- the one sync
         if chain:
             counts = torch.cat([c[2] for c in chain]).cpu().tolist()
@@ -875,9 +946,15 @@ class SparseSequential(SparseModule):
                 continue
             lv = levels[level]
             n = ns[level]
-            x.indice_dict[key] = build_subm_rulebook(lv["indices"], _count_tensor(n, dev), n,
-                                                     max(n, 1), x.batch_size, lv["shape"],
-                                                     m.kernel_size)
+            if ranks is not None and level >= 1 and n > 0:
+                # rows of this level came out of a chain layer in ascending cell order: 27 rank probes per site into
+                # that layer's bitmap + prefix instead of a hash table (one launch)
+                x.indice_dict[key] = build_subm_rulebook_ranked(lv["indices"], lv["n_dev"], n, x.batch_size, lv["shape"],
+                                                                m.kernel_size, ranks[level - 1])
+            else:
+                x.indice_dict[key] = build_subm_rulebook(lv["indices"], _count_tensor(n, dev), n,
+                                                         max(n, 1), x.batch_size, lv["shape"],
+                                                         m.kernel_size)
         return x.indice_dict
 
 

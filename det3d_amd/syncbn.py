@@ -205,6 +205,77 @@ class _SyncBNReLUFusedFn(torch.autograd.Function):
         return dx, grad_gamma.to(gamma.dtype), grad_beta.to(gamma.dtype), None, None, None, None, None, None
 
 
+# ------------------------------------------------------------------ cross-rank statistics inside the fused conv nodes
+# sparse_stack / sparse_block / dense_stack run `conv -> BatchNorm [-> ReLU]` as one autograd node: the convolution's
+# epilogue leaves the LOCAL sum | sum of squares, d3d_bn_apply normalises, and in the backward the next convolution's
+# data-gradient epilogue (or d3d_bn_bwd_reduce) leaves the LOCAL sum dz*xhat | sum dz for d3d_bn_bwd_dx.  With
+# `norm_cfg = dict(type="SyncBN")` (det3d/models/utils/norm.py:60-68 -> det3d/ops/syncbn/syncbn.py:15-118) the same
+# kernels run; only the two [2C] vectors take a detour through ONE packed all-reduce each:
+#
+#   forward   moments = local sums / N  -> all-reduce, / W -> ex, exs;  var = (exs - ex^2) * n / (n - 1), n = N * W
+#             d3d_bn_apply(training = 2, stats = [ex | var])            (reference: unbiased variance normalises too)
+#   backward  local P1 = sum dz*xhat, P0 = sum dz -> all-reduce([P1 cf / std^2 | P0 / std | P1 | P0]) = [a | b | grad_gamma |
+#             grad_beta] (the affine gradients SUMMED over ranks, :99-103); with A, B the rank means of a, b
+#             dx = gamma / std * (dz - B std / N - xhat * A std^2 / N)
+#             -- the reference's  dy * gamma / std + (2 * grad_exs * x + grad_ex) / N  with its rank-averaged grad_exs /
+#             grad_ex (each rank's own cf and std inside) written out in xhat -- i.e. d3d_bn_bwd_dx on [A std^2 | B std].
+def fused_sync(bn):
+    """DistributedSyncBN module in the state where it exchanges statistics (else the fused nodes treat it as what its
+    forward() falls back to: they decline, and the module's own forward runs)"""
+    if type(bn) is not DistributedSyncBN:
+        return False
+    distributed = dist.is_available() and dist.is_initialized()
+    if not (bn.training and bn.sync and distributed and bn.affine and bn.track_running_stats and bn.momentum is not None):
+        return False
+    return all(t.dtype == torch.float32 for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+
+
+def exchange_moments(bn, sums, n):
+    """sums: f32 tensor starting with the local [sum | sum of squares] over `n` rows.  Returns ([ex | var] for
+    d3d_bn_apply(training=2), cf); updates the running statistics like syncbn.py:47-52."""
+    c = bn.num_features
+    group = bn.process_group
+    st = sums[: 2 * c] / float(n)
+    world = _world(group)
+    if _exchange(group):
+        dist.all_reduce(st, group=group)
+        if world > 1:
+            st /= world
+    cnt = n * world
+    if cnt <= 1:
+        raise ValueError("SyncBN needs more than one value per channel (got %d)" % cnt)
+    cf = cnt / (cnt - 1)
+    ex = st[:c]
+    st[c:].addcmul_(ex, ex, value=-1.0).mul_(cf)  # exs -> (exs - ex^2) * cf, in place: st = [ex | var]
+    with torch.no_grad():
+        m = float(bn.momentum)
+        bn.running_mean.lerp_(ex, m)
+        bn.running_var.lerp_(st[c:], m)
+    return st, cf
+
+
+def exchange_backward_sums(bn, partial, cf, invstd):
+    """partial: f32 tensor starting with the local [P1 = sum dz*xhat | P0 = sum dz]; invstd: this rank's [C] save_invstd.
+    Returns (sums for d3d_bn_bwd_dx, grad_gamma, grad_beta).
+
+    N, cf = n / (n - 1) and therefore std differ from rank to rank when the ranks hold different row counts (sparse
+    tensors), and the reference averages grad_exs / grad_ex computed with each rank's OWN cf and std (syncbn.py:84-103).
+    With a_r = P1 * cf / std^2 and b_r = P0 / std (no gamma: nothing is ever divided by it), A = mean_r(a), B = mean_r(b):
+        grad_exs = -gamma * A / 2,  grad_ex = -gamma * B + gamma * ex * A
+        dx = dz * gamma / std + (2 * grad_exs * x + grad_ex) / N = gamma / std * (dz - (B * std) / N - xhat * (A * std^2) / N)
+    i.e. d3d_bn_bwd_dx on the sums [A * std^2 | B * std]; one packed all-reduce of [a | b | P1 | P0]."""
+    c = bn.num_features
+    group = bn.process_group
+    world = _world(group)
+    p1, p0 = partial[:c], partial[c:2 * c]
+    pack = torch.cat([p1 * invstd * invstd * cf, p0 * invstd, p1, p0])
+    if _exchange(group):
+        dist.all_reduce(pack, group=group)
+    std = 1.0 / invstd
+    sums = torch.cat([pack[:c] * (std * std / world), pack[c:2 * c] * (std / world)])
+    return sums, pack[2 * c:3 * c], pack[3 * c:]
+
+
 def sync_bn_relu(bn, x, relu=False):
     """DistributedSyncBN forward (+ fused ReLU) of module `bn` on `x` through the HIP sweeps when `x` is a CUDA
     row matrix / channels-last map, otherwise None (the caller falls back to bn(x) and a separate ReLU)."""

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 8 /* 8: d3d_conv2d_nhwc_dgrad_s2; 7: residual forms of the BatchNorm sweeps, D3dConvEpilogue.addend; 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv; 5: planned strided data gradient, d3d_adam_step; 6: deterministic PillarFeatureNet sums (workspace arguments) */
+#define D3D_ABI_VERSION 9 /* 9: d3d_conv_rulebook_chain / d3d_subm_rulebook_ranked, training = 2 of d3d_bn_apply, d3d_set_tuning knob 10; 8: d3d_conv2d_nhwc_dgrad_s2; 7: residual forms of the BatchNorm sweeps, D3dConvEpilogue.addend; 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv; 5: planned strided data gradient, d3d_adam_step; 6: deterministic PillarFeatureNet sums (workspace arguments) */
 
 #define D3D_OK 0
 #define D3D_EINVAL -1    /* bad argument / unsupported shape           */
@@ -198,6 +198,38 @@ int d3d_dgrad_plan_supported(const int32_t *ksize, const int32_t *stride);
 int d3d_dgrad_plan_build(const int32_t *coords_in, const int32_t *n_in_dev, int cap_in, const int32_t *ksize,
                          const int32_t *stride, const int32_t *padding, int32_t *plan, size_t plan_ints,
                          d3d_stream_t stream);
+/* The rulebooks of a whole sparse backbone as ONE chain of fat launches (ABI 9; csrc/d3d_rbchain.hip).  Same tables, bit
+ * for bit, as d3d_conv_rulebook + d3d_dgrad_plan_build per layer and d3d_subm_rulebook per level -- what
+ * spconv.SparseSequential-style stacks (det3d/models/backbones/scn.py:106-157, :323-355) ask get_indice_pairs for layer
+ * by layer -- in 1 + 4 launches per strided layer (10 per layer there) and 1 launch per submanifold level (3 there):
+ *   d3d_conv_rulebook_chain   layers[l] describes strided layer l (its input grid = layer l-1's output grid; layer 0 reads
+ *       coords0 / *n0_dev / cap0): geometry as in d3d_conv_rulebook, caller-owned outputs coords_out / n_out_dev / nbr_out /
+ *       nbr_in of capacity cap_out rows (cap_in of layer l = cap_out of layer l-1), optional pair_count, optional row plan
+ *       of the data gradient (plan_ints >= d3d_dgrad_plan_ints(cap_in); NULL = none).  On return rank_bitmap / rank_prefix
+ *       point INTO `workspace`: the output grid's occupancy bitmap and per-word popcount prefix -- the rank structure
+ *       of the level the layer produced: row(cell) = rank_prefix[cell / 32] + popcount(rank_bitmap[cell / 32] & bits below cell).
+ *       They stay valid as long as the caller keeps `workspace` (device-side counts throughout: no host sync).
+ *   d3d_subm_rulebook_ranked  the submanifold table of a level that came out of a chain layer, by rank lookups into that
+ *       layer's structure (rows of such a level are in ascending cell order, so rank == row): no table build, no prefill. */
+typedef struct D3dChainLayer {
+  int32_t in_shape[3], ksize[3], stride[3], padding[3], out_shape[3]; /* host, z y x */
+  int32_t cap_out;
+  int32_t *coords_out;       /* dev [cap_out, 4] */
+  int32_t *n_out_dev;        /* dev [1] */
+  int32_t *nbr_out;          /* dev [kvol * cap_out] */
+  int32_t *nbr_in;           /* dev [kvol * cap_in]  */
+  int32_t *pair_count;       /* dev [kvol] or NULL */
+  int32_t *plan;             /* dev [plan_ints] or NULL */
+  uint64_t plan_ints;
+  const uint32_t *rank_bitmap; /* out: dev pointers into the workspace */
+  const int32_t *rank_prefix;
+} D3dChainLayer;
+size_t d3d_conv_rulebook_chain_workspace_bytes(int n_layers, int batch, const D3dChainLayer *layers);
+int d3d_conv_rulebook_chain(int n_layers, D3dChainLayer *layers, int batch, const int32_t *coords0, const int32_t *n0_dev,
+                            int cap0, void *workspace, size_t workspace_bytes, d3d_stream_t stream);
+int d3d_subm_rulebook_ranked(const int32_t *coords, const int32_t *n_dev, int cap, int batch, const int32_t *spatial_shape,
+                             const int32_t *ksize, const uint32_t *rank_bitmap, const int32_t *rank_prefix, int32_t *nbr,
+                             int32_t *pair_count, d3d_stream_t stream);
 int d3d_sparse_conv_dgrad_plan_supported(int cin, int cout, int dtype);
 int d3d_sparse_conv_dgrad_planned(const void *dout, const void *wpack, const int32_t *nbr_in, int cap_in, int n_in,
                                   int kvol, int cin, int cout, int dtype, void *din,
@@ -268,6 +300,9 @@ int d3d_pack_all(const D3dPackDesc *descs, int n, d3d_stream_t stream);
  *              [2c] sums | per-block slabs of the deterministic fold; need not be zeroed),
  *              running stats updated in place, save_mean/save_invstd dev [c] written for the backward
  *  training=0: running statistics, stats_ws unused
+ *  training=2 (d3d_bn_apply and its _residual / _split forms): stats_ws holds the FINISHED per-channel mean | variance
+ *              ([2c] f32; e.g. moments all-reduced over ranks by DistributedSyncBN, det3d/ops/syncbn/syncbn.py:39-52):
+ *              the sweep normalises with them, writes save_mean / save_invstd and leaves the running statistics to the caller
  *  relu=1 fuses max(0, .) into the apply pass (and its mask into the backward).
  *  bwd overwrites dgamma/dbeta dev [c] f32 and dx; partial_ws: scratch of d3d_bn_reduce_ws_floats floats.
  *  Works on any row-major [n,c] matrix, e.g. the [B*H*W, C] view of a channels-last feature map

@@ -28,7 +28,53 @@ def test_binding_table_matches_header(hip_lib):
     from det3d_amd import _lib
 
     assert sorted(_lib.SIGNATURES) == _declared()
-    assert hip_lib.d3d_abi_version() == _lib.ABI_VERSION == 8
+    assert hip_lib.d3d_abi_version() == _lib.ABI_VERSION == 9
+
+
+def test_rulebook_chain_planning_and_argument_checks_without_gpu(hip_lib):
+    """d3d_conv_rulebook_chain (ABI 9): the workspace is two words per 32 output cells of every layer (bitmap + prefix)
+    plus the tile sums; geometry that does not chain, too many layers, key spaces beyond 32 bits and short workspaces are
+    refused before any launch; the test knob of the exact-f32 sparse kernels flips the epilogue predicate."""
+    from det3d_amd import _lib
+
+    err = hip_lib.d3d_last_error
+    arr = (_lib.ChainLayer * 2)()
+
+    def layer(y, ins, k, s, p):
+        outs = [(ins[a] + 2 * p[a] - k[a]) // s[a] + 1 for a in range(3)]
+        for a in range(3):
+            y.in_shape[a], y.ksize[a], y.stride[a], y.padding[a], y.out_shape[a] = ins[a], k[a], s[a], p[a], outs[a]
+        y.cap_out, y.coords_out, y.n_out_dev, y.nbr_out, y.nbr_in = 100, 1, 1, 1, 1
+        return outs
+
+    o1 = layer(arr[0], [41, 1600, 1408], [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    o2 = layer(arr[1], o1, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    assert o1 == [21, 800, 704] and o2 == [11, 400, 352]
+    p = ctypes.cast(arr, ctypes.c_void_p)
+    words = lambda o: ((4 * o[0] * o[1] * o[2] + 31) // 32 + 7) // 8 * 8
+    need = hip_lib.d3d_conv_rulebook_chain_workspace_bytes(2, 4, p)
+    assert 8 * (words(o1) + words(o2)) <= need <= 8 * (words(o1) + words(o2)) + 8192
+    assert hip_lib.d3d_conv_rulebook_chain_workspace_bytes(9, 4, p) == 0
+    assert hip_lib.d3d_conv_rulebook_chain(2, p, 4, 1, 1, 10, 1, 10, None) == -2 and b"workspace" in err()
+    assert hip_lib.d3d_conv_rulebook_chain(9, p, 4, 1, 1, 10, 1, 1 << 30, None) == -1 and b"layers" in err()
+    assert hip_lib.d3d_conv_rulebook_chain(2, p, 4, None, 1, 10, 1, 1 << 30, None) == -1
+    arr[1].in_shape[1] = 799  # (799 + 2 - 3) // 2 + 1 is still 400: only the link to layer 0's grid is broken
+    assert hip_lib.d3d_conv_rulebook_chain(2, p, 4, 1, 1, 10, 1, 1 << 30, None) == -1 and b"continue" in err()
+    arr[1].in_shape[1] = 800
+    assert hip_lib.d3d_conv_rulebook_chain(2, p, 400, 1, 1, 10, 1, 1 << 40, None) == -2 and b"u32" in err()
+    shape, k3 = (ctypes.c_int32 * 3)(21, 800, 704), (ctypes.c_int32 * 3)(3, 3, 3)
+    assert hip_lib.d3d_subm_rulebook_ranked(1, 1, 10, 4, shape, k3, None, 1, 1, None, None) == -1 and b"null" in err()
+    assert hip_lib.d3d_subm_rulebook_ranked(1, 1, 10, 400, shape, k3, 1, 1, 1, None, None) == -2
+    # knob 10 (test knob): exact-f32 VALU kernels for f32 features -> no epilogues, no planned data gradient
+    assert hip_lib.d3d_sparse_conv_has_epilogue(64, 64, _lib.D3D_F32) == 1
+    try:
+        assert hip_lib.d3d_set_tuning(10, 1) == 0
+        assert hip_lib.d3d_sparse_conv_has_epilogue(64, 64, _lib.D3D_F32) == 0
+        assert hip_lib.d3d_sparse_conv_has_epilogue(64, 64, _lib.D3D_BF16) == 1
+        assert hip_lib.d3d_sparse_conv_dgrad_plan_supported(64, 64, _lib.D3D_F32) == 0
+    finally:
+        hip_lib.d3d_set_tuning(10, 0)
+    assert hip_lib.d3d_sparse_conv_dgrad_plan_supported(64, 64, _lib.D3D_F32) == 1
 
 
 def test_argument_validation_without_gpu(hip_lib):

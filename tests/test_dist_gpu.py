@@ -205,6 +205,141 @@ def test_two_ranks_one_gpu_fused_syncbn_equals_the_torch_formulation(dtype_name,
         p.join(120)
 
 
+def _fused_nodes_syncbn_worker(rank, world, port, q):
+    """`norm_cfg = dict(type="SyncBN")` keeps the fused conv nodes.  Each rank runs, on its own
+    data (different row counts), a sparse conv stack, a SparseBasicBlock and a dense RPN run with DistributedSyncBN
+    twice: through the fused nodes (sparse_stack / sparse_block / dense_stack: conv epilogue -> packed all-reduce ->
+    d3d_bn_apply(training=2) and the mirrored backward) and through the per-layer path whose cross-rank BatchNorm is
+    syncbn._SyncBNFn, the torch-op formulation tests/test_syncbn_cpu.py pins to the reference's formulas."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), D3D_DIST_BACKEND="gloo")
+    try:
+        import copy
+
+        from det3d_amd import dense_stack, nn_utils, sparse_block, sparse_stack, spconv, syncbn
+        from det3d_amd import dist as D
+        from det3d_amd.backbones import SparseBasicBlock
+        from det3d_amd.syncbn import DistributedSyncBN
+
+        D.init_dist()
+        dev = torch.device("cuda", 0)
+        NORM = dict(type="SyncBN", eps=1e-3, momentum=0.01)
+        g = torch.Generator().manual_seed(7 + rank)
+        res = {}
+
+        def rel(a, b):
+            return float((a.float() - b.float()).abs().max()) / (float(b.float().abs().max()) + 1e-12)
+
+        def torch_syncbn(monkey):
+            """route every DistributedSyncBN through the torch-op formulation (no HIP sweep) while `monkey` is True"""
+            syncbn._rows_view_saved = getattr(syncbn, "_rows_view_saved", syncbn._rows_view)
+            syncbn._rows_view = (lambda x: None) if monkey else syncbn._rows_view_saved
+
+        # ---------------------------------------------------------------- sparse tensor of this rank
+        n = 2500 if rank == 0 else 3300
+        shape = [9, 40, 36]
+        lin = torch.randperm(shape[0] * shape[1] * shape[2], generator=g)[:n]
+        idx = torch.stack([torch.zeros_like(lin), lin // (shape[1] * shape[2]), (lin // shape[2]) % shape[1], lin % shape[2]], 1).int()
+        feats0 = torch.randn((n, 16), generator=g)
+
+        def sparse_case(name, make):
+            torch.manual_seed(3)  # same parameters on both ranks (replicas)
+            net = make().to(dev).train()
+            ref = copy.deepcopy(net)
+            outs = []
+            for which, m in (("fused", net), ("reference", ref)):
+                fused = which == "fused"
+                sparse_stack.FUSE_STACK, sparse_block.FUSE_BLOCK = fused, fused
+                torch_syncbn(not fused)
+                x = feats0.to(dev).requires_grad_(True)
+                st = spconv.SparseConvTensor(x, idx.to(dev), shape, 1)
+                seq = m if isinstance(m, spconv.SparseSequential) else spconv.SparseSequential(m)
+                seq.plan(st)
+                spconv.ARENA.reset(dev)
+                y = seq(st).features
+                w = torch.linspace(0.5, 1.5, y.shape[1], device=dev)
+                ((y * w) ** 2).sum().backward()
+                # (a conv bias in front of a cross-rank BatchNorm: the GLOBAL mean removes it, so its gradient summed over
+                # the ranks is zero -- the fused block returns exact zeros, the per-layer path each rank's non-zero share
+                # of that zero sum; the data-parallel gradient mean makes them the same thing.  Not compared per rank.)
+                outs.append((y.detach(), x.grad, [p.grad for k, p in m.named_parameters() if not (k.endswith("conv1.bias") or k.endswith("conv2.bias"))],
+                             [b.clone() for k, b in m.named_buffers() if "running" in k]))
+            sparse_stack.FUSE_STACK = sparse_block.FUSE_BLOCK = True
+            torch_syncbn(False)
+            (y, gx, gp, rb_), (y2, gx2, gp2, rb2) = outs
+            gmax = max(float(t.abs().max()) for t in gp2)
+            res[name] = dict(out=rel(y, y2), gin=rel(gx, gx2),
+                             gparam=max(float((a - b).abs().max()) for a, b in zip(gp, gp2)) / gmax,
+                             running=max(rel(a, b) for a, b in zip(rb_, rb2)))
+
+        bn = lambda c: DistributedSyncBN(c, eps=1e-3, momentum=0.01)
+        sparse_case("sparse_stack", lambda: spconv.SparseSequential(
+            spconv.SubMConv3d(16, 32, 3, bias=False, indice_key="a"), bn(32), torch.nn.ReLU(),
+            spconv.SubMConv3d(32, 32, 3, bias=False, indice_key="a"), bn(32), torch.nn.ReLU(),
+            spconv.SparseConv3d(32, 64, 3, 2, padding=1, bias=False), bn(64), torch.nn.ReLU(),
+            spconv.SubMConv3d(64, 64, 3, bias=False, indice_key="b"), bn(64)))
+        sparse_case("sparse_block", lambda: SparseBasicBlock(16, 16, norm_cfg=NORM, indice_key="r"))
+        # fused nodes really ran: the stack / block functions see DistributedSyncBN as eligible
+        assert syncbn.fused_sync(bn(8).train())
+
+        # ---------------------------------------------------------------- dense RPN run
+        h = 24 if rank == 0 else 30
+        x0 = torch.randn((2, 128, h, 20), generator=g)
+        torch.manual_seed(5)
+        net = nn_utils.Sequential(torch.nn.ZeroPad2d(1), torch.nn.Conv2d(128, 128, 3, bias=False), bn(128), torch.nn.ReLU(),
+                                  torch.nn.Conv2d(128, 128, 3, padding=1, bias=False), bn(128), torch.nn.ReLU()).to(dev).train()
+        ref = copy.deepcopy(net)
+        outs = []
+        for which, m in (("fused", net), ("reference", ref)):
+            dense_stack.ENABLED = which == "fused"
+            torch_syncbn(which != "fused")
+            x = x0.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            if which == "fused":
+                layers, _ = dense_stack.collect(list(m._modules.values()), 0, x)
+                assert len(layers) == 2, "the dense stack must take DistributedSyncBN layers"
+            y = m(x)
+            (y ** 2).sum().backward()
+            outs.append((y.detach(), x.grad, [p.grad for p in m.parameters()],
+                         [b.clone() for k, b in m.named_buffers() if "running" in k]))
+        dense_stack.ENABLED = True
+        torch_syncbn(False)
+        (y, gx, gp, rb_), (y2, gx2, gp2, rb2) = outs
+        gmax = max(float(t.abs().max()) for t in gp2)
+        res["dense_stack"] = dict(out=rel(y, y2), gin=rel(gx, gx2),
+                                  gparam=max(float((a - b).abs().max()) for a, b in zip(gp, gp2)) / gmax,
+                                  running=max(rel(a, b) for a, b in zip(rb_, rb2)))
+        torch.cuda.synchronize()
+        q.put((rank, res))
+        D.barrier()
+        torch.distributed.destroy_process_group()
+    except Exception:
+        import traceback
+
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_two_ranks_one_gpu_syncbn_inside_the_fused_conv_nodes():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fused_nodes_syncbn_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for _ in range(world):
+        item = q.get(timeout=600)
+        assert not isinstance(item[1], str), item[2]
+        rank, res = item
+        print("rank %d: fused SyncBN nodes vs per-layer torch formulation: %s" % (rank, res))
+        for name, r in res.items():
+            # sparse: split-arithmetic convs on both sides, only the BatchNorm path differs; dense: split-arithmetic
+            # kernels against MIOpen f32 convolutions on the reference side
+            tol = 2e-4 if name != "dense_stack" else 2e-3
+            assert r["out"] < tol and r["gin"] < 10 * tol and r["gparam"] < 10 * tol and r["running"] < 1e-4, (rank, name, r)
+    for p in procs:
+        p.join(120)
+
+
 _SINGLE_RANK_SCRIPT = r"""
 import os, sys, json
 sys.path.insert(0, %(root)r)

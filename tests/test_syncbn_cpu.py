@@ -108,6 +108,72 @@ def test_syncbn_matches_reference_formulas_world2(shape_kind):
         assert np.allclose(rv, 0.99 + 0.01 * outs[r][1].detach().numpy(), atol=1e-5)
 
 
+def _exchange_worker(rank, world, port, q):
+    """the [2C]-vector algebra of the fused conv nodes (syncbn.exchange_moments / exchange_backward_sums) with the HIP
+    sweeps' formulas written out in torch: d3d_bn_apply(training=2) normalises with the handed-in mean | variance,
+    d3d_bn_bwd_dx computes gamma * invstd * (dz - S0 / N - xhat * S1 / N) from the sums it is given"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from det3d_amd import syncbn
+        from det3d_amd.syncbn import DistributedSyncBN, _SyncBNFn
+
+        x = _data(rank, "sparse")
+        n, c = x.shape
+        mk = lambda: DistributedSyncBN(c, eps=1e-3, momentum=0.01).train()
+        bn, ref = mk(), mk()
+        for m in (bn, ref):
+            with torch.no_grad():
+                m.weight.copy_(torch.linspace(0.5, 2.0, c))
+                m.bias.copy_(torch.linspace(-1.0, 1.0, c))
+        assert syncbn.fused_sync(bn) and not syncbn.fused_sync(mk().eval()) and not syncbn.fused_sync(torch.nn.BatchNorm1d(c))
+        # ---- the fused nodes' data flow
+        sums = torch.cat([x.sum(0), (x * x).sum(0), torch.full((5,), 99.0)])       # conv epilogue: sum | sum of squares | slabs
+        mv, cf = syncbn.exchange_moments(bn, sums, n)
+        mean, invstd = mv[:c], (mv[c:] + bn.eps).rsqrt()                              # bn_apply_kernel, training == 2
+        xhat = (x - mean) * invstd
+        z = xhat * bn.weight + bn.bias
+        y = z.clamp(min=0)                                                            # relu = 1
+        dy = 2 * y * torch.linspace(0.5, 1.5, c) ** 2 * (1.0 + 0.5 * rank)
+        dz = dy * (z > 0)
+        partial = torch.cat([(dz * xhat).sum(0), dz.sum(0), torch.full((3,), -7.0)])  # dgrad epilogue / bn_bwd_reduce
+        p2, g_gamma, g_beta = syncbn.exchange_backward_sums(bn, partial, cf, invstd)
+        dx = bn.weight * invstd * (dz - p2[c:] / n - xhat * p2[:c] / n)                # bn_bwd_dx_kernel
+        # ---- the torch-op formulation pinned to the reference formulas above
+        xr = x.clone().requires_grad_(True)
+        yr = torch.relu(_SyncBNFn.apply(xr, ref.weight, ref.bias, ref.running_mean, ref.running_var, ref.momentum, ref.eps, None))
+        (((yr * torch.linspace(0.5, 1.5, c)) ** 2).sum() * (1.0 + 0.5 * rank)).backward()
+        err = dict(y=float((y - yr.detach()).abs().max()), dx=float((dx.detach() - xr.grad).abs().max() / xr.grad.abs().max()),
+                   dgamma=float((g_gamma.detach() - ref.weight.grad).abs().max() / ref.weight.grad.abs().max()),
+                   dbeta=float((g_beta.detach() - ref.bias.grad).abs().max() / ref.bias.grad.abs().max()),
+                   rmean=float((bn.running_mean - ref.running_mean).abs().max()),
+                   rvar=float((bn.running_var - ref.running_var).abs().max()))
+        q.put((rank, err))
+    except Exception:
+        import traceback
+
+        q.put((rank, "error", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fused_node_exchange_algebra_equals_the_reference_formulation_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for _ in range(2):
+        item = q.get(timeout=180)
+        assert not (isinstance(item[1], str) and item[1] == "error"), item[2]
+        for k, v in item[1].items():
+            assert v < 2e-5, (item[0], k, v)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+
+
 def test_syncbn_without_process_group_is_plain_bn():
     from det3d_amd.nn_utils import build_norm_layer
     from det3d_amd.syncbn import DistributedSyncBN

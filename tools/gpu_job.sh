@@ -28,11 +28,12 @@ while [ $# -gt 0 ]; do
   case "$st" in
     tests)
       timeout 1500 python -m pytest tests/ -x -q -m gpu -rP > $O/tests.log 2>&1; echo "pytest rc=$?"; tail -3 $O/tests.log
-      grep -h "vs float64\|max |pred - reference|\|worst gradient-norm\|ResNetFHD" $O/tests.log | cut -c1-400 > $O/tests_figures.txt; cat $O/tests_figures.txt
+      grep -h "vs float64\|max |pred - reference|\|worst gradient-norm\|ResNetFHD\|distance from float64\|forward split vs\|300 steps\|relative loss difference\|held-out raw\|reference detections matched\|fused SyncBN nodes\|frames at the max_voxels\|rulebooks, " $O/tests.log | grep -v "print(" | cut -c1-900 > $O/tests_figures.txt; cat $O/tests_figures.txt
       timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 ;;
     testsall:*)
-      timeout 1500 python -m pytest tests/ -q -m gpu -k "${st#testsall:}" > $O/tests_all.log 2>&1; echo "pytest rc=$?"
-      grep -n "^FAILED\|^E  .*Error\|passed\|failed" $O/tests_all.log | cut -c1-260 | head -60 ;;
+      timeout 1500 python -m pytest tests/ -q -m gpu -rP -k "${st#testsall:}" > $O/tests_all.log 2>&1; echo "pytest rc=$?"
+      grep -n "^FAILED\|^E  .*Error\|passed\|failed" $O/tests_all.log | cut -c1-260 | head -60
+      grep -h "vs float64\|max |pred - reference|\|worst gradient-norm\|ResNetFHD\|distance from float64\|forward split vs\|300 steps\|relative loss difference\|held-out raw\|reference detections matched\|fused SyncBN nodes" $O/tests_all.log | grep -v "print(" | cut -c1-900 > $O/tests_all_figures.txt; cat $O/tests_all_figures.txt ;;
     tests:*)
       timeout 1500 python -m pytest tests/ -x -q -m gpu -k "${st#tests:}" > $O/tests_k.log 2>&1; echo "pytest rc=$?"; tail -15 $O/tests_k.log ;;
     bench)
@@ -89,6 +90,28 @@ for f in ("mr_plain", "mr_rccl1", "mr_rccl1_b1", "mr_rccl1_b0", "mr_rccl1_nors",
     c = d["config"]
     print("%-22s n_gpus=%d %8.1f frames/s %7.3f ms/step  host %s  loss %s -> %s" % (
         f, d["n_gpus"], d["value"], d["ms_per_step"], c.get("host_ms_per_step"), c.get("first_loss"), c.get("final_loss")))
+PY
+      ;;
+    syncbn)
+      # nuScenes CBGS with norm_cfg SyncBN through the fused nodes, every collective on a 1-rank RCCL
+      # communicator, against the plain-BN step under the same communicator and the plain single-process step
+      B="--steps 10 --warmup 3 --burn-in 0.5 --no-cpu-baseline --no-extras --workload c4"
+      R1="D3D_DIST_SINGLE=1 D3D_DIST_BACKEND=nccl RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1"
+      timeout 400 python bench.py --gpus 1 $B > $O/sb_plain.json 2> $O/sb_plain.err
+      env $R1 MASTER_PORT=$(port) timeout 400 python bench.py --gpus 1 $B > $O/sb_rccl1_bn.json 2> $O/sb_rccl1_bn.err
+      env $R1 MASTER_PORT=$(port) timeout 400 python bench.py --gpus 1 $B --syncbn > $O/sb_rccl1_syncbn.json 2> $O/sb_rccl1_syncbn.err
+      env $R1 MASTER_PORT=$(port) D3D_FUSE_STACK=0 D3D_FUSE_BLOCK=0 D3D_DENSE_CONV=0 timeout 400 python bench.py --gpus 1 $B --syncbn > $O/sb_rccl1_syncbn_unfused.json 2> $O/sb_rccl1_syncbn_unfused.err
+      python - "$O" <<'PY' | tee $O/syncbn.txt
+import json, sys, os
+O = sys.argv[1]
+for f in ("sb_plain", "sb_rccl1_bn", "sb_rccl1_syncbn", "sb_rccl1_syncbn_unfused"):
+    try:
+        d = json.loads([l for l in open(os.path.join(O, f + ".json")) if l.startswith("{")][-1])
+        c = d["config"]
+        print("%-26s %8.1f frames/s %8.3f ms/step  host %s  loss %s -> %s  norm: %s" % (
+            f, d["value"], d["ms_per_step"], c.get("host_ms_per_step"), c.get("first_loss"), c.get("final_loss"), c.get("norm")))
+    except Exception as e:
+        print("%-26s FAILED (%s)" % (f, e))
 PY
       ;;
     mrprio)
