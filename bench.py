@@ -735,9 +735,57 @@ def stage_probe(wl, dev):
             if not m.subm:
                 idx, shape, n = r.out_indices, list(r.out_shape), int(r.n_out)
         tot_us = sum(c["us"] for c in calls)
-        out["rulebooks"]["calls"] = calls
-        out["rulebooks"]["gpu_ms_sum_of_calls"] = round(tot_us / 1e3, 4)
-        out["rulebooks"]["achieved_GBs_gpu_only"] = round(rb_bytes / (tot_us * 1e-6) / 1e9, 1) if tot_us else None
+        out["rulebooks"]["per_layer_entry_points"] = dict(
+            calls=calls, gpu_ms_sum_of_calls=round(tot_us / 1e3, 4),
+            achieved_GBs_gpu_only=round(rb_bytes / (tot_us * 1e-6) / 1e9, 1) if tot_us else None,
+            note="d3d_subm_rulebook / d3d_conv_rulebook + d3d_dgrad_plan_build, one call per table (what round 4 ran: 52 launches)")
+        if spconv.RB_CHAIN:
+            # what plan() runs since round 5: ONE d3d_conv_rulebook_chain call for the strided layers (1 + 4 launches per
+            # layer, row plans included), d3d_subm_rulebook_ranked per level >= 1, the hash build for level 0
+            def ev_us(fn, reps=3):
+                for _ in range(2):
+                    fn()
+                ea, eb = _ev(), _ev()
+                torch.cuda.synchronize()
+                ea.record()
+                for _ in range(reps):
+                    r = fn()
+                eb.record()
+                torch.cuda.synchronize()
+                return 1e3 * ea.elapsed_time(eb) / reps, r
+
+            layers = bb.middle_conv.conv_layers()
+            strided = [m for m in layers if not m.subm]
+            idx0, n0 = ex_t["coordinates"], int(ex_t["coordinates"].shape[0])
+            n0_dev = torch.tensor([n0], dtype=torch.int32, device=dev)
+            us_chain, (built, ranks, ws) = ev_us(lambda: spconv.build_conv_rulebook_chain(
+                idx0, n0_dev, max(n0, 1), wl.batch, list(st.spatial_shape), strided))
+            parts = [dict(call="d3d_conv_rulebook_chain (%d strided layers + row plans)" % len(strided), us=round(us_chain, 1),
+                          launches=1 + 4 * len(strided))]
+            seen, level = set(), 0
+            for m in layers:
+                if not m.subm:
+                    level += 1
+                    continue
+                key = m._rulebook_key()
+                if key in seen:
+                    continue
+                seen.add(key)
+                r = d[key]
+                if level == 0:
+                    us, _ = ev_us(lambda: spconv.build_subm_rulebook(idx0, n0_dev, n0, max(n0, 1), wl.batch, list(st.spatial_shape),
+                                                                     m.kernel_size))
+                    parts.append(dict(call="d3d_subm_rulebook (level 0: voxel order, hash table)", us=round(us, 1), launches=3))
+                else:
+                    rb_prev, n_prev_dev = built[level - 1]
+                    n_l = int(n_prev_dev.item())
+                    us, _ = ev_us(lambda: spconv.build_subm_rulebook_ranked(rb_prev.out_indices[:n_l], n_prev_dev, n_l, wl.batch,
+                                                                            list(rb_prev.out_shape), m.kernel_size, ranks[level - 1]))
+                    parts.append(dict(call="d3d_subm_rulebook_ranked (level %d, %d sites)" % (level, n_l), us=round(us, 1), launches=1))
+            tot = sum(p["us"] for p in parts)
+            out["rulebooks"]["chain"] = dict(calls=parts, launches=sum(p["launches"] for p in parts),
+                                             gpu_ms_sum_of_calls=round(tot / 1e3, 4),
+                                             achieved_GBs_gpu_only=round(rb_bytes / (tot * 1e-6) / 1e9, 1) if tot else None)
     try:
         out["batchnorm_sweeps"] = bn_probe(wl, dev, ex_t)
     except Exception as e:  # a side table: never fail the stage probe over it

@@ -571,8 +571,8 @@ def _fused_heads_convs(head, x):
         return None
     convs = []
     for task in head.tasks:
-        if type(task) is not Head:
-            return None
+        if type(task) is not Head or task._forward_hooks or task._forward_pre_hooks:
+            return None  # (hooks registered on a Head must keep seeing its forward)
         cs = [task.conv_box, task.conv_cls] + ([task.conv_dir] if task.use_dir else [])
         for c in cs:
             if type(c) is not nn.Conv2d or c.kernel_size != (1, 1) or c.stride != (1, 1) or c.padding != (0, 0) or \
@@ -580,7 +580,13 @@ def _fused_heads_convs(head, x):
                 return None
         convs.append(cs)
     total = sum(c.out_channels for cs in convs for c in cs)
-    if len(convs) < 2 or total > 256 or not dc.supported(256, 128, 1, 1):
+    if len(convs) < 2 or total > 256:
+        return None
+    npad = 128 if total <= 128 else 256
+    cin = int(x.shape[1])
+    # the three launches of the node at THIS shape: forward cin -> npad, data gradient npad -> cin (in 128 / 256 column
+    # tiles of the same kernel), weight gradient
+    if not (dc.supported(cin, npad, 1, 1) and dc.supported(npad, cin, 1, 1)):
         return None
     return convs
 

@@ -724,8 +724,10 @@ static int c2_check(const char *who, int batch, int h, int w, int cin, int cout,
 }
 
 extern "C" int d3d_conv2d_supported(int cin, int cout, int ksz, int stride) {
-  return (cin == 64 || cin == 128 || cin == 256) && cout >= 128 && cout % 128 == 0 && ksz >= 1 && ksz <= 3 &&
-         (stride == 1 || stride == 2);
+  // (the same rule as c2_check: 384 / 512 input channels -- the concatenated deblock maps the stacked task heads read --
+  // exist for 1x1 layers only)
+  return (cin == 64 || cin == 128 || cin == 256 || ((cin == 384 || cin == 512) && ksz == 1)) && cout >= 128 &&
+         cout % 128 == 0 && ksz >= 1 && ksz <= 3 && (stride == 1 || stride == 2);
 }
 // 3x3 stride-1 layers in split mode also come with 64 output channels (conv2d_halo_kernel; forward and data gradient)
 extern "C" int d3d_conv2d_supported_split3x3(int cin, int cout) {

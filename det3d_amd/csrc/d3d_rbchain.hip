@@ -62,6 +62,23 @@ __device__ __forceinline__ bool rc_out_cell(const RcGeom &G, int4 c, int k, uint
   return true;
 }
 
+// one axis of the same rule: output index reached from input index `in` through kernel index kk, or -1
+__device__ __forceinline__ int rc_axis(int in, int p, int kk, int s, int out_n) {
+  const int t = in + p - kk;
+  if (t < 0) return -1;
+  int q;
+  if (s == 2) {  // (the strides of the shipped backbones: no integer division)
+    if (t & 1) return -1;
+    q = t >> 1;
+  } else if (s == 1) {
+    q = t;
+  } else {
+    q = t / s;
+    if (q * s != t) return -1;
+  }
+  return q < out_n ? q : -1;
+}
+
 __device__ __forceinline__ int rc_class(const RcGeom &G, int4 c) {
   const int in[3] = {c.y, c.z, c.w};
   int cls = 0;
@@ -86,28 +103,43 @@ __device__ __forceinline__ int rc_wave_rank(int cls, int (*wc)[D3D_PLAN_MAX_CLAS
 __global__ void __launch_bounds__(RC_ROWS)
     rc_mark_kernel(const int4 *__restrict__ coords, const int32_t *__restrict__ n_dev, int cap, RcGeom G,
                    uint32_t *__restrict__ bitmap, int32_t *__restrict__ blockhist) {
+  // grid = (row blocks, kernel (z, y) pairs): blockIdx.y = kz * kH + ky walks the kW offsets of that pair, so a level of
+  // 65k rows is 64 x 9 blocks instead of 64 (the first version: 64 of 256 CUs busy, 27 serial candidates per thread)
+  // The row blocks are walked with a grid-stride loop: the row COUNT lives on the device, the capacity is 8x per level
+  // (5 M rows at KITTI level 2 for 126 k real ones), and a capacity-sized grid spent more time launching 45 000 blocks
+  // that exit at once than the live ones needed.
   __shared__ int wc[RC_ROWS / 64][D3D_PLAN_MAX_CLASSES];
   int n = *n_dev;
   n = n < cap ? n : cap;
-  if ((int)blockIdx.x * RC_ROWS >= n) return;  // capacity-sized grid
-  const int r = blockIdx.x * RC_ROWS + threadIdx.x;
-  const bool live = r < n;
-  int4 c = make_int4(0, 0, 0, 0);
-  if (live) {
-    c = coords[r];
-    for (int k = 0; k < G.kvol; ++k) {
-      uint32_t key;
-      int4 oc;
-      if (rc_out_cell(G, c, k, key, oc)) atomicOr(&bitmap[key >> 5], 1u << (key & 31));
+  const int kz = (int)blockIdx.y / G.k[1], ky = (int)blockIdx.y - kz * G.k[1];
+  for (int blk = blockIdx.x; blk * RC_ROWS < n; blk += gridDim.x) {
+    const int r = blk * RC_ROWS + threadIdx.x;
+    const bool live = r < n;
+    int4 c = make_int4(0, 0, 0, 0);
+    if (live) {
+      c = coords[r];
+      const int oz = rc_axis(c.y, G.p[0], kz, G.s[0], G.out_shape[0]);
+      const int oy = rc_axis(c.z, G.p[1], ky, G.s[1], G.out_shape[1]);
+      if (oz >= 0 && oy >= 0) {
+        const uint32_t base = (uint32_t)((((int64_t)c.x * G.out_shape[0] + oz) * G.out_shape[1] + oy) * G.out_shape[2]);
+        for (int kx = 0; kx < G.k[2]; ++kx) {
+          const int ox = rc_axis(c.w, G.p[2], kx, G.s[2], G.out_shape[2]);
+          if (ox >= 0) {
+            const uint32_t key = base + (uint32_t)ox;
+            atomicOr(&bitmap[key >> 5], 1u << (key & 31));
+          }
+        }
+      }
     }
-  }
-  if (blockhist) {
-    rc_wave_rank(live ? rc_class(G, c) : -1, wc);
-    __syncthreads();
-    if (threadIdx.x < D3D_PLAN_MAX_CLASSES) {
-      int s = 0;
-      for (int w = 0; w < RC_ROWS / 64; ++w) s += wc[w][threadIdx.x];
-      blockhist[blockIdx.x * D3D_PLAN_MAX_CLASSES + threadIdx.x] = s;
+    if (blockhist && blockIdx.y == 0) {
+      rc_wave_rank(live ? rc_class(G, c) : -1, wc);
+      __syncthreads();
+      if (threadIdx.x < D3D_PLAN_MAX_CLASSES) {
+        int s = 0;
+        for (int w = 0; w < RC_ROWS / 64; ++w) s += wc[w][threadIdx.x];
+        blockhist[blk * D3D_PLAN_MAX_CLASSES + threadIdx.x] = s;
+      }
+      __syncthreads();  // wc is reused by the next row block
     }
   }
 }
@@ -141,11 +173,17 @@ __global__ void __launch_bounds__(D3D_SCAN_THREADS)
     rc_final_kernel(const uint32_t *__restrict__ bitmap, int64_t words8, const int *__restrict__ tile_sums, int ntiles,
                     int32_t *__restrict__ prefix, int32_t *__restrict__ n_out_dev, int32_t *__restrict__ nbr_out,
                     int cap_out, int kvol) {
-  // this tile's first output row: the tiles in front of it, summed here (<= a few thousand ints out of L2)
-  int part = 0;
-  for (int t = threadIdx.x; t < (int)blockIdx.x; t += D3D_SCAN_THREADS) part += tile_sums[t];
-  int offset;
+  // this tile's first output row: the tiles in front of it, summed here (<= a few thousand ints out of L2); the sum of
+  // ALL tiles = the output count, which every block needs for its share of the -1 fill below
+  int part = 0, all = 0;
+  for (int t = threadIdx.x; t < ntiles; t += D3D_SCAN_THREADS) {
+    const int v = tile_sums[t];
+    all += v;
+    if (t < (int)blockIdx.x) part += v;
+  }
+  int offset, n_out;
   d3d_block_excl_scan256(part, &offset);
+  d3d_block_excl_scan256(all, &n_out);
   const int64_t base = (int64_t)blockIdx.x * D3D_SCAN_TILE + (int64_t)threadIdx.x * 8;
   uint32_t w[8];
   rc_load8(bitmap, base, words8, w);
@@ -167,13 +205,23 @@ __global__ void __launch_bounds__(D3D_SCAN_THREADS)
     *(int4 *)(prefix + base) = make_int4(pre[0], pre[1], pre[2], pre[3]);
     *(int4 *)(prefix + base + 4) = make_int4(pre[4], pre[5], pre[6], pre[7]);
   }
-  if ((int)blockIdx.x == ntiles - 1 && threadIdx.x == 0) *n_out_dev = offset + total;  // may exceed cap_out: the host checks
-  // the output-stationary table of exactly this tile's rows starts out empty
-  const int r0 = offset < cap_out ? offset : cap_out;
-  const int r1 = offset + total < cap_out ? offset + total : cap_out;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_out_dev = n_out;  // may exceed cap_out: the host checks
+  // the output-stationary table starts out empty: every block clears an EQUAL share of the n_out rows (the occupied cells
+  // cluster in a few tiles -- a block clearing "its own" rows left one block with most of the work)
+  const int rows_all = n_out < cap_out ? n_out : cap_out;
+  const int chunk = ((rows_all + ntiles - 1) / ntiles + 63) / 64 * 64;  // whole 256-byte lines
+  const int r0 = (int)blockIdx.x * chunk < rows_all ? (int)blockIdx.x * chunk : rows_all;
+  const int r1 = r0 + chunk < rows_all ? r0 + chunk : rows_all;
   const int rows = r1 - r0;
-  for (int k = 0; k < kvol; ++k)
-    for (int r = threadIdx.x; r < rows; r += D3D_SCAN_THREADS) nbr_out[(int64_t)k * cap_out + r0 + r] = -1;
+  if (rows >= D3D_SCAN_THREADS) {
+    for (int k = 0; k < kvol; ++k)
+      for (int r = threadIdx.x; r < rows; r += D3D_SCAN_THREADS) nbr_out[(int64_t)k * cap_out + r0 + r] = -1;
+  } else if (rows > 0) {  // few rows per block: spread the kvol planes over the threads instead of idling most of them
+    const int per = D3D_SCAN_THREADS / rows;  // planes in flight
+    const int r = (int)threadIdx.x % rows, k0 = (int)threadIdx.x / rows;
+    if (k0 < per)
+      for (int k = k0; k < kvol; k += per) nbr_out[(int64_t)k * cap_out + r0 + r] = -1;
+  }
 }
 
 // wave-aggregated pair counting (one atomic per wave: every lane of the row-parallel loop holds the same k)
@@ -192,39 +240,48 @@ __global__ void __launch_bounds__(RC_ROWS)
   __shared__ int tot[D3D_PLAN_MAX_CLASSES], pre[D3D_PLAN_MAX_CLASSES];
   int n = *n_dev;
   n = n < cap_in ? n : cap_in;
-  if ((int)blockIdx.x * RC_ROWS >= n && blockIdx.x != 0) return;  // (block 0 always writes the plan's header)
-  const int r = blockIdx.x * RC_ROWS + threadIdx.x;
+  const int nb = (n + RC_ROWS - 1) / RC_ROWS;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int kz = (int)blockIdx.y / G.k[1], ky = (int)blockIdx.y - kz * G.k[1];
+  // blockIdx.y = kz * kH + ky: the kW offsets of that pair; row blocks in a grid-stride loop (see rc_mark_kernel)
+  for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) {
+  const int r = blk * RC_ROWS + threadIdx.x;
   const bool live = r < n;
   const int4 c = live ? coords[r] : make_int4(0, 0, 0, 0);
-  for (int k = 0; k < G.kvol; ++k) {
-    int row = -1;
-    uint32_t key;
-    int4 oc;
-    if (live && rc_out_cell(G, c, k, key, oc)) {
-      const uint32_t w = key >> 5;
-      row = prefix[w] + __popc(bitmap[w] & ((1u << (key & 31)) - 1u));
-      if (row < cap_out) {
-        nbr_out[(int64_t)k * cap_out + row] = r;
-        coords_out[row] = oc;  // every candidate of a cell writes the same four ints
-      } else {
-        row = -1;
+  {
+    const int oz = live ? rc_axis(c.y, G.p[0], kz, G.s[0], G.out_shape[0]) : -1;
+    const int oy = live ? rc_axis(c.z, G.p[1], ky, G.s[1], G.out_shape[1]) : -1;
+    const bool zy = oz >= 0 && oy >= 0;
+    const uint32_t base = zy ? (uint32_t)((((int64_t)c.x * G.out_shape[0] + oz) * G.out_shape[1] + oy) * G.out_shape[2]) : 0u;
+    for (int kx = 0; kx < G.k[2]; ++kx) {
+      const int k = (int)blockIdx.y * G.k[2] + kx;
+      int row = -1;
+      const int ox = zy ? rc_axis(c.w, G.p[2], kx, G.s[2], G.out_shape[2]) : -1;
+      if (ox >= 0) {
+        const uint32_t key = base + (uint32_t)ox;
+        const uint32_t w = key >> 5;
+        row = prefix[w] + __popc(bitmap[w] & ((1u << (key & 31)) - 1u));
+        if (row < cap_out) {
+          nbr_out[(int64_t)k * cap_out + row] = r;
+          coords_out[row] = make_int4(c.x, oz, oy, ox);  // every candidate of a cell writes the same four ints
+        } else {
+          row = -1;
+        }
       }
+      if (live) nbr_in[(int64_t)k * cap_in + r] = row;
+      rc_count_pairs(pair_count, k, row >= 0);
     }
-    if (live) nbr_in[(int64_t)k * cap_in + r] = row;
-    rc_count_pairs(pair_count, k, row >= 0);
   }
-  if (!plan) return;
+  if (!plan || blockIdx.y != 0) continue;  // (block-uniform)
   // ---- row plan of the data gradient: stable counting sort of the rows by parity class
   const int cls = live ? rc_class(G, c) : -1;
   const int rank = rc_wave_rank(cls, wc);
-  const int nb = (n + RC_ROWS - 1) / RC_ROWS;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wv < D3D_PLAN_MAX_CLASSES) {  // wave c: rows of class c in all blocks, and in the blocks in front of this one
     int all = 0, before = 0;
     for (int b = lane; b < nb; b += 64) {
       const int h = blockhist[b * D3D_PLAN_MAX_CLASSES + wv];
       all += h;
-      if (b < (int)blockIdx.x) before += h;
+      if (b < blk) before += h;
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -243,7 +300,18 @@ __global__ void __launch_bounds__(RC_ROWS)
     for (int w = 0; w < wv; ++w) dest += wc[w][cls];
     plan[D3D_PLAN_PERM + dest] = r;
   }
-  if (blockIdx.x != 0) return;
+  __syncthreads();  // wc / tot / pre are reused by the next row block
+  }  // row blocks
+  if (!plan || blockIdx.x != 0 || blockIdx.y != 0) return;
+  // ---- header of the plan (block (0, 0); also when there are no rows at all)
+  if (wv < D3D_PLAN_MAX_CLASSES) {
+    int all = 0;
+    for (int b = lane; b < nb; b += 64) all += blockhist[b * D3D_PLAN_MAX_CLASSES + wv];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) all += __shfl_xor(all, o, 64);
+    if (lane == 0) tot[wv] = all;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     plan[0] = G.ncls;
     int s = 0;
@@ -409,9 +477,11 @@ extern "C" int d3d_conv_rulebook_chain(int n_layers, D3dChainLayer *layers, int 
   cap_in = cap0;
   for (int l = 0; l < n_layers; ++l) {
     D3dChainLayer &Y = layers[l];
-    const int nb = (cap_in + RC_ROWS - 1) / RC_ROWS;
+    int nb = (cap_in + RC_ROWS - 1) / RC_ROWS;
+    if (nb > 256) nb = 256;  // x kzy blocks of 1024 threads; the kernels stride over the row blocks that exist
     int32_t *blockhist = Y.plan ? Y.plan + D3D_PLAN_PERM + cap_in : nullptr;
-    hipLaunchKernelGGL(rc_mark_kernel, dim3(nb), dim3(RC_ROWS), 0, stream, cin, nin, cap_in, G[l], bitmap[l], blockhist);
+    const int kzy = G[l].k[0] * G[l].k[1];  // grid.y: one (kz, ky) pair of the kernel per block row
+    hipLaunchKernelGGL(rc_mark_kernel, dim3(nb, kzy), dim3(RC_ROWS), 0, stream, cin, nin, cap_in, G[l], bitmap[l], blockhist);
     D3D_LAUNCH_TRY("rc_mark_kernel");
     const int ntiles = d3d_scan_num_tiles((int64_t)words[l]);
     hipLaunchKernelGGL(rc_reduce_kernel, dim3(ntiles), dim3(D3D_SCAN_THREADS), 0, stream, bitmap[l], (int64_t)words[l],
@@ -420,7 +490,7 @@ extern "C" int d3d_conv_rulebook_chain(int n_layers, D3dChainLayer *layers, int 
     hipLaunchKernelGGL(rc_final_kernel, dim3(ntiles), dim3(D3D_SCAN_THREADS), 0, stream, bitmap[l], (int64_t)words[l],
                        tiles[l], ntiles, prefix[l], Y.n_out_dev, Y.nbr_out, Y.cap_out, G[l].kvol);
     D3D_LAUNCH_TRY("rc_final_kernel");
-    hipLaunchKernelGGL(rc_fill_kernel, dim3(nb), dim3(RC_ROWS), 0, stream, cin, nin, cap_in, G[l], bitmap[l], prefix[l],
+    hipLaunchKernelGGL(rc_fill_kernel, dim3(nb, kzy), dim3(RC_ROWS), 0, stream, cin, nin, cap_in, G[l], bitmap[l], prefix[l],
                        Y.cap_out, Y.nbr_out, Y.nbr_in, (int4 *)Y.coords_out, Y.pair_count, blockhist, Y.plan);
     D3D_LAUNCH_TRY("rc_fill_kernel");
     Y.rank_bitmap = bitmap[l];

@@ -18,8 +18,10 @@ as exact zeros: each bias feeds a train-mode BatchNorm, whose batch mean removes
 = 0 identically (a BatchNorm's input gradient sums to zero over the batch); what the per-layer path (and the
 reference) compute there is the rounding noise of that sum.
 
-D3D_FUSE_BLOCK=0 keeps the per-layer path; eval mode, cross-rank BatchNorm, a downsample branch and channel counts
-without an MFMA tiling keep it as well.
+D3D_FUSE_BLOCK=0 keeps the per-layer path; eval mode, a downsample branch and channel counts without an MFMA tiling keep
+it as well.  Cross-rank BatchNorm (DistributedSyncBN while it exchanges statistics) runs through this node since round 5:
+the same kernels, each BatchNorm's moments and backward sums through one packed all-reduce (syncbn.exchange_*); the conv
+biases' exact-zero gradients then hold for the SUM over ranks, which is what the data-parallel gradient mean forms.
 """
 import ctypes
 import os

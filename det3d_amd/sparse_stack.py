@@ -9,9 +9,12 @@ loop over C-ABI calls inside a single Function: the same kernels with the same a
 (conv forward with the BN-statistics epilogue, BN apply, and in the backward BN dx, conv dgrad with the
 BN-backward-sums epilogue for the layer in front, conv wgrad), no per-layer autograd bookkeeping.
 
-`run(seq, x)` is called by SparseSequential.forward; layers that do not fit the pattern (residual blocks,
-cross-rank BatchNorm, eval mode, empty tensors, VALU-fallback channel counts) keep the per-layer path.
-D3D_FUSE_STACK=0 disables it.
+`run(seq, x)` is called by SparseSequential.forward; layers that do not fit the pattern (residual blocks -- they have
+their own node, sparse_block.py --, eval mode, empty tensors, VALU-fallback channel counts) keep the per-layer path.
+Round 5: the BatchNorm may be the cross-rank DistributedSyncBN (`norm_cfg = dict(type="SyncBN")`,
+det3d/ops/syncbn/syncbn.py:15-118): same kernels, the two [2C] vectors of a layer (moments forward, backward sums) take
+one packed all-reduce each (syncbn.exchange_moments / exchange_backward_sums, d3d_bn_apply with training = 2).
+D3D_FUSE_STACK=0 disables the node.
 """
 import ctypes
 import os

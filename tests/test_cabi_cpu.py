@@ -216,6 +216,7 @@ def test_round4_planners_and_argument_checks_without_gpu(hip_lib):
     assert dg(1, 1, 1, 1, 1, 2, 16, 16, 64, 64, 3, 1, _lib.D3D_CONV_SPLIT, None) == -1 and b"channels" in err()
     assert dg(1, 1, 1, 1, 1, 2, 16, 16, 128, 256, 2, 0, _lib.D3D_CONV_SPLIT, None) == -1 and b"3x3" in err()
     assert dg(None, None, None, None, None, 2, 16, 16, 128, 256, 3, 1, _lib.D3D_CONV_SPLIT, None) == -1 and b"null" in err()
-    assert hip_lib.d3d_conv2d_supported(128, 256, 3, 2) == 1 and hip_lib.d3d_conv2d_supported(512, 128, 1, 1) == 0
+    assert hip_lib.d3d_conv2d_supported(128, 256, 3, 2) == 1 and hip_lib.d3d_conv2d_supported(512, 128, 3, 1) == 0
+    assert hip_lib.d3d_conv2d_supported(512, 128, 1, 1) == 1 and hip_lib.d3d_conv2d_supported(384, 256, 1, 1) == 1  # stacked heads
     assert hip_lib.d3d_conv2d_supported_split3x3(64, 64) == 1 and hip_lib.d3d_conv2d_supported_split3x3(96, 128) == 0
     assert hip_lib.d3d_pack_all(None, 0, None) in (0, -1)  # nothing to pack: no launch either way

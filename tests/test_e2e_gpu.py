@@ -497,9 +497,16 @@ def test_detector_matches_reference_detector_golden_fp32(name):
     # measured (profiles/round4_tests_figures.txt): HIP / f32-oracle ratios of the norm deviation 43 (KITTI SECOND: the
     # oracle's own 1.6e-4 is the smallest), 10, 4.6, 8.6; of the element deviation 26, 5.2, 4.7, 1.8; of 1 - cos 502,
     # 54, 56, 11 -- against the allowance of 2^7 (2^14 for 1 - cos)
-    K = 2.0 ** 7  # ratio of the unit roundoffs of the two product formats, see above
-    assert norm_hip <= K * dev_o32["norm"] and dev_hip["element"] <= K * dev_o32["element"]
-    assert dev_hip["one_minus_cos"] <= K * K * dev_o32["one_minus_cos"]  # 1 - cos is quadratic in the relative error
+    # Round 5: the allowance (2^7 / 2^14 x the oracle's own deviation) is replaced by what tests/test_precision_gpu.py
+    # DEMONSTRATES on the same cases with three legs: the exact-f32 HIP path (same model, same host code, every conv
+    # product one f32 fma) sits 0.8-2.6x the float32 oracle's distance from float64 -- so the distance of the split path
+    # is its product format, not the kernels' summation order -- and the split path sits at the values below (identical
+    # on every box and in rounds 4 and 5: every reduction is in a fixed order).  Bounds: 2x the measured values
+    # (norm of the gradient tensors | elements of the small ones | 1 - cos).
+    measured = {"kitti_second": (6.95e-3, 5.15e-2, 2.78e-4), "nusc_cbgs": (9.49e-3, 6.11e-2, 5.03e-4),
+                "lyft_cbgs": (1.68e-2, 6.79e-2, 9.70e-4), "nusc_pp": (7.59e-3, 8.95e-2, 2.82e-4)}[name]
+    assert norm_hip <= 2 * measured[0] and dev_hip["element"] <= 2 * measured[1]
+    assert dev_hip["one_minus_cos"] <= 2 * measured[2]
     worst_t, worst_n, worst_c = 0.0, 0.0, 0.0
     gmax = max(g["grad_norms"].values())
     for k, gn in g["grad_norms"].items():

@@ -64,10 +64,19 @@ def _detector_legs(name):
 # measured on MI355X (profiles/round5_precision_figures.txt), per case: the bounds below are <= 2x these
 #   exact-f32 HIP / f32 oracle, distance from float64:  norm, element, 1 - cos
 #   split HIP / exact-f32 HIP, distance from float64:   norm, element, 1 - cos
-EXACT_VS_ORACLE_BOUND = 4.0     # the exact-f32 HIP leg is in the float32 oracle's class: within 4x of its own f64 distance
-# worst per-tensor relative L2 and 1 - cos between the split and the exact-f32 gradients (measured: lyft_cbgs 4.9e-2 / 1.1e-3)
-SPLIT_VS_EXACT_BOUND = {"kitti_second": (1e-1, 2.5e-3), "nusc_cbgs": (1e-1, 2.5e-3), "lyft_cbgs": (1e-1, 2.5e-3),
-                        "nusc_pp": (1e-1, 2.5e-3)}
+#   kitti_second   f32 oracle 1.6e-4 2.0e-3 5.6e-7 | HIP exact-f32 2.5e-4 2.0e-3 6.9e-7 | HIP split 7.0e-3 5.2e-2 2.8e-4
+#   nusc_cbgs                 1.1e-3 1.1e-2 8.9e-6 |               1.7e-3 1.0e-2 1.0e-5 |           9.5e-3 6.1e-2 5.0e-4
+#   lyft_cbgs                 3.5e-3 1.4e-2 1.7e-5 |      4.2..8.8e-3 3.1e-2 0.8..1.7e-4 |           1.7e-2 6.8e-2 9.7e-4
+#   nusc_pp                   4.8e-4 2.1e-2 1.4e-5 |               3.9e-4 2.1e-2 1.2e-5 |           7.6e-3 9.0e-2 2.8e-4
+# (lyft's exact leg moves from run to run: its strided / transposed neck convolutions are MIOpen's f32 kernels)
+# => the exact-f32 HIP leg is in the float32 oracle's class: norms and elements within 0.8-2.6x of the oracle's own distance
+#    from float64, 1 - cos within 0.9-9.7x; the split leg sits 4-28x (norms), 2-26x (elements), 6-400x (1 - cos) beyond it.
+EXACT_VS_ORACLE_BOUND = 5.0       # norms, elements (2x the largest measured ratio)
+EXACT_VS_ORACLE_COS_BOUND = 20.0  # 1 - cos
+# worst per-tensor relative L2 and 1 - cos between the split and the exact-f32 gradients: 2x the measured values
+# (2.4e-2 / 2.8e-4, 3.2e-2 / 4.9e-4, 5.2e-2 / 1.3e-3, 2.4e-2 / 2.8e-4)
+SPLIT_VS_EXACT_BOUND = {"kitti_second": (4.8e-2, 5.6e-4), "nusc_cbgs": (6.4e-2, 1.0e-3), "lyft_cbgs": (1.05e-1, 2.7e-3),
+                        "nusc_pp": (4.8e-2, 5.6e-4)}
 
 
 @pytest.mark.parametrize("name", ["kitti_second", "nusc_cbgs", "lyft_cbgs", "nusc_pp"])
@@ -82,8 +91,9 @@ def test_split_against_exact_f32_on_the_detector_goldens(name):
     fwd = max(float((a[k] - b[k]).abs().max()) for a, b in zip(p_s, p_e) for k in a)
     ref = max(float((a[k][:, ::2, 1::2] - gp[k]).abs().max()) for a, gp in zip(p_e, g["preds"]) for k in gp)
     print("%s: forward split vs exact-f32 %.2e, exact-f32 vs reference golden %.2e (prediction scale %.2f)" % (name, fwd, ref, scale))
-    assert fwd <= 1e-4 * max(scale, 1.0)
-    assert ref <= 1e-4 * max(scale, 1.0)  # exact f32 on the GPU == the reference's f32 to summation order
+    # measured: split vs exact 1.6e-5 .. 2.9e-5 of the prediction scale, exact vs the reference golden 2e-6
+    assert fwd <= 6e-5 * max(scale, 1.0)
+    assert ref <= 1e-5 * max(scale, 1.0)  # exact f32 on the GPU == the reference's f32 to summation order
     for a, b, c in zip(l_s, l_e, g["loss"]):
         assert a == pytest.approx(b, rel=2e-4) and b == pytest.approx(float(c), rel=5e-5)
     # ---- gradients: every leg against the float64 oracle
@@ -106,43 +116,66 @@ def test_split_against_exact_f32_on_the_detector_goldens(name):
     # the exact-f32 HIP leg is a float32 evaluation like the oracle: same class of distance from float64
     assert dev_e["norm"] <= EXACT_VS_ORACLE_BOUND * dev_o["norm"] + 1e-6
     assert dev_e["element"] <= EXACT_VS_ORACLE_BOUND * dev_o["element"] + 1e-6
-    assert dev_e["one_minus_cos"] <= EXACT_VS_ORACLE_BOUND ** 2 * dev_o["one_minus_cos"] + 1e-9
+    assert dev_e["one_minus_cos"] <= EXACT_VS_ORACLE_COS_BOUND * dev_o["one_minus_cos"] + 1e-9
     # split vs exact on the same GPU, tensor by tensor (the ReLU gates that flip at 2^-16 move single elements by O(1);
     # whole tensors stay put): bounds = 2x the measured values per case
     bl2, bcos = SPLIT_VS_EXACT_BOUND[name]
     assert l2 <= bl2 and cos <= bcos
 
 
-def _train_leg(exact, steps):
+def _train_leg(exact, steps, eps=0.0, unfused=False):
+    """one training run of tests/golden/train_run_spec.py on the GPU.  exact: precision.exact_f32(); eps: the initial
+    weights multiplied by (1 + eps) -- the sensitivity probe; unfused: the per-layer sparse path instead of the fused stack"""
     import train_run_spec as T
-    from det3d_amd import build_detector, synthetic
+    from det3d_amd import build_detector, sparse_block, sparse_stack, synthetic
 
     cfg = T.config()
     ds = T.dataset()
     dev = torch.device("cuda")
-    with _mode(exact):
-        model = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg)
-        model.load_state_dict(T.initial_state(cfg))
-        model = model.to(dev).train()
-        step = T.train_step_for(model, cfg)
-        batches = [synthetic.make_example(ds.device_batch(i, T.BATCH, dev), synthetic.KITTI_CAR) for i in range(T.N_BATCHES)]
-        losses = []
-        for i in range(steps):
-            losses.append(step(batches[i % T.N_BATCHES]))
-        losses = [float(l) for l in torch.stack(losses).cpu()]
-        model.eval()
-        with torch.no_grad():
-            ex = synthetic.make_example(ds.device_batch(T.HELD_OUT, T.BATCH, dev), synthetic.KITTI_CAR)
-            data = dict(features=ex["voxel_mean"], num_voxels=ex["num_points"], coors=ex["coordinates"],
-                        batch_size=T.BATCH, input_shape=ex["shape"][0])
-            preds = T.subsample(model.bbox_head(model.extract_feat(data))[0])
+    saved = (sparse_stack.FUSE_STACK, sparse_block.FUSE_BLOCK)
+    try:
+        if unfused:
+            sparse_stack.FUSE_STACK = sparse_block.FUSE_BLOCK = False
+        with _mode(exact):
+            model = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg)
+            model.load_state_dict(T.initial_state(cfg))
+            if eps:
+                with torch.no_grad():
+                    for p in model.parameters():
+                        p.mul_(1.0 + eps)
+            model = model.to(dev).train()
+            step = T.train_step_for(model, cfg)
+            batches = [synthetic.make_example(ds.device_batch(i, T.BATCH, dev), synthetic.KITTI_CAR) for i in range(T.N_BATCHES)]
+            losses = []
+            for i in range(steps):
+                losses.append(step(batches[i % T.N_BATCHES]))
+            losses = [float(l) for l in torch.stack(losses).cpu()]
+            model.eval()
+            with torch.no_grad():
+                ex = synthetic.make_example(ds.device_batch(T.HELD_OUT, T.BATCH, dev), synthetic.KITTI_CAR)
+                data = dict(features=ex["voxel_mean"], num_voxels=ex["num_points"], coors=ex["coordinates"],
+                            batch_size=T.BATCH, input_shape=ex["shape"][0])
+                preds = T.subsample(model.bbox_head(model.extract_feat(data))[0])
+    finally:
+        sparse_stack.FUSE_STACK, sparse_block.FUSE_BLOCK = saved
     return np.array(losses), preds
 
 
 def test_300_training_steps_split_vs_exact_f32_vs_cpu_oracle():
-    """same seed, same batches, same schedule in three arithmetics.  A training run is a chaotic map: two float32
-    evaluations that differ only in summation order (HIP exact-f32 vs the CPU oracle) drift apart, so that drift is the
-    yardstick -- split arithmetic must not drift from exact f32 by more than a small multiple of it."""
+    """Same seed, same batches, same schedule (tests/golden/train_run_spec.py: KITTI SECOND, 2 x 6000 points, the
+    config's one-cycle Adam over 300 steps, loss 244 -> 0.2-0.6) in five legs: HIP split, HIP exact f32, each of them
+    again from initial weights multiplied by (1 + 1e-6), and the committed CPU-oracle curve.
+
+    What the legs show (profiles/round5_train_legs.json, tools/train_legs.py): the run is a CHAOTIC map.  A 1e-6
+    perturbation of the initial weights moves the loss of step 10 by 3 % and the mean loss of the last 20 steps by a factor of
+    two (split: 0.56 vs 0.24; exact f32: 0.30 vs 0.30 vs the CPU oracle's 0.35), and the raw predictions on a held-out
+    frame differ by half their scale between ANY two legs, the two exact-f32 ones (HIP vs CPU) included -- so "final
+    predictions within 1e-3" is not a property any pair of float32 implementations has here, and the comparison has to be
+    statistical: the split legs must (a) follow the oracle to the precision of the product format while the trajectories
+    are still together (the first steps), (b) train as far as the exact ones (final loss inside the band the exact legs
+    span, widened by 2), (c) differ from the exact legs no more than the exact legs differ among themselves or a split
+    leg from its own perturbed twin.  Independently of chaos, (d) the fused sparse stack is the per-layer path BIT for
+    BIT over 60 optimizer steps."""
     import train_run_spec as T
 
     path = os.path.join(GOLDEN, "train_curve_f32.pt")
@@ -151,31 +184,41 @@ def test_300_training_steps_split_vs_exact_f32_vs_cpu_oracle():
     cpu = torch.load(path, weights_only=False)
     steps = cpu["steps"]
     assert steps == T.STEPS
-    l_cpu = np.array(cpu["losses"])
-    l_s, p_s = _train_leg(False, steps)
-    l_e, p_e = _train_leg(True, steps)
-    assert np.isfinite(l_s).all() and np.isfinite(l_e).all()
-    assert l_s[-1] < 0.05 * l_s[0] and l_e[-1] < 0.05 * l_e[0]  # all three actually train (loss 240 -> ~1)
+    legs = {"cpu_oracle": (np.array(cpu["losses"]), cpu["held_out_preds"]),
+            "split": _train_leg(False, steps), "split_eps": _train_leg(False, steps, eps=1e-6),
+            "exact": _train_leg(True, steps), "exact_eps": _train_leg(True, steps, eps=1e-6)}
+    last = {k: float(v[0][-20:].mean()) for k, v in legs.items()}
+    for k, (l, _) in legs.items():
+        assert np.isfinite(l).all() and last[k] < 0.01 * l[0], (k, last[k])  # every leg trains: 244 -> below 2.4
     rel = lambda a, b: np.abs(a - b) / np.maximum(np.abs(b), 1e-3)
-
-    def summary(a, b):
-        r = rel(a, b)
-        return dict(first10=float(r[:10].max()), median=float(np.median(r)), p90=float(np.quantile(r, 0.9)), last20=float(r[-20:].mean()))
-
-    se, ec, sc = summary(l_s, l_e), summary(l_e, l_cpu), summary(l_s, l_cpu)
     dp = lambda a, b: max(float((a[k] - b[k]).abs().max()) for k in a)
-    scale = max(float(v.abs().max()) for v in p_e.values())
-    d_se, d_ec, d_sc = dp(p_s, p_e), dp(p_e, cpu["held_out_preds"]), dp(p_s, cpu["held_out_preds"])
-    print("300 steps, loss %.2f -> split %.4f | exact-f32 %.4f | cpu oracle %.4f" % (l_cpu[0], l_s[-1], l_e[-1], l_cpu[-1]))
-    print("relative loss difference (first 10 steps max | median | p90 | mean of last 20): split vs exact %s ; exact vs cpu "
-          "oracle %s ; split vs cpu oracle %s" % (se, ec, sc))
-    print("held-out raw predictions after 300 steps, max abs difference (scale %.2f): split vs exact %.3e ; exact vs cpu "
-          "oracle %.3e ; split vs cpu oracle %.3e" % (scale, d_se, d_ec, d_sc))
-    # the first steps, before the trajectories have had time to separate: product-format error only
-    assert se["first10"] <= 2e-3 and ec["first10"] <= 2e-3
-    # over the run: split-vs-exact stays within 3x the drift of the two exact-f32 legs (+ a floor of 1e-3 relative)
-    assert se["median"] <= 3.0 * ec["median"] + 1e-3
-    assert se["p90"] <= 3.0 * ec["p90"] + 1e-3
-    assert se["last20"] <= 3.0 * ec["last20"] + 1e-3
-    # final predictions on a frame none of the runs trained on
-    assert d_se <= 3.0 * d_ec + 1e-3 * max(scale, 1.0)
+    scale = max(float(v.abs().max()) for v in legs["exact"][1].values())
+    pairs = [("split", "exact"), ("split", "cpu_oracle"), ("exact", "cpu_oracle"), ("split", "split_eps"), ("exact", "exact_eps")]
+    early = {p: float(rel(legs[p[0]][0][:3], legs[p[1]][0][:3]).max()) for p in pairs}
+    med = {p: float(np.median(rel(legs[p[0]][0], legs[p[1]][0]))) for p in pairs}
+    pred = {p: dp(legs[p[0]][1], legs[p[1]][1]) for p in pairs}
+    print("300 steps, loss %.2f -> mean of the last 20: %s" % (legs["split"][0][0], {k: round(v, 4) for k, v in last.items()}))
+    print("relative loss difference, first 3 steps max: %s" % {"%s vs %s" % p: "%.2e" % v for p, v in early.items()})
+    print("relative loss difference, median over the run: %s" % {"%s vs %s" % p: "%.3f" % v for p, v in med.items()})
+    print("held-out raw predictions after 300 steps, max abs difference (scale %.2f): %s" % (
+        scale, {"%s vs %s" % p: "%.2f" % v for p, v in pred.items()}))
+    # (a) while the trajectories are together.  Step 0 sees identical weights (loss equal to 1e-6), step 1 the weights after
+    #     ONE Adam update from each leg's gradients (measured: split 3e-4, exact 6e-5 from the oracle), step 2 after two
+    #     (split 5e-3, exact 3e-4: Adam's first updates are sign-like, a gradient element that is 1 % off near zero moves its
+    #     weight by the full learning rate) -- bounds 2-3x the measured values
+    first2 = {p: float(rel(legs[p[0]][0][:2], legs[p[1]][0][:2]).max()) for p in pairs}
+    assert first2[("split", "cpu_oracle")] <= 1e-3 and first2[("exact", "cpu_oracle")] <= 2e-4, first2
+    assert early[("split", "exact")] <= 1e-2 and early[("split", "cpu_oracle")] <= 1e-2 and early[("exact", "cpu_oracle")] <= 1e-3
+    # (b) where the runs end: the exact-f32 legs span [lo, hi]; the split legs end inside [lo / 2, 2 hi]
+    lo = min(last["exact"], last["exact_eps"], last["cpu_oracle"])
+    hi = max(last["exact"], last["exact_eps"], last["cpu_oracle"])
+    assert lo / 2 <= last["split"] <= 2 * hi and lo / 2 <= last["split_eps"] <= 2 * hi, (last, lo, hi)
+    # (c) split differs from exact no more than twice what a leg differs from its own 1e-6-perturbed twin / the two exact
+    #     implementations differ from each other
+    yard = max(med[("split", "split_eps")], med[("exact", "exact_eps")], med[("exact", "cpu_oracle")])
+    assert med[("split", "exact")] <= 2.0 * yard + 1e-2, (med, yard)
+    yard_p = max(pred[("split", "split_eps")], pred[("exact", "exact_eps")], pred[("exact", "cpu_oracle")])
+    assert pred[("split", "exact")] <= 2.0 * yard_p + 1e-3 * scale, (pred, yard_p)
+    # (d) fused sparse stack == per-layer path, bit for bit, over 60 optimizer steps
+    l_unfused, _ = _train_leg(False, 60, unfused=True)
+    assert np.array_equal(l_unfused, legs["split"][0][:60])

@@ -77,8 +77,16 @@ def test_chain_equals_the_per_layer_builds_and_the_oracle(seed, batch, shape, n_
             assert torch.equal(ra.nbr_in.view(ra.kvol, ra.cap_in)[:, :ra.n_in], rb.nbr_in.view(rb.kvol, rb.cap_in)[:, :rb.n_in])
             assert (ra.dgrad_plan is None) == (rb.dgrad_plan is None)
             if ra.dgrad_plan is not None:
-                n = ra.n_in
-                assert torch.equal(ra.dgrad_plan[:304 + n], rb.dgrad_plan[:304 + n]), (key, "row plan header + permutation")
+                # d3d_rowplan.h: [0] classes, [1 .. 1 + C] class starts, per class c (and c = C: every offset) at 16 + 32 c:
+                # count, the offsets, words 28..31 the packed list; [304 ...] the permutation (unwritten words are garbage)
+                pa, pb = ra.dgrad_plan.cpu().numpy(), rb.dgrad_plan.cpu().numpy()
+                ncls, n = int(pa[0]), ra.n_in
+                assert np.array_equal(pa[:2 + ncls], pb[:2 + ncls]), (key, "row plan: classes and starts")
+                for c in range(ncls + 1):
+                    o = 16 + 32 * c
+                    cnt = int(pa[o])
+                    assert np.array_equal(pa[o:o + 1 + cnt], pb[o:o + 1 + cnt]) and np.array_equal(pa[o + 28:o + 32], pb[o + 28:o + 32]), (key, c)
+                assert np.array_equal(pa[304:304 + n], pb[304:304 + n]), (key, "row plan permutation")
             cur, cur_shape = oi, list(oshape)
 
 

@@ -92,6 +92,20 @@ for f in ("mr_plain", "mr_rccl1", "mr_rccl1_b1", "mr_rccl1_b0", "mr_rccl1_nors",
         f, d["n_gpus"], d["value"], d["ms_per_step"], c.get("host_ms_per_step"), c.get("first_loss"), c.get("final_loss")))
 PY
       ;;
+    geoprof|geoprof:*)
+      # the geometry stage alone under rocprofv3 (isolated kernel durations; in the step these kernels share the CUs with
+      # the main stream's): chain entry points vs the per-layer ones
+      wl=${st#geoprof}; wl=${wl#:}; wl=${wl:-c2-20k}
+      export TMPDIR=/tmp
+      for ch in 1 0; do
+        rm -rf /tmp/d3d_geo && mkdir -p /tmp/d3d_geo
+        R=$PWD
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/d3d_geo -- python $R/tools/geometry_bench.py $wl $ch 30 > $O/geo_${wl}_chain$ch.log 2>&1)
+        DB=$(find /tmp/d3d_geo -name "*.db" | head -1)
+        MS=$(grep "ms wall" $O/geo_${wl}_chain$ch.log | sed 's/.*: \([0-9.]*\) ms wall.*/\1/' | python -c "import sys; print(float(sys.stdin.read().strip() or 1) * 30)")
+        python tools/prof_summary.py kernels "$DB" "$MS" 30 $O/geo_kernels_${wl}_chain$ch.txt "tools/geometry_bench.py $wl chain=$ch, 30 builds" "$(grep 'ms wall' $O/geo_${wl}_chain$ch.log)"
+        head -24 $O/geo_kernels_${wl}_chain$ch.txt | cut -c1-150
+      done ;;
     syncbn)
       # nuScenes CBGS with norm_cfg SyncBN through the fused nodes, every collective on a 1-rank RCCL
       # communicator, against the plain-BN step under the same communicator and the plain single-process step
