@@ -55,10 +55,13 @@ int g_xcd_remap = getenv("D3D_XCD_REMAP") ? atoi(getenv("D3D_XCD_REMAP")) : 0;
 // d3d_sparse_conv_dgrad_plan_supported then answer 0 for f32, the packers write plain f32 copies, the host side keeps
 // the per-layer path.  10-50x slower: for "split vs exact f32" comparisons, not for use.
 int g_sp_exact_f32 = getenv("D3D_SPCONV_EXACT_F32") ? atoi(getenv("D3D_SPCONV_EXACT_F32")) : 0;
+// knob 11: chunk-resident-weights forward kernel for f32 features (spconv_fwd_resident_kernel).  -1 = the measured
+// default per channel pair (FWD_RESIDENT_DEFAULT below), 0 = off (spconv_fwd_mfma_kernel everywhere), 1..3 = tiling set
+int g_fwd_resident = getenv("D3D_FWD_RESIDENT") ? atoi(getenv("D3D_FWD_RESIDENT")) : -1;
 extern int g_bn_variant, g_bn_skip_global, g_bn_dx_rows, g_bn_stream_blocks;  // d3d_bn.hip
 extern int g_c2_variant, g_c2_wgrad_waves, g_c2_tail;  // d3d_conv2d.hip
 extern "C" int d3d_set_tuning(int knob, int value) {
-  D3D_REQUIRE(knob >= 0 && knob <= 10, "d3d_set_tuning: unknown knob %d (10 = exact-f32 sparse kernels for f32 features (test knob), 9 = cut the last partial round of the dense 3x3 kernel into 32-channel blocks, 8 = waves of the dense weight-gradient kernel, 7 = dense conv tiling variant, 0 = forward 64->64 tiling variant, "
+  D3D_REQUIRE(knob >= 0 && knob <= 11, "d3d_set_tuning: unknown knob %d (11 = chunk-resident-weights f32 forward kernel: -1 default, 0 off, 1..3 tiling set, 10 = exact-f32 sparse kernels for f32 features (test knob), 9 = cut the last partial round of the dense 3x3 kernel into 32-channel blocks, 8 = waves of the dense weight-gradient kernel, 7 = dense conv tiling variant, 0 = forward 64->64 tiling variant, "
               "1 = target block count of the weight-gradient kernel, 2 = XCD-aware tile order on/off, 3 = BatchNorm "
               "reduction variant for large inputs, 4 = skip the BatchNorm global atomics (timing diagnosis), 5 = rows "
               "in flight in bn_bwd_dx, 6 = grid cap of the BatchNorm streaming sweeps)", knob);
@@ -72,7 +75,8 @@ extern "C" int d3d_set_tuning(int knob, int value) {
   else if (knob == 7) g_c2_variant = value;
   else if (knob == 8) g_c2_wgrad_waves = value;
   else if (knob == 9) g_c2_tail = value;
-  else g_sp_exact_f32 = value;
+  else if (knob == 10) g_sp_exact_f32 = value;
+  else g_fwd_resident = value;
   return D3D_OK;
 }
 
@@ -140,21 +144,14 @@ __device__ __forceinline__ void spconv_fwd_epilogue(f32x4_t (&acc)[MT][COUT / 16
   constexpr int NW = NTHREADS / 64;
   const bool want_stats = ep.stats != nullptr, want_bnb = ep.bn_partial != nullptr;
   const int wave = threadIdx.x >> 6;
-  if (want_stats || want_bnb) __syncthreads();  // `red` may alias LDS other waves were still reading
+  // Three passes over the accumulators (round 5; the arithmetic and its order are those of the one-pass version, results
+  // are bit-identical): (1) finish the values -- bias, addend, rounding to the feature dtype -- in place; (2) the
+  // reductions and their cross-block hand-off; (3) the row stores.  The hand-off (d3d_fold.h) waits vmcnt(0) before it
+  // draws its ticket: behind the stores that wait covered the drain of the block's whole output tile, now it sees the
+  // slab stores only and the ticket round trip overlaps the drain instead of following it.
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int co = n * 16 + lg * 4;
-    float r0[4] = {0.f, 0.f, 0.f, 0.f}, r1[4] = {0.f, 0.f, 0.f, 0.f};
-    float bmu[4], bis[4], bga[4], bbe[4];
-    if (want_bnb) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        bmu[j] = ep.bn_mean[co + j];
-        bis[j] = ep.bn_invstd[co + j];
-        bga[j] = ep.bn_gamma ? ep.bn_gamma[co + j] : 1.f;
-        bbe[j] = ep.bn_beta ? ep.bn_beta[co + j] : 0.f;
-      }
-    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       if (!live[m]) continue;
@@ -175,47 +172,59 @@ __device__ __forceinline__ void spconv_fwd_epilogue(f32x4_t (&acc)[MT][COUT / 16
           v[0] += ar.x; v[1] += ar.y; v[2] += ar.z; v[3] += ar.w;
         }
       }
-      float w[4];  // the values as stored (rounded to the feature dtype): what the next pass will read
-      if constexpr (BF16) {
-        uint16_t *o = (uint16_t *)out_ + (int64_t)site[m] * COUT + co;
-        const uint16_t h0 = f32_to_bf16(v[0]), h1 = f32_to_bf16(v[1]), h2 = f32_to_bf16(v[2]), h3 = f32_to_bf16(v[3]);
-        uint2 pk;
-        pk.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
-        pk.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
-        *(uint2 *)o = pk;
-        w[0] = bf16_to_f32(h0); w[1] = bf16_to_f32(h1); w[2] = bf16_to_f32(h2); w[3] = bf16_to_f32(h3);
-      } else {
-        float *o = (float *)out_ + (int64_t)site[m] * COUT + co;
-        *(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);
-        w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3];
+      if constexpr (BF16) {  // the values as stored: what the next pass will read (and what the sums are taken over)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = bf16_to_f32(f32_to_bf16(v[j]));
       }
-      if (want_stats) {
+      acc[m][n] = v;
+    }
+  }
+  if (want_stats || want_bnb) {
+    __syncthreads();  // `red` may alias LDS other waves were still reading
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int co = n * 16 + lg * 4;
+      float r0[4] = {0.f, 0.f, 0.f, 0.f}, r1[4] = {0.f, 0.f, 0.f, 0.f};
+      float bmu[4], bis[4], bga[4], bbe[4];
+      if (want_bnb) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          r0[j] += w[j];
-          r1[j] = fmaf(w[j], w[j], r1[j]);
+          bmu[j] = ep.bn_mean[co + j];
+          bis[j] = ep.bn_invstd[co + j];
+          bga[j] = ep.bn_gamma ? ep.bn_gamma[co + j] : 1.f;
+          bbe[j] = ep.bn_beta ? ep.bn_beta[co + j] : 0.f;
         }
       }
-      if (want_bnb) {
-        float x[4];
-        if constexpr (BF16) {
-          const uint2 xr = *(const uint2 *)((const uint16_t *)ep.bn_x + (int64_t)site[m] * COUT + co);
-          x[0] = bf16_to_f32((uint16_t)(xr.x & 0xffffu)); x[1] = bf16_to_f32((uint16_t)(xr.x >> 16));
-          x[2] = bf16_to_f32((uint16_t)(xr.y & 0xffffu)); x[3] = bf16_to_f32((uint16_t)(xr.y >> 16));
-        } else {
-          const float4 xr = *(const float4 *)((const float *)ep.bn_x + (int64_t)site[m] * COUT + co);
-          x[0] = xr.x; x[1] = xr.y; x[2] = xr.z; x[3] = xr.w;
-        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {  // same arithmetic as bn_bwd_reduce_kernel (d3d_bn.hip)
-          const float xh = (x[j] - bmu[j]) * bis[j];
-          const float dz = (ep.bn_relu && fmaf(xh, bga[j], bbe[j]) <= 0.f) ? 0.f : w[j];
-          r0[j] = fmaf(dz, xh, r0[j]);
-          r1[j] += dz;
+      for (int m = 0; m < MT; ++m) {
+        if (!live[m]) continue;
+        const f32x4_t w = acc[m][n];
+        if (want_stats) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            r0[j] += w[j];
+            r1[j] = fmaf(w[j], w[j], r1[j]);
+          }
+        }
+        if (want_bnb) {
+          float x[4];
+          if constexpr (BF16) {
+            const uint2 xr = *(const uint2 *)((const uint16_t *)ep.bn_x + (int64_t)site[m] * COUT + co);
+            x[0] = bf16_to_f32((uint16_t)(xr.x & 0xffffu)); x[1] = bf16_to_f32((uint16_t)(xr.x >> 16));
+            x[2] = bf16_to_f32((uint16_t)(xr.y & 0xffffu)); x[3] = bf16_to_f32((uint16_t)(xr.y >> 16));
+          } else {
+            const float4 xr = *(const float4 *)((const float *)ep.bn_x + (int64_t)site[m] * COUT + co);
+            x[0] = xr.x; x[1] = xr.y; x[2] = xr.z; x[3] = xr.w;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {  // same arithmetic as bn_bwd_reduce_kernel (d3d_bn.hip)
+            const float xh = (x[j] - bmu[j]) * bis[j];
+            const float dz = (ep.bn_relu && fmaf(xh, bga[j], bbe[j]) <= 0.f) ? 0.f : w[j];
+            r0[j] = fmaf(dz, xh, r0[j]);
+            r1[j] += dz;
+          }
         }
       }
-    }
-    if (want_stats || want_bnb) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float a0 = r0[j], a1 = r1[j];
@@ -230,8 +239,6 @@ __device__ __forceinline__ void spconv_fwd_epilogue(f32x4_t (&acc)[MT][COUT / 16
         }
       }
     }
-  }
-  if (want_stats || want_bnb) {
     __syncthreads();
     float *tot = red + NW * 2 * COUT;
     for (int i = threadIdx.x; i < 2 * COUT; i += NTHREADS) {
@@ -244,6 +251,23 @@ __device__ __forceinline__ void spconv_fwd_epilogue(f32x4_t (&acc)[MT][COUT / 16
     // (sum | sum sq) or (dgamma | dbeta): this block's slab, folded across blocks in a fixed order
     d3d_fold_block<NTHREADS>(tot, 2 * COUT, want_stats ? ep.stats : ep.bn_partial, ep.counters, ep.fold_g,
                              (int *)(tot + 2 * COUT));
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int co = n * 16 + lg * 4;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (!live[m]) continue;
+      const f32x4_t v = acc[m][n];
+      if constexpr (BF16) {
+        uint2 pk;
+        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        *(uint2 *)((uint16_t *)out_ + (int64_t)site[m] * COUT + co) = pk;
+      } else {
+        *(float4 *)((float *)out_ + (int64_t)site[m] * COUT + co) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
   }
 }
 
@@ -662,6 +686,198 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)  // second value: waves per 
     }
   }
   spconv_fwd_epilogue<COUT, MT, true, NTHREADS>(acc, site, live, bias, out_, ep, red, lr, lg);
+}
+
+// ---- chunk-resident weights, f32 features in split arithmetic (round 5) --------------------------------------
+// spconv_fwd_mfma_kernel exchanges W[k] through LDS once per kernel offset: 27 workgroup rendezvous per block.  On the
+// 16 / 32-channel layers a stage is 6-12 MFMAs per wave, so the launch is the latency of 27 barrier-separated stages
+// (`<16,16>` 0.07, `<32,32>` 0.16-0.22 of the algorithmic roofline: VERDICT round 4 item 4).  Here KC weight matrices
+// (both bf16 planes, the padded rows of the kernel above) sit in LDS at a time -- all 27 where they fit -- fenced by
+// one barrier pair per chunk; between the fences every wave walks its offsets at its own pace with its gathers
+// DEPTH offsets ahead.  Tile shapes, the order of a row's products (offset, k-step, hi*hi / hi*lo / lo*hi) and the
+// epilogue are those of spconv_fwd_mfma_kernel: the produced rows are bit-identical (the statistics too where the
+// block shape is the same).  No row plan (the strided layers' data gradients stay on the kernel above).
+template <int CIN, int COUT, int MT, int WAVES, int DEPTH, int KC>
+__global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
+    spconv_fwd_resident_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
+                               const float *__restrict__ bias, const int32_t *__restrict__ nbr, int cap, int n_out,
+                               int kvol, void *__restrict__ out_, ConvEpiDev ep) {
+  constexpr int NT = COUT / 16;
+  constexpr int ESZ = 4;                          // f32 features
+  constexpr int KW = (CIN % 32 == 0) ? 32 : 16;   // channels per k-step
+  constexpr int KS = CIN / KW;
+  constexpr int EPL = KW / 4;                     // elements per lane per step (8 | 4)
+  // LDS row of one bf16 plane: padded by 16 B as in the kernel above, or -- 64 input channels, where nine padded
+  // matrices would not fit -- 128 B unpadded with the 16-byte cell c of row r at cell c ^ ((r >> 1) & 7): the 16 lanes
+  // ds_read_b128 serves per cycle ({lr 0-3, 12-15} of one k-group with {lr 4-11} of the next) then hit 16 distinct cells
+  constexpr bool SWZ = CIN == 64;
+  constexpr int ROWB = SWZ ? CIN * 2 : CIN * 2 + 16;
+  constexpr int WBYTES = 2 * COUT * ROWB;         // one offset: hi plane rows, then lo plane rows
+  constexpr int NTHREADS = WAVES * 64;
+  constexpr int SEGS = CIN * 2 / 16;              // 16-byte vectors per weight row
+  constexpr int WVEC = 2 * COUT * SEGS;           // vectors per offset in global memory
+  constexpr int CHUNKV = KC * WVEC;
+  constexpr int GPW = (CHUNKV + NTHREADS - 1) / NTHREADS;
+  static_assert(KC % DEPTH == 0, "chunk / pipeline shape");
+  static_assert((SEGS & (SEGS - 1)) == 0 && (WVEC & (WVEC - 1)) == 0, "vector -> (offset, row, segment) by shifts");
+  static_assert(KC * WBYTES >= 4 * SPCONV_EPI_LDS_FLOATS(COUT, NTHREADS), "epilogue scratch aliases the W chunk");
+  extern __shared__ __attribute__((aligned(16))) unsigned char rwlds[];  // KC * WBYTES
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int row0 = (blockIdx.x * WAVES + wave) * (MT * 16);
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  int site[MT];
+  bool live[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    site[m] = row0 + m * 16 + lr;
+    live[m] = site[m] < n_out;
+  }
+  struct Frag32 { uint4 a, b; };
+  using FragT = typename std::conditional<KW == 16, uint4, Frag32>::type;  // 4 | 8 f32 of a gathered row
+  using OpT = typename std::conditional<KW == 16, uint2, uint4>::type;     // 4 | 8 bf16: one MFMA operand
+  const __amdgpu_buffer_rsrc_t feat_rs = d3d_make_rsrc(feat_);
+  const uint32_t lane_off = (uint32_t)(lg * EPL * ESZ);
+  const int kmax = kvol - 1;
+  auto load_idx = [&](int k, int (&ix)[MT]) {
+    k = k < kmax ? k : kmax;
+    const int32_t *nk = nbr + (int64_t)k * cap;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ix[m] = nk[(uint32_t)(live[m] ? site[m] : n_out - 1)];
+  };
+  auto gather = [&](const int (&ix)[MT], FragT (&f)[MT][KS]) -> unsigned long long {
+    bool any = false;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const bool ok = live[m] && ix[m] >= 0;
+      any |= ok;
+      const uint32_t base = ok ? (uint32_t)ix[m] * (uint32_t)(CIN * ESZ) + lane_off : D3D_OOB_OFFSET;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const uint32_t off = ok ? base + (uint32_t)(ks * KW * ESZ) : D3D_OOB_OFFSET;
+        if constexpr (KW == 32) {
+          f[m][ks].a = d3d_buffer_load16(feat_rs, off);
+          f[m][ks].b = d3d_buffer_load16(feat_rs, ok ? off + 16u : D3D_OOB_OFFSET);
+        } else {
+          f[m][ks] = d3d_buffer_load16(feat_rs, off);
+        }
+      }
+    }
+    return __ballot(any);
+  };
+  const unsigned char *wg = (const unsigned char *)wpack_;
+  const uint32_t wcells = (uint32_t)kvol * WVEC;
+  // W[k0 .. k0 + KC) -> LDS through registers, SUB loads in flight per thread (an LDS-DMA in flight would make hipcc
+  // wait vmcnt(0) before every use of a gathered row: see spconv_fwd_chunk_kernel)
+  auto load_chunk = [&](int k0) {
+    constexpr int SUB = GPW < 4 ? GPW : 4;
+#pragma unroll
+    for (int j0 = 0; j0 < GPW; j0 += SUB) {
+      d3d_u32x4 w[SUB];
+#pragma unroll
+      for (int u = 0; u < SUB; ++u) {
+        if (j0 + u >= GPW) continue;
+        uint32_t g = (uint32_t)k0 * WVEC + (uint32_t)((j0 + u) * NTHREADS) + threadIdx.x;
+        g = g < wcells ? g : wcells - 1;  // offsets past the last one (kvol < KC): never read
+        w[u] = *(const d3d_u32x4 *)(wg + (size_t)g * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < SUB; ++u) {
+        if (j0 + u >= GPW) continue;
+        const uint32_t e = (uint32_t)((j0 + u) * NTHREADS) + threadIdx.x;
+        const uint32_t kk = e / WVEC, r = e % WVEC;
+        if (CHUNKV % NTHREADS == 0 || e < (uint32_t)CHUNKV)
+          *(d3d_u32x4 *)(rwlds + kk * WBYTES + (r / SEGS) * ROWB + (((r % SEGS) ^ (SWZ ? ((r / SEGS) >> 1) & 7u : 0u)) * 16)) = w[u];
+      }
+    }
+  };
+
+  FragT fr[DEPTH][MT][KS];
+  int ix[DEPTH][MT];
+  unsigned long long okm[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load_idx(d, ix[d]);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    okm[d] = gather(ix[d], fr[d]);
+    load_idx(d + DEPTH, ix[d]);
+  }
+
+  for (int k0 = 0; k0 < kvol; k0 += KC) {
+    if (k0) d3d_lds_barrier();  // every wave has finished reading the previous chunk
+    load_chunk(k0);
+    d3d_lds_barrier();
+#pragma unroll 1
+    for (int kb = k0; kb < k0 + KC && kb < kvol; kb += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const int k = kb + d;
+        if (k < kvol && okm[d] != 0ull) {  // uniform
+          const unsigned char *wcur = rwlds + (uint32_t)(k - k0) * WBYTES;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const int cb = ((ks * KW + lg * EPL) * 2) ^ (SWZ ? ((lr >> 1) & 7) << 4 : 0);  // byte offset in the row
+            OpT xh[MT], xl[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              if constexpr (KW == 32) spconv_split8(fr[d][m][ks].a, fr[d][m][ks].b, xh[m], xl[m]);
+              else spconv_split4(fr[d][m][ks], xh[m], xl[m]);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              const OpT wa = *(const OpT *)(wcur + (n * 16 + lr) * ROWB + cb);
+              const OpT wl = *(const OpT *)(wcur + (COUT + n * 16 + lr) * ROWB + cb);
+#pragma unroll
+              for (int m = 0; m < MT; ++m) {
+                if constexpr (KW == 32) {
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                      __builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, xh[m]), acc[m][n], 0, 0, 0);
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                      __builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, xl[m]), acc[m][n], 0, 0, 0);
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                      __builtin_bit_cast(bf16x8_t, wl), __builtin_bit_cast(bf16x8_t, xh[m]), acc[m][n], 0, 0, 0);
+                } else {
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
+                      __builtin_bit_cast(s16x4_t, wa), __builtin_bit_cast(s16x4_t, xh[m]), acc[m][n], 0, 0, 0);
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
+                      __builtin_bit_cast(s16x4_t, wa), __builtin_bit_cast(s16x4_t, xl[m]), acc[m][n], 0, 0, 0);
+                  acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
+                      __builtin_bit_cast(s16x4_t, wl), __builtin_bit_cast(s16x4_t, xh[m]), acc[m][n], 0, 0, 0);
+                }
+              }
+            }
+          }
+        }
+        okm[d] = gather(ix[d], fr[d]);  // offset k + DEPTH (past the last offset: the last one again, never used)
+        load_idx(k + 2 * DEPTH, ix[d]);
+      }
+    }
+  }
+  // (the epilogue's reductions start behind a workgroup barrier: no wave still reads the chunk its scratch aliases)
+  spconv_fwd_epilogue<COUT, MT, false, NTHREADS>(acc, site, live, bias, out_, ep, (float *)rwlds, lr, lg);
+}
+
+template <int CIN, int COUT, int MT, int WAVES, int DEPTH, int KC>
+static int launch_fwd_resident(const void *feat, const void *wpack, const float *bias, const int32_t *nbr, int cap,
+                               int n_out, int kvol, void *out, ConvEpiDev ep, hipStream_t stream) {
+  const int rows_per_block = WAVES * MT * 16;
+  const int nb = (n_out + rows_per_block - 1) / rows_per_block;
+  if (int rc = epi_prepare(ep, nb, COUT)) return rc;
+  constexpr size_t lds = (size_t)KC * 2 * COUT * (CIN == 64 ? CIN * 2 : CIN * 2 + 16);
+  static_assert(lds <= 160 * 1024, "LDS of one CU");
+  D3D_HIP_TRY(hipFuncSetAttribute((const void *)spconv_fwd_resident_kernel<CIN, COUT, MT, WAVES, DEPTH, KC>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((spconv_fwd_resident_kernel<CIN, COUT, MT, WAVES, DEPTH, KC>), dim3(nb), dim3(WAVES * 64), lds,
+                     stream, feat, wpack, bias, nbr, cap, n_out, kvol, out, ep);
+  D3D_LAUNCH_TRY("spconv_fwd_resident_kernel");
+  return D3D_OK;
 }
 
 // ---- grouped barriers: the pipelined kernel above with ONE rendezvous per DEPTH offsets -----------------------
@@ -1087,6 +1303,34 @@ static int sparse_conv_fwd_impl(const void *feat, const void *wpack, const float
     FWD32_WIDE(62, 128, 64, 1, 16, 2)
     FWD32_WIDE(63, 128, 64, 2, 8, 2)
 #undef FWD32_WIDE
+  }
+  // f32 features on the chunk-resident-weights kernel (round 5).  Tiling sets (knob 11 / D3D_FWD_RESIDENT):
+  //   1: the tile shapes of the per-offset kernel below, all 27 matrices resident where they fit 48 KB, else 9
+  //   2: one tile per wave on the 16 / 32-channel layers (twice the blocks); 64 -> 64 four tiles per wave on 8 waves
+  //   3: 16-wave blocks with all 27 matrices resident (one block per CU)
+  if (dtype == D3D_F32 && g_fwd_resident != 0) {
+    const int rv = g_fwd_resident;
+#define FWD_RES(V, CI, CO, MT, WV, DP, KC)                                                                        \
+    if (rv == V && cin == CI && cout == CO)                                                                        \
+      return launch_fwd_resident<CI, CO, MT, WV, DP, KC>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);
+    FWD_RES(1, 16, 16, 2, 8, 3, 27)
+    FWD_RES(1, 16, 32, 2, 8, 3, 9)
+    FWD_RES(1, 32, 16, 2, 8, 3, 9)
+    FWD_RES(1, 32, 32, 2, 8, 3, 9)
+    FWD_RES(1, 32, 64, 2, 16, 3, 9)
+    FWD_RES(1, 64, 32, 1, 16, 3, 9)
+    FWD_RES(1, 64, 64, 2, 16, 1, 9)
+    FWD_RES(2, 16, 16, 1, 8, 9, 27)
+    FWD_RES(2, 16, 32, 1, 8, 3, 9)
+    FWD_RES(2, 32, 16, 1, 8, 3, 9)
+    FWD_RES(2, 32, 32, 1, 8, 3, 9)
+    FWD_RES(2, 32, 64, 1, 16, 3, 9)
+    FWD_RES(2, 64, 64, 4, 8, 1, 9)
+    FWD_RES(3, 16, 16, 1, 16, 9, 27)
+    FWD_RES(3, 16, 32, 2, 16, 3, 27)
+    FWD_RES(3, 32, 16, 2, 16, 3, 27)
+    FWD_RES(3, 32, 32, 2, 16, 3, 27)
+#undef FWD_RES
   }
   FWD_CASE(16, 16, 2, 8, 5, 4)
   FWD_CASE(16, 32, 2, 8, 5, 4)

@@ -624,3 +624,72 @@ def test_planned_strided_dgrad_is_bit_identical(cin, cout, gi, dtype):
     assert torch.allclose(pa, pb, rtol=2e-4, atol=2e-3 * float(pa.abs().max()))
     b3, pb3 = run(True, True)
     assert torch.equal(pb3, pb)   # ... and reproducibly so
+
+
+RESIDENT_CASES = [(16, 16), (16, 32), (32, 16), (32, 32), (32, 64), (64, 32), (64, 64)]
+
+
+@pytest.mark.parametrize("cin,cout", RESIDENT_CASES)
+@pytest.mark.parametrize("gi", [0, 1, 3])
+def test_resident_weights_kernel_is_the_per_offset_kernel_bit_for_bit(cin, cout, gi):
+    """spconv_fwd_resident_kernel (d3d_set_tuning knob 11, tiling sets 1-3: KC weight matrices resident in LDS, waves
+    free-running between the chunk fences) against spconv_fwd_mfma_kernel (knob 11 = 0) through the C ABI, f32 features:
+    the produced rows bit for bit -- plain, with bias + addend, with the BatchNorm-statistics epilogue, with the
+    BatchNorm-backward epilogue -- on a submanifold table, a strided one and the (3, 1, 1) kernel (kvol 3 < a chunk);
+    the statistics within f32 reassociation (the block shape, hence the fold tree, may differ)."""
+    import ctypes
+
+    from det3d_amd import _lib
+
+    ksize, stride, padding, subm = GEOMS[gi]
+    rng = np.random.default_rng(cin * 7 + cout + gi)
+    shape = [9, 40, 36]
+    idx, _ = _random_sparse(rng, 3, shape, 1500, 1)
+    rb = _build(idx, 3, shape, ksize, stride, padding, subm)
+    n, kvol = rb.n_out, rb.kvol
+    n_in = len(idx)
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    st = _lib.stream_ptr(dev)
+    torch.manual_seed(cin + cout)
+    f = torch.randn(n_in, cin, device=dev)
+    w32 = torch.randn(kvol, cin, cout, device=dev) / np.sqrt(cin * 9.0)
+    wpack = torch.empty((kvol, cin, cout), device=dev)
+    _lib.check(L.d3d_pack_conv_weights(w32.data_ptr(), kvol, cin, cout, _lib.D3D_F32, 1, wpack.data_ptr(), None, st), "pack")
+    bias = torch.randn(cout, device=dev)
+    addend = torch.randn(n, cout, device=dev)
+    bn_x = torch.randn(n, cout, device=dev)
+    mean, invstd = torch.randn(cout, device=dev) * 0.1, torch.rand(cout, device=dev) + 0.5
+    gamma, beta = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.1
+    nws = L.d3d_conv_epilogue_ws_floats(n, cout)
+
+    def run(v, mode):
+        o = torch.full((n, cout), float("nan"), device=dev)
+        ws = torch.zeros(nws, device=dev)
+        ep, b = None, None
+        if mode == "bias_addend":
+            ep, b = _lib.ConvEpilogue(addend=addend.data_ptr()), bias.data_ptr()
+        elif mode == "stats":
+            ep = _lib.ConvEpilogue(stats=ws.data_ptr(), ws_floats=nws)
+        elif mode == "bn_backward":
+            ep = _lib.ConvEpilogue(bn_partial=ws.data_ptr(), ws_floats=nws, bn_x=bn_x.data_ptr(), bn_mean=mean.data_ptr(),
+                                   bn_invstd=invstd.data_ptr(), bn_gamma=gamma.data_ptr(), bn_beta=beta.data_ptr(), bn_relu=1)
+        _lib.check(L.d3d_set_tuning(11, v), "knob")
+        try:
+            _lib.check(L.d3d_sparse_conv_fwd_ex(f.data_ptr(), wpack.data_ptr(), b, rb.nbr_out.data_ptr(), rb.cap_out, n, kvol,
+                                                cin, cout, _lib.D3D_F32, o.data_ptr(), ctypes.byref(ep) if ep else None, st),
+                       "fwd")
+        finally:
+            L.d3d_set_tuning(11, -1)
+        torch.cuda.synchronize()
+        return o, ws[:2 * cout].clone()
+
+    for mode in ("plain", "bias_addend", "stats", "bn_backward"):
+        ref, ref_red = run(0, mode)
+        assert torch.isfinite(ref).all()
+        for v in (1, 2, 3):
+            o, red = run(v, mode)
+            assert torch.equal(o, ref), (mode, v, (o - ref).abs().max().item())
+            if mode in ("stats", "bn_backward"):
+                scale = ref_red.abs().max().item() + 1.0
+                assert (red - ref_red).abs().max().item() <= 2e-5 * scale, (mode, v)
