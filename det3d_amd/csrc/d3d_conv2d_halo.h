@@ -281,45 +281,42 @@ __device__ __forceinline__ void c2h_body(const void *__restrict__ x_hi, const vo
     live[j] = oy < G.ho && ox < G.wo;
     pix[j] = ((int64_t)(img * G.ho + oy) * G.wo + ox) * G.cout;
   }
-  // Statistics FIRST, output stores LAST (round 5).  The fold hand-off (d3d_fold.h) waits vmcnt(0) before it draws its
-  // ticket; with the 128 KB output tile already issued that wait covered the whole store drain (~6 us per block, 20 us
-  // per launch over three rounds of blocks: profiles/round4_conv2d_variants.txt, fwd 124.7 vs fwd + stats 144.5 us).
-  // Now the wait sees the slab stores (and the bn_x loads) only, and the output tile drains while the CU's next block
-  // runs its prologue, as in a launch without statistics.  Same sums, same stores: results are bit-identical.
-  if (want_stats) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int co_base = n0 + wco * (NI * 32) + i * 32 + 4 * (lane >> 5);
+  for (int i = 0; i < NI; ++i) {
+    const int co_base = n0 + wco * (NI * 32) + i * 32 + 4 * (lane >> 5);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = co_base + 8 * g;
-        float is[4], mi[4], zs[4], zb[4];
-        if (want_bnb) {
+    for (int g = 0; g < 4; ++g) {
+      const int co = co_base + 8 * g;
+      float is[4], mi[4], zs[4], zb[4];
+      if (want_bnb) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float gm = ep.bn_gamma ? ep.bn_gamma[co + e] : 1.f, bt = ep.bn_beta ? ep.bn_beta[co + e] : 0.f;
-            is[e] = ep.bn_invstd[co + e];
-            mi[e] = -ep.bn_mean[co + e] * is[e];
-            zs[e] = gm * is[e];
-            zb[e] = fmaf(mi[e], gm, bt);
-          }
+        for (int e = 0; e < 4; ++e) {
+          const float gm = ep.bn_gamma ? ep.bn_gamma[co + e] : 1.f, bt = ep.bn_beta ? ep.bn_beta[co + e] : 0.f;
+          is[e] = ep.bn_invstd[co + e];
+          mi[e] = -ep.bn_mean[co + e] * is[e];
+          zs[e] = gm * is[e];
+          zb[e] = fmaf(mi[e], gm, bt);
         }
+      }
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if (!live[j]) continue;
-          const float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+      for (int j = 0; j < NJ; ++j) {
+        const float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (live[j]) {
+          *(float4 *)(y + pix[j] + co) = make_float4(v[0], v[1], v[2], v[3]);
           if (want_bnb) {
             const float4 xr = *(const float4 *)((const float *)ep.bn_x + pix[j] + co);
-            const float x[4] = {xr.x, xr.y, xr.z, xr.w};
+            x[0] = xr.x; x[1] = xr.y; x[2] = xr.z; x[3] = xr.w;
+          }
+        }
+        if (want_stats && live[j]) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < 4; ++e) {
+            if (want_bnb) {
               const float dz = (ep.bn_relu && fmaf(x[e], zs[e], zb[e]) <= 0.f) ? 0.f : v[e];
               s1[i][4 * g + e] = fmaf(dz, fmaf(x[e], is[e], mi[e]), s1[i][4 * g + e]);
               s2[i][4 * g + e] += dz;
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            } else {
               s1[i][4 * g + e] += v[e];
               s2[i][4 * g + e] = fmaf(v[e], v[e], s2[i][4 * g + e]);
             }
@@ -380,18 +377,6 @@ __device__ __forceinline__ void c2h_body(const void *__restrict__ x_hi, const vo
       const int i = threadIdx.x;
       if (i < 256 && (i & 127) < Q.ct_full) ep.stats[(i >> 7) * G.cout + ct * Q.ct_full + (i & 127)] = ws[i];
     }
-  }
-  // ---- the output tile
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int co_base = n0 + wco * (NI * 32) + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        if (live[j])
-          *(float4 *)(y + pix[j] + co_base + 8 * g) =
-              make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
   }
 }
 

@@ -144,14 +144,21 @@ __device__ __forceinline__ void spconv_fwd_epilogue(f32x4_t (&acc)[MT][COUT / 16
   constexpr int NW = NTHREADS / 64;
   const bool want_stats = ep.stats != nullptr, want_bnb = ep.bn_partial != nullptr;
   const int wave = threadIdx.x >> 6;
-  // Three passes over the accumulators (round 5; the arithmetic and its order are those of the one-pass version, results
-  // are bit-identical): (1) finish the values -- bias, addend, rounding to the feature dtype -- in place; (2) the
-  // reductions and their cross-block hand-off; (3) the row stores.  The hand-off (d3d_fold.h) waits vmcnt(0) before it
-  // draws its ticket: behind the stores that wait covered the drain of the block's whole output tile, now it sees the
-  // slab stores only and the ticket round trip overlaps the drain instead of following it.
+  if (want_stats || want_bnb) __syncthreads();  // `red` may alias LDS other waves were still reading
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int co = n * 16 + lg * 4;
+    float r0[4] = {0.f, 0.f, 0.f, 0.f}, r1[4] = {0.f, 0.f, 0.f, 0.f};
+    float bmu[4], bis[4], bga[4], bbe[4];
+    if (want_bnb) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bmu[j] = ep.bn_mean[co + j];
+        bis[j] = ep.bn_invstd[co + j];
+        bga[j] = ep.bn_gamma ? ep.bn_gamma[co + j] : 1.f;
+        bbe[j] = ep.bn_beta ? ep.bn_beta[co + j] : 0.f;
+      }
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       if (!live[m]) continue;
@@ -172,59 +179,47 @@ __device__ __forceinline__ void spconv_fwd_epilogue(f32x4_t (&acc)[MT][COUT / 16
           v[0] += ar.x; v[1] += ar.y; v[2] += ar.z; v[3] += ar.w;
         }
       }
-      if constexpr (BF16) {  // the values as stored: what the next pass will read (and what the sums are taken over)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = bf16_to_f32(f32_to_bf16(v[j]));
+      float w[4];  // the values as stored (rounded to the feature dtype): what the next pass will read
+      if constexpr (BF16) {
+        uint16_t *o = (uint16_t *)out_ + (int64_t)site[m] * COUT + co;
+        const uint16_t h0 = f32_to_bf16(v[0]), h1 = f32_to_bf16(v[1]), h2 = f32_to_bf16(v[2]), h3 = f32_to_bf16(v[3]);
+        uint2 pk;
+        pk.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        pk.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
+        *(uint2 *)o = pk;
+        w[0] = bf16_to_f32(h0); w[1] = bf16_to_f32(h1); w[2] = bf16_to_f32(h2); w[3] = bf16_to_f32(h3);
+      } else {
+        float *o = (float *)out_ + (int64_t)site[m] * COUT + co;
+        *(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);
+        w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3];
       }
-      acc[m][n] = v;
-    }
-  }
-  if (want_stats || want_bnb) {
-    __syncthreads();  // `red` may alias LDS other waves were still reading
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int co = n * 16 + lg * 4;
-      float r0[4] = {0.f, 0.f, 0.f, 0.f}, r1[4] = {0.f, 0.f, 0.f, 0.f};
-      float bmu[4], bis[4], bga[4], bbe[4];
-      if (want_bnb) {
+      if (want_stats) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          bmu[j] = ep.bn_mean[co + j];
-          bis[j] = ep.bn_invstd[co + j];
-          bga[j] = ep.bn_gamma ? ep.bn_gamma[co + j] : 1.f;
-          bbe[j] = ep.bn_beta ? ep.bn_beta[co + j] : 0.f;
+          r0[j] += w[j];
+          r1[j] = fmaf(w[j], w[j], r1[j]);
         }
       }
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        if (!live[m]) continue;
-        const f32x4_t w = acc[m][n];
-        if (want_stats) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            r0[j] += w[j];
-            r1[j] = fmaf(w[j], w[j], r1[j]);
-          }
+      if (want_bnb) {
+        float x[4];
+        if constexpr (BF16) {
+          const uint2 xr = *(const uint2 *)((const uint16_t *)ep.bn_x + (int64_t)site[m] * COUT + co);
+          x[0] = bf16_to_f32((uint16_t)(xr.x & 0xffffu)); x[1] = bf16_to_f32((uint16_t)(xr.x >> 16));
+          x[2] = bf16_to_f32((uint16_t)(xr.y & 0xffffu)); x[3] = bf16_to_f32((uint16_t)(xr.y >> 16));
+        } else {
+          const float4 xr = *(const float4 *)((const float *)ep.bn_x + (int64_t)site[m] * COUT + co);
+          x[0] = xr.x; x[1] = xr.y; x[2] = xr.z; x[3] = xr.w;
         }
-        if (want_bnb) {
-          float x[4];
-          if constexpr (BF16) {
-            const uint2 xr = *(const uint2 *)((const uint16_t *)ep.bn_x + (int64_t)site[m] * COUT + co);
-            x[0] = bf16_to_f32((uint16_t)(xr.x & 0xffffu)); x[1] = bf16_to_f32((uint16_t)(xr.x >> 16));
-            x[2] = bf16_to_f32((uint16_t)(xr.y & 0xffffu)); x[3] = bf16_to_f32((uint16_t)(xr.y >> 16));
-          } else {
-            const float4 xr = *(const float4 *)((const float *)ep.bn_x + (int64_t)site[m] * COUT + co);
-            x[0] = xr.x; x[1] = xr.y; x[2] = xr.z; x[3] = xr.w;
-          }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {  // same arithmetic as bn_bwd_reduce_kernel (d3d_bn.hip)
-            const float xh = (x[j] - bmu[j]) * bis[j];
-            const float dz = (ep.bn_relu && fmaf(xh, bga[j], bbe[j]) <= 0.f) ? 0.f : w[j];
-            r0[j] = fmaf(dz, xh, r0[j]);
-            r1[j] += dz;
-          }
+        for (int j = 0; j < 4; ++j) {  // same arithmetic as bn_bwd_reduce_kernel (d3d_bn.hip)
+          const float xh = (x[j] - bmu[j]) * bis[j];
+          const float dz = (ep.bn_relu && fmaf(xh, bga[j], bbe[j]) <= 0.f) ? 0.f : w[j];
+          r0[j] = fmaf(dz, xh, r0[j]);
+          r1[j] += dz;
         }
       }
+    }
+    if (want_stats || want_bnb) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float a0 = r0[j], a1 = r1[j];
@@ -239,6 +234,8 @@ __device__ __forceinline__ void spconv_fwd_epilogue(f32x4_t (&acc)[MT][COUT / 16
         }
       }
     }
+  }
+  if (want_stats || want_bnb) {
     __syncthreads();
     float *tot = red + NW * 2 * COUT;
     for (int i = threadIdx.x; i < 2 * COUT; i += NTHREADS) {
@@ -251,23 +248,6 @@ __device__ __forceinline__ void spconv_fwd_epilogue(f32x4_t (&acc)[MT][COUT / 16
     // (sum | sum sq) or (dgamma | dbeta): this block's slab, folded across blocks in a fixed order
     d3d_fold_block<NTHREADS>(tot, 2 * COUT, want_stats ? ep.stats : ep.bn_partial, ep.counters, ep.fold_g,
                              (int *)(tot + 2 * COUT));
-  }
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int co = n * 16 + lg * 4;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      if (!live[m]) continue;
-      const f32x4_t v = acc[m][n];
-      if constexpr (BF16) {
-        uint2 pk;
-        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-        *(uint2 *)((uint16_t *)out_ + (int64_t)site[m] * COUT + co) = pk;
-      } else {
-        *(float4 *)((float *)out_ + (int64_t)site[m] * COUT + co) = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
   }
 }
 
@@ -697,8 +677,8 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)  // second value: waves per 
 // DEPTH offsets ahead.  Tile shapes, the order of a row's products (offset, k-step, hi*hi / hi*lo / lo*hi) and the
 // epilogue are those of spconv_fwd_mfma_kernel: the produced rows are bit-identical (the statistics too where the
 // block shape is the same).  No row plan (the strided layers' data gradients stay on the kernel above).
-template <int CIN, int COUT, int MT, int WAVES, int DEPTH, int KC>
-__global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
+template <int CIN, int COUT, int MT, int WAVES, int DEPTH, int KC, int MINW>
+__global__ void __launch_bounds__(WAVES * 64, MINW)  // second value: waves per SIMD
     spconv_fwd_resident_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_,
                                const float *__restrict__ bias, const int32_t *__restrict__ nbr, int cap, int n_out,
                                int kvol, void *__restrict__ out_, ConvEpiDev ep) {
@@ -864,7 +844,7 @@ __global__ void __launch_bounds__(WAVES * 64, (MT * (COUT / 16) >= 16 ? 2 : 4))
   spconv_fwd_epilogue<COUT, MT, false, NTHREADS>(acc, site, live, bias, out_, ep, (float *)rwlds, lr, lg);
 }
 
-template <int CIN, int COUT, int MT, int WAVES, int DEPTH, int KC>
+template <int CIN, int COUT, int MT, int WAVES, int DEPTH, int KC, int MINW = (MT * (COUT / 16) >= 16 ? 2 : 4)>
 static int launch_fwd_resident(const void *feat, const void *wpack, const float *bias, const int32_t *nbr, int cap,
                                int n_out, int kvol, void *out, ConvEpiDev ep, hipStream_t stream) {
   const int rows_per_block = WAVES * MT * 16;
@@ -872,9 +852,9 @@ static int launch_fwd_resident(const void *feat, const void *wpack, const float 
   if (int rc = epi_prepare(ep, nb, COUT)) return rc;
   constexpr size_t lds = (size_t)KC * 2 * COUT * (CIN == 64 ? CIN * 2 : CIN * 2 + 16);
   static_assert(lds <= 160 * 1024, "LDS of one CU");
-  D3D_HIP_TRY(hipFuncSetAttribute((const void *)spconv_fwd_resident_kernel<CIN, COUT, MT, WAVES, DEPTH, KC>,
+  D3D_HIP_TRY(hipFuncSetAttribute((const void *)spconv_fwd_resident_kernel<CIN, COUT, MT, WAVES, DEPTH, KC, MINW>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((spconv_fwd_resident_kernel<CIN, COUT, MT, WAVES, DEPTH, KC>), dim3(nb), dim3(WAVES * 64), lds,
+  hipLaunchKernelGGL((spconv_fwd_resident_kernel<CIN, COUT, MT, WAVES, DEPTH, KC, MINW>), dim3(nb), dim3(WAVES * 64), lds,
                      stream, feat, wpack, bias, nbr, cap, n_out, kvol, out, ep);
   D3D_LAUNCH_TRY("spconv_fwd_resident_kernel");
   return D3D_OK;
@@ -1309,7 +1289,11 @@ static int sparse_conv_fwd_impl(const void *feat, const void *wpack, const float
   //   2: one tile per wave on the 16 / 32-channel layers (twice the blocks); 64 -> 64 four tiles per wave on 8 waves
   //   3: 16-wave blocks with all 27 matrices resident (one block per CU)
   if (dtype == D3D_F32 && g_fwd_resident != 0) {
-    const int rv = g_fwd_resident;
+    int rv = g_fwd_resident;
+    // the measured default (profiles/round5_tune_resident.txt): set 1 on the 16 / 32-channel layers (-7 ... -22 % alone on
+    // the device; same block shape as the per-offset kernel, so the statistics stay bit-identical too); everything else
+    // stays on the per-offset kernel (64 -> 64: -5 % where 512-site blocks fill the chip, +80 % where they do not)
+    if (rv < 0) rv = (cin <= 32 && cout <= 32) ? 1 : 0;
 #define FWD_RES(V, CI, CO, MT, WV, DP, KC)                                                                        \
     if (rv == V && cin == CI && cout == CO)                                                                        \
       return launch_fwd_resident<CI, CO, MT, WV, DP, KC>(feat, wpack, bias, nbr, cap, n_out, kvol, out, ep, stream);

@@ -631,12 +631,14 @@ RESIDENT_CASES = [(16, 16), (16, 32), (32, 16), (32, 32), (32, 64), (64, 32), (6
 
 @pytest.mark.parametrize("cin,cout", RESIDENT_CASES)
 @pytest.mark.parametrize("gi", [0, 1, 3])
-def test_resident_weights_kernel_is_the_per_offset_kernel_bit_for_bit(cin, cout, gi):
-    """spconv_fwd_resident_kernel (d3d_set_tuning knob 11, tiling sets 1-3: KC weight matrices resident in LDS, waves
+@pytest.mark.parametrize("cell_order", [False, True])
+def test_resident_weights_kernel_is_the_per_offset_kernel_bit_for_bit(cin, cout, gi, cell_order):
+    """spconv_fwd_resident_kernel (d3d_set_tuning knob 11, tiling sets 1-3 and the default policy -1: KC weight matrices resident in LDS, waves
     free-running between the chunk fences) against spconv_fwd_mfma_kernel (knob 11 = 0) through the C ABI, f32 features:
     the produced rows bit for bit -- plain, with bias + addend, with the BatchNorm-statistics epilogue, with the
     BatchNorm-backward epilogue -- on a submanifold table, a strided one and the (3, 1, 1) kernel (kvol 3 < a chunk);
-    the statistics within f32 reassociation (the block shape, hence the fold tree, may differ)."""
+    the statistics within f32 reassociation (the block shape, hence the fold tree, may differ).
+    `cell_order`: input rows in cell order (as behind a strided layer) or shuffled."""
     import ctypes
 
     from det3d_amd import _lib
@@ -645,6 +647,8 @@ def test_resident_weights_kernel_is_the_per_offset_kernel_bit_for_bit(cin, cout,
     rng = np.random.default_rng(cin * 7 + cout + gi)
     shape = [9, 40, 36]
     idx, _ = _random_sparse(rng, 3, shape, 1500, 1)
+    if cell_order:
+        idx = idx[np.lexsort((idx[:, 3], idx[:, 2], idx[:, 1], idx[:, 0]))]
     rb = _build(idx, 3, shape, ksize, stride, padding, subm)
     n, kvol = rb.n_out, rb.kvol
     n_in = len(idx)
@@ -687,7 +691,7 @@ def test_resident_weights_kernel_is_the_per_offset_kernel_bit_for_bit(cin, cout,
     for mode in ("plain", "bias_addend", "stats", "bn_backward"):
         ref, ref_red = run(0, mode)
         assert torch.isfinite(ref).all()
-        for v in (1, 2, 3):
+        for v in (-1, 1, 2, 3):
             o, red = run(v, mode)
             assert torch.equal(o, ref), (mode, v, (o - ref).abs().max().item())
             if mode in ("stats", "bn_backward"):
