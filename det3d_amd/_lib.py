@@ -35,6 +35,10 @@ SIGNATURES = {
     "d3d_pack_conv_weights": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "d3d_sparse_conv_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "d3d_set_tuning": (i32, [i32, i32]),
+    "d3d_ctx_create": (i32, [vp]),
+    "d3d_ctx_bind": (i32, [vp]),
+    "d3d_ctx_destroy": (i32, [vp]),
+    "d3d_ctx_get_tuning": (i32, [i32, vp]),
     "d3d_sparse_conv_has_epilogue": (i32, [i32, i32, i32]),
     "d3d_conv_epilogue_ws_floats": (sz, [i32, i32]),
     "d3d_bn_reduce_ws_floats": (sz, [i32, i32, i32]),
@@ -106,7 +110,7 @@ SIGNATURES = {
     "d3d_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
 }
 
-ABI_VERSION = 9  # include/d3d.h D3D_ABI_VERSION
+ABI_VERSION = 10  # include/d3d.h D3D_ABI_VERSION
 D3D_F32 = 0
 D3D_BF16 = 1
 D3D_CONV_BF16, D3D_CONV_SPLIT = 0, 1
@@ -209,3 +213,28 @@ def stream_ptr(device=None):
             idx = torch.cuda.current_device()
         return _RAW_STREAM(idx)
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class Context:
+    """A caller-owned library context (include/d3d.h, ABI 10): tuning knobs + fold ticket rings.  `with Context():` binds
+    it to the calling thread for the block and destroys it afterwards (the caller synchronises its streams first)."""
+
+    def __init__(self):
+        self.handle = ctypes.c_void_p()
+        check(lib().d3d_ctx_create(ctypes.byref(self.handle)), "d3d_ctx_create")
+
+    def bind(self):
+        check(lib().d3d_ctx_bind(self.handle), "d3d_ctx_bind")
+        return self
+
+    def destroy(self):
+        if self.handle:
+            check(lib().d3d_ctx_destroy(self.handle), "d3d_ctx_destroy")
+            self.handle = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self.bind()
+
+    def __exit__(self, *exc):
+        self.destroy()
+        return False

@@ -442,12 +442,8 @@ static const BnVariant BN_VARIANTS[] = {
 #define BN_NUM_VARIANTS ((int)(sizeof(BN_VARIANTS) / sizeof(BN_VARIANTS[0])))
 // MI355X, [140800, 128] bf16 (profiles/round2_bench_bn.json): variant 9 = 13.5 / 28.8 us (stats / bwd_reduce incl. the
 // accumulator fill launch), variant 0 = 16.9 / 33.3, 2048 x 256-thread blocks (variant 1) = 22.3 / 39.5
-int g_bn_variant = getenv("D3D_BN_VARIANT") ? atoi(getenv("D3D_BN_VARIANT")) : 9;
-int g_bn_skip_global = 0;  // knob 4 of round 2 (skip the global atomics): there are no atomics left, ignored
-int g_bn_dx_rows = getenv("D3D_BN_DX_ROWS") ? atoi(getenv("D3D_BN_DX_ROWS")) : 2;  // rows in flight in bwd_dx (knob 5)
 // grid cap of the apply / bwd_dx / affine sweeps (knob 6, D3D_BN_STREAM_BLOCKS): 512 blocks x 4 rows in flight is
 // 30.1 us for bwd_dx on the 36 MB map, 2048 blocks 40.6 us (same file); inputs under ~8 MB never reach the cap
-int g_bn_stream_blocks = getenv("D3D_BN_STREAM_BLOCKS") ? atoi(getenv("D3D_BN_STREAM_BLOCKS")) : 512;
 static bool bn_big(int n, int c) { return (int64_t)n * c >= ((int64_t)1 << 23); }
 static BnVariant bn_variant_for(int n, int c) {
   if (!bn_big(n, c)) return BnVariant{256, 4, 0};

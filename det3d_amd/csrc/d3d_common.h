@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include "../../include/d3d.h"
+#include "d3d_context.h"
 
 int d3d_set_error(int code, const char *fmt, ...);
 

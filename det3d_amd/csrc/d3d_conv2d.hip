@@ -700,13 +700,11 @@ __global__ void __launch_bounds__(256)
 // bit 1 = 256-pixel tiles (8 waves, one block per CU), bit 2 = half-depth K steps (twice the blocks per CU),
 // 8 = 128-pixel tiles on 8 waves (64 x 32 wave tiles; the default: 62.6 vs 67.7 us bf16, 143.8 vs 150.5 us split on the
 // [4,200,176,128] map), 9 = 8 + interleaved issue
-int g_c2_variant = getenv("D3D_CONV2D_VARIANT") ? atoi(getenv("D3D_CONV2D_VARIANT")) : -1;  // -1: 8 for bf16, 9 for split
 // waves per block of the weight-gradient kernel (knob 8, D3D_CONV2D_WGRAD_WAVES): 8 (64 x 32 wave tiles) or 4;
 // 16 / 17: conv2d_wgrad3_kernel for the 3x3 stride-1 layers in split mode (staggered wave groups / one barrier per K
 // step), other layers as with 8
 // measured (profiles/round4_conv2d_variants.txt, split): [4,200,176,128] -> 128: 166 (8) / 130 (17) / 115 us (16);
 // [4,128,128,256] -> 256: 281 / 206 / 182 us
-int g_c2_wgrad_waves = getenv("D3D_CONV2D_WGRAD_WAVES") ? atoi(getenv("D3D_CONV2D_WGRAD_WAVES")) : 16;
 
 static int c2_check(const char *who, int batch, int h, int w, int cin, int cout, int ksz, int stride, int pad,
                     int mode) {
@@ -737,7 +735,6 @@ extern "C" int d3d_conv2d_supported_split3x3(int cin, int cout) {
 // conv2d_halo_kernel's grid (d3d_conv2d_halo.h): items = 16 x 16 patches x 128-channel tiles; the items past the last
 // multiple of 256 (one block per CU and round) are cut into four 32-channel blocks each when that fills the last round
 // better than whole blocks would -- at most 128 such items, i.e. two rounds of short blocks (D3D_CONV2D_TAIL=0: never)
-int g_c2_tail = getenv("D3D_CONV2D_TAIL") ? atoi(getenv("D3D_CONV2D_TAIL")) : 1;  // knob 9
 struct C2hPlan {
   C2hGrid q;
   int blocks;    // grid size

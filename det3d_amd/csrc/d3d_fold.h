@@ -16,7 +16,8 @@
 // write back every dirty line of the XCD's L2 -- i.e. the conv's own output tile -- once per block: measured +15 us
 // on a 44 us launch); the folding block issues one agent-scope acquire fence, then reads the slabs with sc1 loads.
 //
-// Ticket counters live in a library-owned ring of zeroed words (d3d_fold_counters, d3d_core.hip): a counter is
+// Ticket counters live in the ring of zeroed words of the calling thread's context (d3d_fold_counters, d3d_core.hip;
+// d3d_context.h: one ring per context and device, so two contexts never share a word): a counter is
 // in use for the duration of ONE kernel and is reset by the block that draws the last ticket, so the ring never
 // needs re-zeroing; the ring is long enough (2^16 words) that two launches in flight never share a word.
 #pragma once

@@ -40,26 +40,20 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round to nearest 
 
 // tuning hook (tools/tune_fwd.py): alternative tilings of the dominant 64->64 bf16 layer, selectable per process
 // (D3D_FWD_VARIANT) or at run time (d3d_set_tuning)
-static int g_fwd_variant = -1;
+// (the knobs live in the calling thread's D3dContext: d3d_context.h, d3d_core.hip)
 static int fwd_variant_env() {
   static const int v = getenv("D3D_FWD_VARIANT") ? atoi(getenv("D3D_FWD_VARIANT")) : 0;
   return v;
 }
-int g_d3d_wgrad_blocks = -1;  // d3d_wgrad.hip reads these two
 // XCD-aware tile order: measured neutral-to-slightly-negative on MI355X for these gathers (profiles/round2_tune_fwd.txt:
 // 50.6 vs 50.6-54 us on the 126k-site 64->64 layer, 578 vs 566 frames/s end to end), so it is off by default
-int g_xcd_remap = getenv("D3D_XCD_REMAP") ? atoi(getenv("D3D_XCD_REMAP")) : 0;
 // knob 10 (test knob): f32 features on the EXACT-f32 kernels -- every product one fmaf on the VALU
 // (spconv_fwd_generic_kernel for forward and data gradient, spconv_wgrad_generic_kernel with one split per offset, i.e. a
 // deterministic sum) instead of three bf16 MFMAs on hi / lo pairs.  d3d_sparse_conv_has_epilogue and
 // d3d_sparse_conv_dgrad_plan_supported then answer 0 for f32, the packers write plain f32 copies, the host side keeps
 // the per-layer path.  10-50x slower: for "split vs exact f32" comparisons, not for use.
-int g_sp_exact_f32 = getenv("D3D_SPCONV_EXACT_F32") ? atoi(getenv("D3D_SPCONV_EXACT_F32")) : 0;
 // knob 11: chunk-resident-weights forward kernel for f32 features (spconv_fwd_resident_kernel).  -1 = the measured
 // default per channel pair (FWD_RESIDENT_DEFAULT below), 0 = off (spconv_fwd_mfma_kernel everywhere), 1..3 = tiling set
-int g_fwd_resident = getenv("D3D_FWD_RESIDENT") ? atoi(getenv("D3D_FWD_RESIDENT")) : -1;
-extern int g_bn_variant, g_bn_skip_global, g_bn_dx_rows, g_bn_stream_blocks;  // d3d_bn.hip
-extern int g_c2_variant, g_c2_wgrad_waves, g_c2_tail;  // d3d_conv2d.hip
 extern "C" int d3d_set_tuning(int knob, int value) {
   D3D_REQUIRE(knob >= 0 && knob <= 11, "d3d_set_tuning: unknown knob %d (11 = chunk-resident-weights f32 forward kernel: -1 default, 0 off, 1..3 tiling set, 10 = exact-f32 sparse kernels for f32 features (test knob), 9 = cut the last partial round of the dense 3x3 kernel into 32-channel blocks, 8 = waves of the dense weight-gradient kernel, 7 = dense conv tiling variant, 0 = forward 64->64 tiling variant, "
               "1 = target block count of the weight-gradient kernel, 2 = XCD-aware tile order on/off, 3 = BatchNorm "

@@ -8,7 +8,4 @@ int d3d_wgrad_legacy(const void *feat, const void *dout, const int32_t *nbr, int
                      int cin, int cout, int dtype, float *dw, hipStream_t stream);
 
 // d3d_set_tuning(1, blocks): run-time override of the weight-gradient kernel's target block count (-1 = default)
-extern int g_d3d_wgrad_blocks;
 // d3d_set_tuning(2, 0|1): XCD-aware block -> tile order of the gather kernels (default off: measured neutral)
-extern int g_xcd_remap;
-extern int g_sp_exact_f32;  // d3d_set_tuning knob 10 (test knob): exact-f32 VALU kernels for f32 features

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 9 /* 9: d3d_conv_rulebook_chain / d3d_subm_rulebook_ranked, training = 2 of d3d_bn_apply, d3d_set_tuning knob 10; 8: d3d_conv2d_nhwc_dgrad_s2; 7: residual forms of the BatchNorm sweeps, D3dConvEpilogue.addend; 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv; 5: planned strided data gradient, d3d_adam_step; 6: deterministic PillarFeatureNet sums (workspace arguments) */
+#define D3D_ABI_VERSION 10 /* 10: caller-owned contexts (d3d_ctx_*), d3d_set_tuning knob 11; 9: d3d_conv_rulebook_chain / d3d_subm_rulebook_ranked, training = 2 of d3d_bn_apply, d3d_set_tuning knob 10; 8: d3d_conv2d_nhwc_dgrad_s2; 7: residual forms of the BatchNorm sweeps, D3dConvEpilogue.addend; 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv; 5: planned strided data gradient, d3d_adam_step; 6: deterministic PillarFeatureNet sums (workspace arguments) */
 
 #define D3D_OK 0
 #define D3D_EINVAL -1    /* bad argument / unsupported shape           */
@@ -175,8 +175,29 @@ size_t d3d_conv_epilogue_ws_floats(int n_out, int cout);
  * 8 = dense weight-gradient kernel / waves, 9 = cut the last partial round of the dense 3x3 kernel into 32-channel
  * blocks (1 default), 10 = TEST knob: f32 sparse features on exact-f32 VALU kernels (one fmaf per product, deterministic
  * sums) instead of the split-arithmetic MFMA kernels -- d3d_sparse_conv_has_epilogue / _dgrad_plan_supported then answer
- * 0 for f32 and the packers write plain f32 copies; for "split vs exact" comparisons (det3d_amd/precision.py) */
+ * 0 for f32 and the packers write plain f32 copies; for "split vs exact" comparisons (det3d_amd/precision.py),
+ * 11 = f32 sparse forward with the weights resident in LDS (spconv_fwd_resident_kernel): -1 = the measured default (the
+ * 16 / 32-channel layers), 0 = off, 1..3 = tiling set (tools/tune_resident.py).
+ * The knobs belong to the calling thread's context (below): d3d_set_tuning changes the bound context, or the process
+ * default context when the thread has bound none. */
 int d3d_set_tuning(int knob, int value);
+
+/* Caller-owned library state (ABI 10).  SURVEY 8(b) asks for a re-entrant C ABI without process-global state; what the
+ * library keeps between calls is (a) the tuning knobs above and (b) the zeroed ticket words of the deterministic
+ * cross-block folds (csrc/d3d_fold.h), one ring of 2^16 words per device, allocated on first use.  Both live in a
+ * context.  d3d_ctx_create makes one (knobs start from the D3D_* environment defaults), d3d_ctx_bind attaches it to the
+ * CALLING HOST THREAD -- every entry point that thread calls afterwards reads its knobs and draws its ticket words
+ * there -- and d3d_ctx_bind(NULL) returns the thread to the process default context, which is what threads that never
+ * bind anything share (the behaviour of ABI <= 9).  One context per stream-owning thread makes two concurrent callers
+ * independent.  d3d_ctx_destroy frees the rings; the caller guarantees that none of the context's launches is still in
+ * flight and that no other thread has it bound.  d3d_ctx_get_tuning reads a knob of the calling thread's context.
+ * (The reference keeps the corresponding state -- spconv's algorithm choice, cuDNN handles -- in module globals:
+ * det3d/ops/syncbn/syncbn.py:1-40, spconv's ConvAlgo.) */
+typedef struct D3dContext *d3d_ctx_t;
+int d3d_ctx_create(d3d_ctx_t *ctx);
+int d3d_ctx_bind(d3d_ctx_t ctx);
+int d3d_ctx_destroy(d3d_ctx_t ctx);
+int d3d_ctx_get_tuning(int knob, int *value);
 int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const float *bias,
                            const int32_t *nbr, int cap, int n_out, int kvol, int cin, int cout,
                            int dtype, void *out, const D3dConvEpilogue *epilogue, d3d_stream_t stream);

@@ -28,7 +28,7 @@ def test_binding_table_matches_header(hip_lib):
     from det3d_amd import _lib
 
     assert sorted(_lib.SIGNATURES) == _declared()
-    assert hip_lib.d3d_abi_version() == _lib.ABI_VERSION == 9
+    assert hip_lib.d3d_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_rulebook_chain_planning_and_argument_checks_without_gpu(hip_lib):
@@ -220,3 +220,48 @@ def test_round4_planners_and_argument_checks_without_gpu(hip_lib):
     assert hip_lib.d3d_conv2d_supported(512, 128, 1, 1) == 1 and hip_lib.d3d_conv2d_supported(384, 256, 1, 1) == 1  # stacked heads
     assert hip_lib.d3d_conv2d_supported_split3x3(64, 64) == 1 and hip_lib.d3d_conv2d_supported_split3x3(96, 128) == 0
     assert hip_lib.d3d_pack_all(None, 0, None) in (0, -1)  # nothing to pack: no launch either way
+
+
+def test_contexts_own_the_tuning_state_per_thread(hip_lib):
+    """ABI 10 (no process-global state): the d3d_set_tuning knobs belong to the context the CALLING THREAD has
+    bound -- another thread, or the same thread after d3d_ctx_bind(NULL), sees the process default context; a context is
+    created, bound, used and destroyed by the caller; the default context cannot be destroyed.  (The ticket rings of a
+    context are allocated on the first reducing launch: nothing here touches a GPU.)"""
+    import threading
+
+    def knob(k):
+        v = ctypes.c_int(12345)
+        assert hip_lib.d3d_ctx_get_tuning(k, ctypes.byref(v)) == 0
+        return v.value
+
+    base = knob(11)
+    ctx = ctypes.c_void_p()
+    assert hip_lib.d3d_ctx_create(ctypes.byref(ctx)) == 0 and ctx.value
+    assert hip_lib.d3d_ctx_bind(ctx) == 0
+    assert knob(11) == base                      # a new context starts from the environment defaults
+    assert hip_lib.d3d_set_tuning(11, 2) == 0 and hip_lib.d3d_set_tuning(10, 1) == 0
+    assert (knob(11), knob(10)) == (2, 1)
+    assert hip_lib.d3d_sparse_conv_has_epilogue(64, 64, 0) == 0   # knob 10 of THIS context: exact-f32 kernels
+    seen = {}
+
+    def other():
+        seen["default"] = (knob(11), knob(10), hip_lib.d3d_sparse_conv_has_epilogue(64, 64, 0))
+        c2 = ctypes.c_void_p()
+        hip_lib.d3d_ctx_create(ctypes.byref(c2))
+        hip_lib.d3d_ctx_bind(c2)
+        hip_lib.d3d_set_tuning(11, 3)
+        seen["own"] = knob(11)
+        assert hip_lib.d3d_ctx_destroy(c2) == 0  # unbinds the calling thread
+        seen["after"] = knob(11)
+
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert seen == {"default": (base, 0, 1), "own": 3, "after": base}
+    assert (knob(11), knob(10)) == (2, 1)        # untouched by the other thread
+    assert hip_lib.d3d_ctx_bind(None) == 0
+    assert (knob(11), knob(10)) == (base, 0)
+    assert hip_lib.d3d_ctx_destroy(ctx) == 0
+    assert hip_lib.d3d_ctx_destroy(None) == -1 and b"d3d_ctx_destroy" in hip_lib.d3d_last_error()
+    assert hip_lib.d3d_ctx_get_tuning(99, ctypes.byref(ctypes.c_int())) == -1
+    assert hip_lib.d3d_set_tuning(12, 0) == -1 and b"unknown knob" in hip_lib.d3d_last_error()
