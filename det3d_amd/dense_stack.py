@@ -22,7 +22,7 @@ import os
 import torch
 from torch import nn
 
-from . import _lib, syncbn
+from . import _lib, repack, syncbn
 from . import dense_conv as dc
 
 ENABLED = os.environ.get("D3D_DENSE_CONV", "1") != "0"
@@ -203,6 +203,7 @@ class _DenseStackFn(torch.autograd.Function):
             rec.append((a_hi, a_lo, y, save, cf))
             a_hi, a_lo = nxt
         ctx.layers, ctx.rec, ctx.mode, ctx.training = layers, rec, mode, training
+        ctx.repack_stamp = repack.stamp()  # the backward reads the layers' cached packs, rewritten in place by Repacker.run()
         ctx.in_dtype = x.dtype
         ctx.need_in_grad = need_in_grad
         return out.permute(0, 3, 1, 2)  # channels-last [B, C, H, W]
@@ -212,6 +213,7 @@ class _DenseStackFn(torch.autograd.Function):
         if not ctx.training:
             raise _lib.D3dError("dense conv stack: backward is implemented for training-mode BatchNorm only")
         L = _lib.lib()
+        repack.check(ctx.repack_stamp, "dense conv stack")
         layers, rec, mode = ctx.layers, ctx.rec, ctx.mode
         split = mode == "split"
         dt = _lib.D3D_F32 if split else _lib.D3D_BF16

@@ -7,6 +7,13 @@ kernel.  `Repacker.run()` is called by TrainStep right after `d3d_adam_step`: it
 cached (parameter, packed buffers) pair to one launch that rewrites the SAME buffers, and stamps the entries with the
 parameters' new versions -- the next forward finds them fresh.  The backward of the step that just ended is complete on
 the stream by then, so nothing still reads the old bytes.  D3D_PACK_ALL=0 keeps the per-layer repacks.
+
+PRECONDITION (enforced): the rewrite is in place, so no autograd graph built before `run()` may run its backward after
+it -- its nodes hold the very buffers that now contain the NEW weights.  Every node that keeps packed operands
+(spconv._SparseConvFn, sparse_stack, sparse_block, dense_stack) takes `stamp()` in its forward and calls `check()` in
+its backward, which raises instead of silently differentiating with the wrong weights.  TrainStep (backward, then
+optimizer step, then `run()`) never trips it; a loop that steps the optimizer between forward and backward, or keeps a
+graph alive across a step, must set D3D_PACK_ALL=0.
 """
 import ctypes
 import os
@@ -16,6 +23,18 @@ import torch
 from . import _lib
 
 ENABLED = os.environ.get("D3D_PACK_ALL", "1") != "0"
+EPOCH = 0  # number of in-place rewrites so far (any Repacker)
+
+
+def stamp():
+    return EPOCH
+
+
+def check(stamped, who):
+    if stamped != EPOCH:
+        raise RuntimeError("%s: backward of a graph built before Repacker.run() rewrote the packed conv operands in place "
+                           "(optimizer step between forward and backward, or a graph kept across steps); run the "
+                           "backward first or set D3D_PACK_ALL=0" % who)
 
 
 class Repacker:
@@ -73,6 +92,8 @@ class Repacker:
                                            dgrad=d[0].data_ptr(), dgrad_lo=_lib.ptr(d[1]), kind=1, a=int(p.shape[0]),
                                            b=int(p.shape[1]), c=int(p.shape[2] * p.shape[3]), flip=0, dtype=0)
             self._key, self._table, self._n = key, arr, len(ents)
+        global EPOCH
+        EPOCH += 1
         dev = ents[0][1].device
         rc = _lib.lib().d3d_pack_all(ctypes.cast(self._table, ctypes.c_void_p), self._n, _lib.stream_ptr(dev))
         _lib.check(rc, "d3d_pack_all")

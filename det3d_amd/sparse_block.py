@@ -29,7 +29,7 @@ import os
 import torch
 from torch import nn
 
-from . import _lib, syncbn
+from . import _lib, repack, syncbn
 
 FUSE_BLOCK = os.environ.get("D3D_FUSE_BLOCK", "1") != "0"
 
@@ -128,7 +128,12 @@ class _BlockFn(torch.autograd.Function):
         _lib.check(rc, "d3d_bn_apply_residual")
         ctx.block, ctx.rb, ctx.sp = block, rb, sp
         ctx.cf = (cf1, cf2)
-        ctx.rec = (x, out1, y1, out2, save1, save2, wd1, wd2, partial1)
+        # activations through save_for_backward: autograd then refuses a backward after an in-place change of any of them
+        # (x is the caller's tensor); the packed weights are not autograd's to version -- repack.check guards them
+        ctx.save_for_backward(x, out1, y1, out2, save1, save2)
+        ctx.rec = (wd1, wd2, partial1)
+        ctx.repack_stamp = repack.stamp()
+        ctx.backward_runs = 0
         ctx.generation = sp.ARENA.generation
         ctx.dtype = dtype
         return y
@@ -138,7 +143,9 @@ class _BlockFn(torch.autograd.Function):
         L = _lib.lib()
         sp, block, rb = ctx.sp, ctx.block, ctx.rb
         conv1, bn1, conv2, bn2 = block.conv1, block.bn1, block.conv2, block.bn2
-        x, out1, y1, out2, save1, save2, wd1, wd2, partial1 = ctx.rec
+        repack.check(ctx.repack_stamp, "SparseBasicBlock")
+        x, out1, y1, out2, save1, save2 = ctx.saved_tensors
+        wd1, wd2, partial1 = ctx.rec
         dtype = ctx.dtype
         dt = sp._DT[dtype]
         dev = g.device
@@ -180,7 +187,9 @@ class _BlockFn(torch.autograd.Function):
 
         # ---- conv2: data gradient (reducing bn1's backward sums while the arena slice is still this pass's), weights
         gy1 = torch.empty((n, c), dtype=dtype, device=dev)
-        fused = sp.ARENA.generation == ctx.generation
+        # (a second backward over a retained graph takes the stand-alone reduction: the arena slice belongs to the first)
+        fused = sp.ARENA.generation == ctx.generation and ctx.backward_runs == 0
+        ctx.backward_runs += 1
         ep = None
         if fused:
             ep = _lib.ConvEpilogue(bn_x=out1.data_ptr(), bn_mean=save1[0].data_ptr(), bn_invstd=save1[1].data_ptr(),

@@ -22,7 +22,7 @@ import os
 import torch
 from torch import nn
 
-from . import _lib, syncbn
+from . import _lib, repack, syncbn
 
 FUSE_STACK = os.environ.get("D3D_FUSE_STACK", "1") != "0"
 
@@ -122,6 +122,7 @@ class _StackFn(torch.autograd.Function):
             rec.append((x, out, save, wd, partial, cf))
             x = y
         ctx.layers, ctx.rec, ctx.sp = layers, rec, sp
+        ctx.repack_stamp = repack.stamp()  # the packed weights in `rec` are rewritten in place by Repacker.run()
         ctx.generation = arena.generation
         ctx.dtype = dtype
         return x
@@ -129,6 +130,7 @@ class _StackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         L = _lib.lib()
+        repack.check(ctx.repack_stamp, "sparse conv stack")
         sp, layers, rec = ctx.sp, ctx.layers, ctx.rec
         dtype = ctx.dtype
         dt = sp._DT[dtype]

@@ -418,6 +418,8 @@ class _SparseConvFn(torch.autograd.Function):
         ctx.stats_done = ep is not None
         ctx.save_for_backward(feats, weight)
         ctx.wd = wd
+        from . import repack
+        ctx.repack_stamp = repack.stamp()  # `wd` is rewritten in place by Repacker.run()
         ctx.rb = rb
         ctx.has_bias = bias is not None
         ctx.pad = (cin, pad_cin)
@@ -438,6 +440,8 @@ class _SparseConvFn(torch.autograd.Function):
         stream = _lib.stream_ptr(feats.device)
         gin = gw = gb = None
         if ctx.needs_input_grad[0]:
+            from . import repack
+            repack.check(ctx.repack_stamp, "sparse conv")
             wd = ctx.wd  # packed in the forward: W[k] as is; k mirrored for submanifold layers because
             #              (j -> i at offset k)  <=>  (i -> j at offset kvol-1-k) on the same table
             gin = torch.empty((rb.n_in, pad_cin), dtype=feats.dtype, device=feats.device)

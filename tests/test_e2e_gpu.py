@@ -627,3 +627,61 @@ def test_resnet_fhd_backbone_vs_oracle_on_a_larger_cloud(name):
         name, len(feats), gi, worst, worst_cos))
     # (measured: 9e-3 / 2e-2 / 2e-4 -- 27 train-mode BN + ReLU layers with random O(1) weights amplify the last bits)
     assert worst < 5e-2 and worst_cos < 1e-3
+
+
+def test_nodes_that_hold_packed_weights_refuse_a_backward_behind_the_in_place_repack():
+    """ADVICE round 4 (sparse_block.py:118, repack.py:78): Repacker.run() rewrites the cached packed operands IN PLACE.
+    A graph built before it holds those very buffers, so its backward would differentiate with the NEW weights -- the
+    nodes take repack.stamp() in their forward and raise in their backward instead.  Also: the fused block keeps its
+    activations in save_for_backward (an in-place change of the input between forward and backward is an autograd error,
+    not a silent wrong gradient), and a second backward over a retained graph equals the first to rounding."""
+    from det3d_amd import repack, spconv
+    from det3d_amd.backbones import SparseBasicBlock
+
+    torch.manual_seed(7)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(2)
+    cells = np.unique(rng.integers(0, [2, 12, 40, 40], size=(6000, 4)), axis=0).astype(np.int32)
+    idx = torch.from_numpy(cells).to(dev)
+    blk = SparseBasicBlock(64, 64, indice_key="res").to(dev).train()
+    conv = spconv.SubMConv3d(64, 64, 3, bias=False, indice_key="res").to(dev)
+    w = torch.randn((len(cells), 64), device=dev)
+
+    def forward(m, leaf=True):
+        f = torch.randn((len(cells), 64), device=dev, requires_grad=True)
+        src = f if leaf else f * 1.0
+        x = spconv.SparseConvTensor(src, idx, [12, 40, 40], 2)
+        spconv.SparseSequential(m).plan(x)
+        spconv.ARENA.reset(dev)
+        return f, src, (m(x).features * w).sum()
+
+    # retained graph: two backward runs, same gradients
+    f, _, loss = forward(blk)
+    loss.backward(retain_graph=True)
+    g1, p1 = f.grad.clone(), [p.grad.clone() for p in blk.parameters()]
+    f.grad = None
+    blk.zero_grad()
+    loss.backward()
+    # (the second run takes bn1's backward sums from the stand-alone sweep instead of conv2's epilogue: equal to rounding)
+    rel = lambda a, b: float((a - b).norm()) / (float(b.norm()) + 1e-30)
+    assert rel(f.grad, g1) < 1e-5 and all(rel(p.grad, q) < 1e-5 for p, q in zip(blk.parameters(), p1))
+
+    # in-place change of the (non-leaf) input between forward and backward: autograd notices
+    f, src, loss = forward(blk, leaf=False)
+    with torch.no_grad():
+        src.mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss.backward()
+
+    # a repack between forward and backward
+    for m in (blk, conv):
+        f, _, loss = forward(m)
+        rp = repack.Repacker(list(m.parameters()))
+        for p in m.parameters():
+            p.data.mul_(1.01)  # as the fused Adam kernel does: through the storage, no autograd version bump
+        assert rp.run() >= 1
+        with pytest.raises(RuntimeError, match="Repacker.run"):
+            loss.backward()
+        f, _, loss = forward(m)  # a fresh graph is fine
+        loss.backward()
+        assert torch.isfinite(f.grad).all()
