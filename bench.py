@@ -562,6 +562,8 @@ def group_launches(entries, esz):
             key = ("spconv_fwd_mfma_kernel<%d,%d>" if mfma else "spconv_fwd_generic<%d,%d>") % (cin, cout)
             if esz == 2 and cin == 64 and cout == 64:
                 key = FWD64_BF16  # the grouped-barrier kernel serves this shape in bf16 (d3d_sparse_conv_fwd_ex)
+            elif esz == 4 and mfma and cin <= 32 and cout <= 32 and kind == "fwd" and os.environ.get("D3D_FWD_RESIDENT", "-1") == "-1":
+                key = "spconv_fwd_resident_kernel<%d,%d>" % (cin, cout)  # d3d_set_tuning knob 11, default policy
             byts = b_alg(kind, cin, cout, n_out, P, rb.kvol, esz)
         g = groups.setdefault(key, dict(ms=0.0, bytes=0.0, launches=0))
         g["ms"] += ms
@@ -644,7 +646,11 @@ def roofline_sources(roof, wl, extra_groups, key):
             src["rocprof"] = dict(stale="%s was taken on other sources: not used" % name)
         elif (rp["workload"], rp["dtype"]) == (wl.name, wl.dtype) and rp.get("avg_launch_us"):
             src["rocprof"] = entry(rp["avg_launch_us"], rp["launches_per_step"],
-                                   "%s: rocprofv3 --kernel-trace average over the steady-state window of a separate run" % name)
+                                   "%s: rocprofv3 --kernel-trace average over the steady-state window of a separate run "
+                                   "(all launches, the data-gradient ones next to the weight-gradient stream)" % name)
+            if (rp.get("solo") or {}).get("avg_launch_us"):
+                src["rocprof_solo"] = entry(rp["solo"]["avg_launch_us"], rp["solo"]["launches_per_step"],
+                                            "same trace, the launches with no weight-gradient kernel running beside them")
     except (OSError, KeyError, ValueError):
         pass
     roof["sources"] = src
@@ -1210,7 +1216,21 @@ def main():
                    "host_ms_per_step": getattr(wl, "host_ms", None)},
     }
     if rank == 0 and records:
+        from det3d_amd import sparse_stack
         roof = roofline_object(group_launches(records, esz), roof_key, args.dtype)
+        if roof and sparse_stack.WGRAD_STREAM:
+            # the weight gradients run on a second stream next to the data-gradient chain (sparse_stack.WGRAD_STREAM): a
+            # data-gradient launch of this kernel shares the CUs with a weight-gradient kernel, and its event pair times
+            # both.  The roofline figure is the kernel ALONE on the device -- the forward launches of the same step --,
+            # the all-launch figure stays next to it.
+            solo = roofline_object(group_launches([r for r in records if r[0] == "fwd"], esz), roof_key, args.dtype)
+            if solo:
+                solo["all_launches"] = dict(avg_launch_us=roof["avg_launch_us"], frac=roof["frac"], launches=roof["launches_timed"],
+                                            note="forward AND data-gradient launches; the data-gradient launches overlap the "
+                                                 "weight-gradient stream (D3D_WGRAD_STREAM=0: one stream, -4 ... -5 % frames/s)")
+                solo["note"] = "HIP events on the launch stream, FORWARD launches of the last timed step (they run alone " \
+                               "on the device); B_alg per SURVEY.md 8(d)"
+                roof = solo
         if roof:
             attach_pmc_traffic(roof, wl)
             out["roofline"] = roof

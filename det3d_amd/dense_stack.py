@@ -227,6 +227,12 @@ class _DenseStackFn(torch.autograd.Function):
             dy = dy.contiguous()
         grads = []
         partial = None  # BN-backward sums of layer li, left behind by the dgrad epilogue of layer li + 1
+        # weight gradients on the second stream (sparse_stack.WGRAD_STREAM): they fill the partial last round of the data
+        # gradient's blocks (572 work items on 256 CUs) and its statistics epilogue
+        from . import sparse_stack
+        main = torch.cuda.current_stream(dev)
+        side = sparse_stack.wgrad_stream(dev) if sparse_stack.WGRAD_STREAM and len(layers) > 1 else None
+        keep = []  # the gradient planes the side stream reads stay referenced until it has been joined
         for li in range(len(layers) - 1, -1, -1):
             ly = layers[li]
             bn = ly.bn
@@ -257,7 +263,14 @@ class _DenseStackFn(torch.autograd.Function):
                                      save[0].data_ptr(), save[1].data_ptr(), int(ly.relu), partial.data_ptr(), 1,
                                      g_hi.data_ptr(), gbn[0].data_ptr(), gbn[1].data_ptr(), st)
                 _lib.check(rc, "d3d_bn_bwd_dx")
-            gw = dc.wgrad_raw(g_hi, g_lo, a_hi, a_lo, ly.ksz, ly.stride, ly.pad, mode)
+            if side is not None:
+                side.wait_event(main.record_event())
+                keep.append((g_hi, g_lo))
+                with torch.cuda.stream(side):  # (its workspace comes from, and returns to, the side stream's pool)
+                    gw = dc.wgrad_raw(g_hi, g_lo, a_hi, a_lo, ly.ksz, ly.stride, ly.pad, mode)
+                gw.record_stream(main)
+            else:
+                gw = dc.wgrad_raw(g_hi, g_lo, a_hi, a_lo, ly.ksz, ly.stride, ly.pad, mode)
             partial = None
             if li > 0 or ctx.need_in_grad:
                 wd_hi, wd_lo = dc._packed(ly.conv.weight, "dgrad", mode)
@@ -277,6 +290,9 @@ class _DenseStackFn(torch.autograd.Function):
             if sync is not None:
                 gbn = sync  # grad_gamma / grad_beta summed over ranks (syncbn.py:99-103)
             grads.append([gw, gbn[0], gbn[1]])
+        if side is not None:
+            main.wait_stream(side)
+            keep.clear()
         gin = None
         if dy is not None:
             gin = dy.permute(0, 3, 1, 2)

@@ -175,13 +175,26 @@ class _BlockFn(torch.autograd.Function):
         _lib.check(rc, "d3d_bn_bwd_dx_residual")
         sp.check_gather_source(gout2, "the output gradient")
 
+        # weight gradients on the second stream (sparse_stack.WGRAD_STREAM): they depend on nothing the data-gradient chain
+        # produces afterwards; joined before the gradients are handed back
+        from . import sparse_stack
+        main = torch.cuda.current_stream(dev)
+        side = sparse_stack.wgrad_stream(dev) if sparse_stack.WGRAD_STREAM else None
+        keep = []
+
         def wgrad(src, gout):
             gw = torch.empty((rb.kvol, c, c), dtype=torch.float32, device=dev)
             wsb = L.d3d_sparse_conv_wgrad_workspace_bytes(n, rb.kvol, c, c, dt)
             ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
-            rc = sp._timed("wgrad", c, c, n, rb, dev, lambda: L.d3d_sparse_conv_wgrad(
-                src.data_ptr(), gout.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, n, rb.kvol, c, c, dt, gw.data_ptr(),
-                ws.data_ptr(), wsb, st))
+            launch = lambda s: L.d3d_sparse_conv_wgrad(src.data_ptr(), gout.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, n,
+                                                       rb.kvol, c, c, dt, gw.data_ptr(), ws.data_ptr(), wsb, s)
+            if side is not None:  # `gout` was finished on the main stream just before this call
+                side.wait_event(main.record_event())
+                keep.append((src, gout, ws, gw))
+                with torch.cuda.stream(side):
+                    rc = sp._timed("wgrad", c, c, n, rb, dev, lambda: launch(_lib.stream_ptr(dev)))
+            else:
+                rc = sp._timed("wgrad", c, c, n, rb, dev, lambda: launch(st))
             _lib.check(rc, "d3d_sparse_conv_wgrad")
             return gw
 
@@ -195,8 +208,8 @@ class _BlockFn(torch.autograd.Function):
             ep = _lib.ConvEpilogue(bn_x=out1.data_ptr(), bn_mean=save1[0].data_ptr(), bn_invstd=save1[1].data_ptr(),
                                    bn_gamma=bn1.weight.data_ptr(), bn_beta=_lib.ptr(bn1.bias), bn_relu=1,
                                    bn_partial=partial1.data_ptr(), ws_floats=partial1.numel())
+        gw2 = wgrad(y1, gout2)  # (first: on the second stream it then runs next to the data gradient)
         sp.launch_dgrad(rb, gout2, wd2, c, c, gy1, ep, st)
-        gw2 = wgrad(y1, gout2)
         if not fused:
             partial1 = sp.reduce_ws(dev, n, c, dtype)
             rc = L.d3d_bn_bwd_reduce(out1.data_ptr(), gy1.data_ptr(), n, c, dt, bn1.weight.data_ptr(), _lib.ptr(bn1.bias),
@@ -218,6 +231,9 @@ class _BlockFn(torch.autograd.Function):
             gin = torch.empty((n, c), dtype=dtype, device=dev)
             ep = _lib.ConvEpilogue(addend=dres.data_ptr())  # + the gradient that arrived through the identity branch
             sp.launch_dgrad(rb, gout1, wd1, c, c, gin, ep, st)
+        if side is not None:
+            main.wait_stream(side)
+            keep.clear()
         zero = lambda p: torch.zeros_like(p)  # the batch mean removes a bias in front of a train-mode BatchNorm
         grads = []
         for conv, bn, gw, gbn in ((conv1, bn1, gw1, sync1 or gbn1), (conv2, bn2, gw2, sync2 or gbn2)):

@@ -25,6 +25,20 @@ from torch import nn
 from . import _lib, repack, syncbn
 
 FUSE_STACK = os.environ.get("D3D_FUSE_STACK", "1") != "0"
+# weight gradients of the stack's backward on a second stream (round 5): a layer's weight gradient depends on nothing the
+# data-gradient chain produces after it, and every sparse kernel leaves CUs idle in its ramp and tail (its waves are resident
+# 61-63 % of its duration: profiles/round5_fwd_anatomy.txt) -- the weight gradient of layer l fills them while the chain goes
+# on with the BatchNorm sweeps and data gradient of layer l - 1.  Same kernels, same arguments: bit-identical gradients.
+WGRAD_STREAM = os.environ.get("D3D_WGRAD_STREAM", "1") != "0"
+_SIDE = {}
+
+
+def wgrad_stream(dev):
+    key = (dev.type, dev.index)
+    if key not in _SIDE:
+        # D3D_WGRAD_PRIORITY: the chain on the main stream is the critical path; a lower priority (1) lets its blocks go first
+        _SIDE[key] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("D3D_WGRAD_PRIORITY", "0")))
+    return _SIDE[key]
 
 
 class _Layer:
@@ -140,6 +154,9 @@ class _StackFn(torch.autograd.Function):
         fused = sp.ARENA.generation == ctx.generation
         grads = []  # per layer, in parameter order
         reduced_next = False  # the previous iteration's dgrad filled rec[li][4]
+        main = torch.cuda.current_stream(dev)
+        side = wgrad_stream(dev) if WGRAD_STREAM and len(layers) > 1 else None
+        keep = []  # what the side stream reads / writes stays referenced until it has been joined
         for li in range(len(layers) - 1, -1, -1):
             ly = layers[li]
             rb, conv, bn = ly.rb, ly.conv, ly.bn
@@ -165,6 +182,7 @@ class _StackFn(torch.autograd.Function):
                                  _lib.ptr(bn.bias), save[0].data_ptr(), save[1].data_ptr(), int(ly.relu),
                                  partial.data_ptr(), 1, gout.data_ptr(), gbn[0].data_ptr(), gbn[1].data_ptr(), st)
             _lib.check(rc, "d3d_bn_bwd_dx")
+            gout_ready = main.record_event() if side is not None else None
             # ---- conv backward
             gin = None
             reduced_next = False
@@ -185,9 +203,17 @@ class _StackFn(torch.autograd.Function):
             gw = torch.empty((rb.kvol, pad_cin, cout), dtype=torch.float32, device=dev)
             wsb = L.d3d_sparse_conv_wgrad_workspace_bytes(rb.n_out, rb.kvol, pad_cin, cout, dt)
             ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
-            rc = sp._timed("wgrad", pad_cin, cout, rb.n_out, rb, dev, lambda: L.d3d_sparse_conv_wgrad(
-                x.data_ptr(), gout.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, rb.n_out, rb.kvol, pad_cin, cout,
-                dt, gw.data_ptr(), ws.data_ptr(), wsb, st))
+            if side is not None:  # (buffers from the main stream's pool; `gout` was finished on the main stream)
+                side.wait_event(gout_ready)
+                keep.append((gout, ws, gw, x))
+                with torch.cuda.stream(side):
+                    rc = sp._timed("wgrad", pad_cin, cout, rb.n_out, rb, dev, lambda: L.d3d_sparse_conv_wgrad(
+                        x.data_ptr(), gout.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, rb.n_out, rb.kvol, pad_cin, cout,
+                        dt, gw.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev)))
+            else:
+                rc = sp._timed("wgrad", pad_cin, cout, rb.n_out, rb, dev, lambda: L.d3d_sparse_conv_wgrad(
+                    x.data_ptr(), gout.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, rb.n_out, rb.kvol, pad_cin, cout,
+                    dt, gw.data_ptr(), ws.data_ptr(), wsb, st))
             _lib.check(rc, "d3d_sparse_conv_wgrad")
             if pad_cin != cin:
                 gw = gw[:, :cin]
@@ -201,6 +227,9 @@ class _StackFn(torch.autograd.Function):
                 lg.append(gbn[1])
             grads.append(lg)
             g = gin
+        if side is not None:
+            main.wait_stream(side)  # the weight gradients are the caller's from here on
+            keep.clear()
         flat = [t for lg in reversed(grads) for t in lg]
         return (g, None, None) + tuple(flat)
 

@@ -107,6 +107,38 @@ def test_two_identical_training_steps_are_bit_equal(dtype):
     assert not bad, "not bit-equal across two steps of one model: %s" % bad[:6]
 
 
+@pytest.mark.parametrize("config", ["kitti_car_second.py", "nusc_cbgs.py"])
+def test_weight_gradients_on_the_second_stream_change_no_bit(config):
+    """sparse_stack.WGRAD_STREAM (round 5): the weight-gradient kernels of the fused sparse stack, the fused residual
+    blocks and the dense RPN stack run on a second stream next to the data-gradient chain.  Same kernels, same arguments:
+    loss and every gradient of a step must equal the one-stream step bit for bit (and a racing read of an unfinished
+    buffer would show up here as a difference)."""
+    from det3d_amd import sparse_stack, synthetic
+
+    cfg, a = _model(config)
+    b = copy.deepcopy(a)
+    dev = torch.device("cuda", 0)
+    if config.startswith("kitti"):
+        ds = synthetic.KittiCarSynthetic(n_points=20000, n_seeds=4)
+        ex = synthetic.make_example(ds.device_batch(0, 4, dev), synthetic.KITTI_CAR)
+    else:
+        ds = synthetic.TaskGroupSynthetic(cfg, n_points=30000, n_seeds=2)
+        ex = ds.make_example(ds.device_batch(0, 2, dev))
+    prev = sparse_stack.WGRAD_STREAM
+    try:
+        with torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=True):
+            sparse_stack.WGRAD_STREAM = True
+            la, ga = _step(a, ex, None)
+            la2, ga2 = _step(a, ex, None)
+            sparse_stack.WGRAD_STREAM = False
+            lb, gb = _step(b, ex, None)
+    finally:
+        sparse_stack.WGRAD_STREAM = prev
+    assert la == lb == la2 and ga.keys() == gb.keys()
+    bad = [k for k in ga if not (torch.equal(ga[k], gb[k]) and torch.equal(ga[k], ga2[k]))]
+    assert not bad, "second stream changed: %s" % bad[:6]
+
+
 @pytest.mark.parametrize("config", ["nusc_cbgs.py", "lyft_cbgs.py", "nusc_point_pillars.py"])
 def test_two_identical_steps_of_the_multi_task_configs_are_bit_equal(config):
     """The same for the CBGS (SpMiddleResNetFHD: fused residual blocks, 128-channel sparse layers; rpn2 neck; 5-6 task

@@ -111,11 +111,28 @@ def roofjson(db, window_ms, steps, out, workload, dtype):
     mine = [(n, c, us) for n, c, us in rows if re.search(pat, n)]
     launches = sum(c for _, c, _ in mine)
     total_us = sum(us for _, _, us in mine)
+    # launches that had the device to themselves: no weight-gradient kernel (the second stream of the backward pass,
+    # sparse_stack.WGRAD_STREAM) running at any time between their start and end
+    allk = cur.execute("select name, start, end from kernels where start > ? order by start", (w0,)).fetchall()
+    wg = sorted((a, b) for n, a, b in allk if "wgrad" in n)
+    import bisect
+    starts = [a for a, _ in wg]
+    solo_n, solo_us = 0, 0.0
+    for n, a, b in allk:
+        if not re.search(pat, n):
+            continue
+        i = bisect.bisect_left(starts, b)  # intervals starting before this launch ends
+        if any(e > a for _, e in wg[max(0, i - 8):i]):
+            continue
+        solo_n += 1
+        solo_us += (b - a) / 1e3
     d = {"_comment": "rocprofv3 --kernel-trace --stats of `bench.py --steps N --warmup 5` (tools/profile_step.sh): every forward / "
                      "data-gradient launch of the 64->64 sparse gather kernel (plain and parity-class-planned variants) in the "
                      "steady-state window",
          "workload": workload, "dtype": dtype, "steps": float(steps), "source_sha16": stamp.source_sha16(),
          "launches_per_step": launches / float(steps), "avg_launch_us": round(total_us / launches, 3) if launches else None,
+         "solo": {"launches_per_step": solo_n / float(steps), "avg_launch_us": round(solo_us / solo_n, 3) if solo_n else None,
+                  "what": "launches with no weight-gradient kernel (second stream) running between their start and end"},
          "variants": {n[:100]: {"launches": c, "avg_us": round(us / c, 3)} for n, c, us in mine}}
     json.dump(d, open(out, "w"), indent=1)
     print("wrote", out, d["avg_launch_us"])
