@@ -12,8 +12,9 @@ sparse conv fwd with the BN statistics in its epilogue) -> RPN (the library's NH
 BN statistics in their epilogue) -> head 1x1 convs (the library's d3d_head_conv_* kernels) -> fused loss -> backward
 (HIP dgrad / two-pass wgrad, sparse and dense) -> gradient mean over ranks (RCCL) -> clip -> true-WD Adam.  The input-side geometry of step i+1
 (voxelizer, targets, rulebooks) is built on a second HIP stream while step i runs (det3d_amd/prefetch.py;
---no-prefetch builds it inline): K timed steps contain K geometry builds.  Rank 0 prints ONE JSON line and refuses
-to if the loss or the gradient norm after the timed region is not finite.
+--no-prefetch builds it inline): K timed steps contain K geometry builds; inside the backward pass the weight gradients
+run on a third stream next to the data-gradient chain (det3d_amd/sparse_stack.py WGRAD_STREAM; D3D_WGRAD_STREAM=0: one
+stream).  Rank 0 prints ONE JSON line and refuses to if the loss or the gradient norm after the timed region is not finite.
 
 PRECISION (round 3).  The headline (`--dtype fp32`, the default) is the precision that meets north_star's "boxes
 within 1e-3 of the reference": f32 storage of every activation, and every product of the sparse and the dense
@@ -24,8 +25,9 @@ line) is ~1.5x faster and misses the tolerance by 37x; round 2's headline was th
 
 Besides the contract fields the line carries
   roofline      the hand-written sparse-conv gather kernel of the dominant 64->64 layers, HIP events on the launch
-                stream inside the timed region (last step); `frac` is the SURVEY.md 8(d) algorithmic-bytes figure
-                against the HBM peak; `sources` lists every duration this run and the committed profile have for that
+                stream inside the timed region (last step: its FORWARD launches, which have the device to themselves;
+                `all_launches` adds the data-gradient launches that overlap the weight-gradient stream); `frac` is the
+                SURVEY.md 8(d) algorithmic-bytes figure against the HBM peak; `sources` lists every duration this run and the committed profile have for that
                 kernel (timed-region events, the extra all-launches step, the rocprofv3 kernel-trace average) with the
                 frac each gives; `traffic` from committed rocprofv3 PMC passes when they match the kernel AND host sources
   bf16 | fp32   the same workload in the other precision
