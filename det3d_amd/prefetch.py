@@ -78,6 +78,15 @@ def reserve_stream(dev):
             torch.zeros(1, device=torch.device("cuda", idx))
         st.synchronize()
         _RESERVED[idx] = st
+        # the same for the weight-gradient stream of the backward pass (sparse_stack.WGRAD_STREAM): created lazily it
+        # would come after the communication library's streams
+        from . import sparse_stack
+
+        if sparse_stack.WGRAD_STREAM:
+            ws = sparse_stack.wgrad_stream(torch.device("cuda", idx))
+            with torch.cuda.stream(ws):
+                torch.zeros(1, device=torch.device("cuda", idx))
+            ws.synchronize()
     return _RESERVED[idx]
 
 

@@ -13,6 +13,7 @@
 #   pmc              separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES) -> <tag>/pmc/round4_pmc_*
 #   wl:<workload>    bench.py --workload c4|c5|c3|c2-60k, no extras
 #   conv2d           tools/bench_conv2d.py (dense conv kernel variants)
+#   wgradstream      the weight-gradient stream off / on, plain and under a 1-rank RCCL communicator
 #   py:<script> ...  python <script> (rest of the line), log to <tag>/<script>.log
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -128,6 +129,15 @@ for f in ("sb_plain", "sb_rccl1_bn", "sb_rccl1_syncbn", "sb_rccl1_syncbn_unfused
         print("%-26s FAILED (%s)" % (f, e))
 PY
       ;;
+    wgradstream)
+      # the weight-gradient stream (sparse_stack.WGRAD_STREAM) off / on, plain and next to a 1-rank RCCL process group
+      B="--gpus 1 --steps 40 --warmup 3 --no-cpu-baseline --no-extras"
+      R1="D3D_DIST_SINGLE=1 D3D_DIST_BACKEND=nccl RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1"
+      for rep in 1 2; do for w in 0 1; do
+        D3D_WGRAD_STREAM=$w timeout 300 python bench.py $B > $O/ws_plain_${w}_$rep.json 2> $O/ws_plain_${w}_$rep.err
+        env $R1 MASTER_PORT=$(port) D3D_WGRAD_STREAM=$w timeout 300 python bench.py $B > $O/ws_rccl1_${w}_$rep.json 2> $O/ws_rccl1_${w}_$rep.err
+        echo "wgrad stream $w: plain $(show $O/ws_plain_${w}_$rep.json 1 | cut -c1-45)  1-rank RCCL $(show $O/ws_rccl1_${w}_$rep.json 1 | cut -c1-45)"
+      done; done | tee $O/wgradstream.txt ;;
     mrprio)
       # does the geometry stream keep its priority next to an RCCL process group?  (profiles/round4_multirank.txt)
       B="--steps 20 --warmup 3 --no-cpu-baseline --no-extras"
