@@ -2,7 +2,7 @@
 import json
 import sys
 
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+d = json.loads([ln for ln in open(sys.argv[1]).read().splitlines() if ln.startswith("{")][-1])
 r = d.get("roofline", {})
 print("value %.1f %s  %.3f ms/step  roofline %s (%s us, %s GB/s)  sparse %s ms" % (
     d["value"], d["unit"], d["ms_per_step"], r.get("frac"), r.get("avg_launch_us"), r.get("achieved"),
