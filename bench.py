@@ -89,6 +89,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300, help="timed steps (default: a > 2 s timed region)")
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--windows", type=int, default=None,
+                    help="back-to-back timed windows of --steps steps each, every one bracketed by barrier + synchronize; "
+                         "`value` is the MEDIAN window (all of them in `windows_ms`).  Default: 9 when a window is short "
+                         "(--steps <= 60: the driver's 20 steps are 0.13 s, one hiccup of the host moves them by 10 %%), else 1")
     ap.add_argument("--batch", type=int, default=None,
                     help="frames per GPU (default: the workload's configured samples_per_gpu; 4 for the headline)")
     ap.add_argument("--points", type=int, default=None, help="points per synthetic frame (default: the workload's)")
@@ -319,9 +323,12 @@ class Workload:
         import numpy as np
 
         self.aug_rng = np.random.RandomState(1234 + rank)
-        # distinct clouds per step -- at least four different batches per rank before a cloud repeats
-        # (frames are generated lazily: a rank pays for the 4 x batch seeds it reads out of the job's 4 x batch x world)
-        n_seeds = 4 * self.batch * world
+        # distinct clouds per step -- 16 different batches per rank before a cloud repeats (the KITTI
+        # clouds; the 250k-point multi-sweep clouds of the task-group workloads cost 0.3 s of host time each to synthesise,
+        # so those cycle through 64 frames: 4 batches at batch 16, 10 at batch 6, 16 at batch 4).  Frames are generated
+        # lazily: a rank pays for the n_batches x batch seeds it reads out of the job's n_batches x batch x world
+        self.n_batches = 16 if spec["kind"] == "kitti" else max(4, min(16, 64 // self.batch))
+        n_seeds = self.n_batches * self.batch * world
         self.pillars = bool(spec.get("pillars"))
         if self.pillars:
             # the KITTI generator on the PointPillars geometry (0.16 m pillars, 100 points each, 12000 pillars)
@@ -338,7 +345,6 @@ class Workload:
         else:
             self.ds = synthetic.TaskGroupSynthetic(cfg, self.points, n_seeds=n_seeds, beams=spec["beams"],
                                                    sweeps=spec["sweeps"])
-        self.n_batches = 4
         self.batches = [self.ds.device_batch(i, self.batch, dev, rank, world) for i in range(self.n_batches)]
         self.step_fn = TrainStep(model, total_steps=max(total_steps, 100), lr_max=cfg.lr_config.lr_max,
                                  wd=cfg.optimizer.VALUE.wd, moms=cfg.lr_config.moms,
@@ -371,9 +377,11 @@ class Workload:
 
 
 def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, freeze=True, burn_in_s=0.0,
-                 prefetch=True, prefetch_thread=True):
-    """W untimed warm-up steps, then exactly `steps` steps bracketed by barrier + synchronize; returns
-    (max-over-ranks elapsed seconds, launch records of the sampled steps, final loss)."""
+                 prefetch=True, prefetch_thread=True, windows=1):
+    """W untimed warm-up steps, then `windows` back-to-back windows of exactly `steps` steps, each bracketed by
+    barrier + synchronize on both sides and reduced with MAX over ranks; returns (the MEDIAN window's elapsed seconds,
+    launch records of the sampled step, final loss).  wl.windows_ms keeps every window, wl.alloc the caching
+    allocator's counters over all of them."""
     from det3d_amd import dist as D
     from det3d_amd import spconv, trainer
 
@@ -391,6 +399,7 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
             for kind, cin, cout, n_out, rb, e0, e1 in spconv.LAUNCH_LOG:
                 e1.synchronize()
                 records.append((kind, cin, cout, n_out, rb, e0.elapsed_time(e1)))
+                _pairs_of(rb)  # now: the table lives in a slot of the geometry ring that a later build overwrites
             spconv.LAUNCH_LOG.clear()
 
     state = {"ex": pf.prepare(0)}
@@ -458,31 +467,47 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
     torch.cuda.synchronize()
     ms0 = torch.cuda.memory_stats(dev)
     host["enqueue"] = host["geometry"] = 0.0
-    t0 = time.perf_counter()
     loss = None
-    for i in range(steps):
-        if i == sample_from and launch_filter is not None:
-            spconv.LAUNCH_LOG = []
-        loss = one(burn + warmup + i)  # K steps and K geometry builds (the last one for a step that is not run)
-    if threaded:
-        state["next"].result()  # the K-th build of the region is complete (enqueued) before the clock stops
-    torch.cuda.synchronize()
-    D.barrier()
-    elapsed = time.perf_counter() - t0
+    done = burn + warmup
+    times = []
+    for w in range(max(windows, 1)):
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if w == windows - 1 and i == sample_from and launch_filter is not None:
+                spconv.LAUNCH_LOG = []
+            loss = one(done + i)  # K steps and K geometry builds (the last one for a step of the next window / not run)
+        if threaded:
+            state["next"].result()  # the K-th build of the window is complete (enqueued) before the clock stops
+        torch.cuda.synchronize()
+        D.barrier()
+        times.append(time.perf_counter() - t0)
+        done += steps
     ms1 = torch.cuda.memory_stats(dev)
     alloc = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
     alloc["reserved_MB"] = int(ms1.get("reserved_bytes.all.current", 0) >> 20)
-    note("%s %s timed region done: %.3f s for %d steps; allocator during it: %s" % (wl.name, wl.dtype, elapsed, steps, alloc))
+    alloc["steps"] = steps * len(times)
+    from det3d_amd import arena as _arena
+    alloc["step_arena"] = _arena.step_arena(dev).stats()
+    alloc["geometry_ring"] = pf.arena_stats()
+    wl.alloc = alloc
     drain()
     pf.close()
     spconv.LAUNCH_LOG = None
     spconv.LAUNCH_FILTER = None
-    wl.host_ms = {k: round(1e3 * v / max(steps, 1), 3) for k, v in host.items()}
+    wl.host_ms = {k: round(1e3 * v / max(steps * len(times), 1), 3) for k, v in host.items()}
     wl.first_loss = float(state["first"]) if "first" in state else None
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    wl.steps_run = done
+    t = torch.tensor(times, dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    return float(t.item()), records, loss
+    times = [float(v) for v in t.tolist()]
+    wl.windows_ms = [round(1e3 * v, 3) for v in times]
+    elapsed = statistics.median(times)
+    note("%s %s timed region done: %d window(s) of %d steps, median %.3f s (min %.3f, max %.3f); allocator during them: %s"
+         % (wl.name, wl.dtype, len(times), steps, elapsed, min(times), max(times), alloc))
+    return elapsed, records, loss
 
 
 def rank_diagnostics(wl, dev, rank, world, steps=8):
@@ -545,6 +570,13 @@ def kernel_table(wl, step_index, rank, esz):
 _PAIRS = {}
 
 
+def _pairs_of(rb):
+    P = _PAIRS.get(id(rb))
+    if P is None:
+        P = _PAIRS[id(rb)] = (rb, rb.pairs())  # keep rb alive: id() must stay unique
+    return P[1]
+
+
 SUBMIT_MID = os.environ.get("D3D_SUBMIT_MID", "0") == "1"  # geometry builds start mid-step (measured neutral: 579.6 vs 579.0 frames/s)
 FWD64_BF16 = "spconv_fwd_group_kernel<64,64>"
 FIND_MODE = [0]  # D3D_MIOPEN_FIND, set in main()
@@ -553,10 +585,7 @@ FIND_MODE = [0]  # D3D_MIOPEN_FIND, set in main()
 def group_launches(entries, esz):
     groups = {}
     for kind, cin, cout, n_out, rb, ms in entries:
-        P = _PAIRS.get(id(rb))
-        if P is None:
-            P = _PAIRS[id(rb)] = (rb, rb.pairs())  # keep rb alive: id() must stay unique
-        P = P[1]
+        P = _pairs_of(rb)
         if kind == "wgrad":
             key, byts = "spconv_wgrad_tile %dx%d" % (cin, cout), P * (cin + cout) * esz
         else:
@@ -588,8 +617,8 @@ def roofline_object(groups, key, dtype):
                       "counter passes, profiles/round2_pmc_fwd.txt: texture addresser 44-50 % busy, LDS 28 %, MFMA "
                       "17-20 %); the f32 kernel gathers twice the bytes and issues three bf16 MFMAs per product -- "
                       "see DESIGN.md section 5",
-           "note": "HIP events on the launch stream, fwd+dgrad launches of the last timed step; B_alg per "
-                   "SURVEY.md 8(d)"}
+           "note": "HIP events on the launch stream, ALL fwd + dgrad launches of this kernel in the last timed step; "
+                   "B_alg per SURVEY.md 8(d)"}
     return out
 
 
@@ -635,7 +664,10 @@ def roofline_sources(roof, wl, extra_groups, key):
         return dict(avg_launch_us=round(us, 2), launches=n, frac=round(b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), how=what)
 
     src = {"timed_region_events": entry(roof["avg_launch_us"], roof["launches_timed"],
-                                        "HIP events around the launches of the last timed step (the line's `frac`)")}
+                                        "HIP events around ALL forward + data-gradient launches of the last timed step (the line's `frac`)")}
+    if roof.get("forward_only"):
+        f = roof.pop("forward_only")
+        src["forward_only"] = dict(avg_launch_us=f["avg_launch_us"], launches=f["launches"], frac=f["frac"], how=f["note"])
     g = (extra_groups or {}).get(key)
     if g:
         src["extra_step_events"] = entry(1e3 * g["ms"] / g["launches"], g["launches"],
@@ -1145,10 +1177,61 @@ def child_workload(name, dtype, steps=8, warmup=3, budget_s=200):
 
 
 # ----------------------------------------------------------------------------------------------------- main
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: become the launcher.  Re-executes this file under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (tools/train.py:73-110 expects
+    exactly that environment: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), one rank per device over RCCL; on a box with
+    fewer devices than N the ranks share them round-robin over gloo (a flow test, said so in the line).  Returns the
+    launcher's exit code; rank 0's JSON line goes to this process's stdout."""
+    import socket
+    import subprocess
+
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev == 0:
+        raise SystemExit("bench.py needs a GPU: the det3d_amd hot path has no CPU fallback")
+    env = dict(os.environ)
+    if n_dev < args.gpus:
+        env.setdefault("D3D_DIST_BACKEND", "gloo")
+        print("[bench] --gpus %d on a box with %d device(s): ranks share devices, gradient exchange over gloo"
+              % (args.gpus, n_dev), file=sys.stderr, flush=True)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")  # what torch.distributed.run would set (and warn about)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def pin_rank_cores(local_rank, local_world):
+    """one contiguous share of the host's cores per rank (enqueue thread, geometry thread, autograd thread and the
+    communication library's proxy threads of a rank stay on one NUMA side and off the other ranks' cores).  Only when a
+    share is at least 4 cores; D3D_RANK_AFFINITY=0 disables.  Returns the share or None."""
+    if local_world <= 1 or os.environ.get("D3D_RANK_AFFINITY", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    per = len(cores) // local_world
+    if per < 4:
+        return None
+    share = cores[local_rank * per: (local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, share)
+    except OSError:
+        return None
+    return share
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
         return cpu_baseline_worker(args.batch or 4, args.points or 20000, args.cpu_steps)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ and env_world == 1:
+        sys.exit(spawn_ranks(args))  # VERDICT round 5: --gpus N creates its N ranks
+    if args.gpus != env_world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d -- the line's n_gpus would not be the requested one"
+                         % (args.gpus, env_world))
     from det3d_amd import dist as D
 
     t_start = time.perf_counter()
@@ -1157,6 +1240,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the det3d_amd hot path has no CPU fallback")
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
+    cores = pin_rank_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     # the geometry stream first: which hardware queue a stream lands on depends on what was created before it
     # (det3d_amd/prefetch.reserve_stream; D.init_dist has already done this when there is a process group)
     from det3d_amd import prefetch as _prefetch
@@ -1180,13 +1264,18 @@ def main():
     head = "c2-20k" if args.workload == "all" else args.workload
     wl = Workload(head, args, dev, rank, world, args.dtype, args.steps + args.warmup, batch=args.batch, points=args.points)
     esz = 2 if args.dtype == "bf16" else 4
-    dominant = (lambda kind, cin, cout: kind != "wgrad" and cin == 64 and cout == 64) if not args.no_launch_log else None
-    roof_key = FWD64_BF16 if args.dtype == "bf16" else "spconv_fwd_mfma_kernel<64,64>"
+    # the roofline kernel of a workload = the sparse gather kernel its step spends most time in: the 64 -> 64 layers of
+    # SpMiddleFHD (KITTI), the 128 -> 128 residual blocks of SpMiddleResNetFHD (nuScenes / Lyft CBGS)
+    dom_c = 128 if head in ("c4", "c5") else 64
+    dominant = (lambda kind, cin, cout: kind != "wgrad" and cin == dom_c and cout == dom_c) if not args.no_launch_log else None
+    roof_key = FWD64_BF16 if (args.dtype == "bf16" and dom_c == 64) else "spconv_fwd_mfma_kernel<%d,%d>" % (dom_c, dom_c)
     if head in ("c3", "c1"):
         dominant = None  # PointPillars has no sparse convolutions
+    windows = args.windows if args.windows else (9 if args.steps <= 60 else 1)
     elapsed, records, loss = timed_region(wl, args.steps, args.warmup, rank, world, dev, note, dominant,
                                           freeze=not args.no_gc_freeze, burn_in_s=args.burn_in,
-                                          prefetch=not args.no_prefetch, prefetch_thread=not args.no_prefetch_thread)
+                                          prefetch=not args.no_prefetch, prefetch_thread=not args.no_prefetch_thread,
+                                          windows=windows)
     frames = args.steps * wl.batch * world
     value = frames / elapsed
     gnorm = float(wl.step_fn.last["grad_norm"])
@@ -1205,9 +1294,15 @@ def main():
         "config": {"workload": wl.describe(), "name": wl.name, "frames_per_gpu": wl.batch,
                    "points_per_frame": wl.points, "parallelism": "dp%d" % world,
                    "first_loss": None if getattr(wl, "first_loss", None) is None else round(wl.first_loss, 4),
-                   "steps_before_final_loss": getattr(wl, "burn_in_steps", 0) + args.warmup + args.steps,
+                   "steps_before_final_loss": getattr(wl, "steps_run", 0),
                    "final_loss": round(float(loss), 4), "final_grad_norm": round(gnorm, 4),
                    "timed_region_s": round(elapsed, 3),
+                   "windows": len(wl.windows_ms), "windows_ms": wl.windows_ms,
+                   "value_is": "the median of %d back-to-back windows of %d steps, each bracketed by barrier + synchronize "
+                               "(max over ranks per window)" % (len(wl.windows_ms), args.steps) if len(wl.windows_ms) > 1
+                               else "one window of %d steps" % args.steps,
+                   "distinct_batches": wl.n_batches,
+                   "allocator": wl.alloc,
                    "burn_in_steps": getattr(wl, "burn_in_steps", 0),
                    "graphed_tail": bool(wl.model.__dict__.get("_graph_tails")),
                    "norm": "SyncBN (DistributedSyncBN, statistics exchanged %s)" % (
@@ -1219,20 +1314,15 @@ def main():
     }
     if rank == 0 and records:
         from det3d_amd import sparse_stack
+        # `frac` is the kernel AS IT RUNS IN THE BENCHED STEP: every forward and data-gradient launch of the last timed
+        # step (the data-gradient launches share the CUs with the weight-gradient stream).  The forward launches alone
+        # -- nothing beside them on the device -- are kept in `sources.forward_only`.
         roof = roofline_object(group_launches(records, esz), roof_key, args.dtype)
-        if roof and sparse_stack.WGRAD_STREAM:
-            # the weight gradients run on a second stream next to the data-gradient chain (sparse_stack.WGRAD_STREAM): a
-            # data-gradient launch of this kernel shares the CUs with a weight-gradient kernel, and its event pair times
-            # both.  The roofline figure is the kernel ALONE on the device -- the forward launches of the same step --,
-            # the all-launch figure stays next to it.
+        if roof:
             solo = roofline_object(group_launches([r for r in records if r[0] == "fwd"], esz), roof_key, args.dtype)
             if solo:
-                solo["all_launches"] = dict(avg_launch_us=roof["avg_launch_us"], frac=roof["frac"], launches=roof["launches_timed"],
-                                            note="forward AND data-gradient launches; the data-gradient launches overlap the "
-                                                 "weight-gradient stream (D3D_WGRAD_STREAM=0: one stream, -4 ... -5 % frames/s)")
-                solo["note"] = "HIP events on the launch stream, FORWARD launches of the last timed step (they run alone " \
-                               "on the device); B_alg per SURVEY.md 8(d)"
-                roof = solo
+                roof["forward_only"] = dict(avg_launch_us=solo["avg_launch_us"], frac=solo["frac"], launches=solo["launches_timed"],
+                                            note="the forward launches of the same step: no weight-gradient kernel beside them")
         if roof:
             attach_pmc_traffic(roof, wl)
             out["roofline"] = roof

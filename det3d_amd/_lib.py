@@ -39,6 +39,7 @@ SIGNATURES = {
     "d3d_ctx_bind": (i32, [vp]),
     "d3d_ctx_destroy": (i32, [vp]),
     "d3d_ctx_get_tuning": (i32, [i32, vp]),
+    "d3d_ctx_current": (i32, [vp]),
     "d3d_sparse_conv_has_epilogue": (i32, [i32, i32, i32]),
     "d3d_conv_epilogue_ws_floats": (sz, [i32, i32]),
     "d3d_bn_reduce_ws_floats": (sz, [i32, i32, i32]),
@@ -110,7 +111,7 @@ SIGNATURES = {
     "d3d_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
 }
 
-ABI_VERSION = 10  # include/d3d.h D3D_ABI_VERSION
+ABI_VERSION = 11  # include/d3d.h D3D_ABI_VERSION
 D3D_F32 = 0
 D3D_BF16 = 1
 D3D_CONV_BF16, D3D_CONV_SPLIT = 0, 1
@@ -238,3 +239,42 @@ class Context:
     def __exit__(self, *exc):
         self.destroy()
         return False
+
+
+def current_ctx():
+    """handle (int) of the library context bound to the calling thread, None for the process default"""
+    h = ctypes.c_void_p()
+    check(lib().d3d_ctx_current(ctypes.byref(h)), "d3d_ctx_current")
+    return h.value
+
+
+def ctx_forward(fn):
+    """decorator of an autograd Function's forward: remember the library context the forward ran under"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrap(ctx, *args, **kwargs):
+        ctx._d3d_ctx = current_ctx()
+        return fn(ctx, *args, **kwargs)
+    return wrap
+
+
+def ctx_backward(fn):
+    """decorator of an autograd Function's backward: PyTorch runs it on the autograd engine's thread, which has no
+    library context bound -- re-bind the forward's for the duration (its knobs can change operand formats: knob 10 makes
+    the forward pack plain-f32 weights that a default-context backward would read as hi/lo bf16 planes)"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrap(ctx, *grads):
+        want = getattr(ctx, "_d3d_ctx", None)
+        have = current_ctx()
+        if want == have:
+            return fn(ctx, *grads)
+        L = lib()
+        check(L.d3d_ctx_bind(ctypes.c_void_p(want)), "d3d_ctx_bind")
+        try:
+            return fn(ctx, *grads)
+        finally:
+            L.d3d_ctx_bind(ctypes.c_void_p(have))
+    return wrap

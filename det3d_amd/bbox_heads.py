@@ -19,7 +19,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import box_ops
+from . import _lib, box_ops
 from . import losses  # noqa: F401  (registers the loss classes)
 from .builder import build_loss
 from .registry import HEADS
@@ -37,6 +37,7 @@ class _HeadLossFn(torch.autograd.Function):
     """loss of one task group; returns the [D3D_LOSS_SCALARS] vector (element 0 is the loss)."""
 
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, box_preds, cls_preds, dir_preds, labels, reg_targets, anchors, cfg):
         from . import _lib
 
@@ -69,6 +70,7 @@ class _HeadLossFn(torch.autograd.Function):
         return scalars
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, gs):
         saved = ctx.saved_tensors
         g = gs[0]  # only element 0 (the loss) is differentiable; the rest are logging sums
@@ -163,6 +165,7 @@ class _HeadConvFn(torch.autograd.Function):
     `.permute(0, 2, 3, 1).contiguous()` of the reference's NCHW conv outputs is, mg_head.py:223-231)"""
 
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, x, count, *params):
         from . import _lib
 
@@ -183,6 +186,7 @@ class _HeadConvFn(torch.autograd.Function):
         return tuple(outs)
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, *gouts):
         from . import _lib
 
@@ -597,6 +601,7 @@ _STACKED_PACKS = {}  # ids of the heads' conv weights -> (versions, weakrefs, pa
 
 class _FusedHeadsFn(torch.autograd.Function):
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, x, sizes, *params):
         from . import _lib
         from . import dense_conv as dc
@@ -641,6 +646,7 @@ class _FusedHeadsFn(torch.autograd.Function):
         return tuple(outs)
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, *gouts):
         from . import dense_conv as dc
 

@@ -88,6 +88,11 @@ extern "C" int d3d_ctx_bind(d3d_ctx_t ctx) {
   t_ctx = (D3dContext *)ctx;  // null: back to the process default
   return D3D_OK;
 }
+extern "C" int d3d_ctx_current(d3d_ctx_t *ctx) {
+  D3D_REQUIRE(ctx, "d3d_ctx_current: null pointer");
+  *ctx = (d3d_ctx_t)t_ctx;
+  return D3D_OK;
+}
 extern "C" int d3d_ctx_destroy(d3d_ctx_t ctx) {
   D3dContext *c = (D3dContext *)ctx;
   D3D_REQUIRE(c && c != default_ctx(), "d3d_ctx_destroy: null or the default context");

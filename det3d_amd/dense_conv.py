@@ -260,6 +260,7 @@ class _KsConvFn(torch.autograd.Function):
     """y = Conv2d(k = s)(x) or ConvTranspose2d(k = s)(x) on [B, C, H, W] channels-last f32 maps, split arithmetic"""
 
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, x, weight, transposed, s):
         rows = x.permute(0, 2, 3, 1)
         if not rows.is_contiguous():
@@ -292,6 +293,7 @@ class _KsConvFn(torch.autograd.Function):
         return y.reshape(b, h * s, w * s, cout).permute(0, 3, 1, 2)
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, g):
         s = ctx.s
         b, h, w, cin = ctx.in_shape

@@ -144,6 +144,7 @@ def _params(layers):
 
 class _DenseStackFn(torch.autograd.Function):
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, x, layers, *params):
         L = _lib.lib()
         dev = x.device
@@ -209,6 +210,7 @@ class _DenseStackFn(torch.autograd.Function):
         return out.permute(0, 3, 1, 2)  # channels-last [B, C, H, W]
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, g):
         if not ctx.training:
             raise _lib.D3dError("dense conv stack: backward is implemented for training-mode BatchNorm only")

@@ -20,6 +20,7 @@ class _PFNFn(torch.autograd.Function):
     """decorate + Linear + BatchNorm1d + ReLU + max over T in three launches (d3d_pfn_fwd: statistics slabs, fixed-order fold, apply)."""
 
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, voxels, num_points, coors, weight, gamma, beta, running_mean, running_var, momentum,
                 eps, training, geom):
         L = _lib.lib()
@@ -47,6 +48,7 @@ class _PFNFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, dout):
         if not ctx.training:
             raise _lib.D3dError("fused PFN backward is implemented for training mode only")

@@ -29,7 +29,7 @@ import os
 import torch
 from torch import nn
 
-from . import _lib, repack, syncbn
+from . import _lib, arena as mem, repack, syncbn
 
 FUSE_BLOCK = os.environ.get("D3D_FUSE_BLOCK", "1") != "0"
 
@@ -75,6 +75,7 @@ def rulebook_of(sp, block, x):
 
 class _BlockFn(torch.autograd.Function):
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, feats, block, rb, sp, *params):
         L = _lib.lib()
         dev, dtype = feats.device, feats.dtype
@@ -85,11 +86,13 @@ class _BlockFn(torch.autograd.Function):
         n, c = rb.n_out, conv1.in_channels
         sp.check_gather_source(x, "the feature matrix")
         need_in_grad = ctx.needs_input_grad[0]
+        lease = mem.Lease()  # the step arena, if the caller runs under one (arena.py)
+        A = lease.arena
         wp1, wd1 = sp._packed_weights(conv1.weight, rb.kvol, c, c, dtype, True, need_in_grad, c)
         wp2, wd2 = sp._packed_weights(conv2.weight, rb.kvol, c, c, dtype, True, True, c)
 
         def conv(src, wpack, bias):
-            out = torch.empty((n, c), dtype=dtype, device=dev)
+            out = mem.empty((n, c), dtype, dev, A)
             stats = sp.epilogue_ws(dev, n, c)
             ep = _lib.ConvEpilogue(stats=stats.data_ptr(), ws_floats=stats.numel())
             b = bias.detach() if bias is not None else None
@@ -108,7 +111,7 @@ class _BlockFn(torch.autograd.Function):
             return 2, mv, cf
 
         out1, stats1 = conv(x, wp1, conv1.bias)
-        y1 = torch.empty_like(out1)
+        y1 = mem.empty((n, c), dtype, dev, A)
         save1 = torch.empty((2, c), dtype=torch.float32, device=dev)
         mode1, stats1, cf1 = moments(bn1, stats1)
         rc = L.d3d_bn_apply(out1.data_ptr(), n, c, dt, bn1.weight.data_ptr(), _lib.ptr(bn1.bias),
@@ -118,7 +121,7 @@ class _BlockFn(torch.autograd.Function):
         partial1 = sp.epilogue_ws(dev, n, c)  # conv2's dgrad launch reduces bn1's backward sums into this
         sp.check_gather_source(y1, "the feature matrix")
         out2, stats2 = conv(y1, wp2, conv2.bias)
-        y = torch.empty_like(out2)
+        y = mem.empty((n, c), dtype, dev, A)
         save2 = torch.empty((2, c), dtype=torch.float32, device=dev)
         mode2, stats2, cf2 = moments(bn2, stats2)
         rc = L.d3d_bn_apply_residual(out2.data_ptr(), x.data_ptr(), n, c, dt, bn2.weight.data_ptr(), _lib.ptr(bn2.bias),
@@ -135,10 +138,12 @@ class _BlockFn(torch.autograd.Function):
         ctx.repack_stamp = repack.stamp()
         ctx.backward_runs = 0
         ctx.generation = sp.ARENA.generation
+        ctx.lease = lease
         ctx.dtype = dtype
         return y
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, g):
         L = _lib.lib()
         sp, block, rb = ctx.sp, ctx.block, ctx.rb
@@ -151,11 +156,12 @@ class _BlockFn(torch.autograd.Function):
         dev = g.device
         st = _lib.stream_ptr(dev)
         n, c = rb.n_out, conv1.in_channels
+        A = ctx.lease.check("SparseBasicBlock")
         dy = g.contiguous()
         if dy.dtype != dtype:
             dy = dy.to(dtype)
         # ---- relu(bn2(.) + x): the mask needs the residual; d(identity) comes out of the same sweep as dx
-        partial2 = sp.reduce_ws(dev, n, c, dtype)
+        partial2 = sp.reduce_ws(dev, n, c, dtype, A)
         rc = L.d3d_bn_bwd_reduce_residual(out2.data_ptr(), x.data_ptr(), dy.data_ptr(), n, c, dt, bn2.weight.data_ptr(),
                                           _lib.ptr(bn2.bias), save2[0].data_ptr(), save2[1].data_ptr(), 1,
                                           partial2.data_ptr(), st)
@@ -165,8 +171,8 @@ class _BlockFn(torch.autograd.Function):
         if cf2 is not None:  # cross-rank BN: the sums over ranks; d3d_bn_bwd_dx takes their rank means
             partial2, gg, gb = syncbn.exchange_backward_sums(bn2, partial2, cf2, save2[1])
             sync2 = (gg, gb)
-        gout2 = torch.empty_like(out2)
-        dres = torch.empty_like(x)
+        gout2 = mem.empty((n, c), dtype, dev, A)
+        dres = mem.empty((n, c), dtype, dev, A)
         gbn2 = torch.empty((2, c), dtype=torch.float32, device=dev)
         rc = L.d3d_bn_bwd_dx_residual(out2.data_ptr(), x.data_ptr(), dy.data_ptr(), n, c, dt, bn2.weight.data_ptr(),
                                       _lib.ptr(bn2.bias), save2[0].data_ptr(), save2[1].data_ptr(), 1,
@@ -185,7 +191,7 @@ class _BlockFn(torch.autograd.Function):
         def wgrad(src, gout):
             gw = torch.empty((rb.kvol, c, c), dtype=torch.float32, device=dev)
             wsb = L.d3d_sparse_conv_wgrad_workspace_bytes(n, rb.kvol, c, c, dt)
-            ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+            ws = mem.empty((wsb,), torch.uint8, dev, A)
             launch = lambda s: L.d3d_sparse_conv_wgrad(src.data_ptr(), gout.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, n,
                                                        rb.kvol, c, c, dt, gw.data_ptr(), ws.data_ptr(), wsb, s)
             if side is not None:  # `gout` was finished on the main stream just before this call
@@ -199,7 +205,7 @@ class _BlockFn(torch.autograd.Function):
             return gw
 
         # ---- conv2: data gradient (reducing bn1's backward sums while the arena slice is still this pass's), weights
-        gy1 = torch.empty((n, c), dtype=dtype, device=dev)
+        gy1 = mem.empty((n, c), dtype, dev, A)
         # (a second backward over a retained graph takes the stand-alone reduction: the arena slice belongs to the first)
         fused = sp.ARENA.generation == ctx.generation and ctx.backward_runs == 0
         ctx.backward_runs += 1
@@ -211,14 +217,14 @@ class _BlockFn(torch.autograd.Function):
         gw2 = wgrad(y1, gout2)  # (first: on the second stream it then runs next to the data gradient)
         sp.launch_dgrad(rb, gout2, wd2, c, c, gy1, ep, st)
         if not fused:
-            partial1 = sp.reduce_ws(dev, n, c, dtype)
+            partial1 = sp.reduce_ws(dev, n, c, dtype, A)
             rc = L.d3d_bn_bwd_reduce(out1.data_ptr(), gy1.data_ptr(), n, c, dt, bn1.weight.data_ptr(), _lib.ptr(bn1.bias),
                                      save1[0].data_ptr(), save1[1].data_ptr(), 1, partial1.data_ptr(), st)
             _lib.check(rc, "d3d_bn_bwd_reduce")
         if cf1 is not None:
             partial1, gg, gb = syncbn.exchange_backward_sums(bn1, partial1, cf1, save1[1])
             sync1 = (gg, gb)
-        gout1 = torch.empty_like(out1)
+        gout1 = mem.empty((n, c), dtype, dev, A)
         gbn1 = torch.empty((2, c), dtype=torch.float32, device=dev)
         rc = L.d3d_bn_bwd_dx(out1.data_ptr(), gy1.data_ptr(), n, c, dt, bn1.weight.data_ptr(), _lib.ptr(bn1.bias),
                              save1[0].data_ptr(), save1[1].data_ptr(), 1, partial1.data_ptr(), 1, gout1.data_ptr(),
@@ -228,7 +234,7 @@ class _BlockFn(torch.autograd.Function):
         gw1 = wgrad(x, gout1)
         gin = None
         if ctx.needs_input_grad[0]:
-            gin = torch.empty((n, c), dtype=dtype, device=dev)
+            gin = mem.empty((n, c), dtype, dev, A)
             ep = _lib.ConvEpilogue(addend=dres.data_ptr())  # + the gradient that arrived through the identity branch
             sp.launch_dgrad(rb, gout1, wd1, c, c, gin, ep, st)
         if side is not None:

@@ -22,7 +22,7 @@ import os
 import torch
 from torch import nn
 
-from . import _lib, repack, syncbn
+from . import _lib, arena as mem, repack, syncbn
 
 FUSE_STACK = os.environ.get("D3D_FUSE_STACK", "1") != "0"
 # weight gradients of the stack's backward on a second stream (round 5): a layer's weight gradient depends on nothing the
@@ -90,6 +90,7 @@ def segment(sp, mods, start, x):
 
 class _StackFn(torch.autograd.Function):
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, feats, layers, sp, *params):
         L = _lib.lib()
         dev = feats.device
@@ -97,6 +98,8 @@ class _StackFn(torch.autograd.Function):
         dt = sp._DT[dtype]
         st = _lib.stream_ptr(dev)
         arena = sp.ARENA
+        lease = mem.Lease()  # the step arena (arena.py) if the caller runs under one: the backward allocates from it too
+        A = lease.arena
         feats = feats.contiguous()
         need_in_grad = ctx.needs_input_grad[0]
         rec = []
@@ -112,7 +115,7 @@ class _StackFn(torch.autograd.Function):
             sp.check_gather_source(x, "the feature matrix")
             wpack, wd = sp._packed_weights(conv.weight, rb.kvol, cin, cout, dtype, rb.subm,
                                            li > 0 or need_in_grad, pad_cin)
-            out = torch.empty((rb.n_out, cout), dtype=dtype, device=dev)
+            out = mem.empty((rb.n_out, cout), dtype, dev, A)
             stats = sp.epilogue_ws(dev, rb.n_out, cout)
             ep = _lib.ConvEpilogue(stats=stats.data_ptr(), ws_floats=stats.numel())
             b = conv.bias.detach() if conv.bias is not None else None
@@ -120,7 +123,7 @@ class _StackFn(torch.autograd.Function):
                 x.data_ptr(), wpack.data_ptr(), _lib.ptr(b), rb.nbr_out.data_ptr(), rb.cap_out, rb.n_out, rb.kvol,
                 pad_cin, cout, dt, out.data_ptr(), ctypes.byref(ep), st))
             _lib.check(rc, "d3d_sparse_conv_fwd")
-            y = torch.empty_like(out)
+            y = mem.empty((rb.n_out, cout), dtype, dev, A)
             save = torch.empty((2, cout), dtype=torch.float32, device=dev)
             mode, cf = 1, None
             if type(bn) is not nn.BatchNorm1d:  # DistributedSyncBN: the moments travel through one packed all-reduce
@@ -138,10 +141,12 @@ class _StackFn(torch.autograd.Function):
         ctx.layers, ctx.rec, ctx.sp = layers, rec, sp
         ctx.repack_stamp = repack.stamp()  # the packed weights in `rec` are rewritten in place by Repacker.run()
         ctx.generation = arena.generation
+        ctx.lease = lease
         ctx.dtype = dtype
         return x
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, g):
         L = _lib.lib()
         repack.check(ctx.repack_stamp, "sparse conv stack")
@@ -150,6 +155,7 @@ class _StackFn(torch.autograd.Function):
         dt = sp._DT[dtype]
         dev = g.device
         st = _lib.stream_ptr(dev)
+        A = ctx.lease.check("sparse conv stack")
         # arena slices are only ours until the next ARENA.reset(): a second forward in between -> separate sweeps
         fused = sp.ARENA.generation == ctx.generation
         grads = []  # per layer, in parameter order
@@ -166,7 +172,7 @@ class _StackFn(torch.autograd.Function):
             if dy.dtype != dtype:
                 dy = dy.to(dtype)
             if not reduced_next:
-                partial = sp.reduce_ws(dev, rb.n_out, cout, dtype)
+                partial = sp.reduce_ws(dev, rb.n_out, cout, dtype, A)
                 rc = L.d3d_bn_bwd_reduce(out.data_ptr(), dy.data_ptr(), rb.n_out, cout, dt, bn.weight.data_ptr(),
                                          _lib.ptr(bn.bias), save[0].data_ptr(), save[1].data_ptr(), int(ly.relu),
                                          partial.data_ptr(), st)
@@ -175,9 +181,14 @@ class _StackFn(torch.autograd.Function):
             if cf is not None:  # cross-rank BN: sum the two vectors over ranks, hand d3d_bn_bwd_dx the rank means
                 partial, g_gamma, g_beta = syncbn.exchange_backward_sums(bn, partial, cf, save[1])
                 sync = (g_gamma, g_beta)
-            gout = torch.empty_like(out)
+            gout = mem.empty((rb.n_out, cout), dtype, dev, A)
             sp.check_gather_source(gout, "the output gradient")
             gbn = torch.empty((2, cout), dtype=torch.float32, device=dev)
+            # (everything the side stream will touch is allocated BEFORE `gout_ready` is recorded: a block the main
+            # stream's pool recycles after that event could still be in use by an earlier main-stream kernel)
+            gw = torch.empty((rb.kvol, pad_cin, cout), dtype=torch.float32, device=dev)
+            wsb = L.d3d_sparse_conv_wgrad_workspace_bytes(rb.n_out, rb.kvol, pad_cin, cout, dt)
+            ws = mem.empty((wsb,), torch.uint8, dev, A)
             rc = L.d3d_bn_bwd_dx(out.data_ptr(), dy.data_ptr(), rb.n_out, cout, dt, bn.weight.data_ptr(),
                                  _lib.ptr(bn.bias), save[0].data_ptr(), save[1].data_ptr(), int(ly.relu),
                                  partial.data_ptr(), 1, gout.data_ptr(), gbn[0].data_ptr(), gbn[1].data_ptr(), st)
@@ -187,7 +198,7 @@ class _StackFn(torch.autograd.Function):
             gin = None
             reduced_next = False
             if li > 0 or ctx.needs_input_grad[0]:
-                gin = torch.empty((rb.n_in, pad_cin), dtype=dtype, device=dev)
+                gin = mem.empty((rb.n_in, pad_cin), dtype, dev, A)
                 ep = None
                 if li > 0 and fused and pad_cin == cin and sp.has_epilogue(cout, pad_cin, dtype):
                     pl = layers[li - 1]
@@ -200,9 +211,6 @@ class _StackFn(torch.autograd.Function):
                 sp.launch_dgrad(rb, gout, wd, cout, pad_cin, gin, ep, st)
                 if pad_cin != cin:
                     gin = gin[:, :cin].contiguous()
-            gw = torch.empty((rb.kvol, pad_cin, cout), dtype=torch.float32, device=dev)
-            wsb = L.d3d_sparse_conv_wgrad_workspace_bytes(rb.n_out, rb.kvol, pad_cin, cout, dt)
-            ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
             if side is not None:  # (buffers from the main stream's pool; `gout` was finished on the main stream)
                 side.wait_event(gout_ready)
                 keep.append((gout, ws, gw, x))

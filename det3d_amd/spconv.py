@@ -25,7 +25,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import _lib, sparse_stack
+from . import _lib, arena as mem, sparse_stack
 
 _SELF = sys.modules[__name__]
 _DT = {torch.float32: _lib.D3D_F32, torch.bfloat16: _lib.D3D_BF16}
@@ -102,10 +102,9 @@ def epilogue_ws(dev, n_out, cout):
     return ARENA.take(dev, _lib.lib().d3d_conv_epilogue_ws_floats(int(n_out), int(cout)))
 
 
-def reduce_ws(dev, n, c, dtype):
+def reduce_ws(dev, n, c, dtype, arena=None):
     """workspace of d3d_bn_stats / d3d_bn_bwd_reduce on an [n, c] matrix; the [2c] result sits at its start"""
-    return torch.empty((_lib.lib().d3d_bn_reduce_ws_floats(int(n), int(c), _DT[dtype]),), dtype=torch.float32,
-                       device=dev)
+    return mem.empty((_lib.lib().d3d_bn_reduce_ws_floats(int(n), int(c), _DT[dtype]),), torch.float32, dev, arena)
 
 
 def has_epilogue(cin, cout, dtype):
@@ -231,10 +230,10 @@ def build_subm_rulebook(indices, n_dev, n, cap, batch, spatial_shape, ksize, cou
     L = _lib.lib()
     dev = indices.device
     kvol = ksize[0] * ksize[1] * ksize[2]
-    nbr = torch.empty((kvol * cap,), dtype=torch.int32, device=dev)
+    nbr = mem.empty((kvol * cap,), torch.int32, dev)
     pc = torch.empty((kvol,), dtype=torch.int32, device=dev) if count_pairs else None
     wsb = L.d3d_subm_rulebook_workspace_bytes(cap)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    ws = mem.empty((wsb,), torch.uint8, dev)
     rc = L.d3d_subm_rulebook(indices.data_ptr(), n_dev.data_ptr(), cap, batch,
                              _lib.i32_array(spatial_shape), _lib.i32_array(ksize), nbr.data_ptr(),
                              _lib.ptr(pc), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
@@ -255,14 +254,14 @@ def build_conv_rulebook(indices, n_dev, n, cap_in, batch, in_shape, ksize, strid
         fan *= -(-ksize[j] // stride[j])  # ceil(k/s): outputs one input can reach per axis
     cells = batch * out_shape[0] * out_shape[1] * out_shape[2]
     cap_out = int(max(1, min(cap_in * fan, cells)))
-    coords_out = torch.empty((cap_out, 4), dtype=torch.int32, device=dev)
+    coords_out = mem.empty((cap_out, 4), torch.int32, dev)
     n_out_dev = torch.empty((1,), dtype=torch.int32, device=dev)
-    nbr_out = torch.empty((kvol * cap_out,), dtype=torch.int32, device=dev)
-    nbr_in = torch.empty((kvol * cap_in,), dtype=torch.int32, device=dev)
+    nbr_out = mem.empty((kvol * cap_out,), torch.int32, dev)
+    nbr_in = mem.empty((kvol * cap_in,), torch.int32, dev)
     pc = torch.empty((kvol,), dtype=torch.int32, device=dev) if count_pairs else None
     oshape = _lib.i32_array(out_shape)
     wsb = L.d3d_conv_rulebook_workspace_bytes(batch, oshape)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    ws = mem.empty((wsb,), torch.uint8, dev)
     rc = L.d3d_conv_rulebook(indices.data_ptr(), n_dev.data_ptr(), cap_in, batch,
                              _lib.i32_array(in_shape), _lib.i32_array(ksize),
                              _lib.i32_array(stride), _lib.i32_array(padding), oshape,
@@ -275,7 +274,7 @@ def build_conv_rulebook(indices, n_dev, n, cap_in, batch, in_shape, ksize, strid
         # rows of the data gradient in parity-class order: 27 / 8 offsets per block instead of 27 (three small
         # launches next to the rulebook's, on the same stream)
         words = L.d3d_dgrad_plan_ints(cap_in)
-        plan = torch.empty((words,), dtype=torch.int32, device=dev)
+        plan = mem.empty((words,), torch.int32, dev)
         rc = L.d3d_dgrad_plan_build(indices.data_ptr(), n_dev.data_ptr(), cap_in, _lib.i32_array(ksize),
                                     _lib.i32_array(stride), _lib.i32_array(padding), plan.data_ptr(), words,
                                     _lib.stream_ptr(dev))
@@ -305,13 +304,13 @@ def build_conv_rulebook_chain(indices, n_dev, cap0, batch, in_shape, convs):
             fan *= -(-ksize[a] // stride[a])
         cells = batch * out_shape[0] * out_shape[1] * out_shape[2]
         cap_out = int(max(1, min(cap_in * fan, cells)))
-        coords_out = torch.empty((cap_out, 4), dtype=torch.int32, device=dev)
+        coords_out = mem.empty((cap_out, 4), torch.int32, dev)
         n_out_dev = torch.empty((1,), dtype=torch.int32, device=dev)
-        nbr_out = torch.empty((kvol * cap_out,), dtype=torch.int32, device=dev)
-        nbr_in = torch.empty((kvol * cap_in,), dtype=torch.int32, device=dev)
+        nbr_out = mem.empty((kvol * cap_out,), torch.int32, dev)
+        nbr_in = mem.empty((kvol * cap_in,), torch.int32, dev)
         plan = None
         if DGRAD_PLAN and L.d3d_dgrad_plan_supported(_lib.i32_array(ksize), _lib.i32_array(stride)):
-            plan = torch.empty((L.d3d_dgrad_plan_ints(cap_in),), dtype=torch.int32, device=dev)
+            plan = mem.empty((L.d3d_dgrad_plan_ints(cap_in),), torch.int32, dev)
         y = arr[j]
         for a in range(3):
             y.in_shape[a], y.ksize[a], y.stride[a], y.padding[a], y.out_shape[a] = shape[a], ksize[a], stride[a], padding[a], out_shape[a]
@@ -326,7 +325,7 @@ def build_conv_rulebook_chain(indices, n_dev, cap0, batch, in_shape, convs):
     wsb = L.d3d_conv_rulebook_chain_workspace_bytes(len(convs), batch, ctypes.cast(arr, ctypes.c_void_p))
     if wsb == 0:
         raise _lib.D3dError("d3d_conv_rulebook_chain: unsupported chain of %d layers" % len(convs))
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    ws = mem.empty((wsb,), torch.uint8, dev)
     rc = L.d3d_conv_rulebook_chain(len(convs), ctypes.cast(arr, ctypes.c_void_p), batch, indices.data_ptr(),
                                    n_dev.data_ptr(), int(cap0), ws.data_ptr(), wsb, _lib.stream_ptr(dev))
     _lib.check(rc, "d3d_conv_rulebook_chain")
@@ -341,7 +340,7 @@ def build_subm_rulebook_ranked(indices, n_dev, n, batch, spatial_shape, ksize, r
     dev = indices.device
     kvol = ksize[0] * ksize[1] * ksize[2]
     cap = max(int(n), 1)
-    nbr = torch.empty((kvol * cap,), dtype=torch.int32, device=dev)
+    nbr = mem.empty((kvol * cap,), torch.int32, dev)
     rc = L.d3d_subm_rulebook_ranked(indices.data_ptr(), n_dev.data_ptr(), cap, batch, _lib.i32_array(spatial_shape),
                                     _lib.i32_array(ksize), rank[0], rank[1], nbr.data_ptr(), None, _lib.stream_ptr(dev))
     _lib.check(rc, "d3d_subm_rulebook_ranked")
@@ -379,6 +378,7 @@ def launch_dgrad(rb, gout, wd, cout, pad_cin, gin, ep, stream):
 # --------------------------------------------------------------------- autograd
 class _SparseConvFn(torch.autograd.Function):
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, feats, weight, bias, rb, stats, link):
         """stats: epilogue_ws() buffer or None -- the launch leaves sum / sum-of-squares of its output rows (the
         batch statistics of the BatchNorm that follows) in stats[:2*cout].  link: _BnLink of the fused BN(+ReLU)
@@ -404,7 +404,8 @@ class _SparseConvFn(torch.autograd.Function):
         check_gather_source(feats, "the feature matrix")
         need_dgrad = ctx.needs_input_grad[0]
         wpack, wd = _packed_weights(weight, kvol, cin, cout, feats.dtype, rb.subm, need_dgrad, pad_cin)
-        out = torch.empty((rb.n_out, cout), dtype=feats.dtype, device=feats.device)
+        lease = mem.Lease()
+        out = mem.empty((rb.n_out, cout), feats.dtype, feats.device, lease.arena)
         b = bias.detach().float().contiguous() if bias is not None else None
         mfma = has_epilogue(pad_cin, cout, feats.dtype)
         ep = None
@@ -425,9 +426,11 @@ class _SparseConvFn(torch.autograd.Function):
         ctx.pad = (cin, pad_cin)
         ctx.link = link
         ctx.mfma = mfma
+        ctx.lease = lease
         return out
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, gout):
         L = _lib.lib()
         feats, weight = ctx.saved_tensors
@@ -438,13 +441,14 @@ class _SparseConvFn(torch.autograd.Function):
         check_gather_source(gout, "the output gradient")
         dt = _DT[feats.dtype]
         stream = _lib.stream_ptr(feats.device)
+        A = ctx.lease.check("sparse conv")
         gin = gw = gb = None
         if ctx.needs_input_grad[0]:
             from . import repack
             repack.check(ctx.repack_stamp, "sparse conv")
             wd = ctx.wd  # packed in the forward: W[k] as is; k mirrored for submanifold layers because
             #              (j -> i at offset k)  <=>  (i -> j at offset kvol-1-k) on the same table
-            gin = torch.empty((rb.n_in, pad_cin), dtype=feats.dtype, device=feats.device)
+            gin = mem.empty((rb.n_in, pad_cin), feats.dtype, feats.device, A)
             ep = None
             link = ctx.link
             if link is not None and has_epilogue(cout, pad_cin, feats.dtype) and pad_cin == cin and rb.n_in > 0 and \
@@ -462,7 +466,7 @@ class _SparseConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = torch.empty((kvol, pad_cin, cout), dtype=torch.float32, device=feats.device)
             wsb = L.d3d_sparse_conv_wgrad_workspace_bytes(rb.n_out, kvol, pad_cin, cout, dt)
-            ws = torch.empty((wsb,), dtype=torch.uint8, device=feats.device)
+            ws = mem.empty((wsb,), torch.uint8, feats.device, A)
             rc = _timed("wgrad", pad_cin, cout, rb.n_out, rb, feats.device, lambda: L.d3d_sparse_conv_wgrad(
                 feats.data_ptr(), gout.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, rb.n_out, kvol,
                 pad_cin, cout, dt, gw.data_ptr(), ws.data_ptr(), wsb, stream))
@@ -481,17 +485,19 @@ class _BNReLUFn(torch.autograd.Function):
     for the single conv consuming the output, whose dgrad epilogue then does this op's backward reduction."""
 
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, training, relu, stats, link):
         L = _lib.lib()
         x = x.contiguous()
         n, c = x.shape
         dev = x.device
-        y = torch.empty_like(x)
+        lease = mem.Lease()
+        y = mem.empty((n, c), x.dtype, dev, lease.arena)
         save = torch.empty((2, c), dtype=torch.float32, device=dev)  # mean, invstd
         st = _lib.stream_ptr(dev)
         copies = 1  # every producer (conv epilogue, d3d_bn_stats) folds its sums into one [2c] vector
         if training and stats is None:
-            stats = reduce_ws(dev, n, c, x.dtype)
+            stats = reduce_ws(dev, n, c, x.dtype, lease.arena)
             _lib.check(L.d3d_bn_stats(x.data_ptr(), n, c, _DT[x.dtype], stats.data_ptr(), st), "d3d_bn_stats")
         rc = L.d3d_bn_apply(x.data_ptr(), n, c, _DT[x.dtype], _lib.ptr(weight), _lib.ptr(bias),
                             _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum), float(eps),
@@ -502,6 +508,7 @@ class _BNReLUFn(torch.autograd.Function):
         ctx.relu = relu
         ctx.training = training
         ctx.link = link
+        ctx.lease = lease
         if link is not None and training:
             link.x, link.save, link.gamma, link.beta, link.relu = x, save, weight, bias, bool(relu)
             link.partial = epilogue_ws(dev, n, c)
@@ -510,6 +517,7 @@ class _BNReLUFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, dy):
         if not ctx.training:
             raise _lib.D3dError("fused sparse BN backward is implemented for training mode only")
@@ -517,7 +525,8 @@ class _BNReLUFn(torch.autograd.Function):
         x, weight, bias, save = ctx.saved_tensors
         n, c = x.shape
         dy = dy.contiguous().to(x.dtype)
-        dx = torch.empty_like(x)
+        A = ctx.lease.check("sparse BatchNorm")
+        dx = mem.empty((n, c), x.dtype, x.device, A)
         g = torch.empty((2, c), dtype=torch.float32, device=x.device)
         st = _lib.stream_ptr(x.device)
         link = ctx.link
@@ -525,7 +534,7 @@ class _BNReLUFn(torch.autograd.Function):
         if link is not None and link.reduced and link.generation == ARENA.generation and link.partial is not None:
             partial = link.partial  # reduced by the consuming conv's dgrad epilogue
         else:
-            partial = reduce_ws(x.device, n, c, x.dtype)
+            partial = reduce_ws(x.device, n, c, x.dtype, A)
             rc = L.d3d_bn_bwd_reduce(x.data_ptr(), dy.data_ptr(), n, c, _DT[x.dtype], _lib.ptr(weight),
                                      _lib.ptr(bias), save[0].data_ptr(), save[1].data_ptr(), int(ctx.relu),
                                      partial.data_ptr(), st)
@@ -613,6 +622,7 @@ def bn_relu_2d(bn, x, relu):
 
 class _DenseFn(torch.autograd.Function):
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, feats, indices, batch, shape, channels_last):
         _need_cuda(feats, "SparseConvTensor.dense")
         L = _lib.lib()
@@ -630,15 +640,17 @@ class _DenseFn(torch.autograd.Function):
         _lib.check(rc, "d3d_dense_scatter")
         ctx.save_for_backward(indices)
         ctx.meta = (n, c, batch, list(shape), channels_last)
+        ctx.lease = mem.Lease()
         return out
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, g):
         L = _lib.lib()
         (indices,) = ctx.saved_tensors
         n, c, batch, shape, channels_last = ctx.meta
         g = g.contiguous(memory_format=torch.channels_last) if channels_last else g.contiguous()
-        gf = torch.empty((n, c), dtype=g.dtype, device=g.device)
+        gf = mem.empty((n, c), g.dtype, g.device, ctx.lease.check("dense()"))
         rc = L.d3d_dense_gather(g.data_ptr(), indices.data_ptr(), n, c, batch,
                                 _lib.i32_array(shape), _DT[g.dtype], int(channels_last),
                                 gf.data_ptr(), _lib.stream_ptr(g.device))

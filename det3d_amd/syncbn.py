@@ -33,6 +33,8 @@ from torch import nn
 from torch.autograd.function import once_differentiable
 from torch.nn.modules.batchnorm import _BatchNorm
 
+from . import _lib
+
 
 def _world(group):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -53,6 +55,7 @@ def _per_channel(v, x):
 
 class _SyncBNFn(torch.autograd.Function):
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, group):
         c = x.shape[1]
         dims = [0] + list(range(2, x.dim()))
@@ -80,6 +83,7 @@ class _SyncBNFn(torch.autograd.Function):
         return y.to(x.dtype)
 
     @staticmethod
+    @_lib.ctx_backward
     @once_differentiable
     def backward(ctx, dy):
         x, ex, std, gamma = ctx.saved_tensors
@@ -128,6 +132,7 @@ class _SyncBNReLUFusedFn(torch.autograd.Function):
     algebra in between is a handful of tiny torch ops."""
 
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, rows, gamma, beta, running_mean, running_var, momentum, eps, group, relu):
         from . import _lib
 
@@ -164,6 +169,7 @@ class _SyncBNReLUFusedFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_lib.ctx_backward
     @once_differentiable
     def backward(ctx, dy):
         from . import _lib

@@ -51,8 +51,13 @@ class OneCycle:
 
 class TrainStep:
     def __init__(self, model, total_steps, lr_max=3e-3, wd=0.01, moms=(0.95, 0.85), div_factor=10.0,
-                 pct_start=0.4, grad_clip=35.0, autocast_dtype=None):
+                 pct_start=0.4, grad_clip=35.0, autocast_dtype=None, step_arena=True):
+        """step_arena: the data-dependent tensors of the sparse forward / backward (activations, their gradients,
+        workspaces) come from the device's step arena, rewound at the start of every call (arena.py) -- a steady-state
+        step then allocates nothing from the device.  Needs forward, backward and optimizer inside this call on one
+        stream, which is what __call__ does."""
         self.model = model
+        self.step_arena = bool(step_arena)
         self.sched = OneCycle(total_steps, lr_max, moms, div_factor, pct_start)
         self.wd = wd
         self.grad_clip = grad_clip
@@ -113,6 +118,16 @@ class TrainStep:
         """one optimizer step on `example`.  after_forward: called between the forward and the backward enqueue -- the
         place to start host work for a LATER step (the next geometry build on its worker thread): the forward phase is
         the host-bound part of the step, the backward's large dense kernels leave the host time to spare."""
+        from . import arena
+
+        A = None
+        dev = self.params[0].device
+        if self.step_arena and dev.type == "cuda":
+            A = arena.step_arena(dev).begin()
+        with arena.bound(A):
+            return self._step(example, after_forward)
+
+    def _step(self, example, after_forward):
         lr, mom = self.sched.at(self.global_step)
         ev = None
         if self.probe is not None:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 10 /* 10: caller-owned contexts (d3d_ctx_*), d3d_set_tuning knob 11; 9: d3d_conv_rulebook_chain / d3d_subm_rulebook_ranked, training = 2 of d3d_bn_apply, d3d_set_tuning knob 10; 8: d3d_conv2d_nhwc_dgrad_s2; 7: residual forms of the BatchNorm sweeps, D3dConvEpilogue.addend; 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv; 5: planned strided data gradient, d3d_adam_step; 6: deterministic PillarFeatureNet sums (workspace arguments) */
+#define D3D_ABI_VERSION 11 /* 11: d3d_ctx_current; 10: caller-owned contexts (d3d_ctx_*), d3d_set_tuning knob 11; 9: d3d_conv_rulebook_chain / d3d_subm_rulebook_ranked, training = 2 of d3d_bn_apply, d3d_set_tuning knob 10; 8: d3d_conv2d_nhwc_dgrad_s2; 7: residual forms of the BatchNorm sweeps, D3dConvEpilogue.addend; 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv; 5: planned strided data gradient, d3d_adam_step; 6: deterministic PillarFeatureNet sums (workspace arguments) */
 
 #define D3D_OK 0
 #define D3D_EINVAL -1    /* bad argument / unsupported shape           */
@@ -191,6 +191,9 @@ int d3d_set_tuning(int knob, int value);
  * bind anything share (the behaviour of ABI <= 9).  One context per stream-owning thread makes two concurrent callers
  * independent.  d3d_ctx_destroy frees the rings; the caller guarantees that none of the context's launches is still in
  * flight and that no other thread has it bound.  d3d_ctx_get_tuning reads a knob of the calling thread's context.
+ * d3d_ctx_current (ABI 11) returns the handle the calling thread has bound (NULL: the process default) -- a host framework
+ * whose backward pass runs on another thread than its forward (PyTorch's autograd engine) reads it in the forward and
+ * re-binds it around the backward, so that knobs which change operand formats (10) apply to both directions.
  * (The reference keeps the corresponding state -- spconv's algorithm choice, cuDNN handles -- in module globals:
  * det3d/ops/syncbn/syncbn.py:1-40, spconv's ConvAlgo.) */
 typedef struct D3dContext *d3d_ctx_t;
@@ -198,6 +201,7 @@ int d3d_ctx_create(d3d_ctx_t *ctx);
 int d3d_ctx_bind(d3d_ctx_t ctx);
 int d3d_ctx_destroy(d3d_ctx_t ctx);
 int d3d_ctx_get_tuning(int knob, int *value);
+int d3d_ctx_current(d3d_ctx_t *ctx);
 int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const float *bias,
                            const int32_t *nbr, int cap, int n_out, int kvol, int cin, int cout,
                            int dtype, void *out, const D3dConvEpilogue *epilogue, d3d_stream_t stream);

@@ -196,6 +196,15 @@ PY
         env $v=$val timeout 300 python bench.py --gpus 1 --steps 60 --warmup 3 --no-cpu-baseline --no-extras > $O/ab_${v}_${val}_$rep.json 2> $O/ab_${v}_${val}_$rep.err
         echo "$v=$val: $(show $O/ab_${v}_${val}_$rep.json 2 | tr '\n' ' ' | cut -c1-200)"
       done; done ;;
+    allocx)
+      # allocator experiment: the driver's 20-step window under caching-allocator settings; the line of
+      # interest is bench.py's "allocator during it" note
+      i=0
+      for conf in "" "roundup_power2_divisions:8" "expandable_segments:True" "max_split_size_mb:32" "roundup_power2_divisions:8,max_split_size_mb:32" "expandable_segments:True,roundup_power2_divisions:8"; do
+        i=$((i+1))
+        PYTORCH_HIP_ALLOC_CONF="$conf" PYTORCH_ALLOC_CONF="$conf" timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/allocx_$i.json 2> $O/allocx_$i.err
+        echo "[$conf] $(show $O/allocx_$i.json 1 | cut -c1-120)"; grep "c2-20k fp32 timed region" $O/allocx_$i.err | cut -c1-260; grep -i "warn\|not supported" $O/allocx_$i.err | head -3
+      done ;;
     env:*)
       # one 60-step bench.py run under VAR=VALUE (comma-separated list):  env:D3D_BN_STREAM_BLOCKS=1024
       v=${st#env:}
