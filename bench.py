@@ -16,6 +16,16 @@ BN statistics in their epilogue) -> head 1x1 convs (the library's d3d_head_conv_
 run on a third stream next to the data-gradient chain (det3d_amd/sparse_stack.py WGRAD_STREAM; D3D_WGRAD_STREAM=0: one
 stream).  Rank 0 prints ONE JSON line and refuses to if the loss or the gradient norm after the timed region is not finite.
 
+ROUND 6.  `--gpus N` started without a launcher becomes one (spawn_ranks: torch.distributed.run, one rank per device over
+RCCL, each rank pinned to its share of the host cores) and a line whose n_gpus is not N is refused.  The timed region is
+`--windows` back-to-back windows of `--steps` steps (default 9 when --steps <= 60), each bracketed by barrier +
+synchronize; `value` is the MEDIAN window (`config.windows_ms` has all of them) -- 20 steps are 0.13 s, and one window is
+at the mercy of a single host hiccup.  The data-dependent tensors of the step come from bump arenas (det3d_amd/arena.py:
+step arena + geometry ring), `config.allocator` reports what the caching allocator still had to do during the windows
+(num_device_alloc: hipMalloc calls).  16 distinct batches cycle.  `roofline.frac` is the dominant sparse kernel over ALL its
+launches of the last timed step (forward and data gradient, the latter next to the weight-gradient stream); the
+forward-only figure and the rocprofv3 averages are in `roofline.sources`.
+
 PRECISION (round 3).  The headline (`--dtype fp32`, the default) is the precision that meets north_star's "boxes
 within 1e-3 of the reference": f32 storage of every activation, and every product of the sparse and the dense
 convolutions in SPLIT arithmetic -- operands as bf16 pairs hi = bf16(v), lo = bf16(v - hi), three bf16 MFMAs per
@@ -1157,14 +1167,17 @@ def child_workload(name, dtype, steps=8, warmup=3, budget_s=200):
 
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(steps),
-                            "--warmup", str(warmup), "--dtype", dtype, "--no-cpu-baseline", "--no-extras", "--burn-in", "0.5"],
+                            "--warmup", str(warmup), "--dtype", dtype, "--no-cpu-baseline", "--no-extras", "--burn-in", "0.5",
+                            "--windows", "3"],
                            capture_output=True, text=True, timeout=budget_s)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not line:
             return {"error": "rc=%d %s" % (r.returncode, r.stderr[-300:])}
         d = json.loads(line[-1])
         row = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
-               "steps": d["steps"], "dtype": d["dtype"], "first_loss": d["config"].get("first_loss"),
+               "steps": d["steps"], "windows_ms": d["config"].get("windows_ms"), "dtype": d["dtype"],
+               "allocator": {k: d["config"].get("allocator", {}).get(k) for k in ("num_device_alloc", "reserved_MB", "steps")},
+               "first_loss": d["config"].get("first_loss"),
                "final_loss": d["config"]["final_loss"], "optimizer_steps": d["config"].get("steps_before_final_loss")}
         if "roofline" in d:
             row["roofline"] = {k: d["roofline"][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",

@@ -44,6 +44,10 @@ SIGNATURES = {
     "d3d_conv_epilogue_ws_floats": (sz, [i32, i32]),
     "d3d_bn_reduce_ws_floats": (sz, [i32, i32, i32]),
     "d3d_sparse_conv_fwd_ex": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "d3d_pair_table_bytes": (sz, [i32, i32]),
+    "d3d_pair_table_build": (i32, [vp, i32, i32, i32, vp, sz, vp]),
+    "d3d_sparse_conv_pairs_supported": (i32, [i32, i32, i32]),
+    "d3d_sparse_conv_fwd_pairs": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "d3d_dgrad_plan_ints": (sz, [i32]),
     "d3d_dgrad_plan_supported": (i32, [vp, vp]),
     "d3d_dgrad_plan_build": (i32, [vp, vp, i32, vp, vp, vp, vp, sz, vp]),

@@ -21,6 +21,7 @@ SOURCES = [
     "d3d_rulebook.hip",
     "d3d_rbchain.hip",
     "d3d_spconv.hip",
+    "d3d_spconv_pairs.hip",
     "d3d_wgrad.hip",
     "d3d_bn.hip",
     "d3d_conv2d.hip",

@@ -566,6 +566,8 @@ static int bn_apply_impl(const void *x, int n, int c, int dtype, const float *ga
   int rc = bn_check(n, c, dtype, "d3d_bn_apply");
   if (rc) return rc;
   D3D_REQUIRE(copies >= 1 && copies <= 256, "d3d_bn_apply: copies=%d", copies);
+  D3D_REQUIRE(training >= 0 && training <= 2, "d3d_bn_apply: training=%d (0 running statistics, 1 batch sums in stats_ws, "
+              "2 finished mean | variance in stats_ws)", training);
   D3D_REQUIRE(x && y, "d3d_bn_apply: null pointer");
   D3D_REQUIRE(training ? stats_ws != nullptr : (running_mean && running_var),
               "d3d_bn_apply: training needs stats_ws, eval needs running stats");
@@ -747,6 +749,10 @@ extern "C" int d3d_bn_relu_fwd(const void *x, int n, int c, int dtype, const flo
                                float momentum, float eps, int training, int relu, void *y,
                                float *save_mean, float *save_invstd, float *stats_ws,
                                d3d_stream_t stream_) {
+  // (training = 2, finished moments handed in by the caller, exists for d3d_bn_apply and its forms only: here the
+  // statistics sweep below would overwrite them with local sums)
+  D3D_REQUIRE(training == 0 || training == 1, "d3d_bn_relu_fwd: training=%d (0 or 1; finished cross-rank moments go to "
+              "d3d_bn_apply with training = 2)", training);
   D3D_REQUIRE(training ? stats_ws != nullptr : (running_mean && running_var),
               "d3d_bn_relu_fwd: training needs stats_ws, eval needs running stats");
   if (training) {

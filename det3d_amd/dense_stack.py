@@ -204,7 +204,7 @@ class _DenseStackFn(torch.autograd.Function):
             rec.append((a_hi, a_lo, y, save, cf))
             a_hi, a_lo = nxt
         ctx.layers, ctx.rec, ctx.mode, ctx.training = layers, rec, mode, training
-        ctx.repack_stamp = repack.stamp()  # the backward reads the layers' cached packs, rewritten in place by Repacker.run()
+        ctx.repack_stamp = repack.stamp([ly.conv.weight for ly in layers])  # the backward reads the layers' cached packs, rewritten in place by Repacker.run()
         ctx.in_dtype = x.dtype
         ctx.need_in_grad = need_in_grad
         return out.permute(0, 3, 1, 2)  # channels-last [B, C, H, W]

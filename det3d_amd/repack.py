@@ -23,15 +23,18 @@ import torch
 from . import _lib
 
 ENABLED = os.environ.get("D3D_PACK_ALL", "1") != "0"
-EPOCH = 0  # number of in-place rewrites so far (any Repacker)
+_EPOCH = {}  # id(parameter) -> number of in-place rewrites of ITS packed operands so far
 
 
-def stamp():
-    return EPOCH
+def stamp(weights=()):
+    """what a node remembers in its forward: the rewrite counts of the parameters whose packed operands it keeps.  (One
+    process-global counter made every pending node fail when ANOTHER model's Repacker ran between its forward and
+    backward -- a teacher / EMA copy, a second optimizer: ADVICE round 5.)"""
+    return tuple((id(w), _EPOCH.get(id(w), 0)) for w in weights)
 
 
 def check(stamped, who):
-    if stamped != EPOCH:
+    if any(_EPOCH.get(k, 0) != v for k, v in stamped):
         raise RuntimeError("%s: backward of a graph built before Repacker.run() rewrote the packed conv operands in place "
                            "(optimizer step between forward and backward, or a graph kept across steps); run the "
                            "backward first or set D3D_PACK_ALL=0" % who)
@@ -92,8 +95,8 @@ class Repacker:
                                            dgrad=d[0].data_ptr(), dgrad_lo=_lib.ptr(d[1]), kind=1, a=int(p.shape[0]),
                                            b=int(p.shape[1]), c=int(p.shape[2] * p.shape[3]), flip=0, dtype=0)
             self._key, self._table, self._n = key, arr, len(ents)
-        global EPOCH
-        EPOCH += 1
+        for kind, p, e, mode in ents:
+            _EPOCH[id(p)] = _EPOCH.get(id(p), 0) + 1
         dev = ents[0][1].device
         rc = _lib.lib().d3d_pack_all(ctypes.cast(self._table, ctypes.c_void_p), self._n, _lib.stream_ptr(dev))
         _lib.check(rc, "d3d_pack_all")

@@ -96,9 +96,7 @@ class _BlockFn(torch.autograd.Function):
             stats = sp.epilogue_ws(dev, n, c)
             ep = _lib.ConvEpilogue(stats=stats.data_ptr(), ws_floats=stats.numel())
             b = bias.detach() if bias is not None else None
-            rc = sp._timed("fwd", c, c, n, rb, dev, lambda: L.d3d_sparse_conv_fwd_ex(
-                src.data_ptr(), wpack.data_ptr(), _lib.ptr(b), rb.nbr_out.data_ptr(), rb.cap_out, n, rb.kvol, c, c, dt,
-                out.data_ptr(), ctypes.byref(ep), st))
+            rc = sp.launch_fwd(rb, src, wpack, b, c, c, out, ep, st)
             _lib.check(rc, "d3d_sparse_conv_fwd")
             return out, stats
 
@@ -135,7 +133,7 @@ class _BlockFn(torch.autograd.Function):
         # (x is the caller's tensor); the packed weights are not autograd's to version -- repack.check guards them
         ctx.save_for_backward(x, out1, y1, out2, save1, save2)
         ctx.rec = (wd1, wd2, partial1)
-        ctx.repack_stamp = repack.stamp()
+        ctx.repack_stamp = repack.stamp((conv1.weight, conv2.weight))
         ctx.backward_runs = 0
         ctx.generation = sp.ARENA.generation
         ctx.lease = lease

@@ -57,10 +57,22 @@ def _eligible(sp, conv, bn, feats_dtype, rb):
     pad_cin = 16 if (cin < 16 and cout % 16 == 0) else cin
     if not sp.has_epilogue(pad_cin, cout, feats_dtype):
         return False  # VALU fallback kernels have no epilogues
-    if rb is None or rb.subm != conv.subm or rb.n_out <= 1 or rb.n_in <= 0:
+    if rb is None or rb.subm != conv.subm:
         return False
-    if type(bn) is not nn.BatchNorm1d and not syncbn.fused_sync(bn):  # (cross-rank BN: the same kernels around two
-        return False                                                  # packed all-reduces, syncbn.exchange_*)
+    sync = syncbn.fused_sync(bn)  # cross-rank BN: the same kernels around two packed all-reduces, syncbn.exchange_*
+    if type(bn) is not nn.BatchNorm1d and not sync:
+        return False
+    if sync:
+        # The decision must be the SAME ON EVERY RANK: a rank that left the fused node would issue its
+        # SyncBN all-reduces layer by layer, with the gradient buckets' all-reduces in between, while the others issue
+        # them after the whole stack -- different collective orders on one process group.  So nothing rank-local may
+        # decline here; a rank without active sites at a cross-rank BatchNorm is an error (the reference divides by the
+        # local count as well: det3d/ops/syncbn/syncbn.py:39-46).
+        if rb.n_out < 1 or rb.n_in < 1:
+            raise _lib.D3dError("sparse stack: this rank has no active sites (%d -> %d rows) at a SyncBN layer; its "
+                                "statistics are undefined and the other ranks are waiting in the exchange" % (rb.n_in, rb.n_out))
+    elif rb.n_out <= 1 or rb.n_in <= 0:
+        return False
     if not bn.training or bn.momentum is None or not bn.track_running_stats:
         return False
     if bn.weight is None or bn.num_features != cout:
@@ -119,9 +131,7 @@ class _StackFn(torch.autograd.Function):
             stats = sp.epilogue_ws(dev, rb.n_out, cout)
             ep = _lib.ConvEpilogue(stats=stats.data_ptr(), ws_floats=stats.numel())
             b = conv.bias.detach() if conv.bias is not None else None
-            rc = sp._timed("fwd", pad_cin, cout, rb.n_out, rb, dev, lambda: L.d3d_sparse_conv_fwd_ex(
-                x.data_ptr(), wpack.data_ptr(), _lib.ptr(b), rb.nbr_out.data_ptr(), rb.cap_out, rb.n_out, rb.kvol,
-                pad_cin, cout, dt, out.data_ptr(), ctypes.byref(ep), st))
+            rc = sp.launch_fwd(rb, x, wpack, b, pad_cin, cout, out, ep, st)
             _lib.check(rc, "d3d_sparse_conv_fwd")
             y = mem.empty((rb.n_out, cout), dtype, dev, A)
             save = torch.empty((2, cout), dtype=torch.float32, device=dev)
@@ -139,7 +149,7 @@ class _StackFn(torch.autograd.Function):
             rec.append((x, out, save, wd, partial, cf))
             x = y
         ctx.layers, ctx.rec, ctx.sp = layers, rec, sp
-        ctx.repack_stamp = repack.stamp()  # the packed weights in `rec` are rewritten in place by Repacker.run()
+        ctx.repack_stamp = repack.stamp([ly.conv.weight for ly in layers])  # the packed weights in `rec` are rewritten in place by Repacker.run()
         ctx.generation = arena.generation
         ctx.lease = lease
         ctx.dtype = dtype

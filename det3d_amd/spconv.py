@@ -194,6 +194,26 @@ class Rulebook:
         self.out_shape = out_shape
         self.subm = subm
         self.dgrad_plan = None      # int32 row plan of the strided data gradient (csrc/d3d_rowplan.h) or None
+        self._pair_tables = {}      # "out" / "in" -> uint8 buffer of d3d_pair_table_build
+
+    def pair_table(self, side="out"):
+        """the pair-compacted form of a neighbour table (include/d3d.h, d3d_pair_table_build): "out" = the
+        output-stationary table (forward; data gradient of submanifold layers), "in" = the input-stationary twin of a
+        strided layer (its data gradient).  Built on first use on the current stream -- SparseSequential.plan() does
+        that ahead of time on the geometry stream -- and kept with the rulebook."""
+        hit = self._pair_tables.get(side)
+        # (a table that was allocated from a bump arena dies with that arena's generation: rebuilt if the rulebook outlives it)
+        t = hit[0] if hit is not None and (hit[1].arena is None or hit[1].arena.generation == hit[1].generation) else None
+        if t is None:
+            L = _lib.lib()
+            lease = mem.Lease()
+            nbr, cap, n = (self.nbr_out, self.cap_out, self.n_out) if side == "out" else (self.nbr_in, self.cap_in, self.n_in)
+            nb = L.d3d_pair_table_bytes(int(n), self.kvol)
+            t = mem.empty((nb,), torch.uint8, nbr.device)
+            _lib.check(L.d3d_pair_table_build(nbr.data_ptr(), cap, int(n), self.kvol, t.data_ptr(), nb,
+                                              _lib.stream_ptr(nbr.device)), "d3d_pair_table_build")
+            self._pair_tables[side] = (t, lease)
+        return t
 
     def pair_counts(self):
         """pairs per kernel offset, int64 [kvol] on the device.  Counted on demand from the
@@ -356,14 +376,63 @@ def finalize_conv_rulebook(rb, n_in, n_out):
     return rb
 
 
+# Pair-compacted kernel (d3d_sparse_conv_fwd_pairs, round 6): which launches take it.
+#   "off"     none (the output-stationary tile kernels everywhere)
+#   "all"     every f32 launch whose channel pair has the tiling (tests, tools/bench_pairs.py)
+#   "measured" the launches it measured faster on MI355X alone on the device (profiles/round6_pairs_kernel.txt): the data
+#             gradients of strided layers into 32 channels.  At two waves per SIMD (the 16 KB accumulator slab per wave
+#             fills the LDS with 8 waves) it is bound by the instruction issue of its own waves, not by the MFMA pipe or
+#             the gathers it saves: DESIGN.md section 10.
+# Default "off": inside the training step those data gradients share the CUs with the weight-gradient stream, which a
+# 160 KB block locks out.
+PAIR_KERNELS = "off"
+_PAIRS_OK = {}
+
+
+def pairs_ok(rb, cin, cout, dtype, strided_dgrad=False):
+    """does the launch (cin -> cout channels, features of `dtype`) over rulebook `rb` take the pair-compacted kernel?"""
+    if PAIR_KERNELS == "off" or not PAIR_KERNELS or dtype != torch.float32 or rb.kvol > 32:
+        return False
+    if PAIR_KERNELS == "measured" and not (strided_dgrad and cout == 32):
+        return False
+    L = _lib.lib()
+    key = (cin, cout, L.d3d_sparse_conv_has_epilogue(cin, cout, _lib.D3D_F32))  # (knob 10 switches both answers off)
+    ok = _PAIRS_OK.get(key)
+    if ok is None:
+        ok = _PAIRS_OK[key] = bool(L.d3d_sparse_conv_pairs_supported(cin, cout, _lib.D3D_F32))
+    return ok
+
+
+def launch_fwd(rb, x, wpack, bias, pad_cin, cout, out, ep, stream):
+    """forward of one sparse conv over the output-stationary table: the pair-compacted kernel where the channel pair has
+    one, else the tile kernel that walks every offset"""
+    L = _lib.lib()
+    epp = ctypes.byref(ep) if ep is not None else None
+    if pairs_ok(rb, pad_cin, cout, x.dtype):
+        table = rb.pair_table("out")
+        return _timed("fwd", pad_cin, cout, rb.n_out, rb, x.device, lambda: L.d3d_sparse_conv_fwd_pairs(
+            x.data_ptr(), wpack.data_ptr(), _lib.ptr(bias), table.data_ptr(), rb.n_out, rb.kvol, pad_cin, cout,
+            _DT[x.dtype], out.data_ptr(), epp, stream))
+    return _timed("fwd", pad_cin, cout, rb.n_out, rb, x.device, lambda: L.d3d_sparse_conv_fwd_ex(
+        x.data_ptr(), wpack.data_ptr(), _lib.ptr(bias), rb.nbr_out.data_ptr(), rb.cap_out, rb.n_out, rb.kvol, pad_cin,
+        cout, _DT[x.dtype], out.data_ptr(), epp, stream))
+
+
 def launch_dgrad(rb, gout, wd, cout, pad_cin, gin, ep, stream):
     """data gradient of one sparse conv: the gather kernel over the table that is stationary in the INPUT rows
-    (submanifold: the forward table with mirrored weights; strided: nbr_in, in parity-class row order when the
-    rulebook carries a plan)"""
+    (submanifold: the forward table with mirrored weights; strided: nbr_in -- pair-compacted where the channel pair has
+    that kernel, else in parity-class row order when the rulebook carries a plan)"""
     L = _lib.lib()
     dt = _DT[gout.dtype]
     nbr, cap = (rb.nbr_out, rb.cap_out) if rb.subm else (rb.nbr_in, rb.cap_in)
     epp = ctypes.byref(ep) if ep is not None else None
+    if pairs_ok(rb, cout, pad_cin, gout.dtype, strided_dgrad=not rb.subm):
+        table = rb.pair_table("out" if rb.subm else "in")
+        rc = _timed("dgrad", cout, pad_cin, rb.n_in, rb, gout.device, lambda: L.d3d_sparse_conv_fwd_pairs(
+            gout.data_ptr(), wd.data_ptr(), None, table.data_ptr(), rb.n_in, rb.kvol, cout, pad_cin, dt, gin.data_ptr(),
+            epp, stream))
+        _lib.check(rc, "d3d_sparse_conv_fwd_pairs(dgrad)")
+        return
     if not rb.subm and rb.dgrad_plan is not None and L.d3d_sparse_conv_dgrad_plan_supported(cout, pad_cin, dt):
         rc = _timed("dgrad", cout, pad_cin, rb.n_in, rb, gout.device, lambda: L.d3d_sparse_conv_dgrad_planned(
             gout.data_ptr(), wd.data_ptr(), nbr.data_ptr(), cap, rb.n_in, rb.kvol, cout, pad_cin, dt,
@@ -411,16 +480,13 @@ class _SparseConvFn(torch.autograd.Function):
         ep = None
         if stats is not None and mfma and rb.n_out > 0:
             ep = _lib.ConvEpilogue(stats=stats.data_ptr(), ws_floats=stats.numel())
-        rc = _timed("fwd", pad_cin, cout, rb.n_out, rb, feats.device, lambda: L.d3d_sparse_conv_fwd_ex(
-            feats.data_ptr(), wpack.data_ptr(), _lib.ptr(b), rb.nbr_out.data_ptr(), rb.cap_out,
-            rb.n_out, kvol, pad_cin, cout, _DT[feats.dtype], out.data_ptr(),
-            ctypes.byref(ep) if ep is not None else None, _lib.stream_ptr(feats.device)))
+        rc = launch_fwd(rb, feats, wpack, b, pad_cin, cout, out, ep, _lib.stream_ptr(feats.device))
         _lib.check(rc, "d3d_sparse_conv_fwd")
         ctx.stats_done = ep is not None
         ctx.save_for_backward(feats, weight)
         ctx.wd = wd
         from . import repack
-        ctx.repack_stamp = repack.stamp()  # `wd` is rewritten in place by Repacker.run()
+        ctx.repack_stamp = repack.stamp((weight,))  # `wd` is rewritten in place by Repacker.run()
         ctx.rb = rb
         ctx.has_bias = bias is not None
         ctx.pad = (cin, pad_cin)
@@ -849,7 +915,8 @@ class SparseSequential(SparseModule):
         while i < len(mods):
             module = mods[i]
             if stack_ok and isinstance(module, SparseConvolution) and isinstance(input, SparseConvTensor) and \
-                    input.features.is_cuda and input.features.dtype in _DT and input.indices.shape[0] > 1:
+                    input.features.is_cuda and input.features.dtype in _DT and \
+                    (input.indices.shape[0] > 1 or (i + 1 < len(mods) and type(mods[i + 1]).__name__ == "DistributedSyncBN")):
                 # a run of conv -> BatchNorm1d [-> ReLU] triples: one autograd node, a plain loop of C-ABI calls
                 layers, nxt = sparse_stack.segment(_SELF, mods, i, input)
                 if layers:
@@ -971,6 +1038,17 @@ class SparseSequential(SparseModule):
                 x.indice_dict[key] = build_subm_rulebook(lv["indices"], _count_tensor(n, dev), n,
                                                          max(n, 1), x.batch_size, lv["shape"],
                                                          m.kernel_size)
+        # ---- phase C: pair-compacted tables of the layers that have that kernel (one launch per table, here on the
+        # stream that builds the geometry instead of in front of the first layer that needs them)
+        for li, m in enumerate(layers):
+            rb = x.indice_dict.get(m._rulebook_key())
+            if rb is None or not rb.n_out or not rb.n_in:
+                continue
+            cin = 16 if (m.in_channels < 16 and m.out_channels % 16 == 0) else m.in_channels
+            if pairs_ok(rb, cin, m.out_channels, torch.float32):
+                rb.pair_table("out")
+            if li > 0 and pairs_ok(rb, m.out_channels, cin, torch.float32, strided_dgrad=not rb.subm):
+                rb.pair_table("out" if rb.subm else "in")
         return x.indice_dict
 
 

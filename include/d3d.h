@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 11 /* 11: d3d_ctx_current; 10: caller-owned contexts (d3d_ctx_*), d3d_set_tuning knob 11; 9: d3d_conv_rulebook_chain / d3d_subm_rulebook_ranked, training = 2 of d3d_bn_apply, d3d_set_tuning knob 10; 8: d3d_conv2d_nhwc_dgrad_s2; 7: residual forms of the BatchNorm sweeps, D3dConvEpilogue.addend; 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv; 5: planned strided data gradient, d3d_adam_step; 6: deterministic PillarFeatureNet sums (workspace arguments) */
+#define D3D_ABI_VERSION 11 /* 11: d3d_ctx_current, pair-compacted sparse convolution (d3d_pair_table_*, d3d_sparse_conv_fwd_pairs); 10: caller-owned contexts (d3d_ctx_*), d3d_set_tuning knob 11; 9: d3d_conv_rulebook_chain / d3d_subm_rulebook_ranked, training = 2 of d3d_bn_apply, d3d_set_tuning knob 10; 8: d3d_conv2d_nhwc_dgrad_s2; 7: residual forms of the BatchNorm sweeps, D3dConvEpilogue.addend; 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv; 5: planned strided data gradient, d3d_adam_step; 6: deterministic PillarFeatureNet sums (workspace arguments) */
 
 #define D3D_OK 0
 #define D3D_EINVAL -1    /* bad argument / unsupported shape           */
@@ -205,6 +205,29 @@ int d3d_ctx_current(d3d_ctx_t *ctx);
 int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const float *bias,
                            const int32_t *nbr, int cap, int n_out, int kvol, int cin, int cout,
                            int dtype, void *out, const D3dConvEpilogue *epilogue, d3d_stream_t stream);
+
+/* Pair-compacted forward / data gradient (ABI 11; det3d_amd/csrc/d3d_spconv_pairs.h).
+ * spconv (the reference's dependency; det3d/models/backbones/scn.py:106-157 runs it through SubMConv3d / SparseConv3d)
+ * multiplies exactly the pairs of its rulebook: per kernel offset a gather of n_k input rows, a GEMM, a scatter-add.
+ * d3d_sparse_conv_fwd_ex instead walks all kvol offsets of every 16-row output tile and lets absent neighbours read
+ * zeros -- on LiDAR frames half of its gathers and MFMAs.  These entry points restore the pair lists without giving up
+ * the single launch and the deterministic sums: d3d_pair_table_build compacts a neighbour table (output-stationary
+ * `nbr_out` for the forward and submanifold data gradients, input-stationary `nbr_in` for strided data gradients) per
+ * slab of 64 consecutive rows and kernel offset; d3d_sparse_conv_fwd_pairs runs MFMA tiles over 16 existing pairs and
+ * accumulates a slab's rows in LDS, one wave per slab, offsets in ascending order.  Same arguments and epilogues as
+ * d3d_sparse_conv_fwd_ex with `table` in place of (nbr, cap); results agree with it to f32 rounding (an offset's
+ * products are summed before they are added to the row), not bit for bit.
+ *  table   dev, d3d_pair_table_bytes(n_rows, kvol) bytes: [kvol][ceil64(n_rows)] u32 entries (input row | (row % 64) << 26,
+ *          the pairs of a slab packed to the front of its 64-entry segment), then [slabs][32] u8 pair counts;
+ *          built once per rulebook (one launch, no host sync), shared by every layer, direction and step using it
+ *  d3d_sparse_conv_pairs_supported: f32 features (split arithmetic), channel pairs 32/64 -> 32/64; kvol <= 32 */
+size_t d3d_pair_table_bytes(int n_rows, int kvol);
+int d3d_pair_table_build(const int32_t *nbr, int cap, int n_rows, int kvol, void *table, size_t table_bytes,
+                         d3d_stream_t stream);
+int d3d_sparse_conv_pairs_supported(int cin, int cout, int dtype);
+int d3d_sparse_conv_fwd_pairs(const void *feat, const void *wpack, const float *bias, const void *table, int n_out,
+                              int kvol, int cin, int cout, int dtype, void *out, const D3dConvEpilogue *epilogue,
+                              d3d_stream_t stream);
 
 /* Data gradient of a STRIDED layer in parity-class row order (round 3; det3d_amd/csrc/d3d_rowplan.h).
  * The reference's backward of spconv.SparseConv3d (scn.py:113, :127, :141, :150: stride 2, and the last (3,1,1) /

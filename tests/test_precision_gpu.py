@@ -123,9 +123,10 @@ def test_split_against_exact_f32_on_the_detector_goldens(name):
     assert l2 <= bl2 and cos <= bcos
 
 
-def _train_leg(exact, steps, eps=0.0, unfused=False):
+def _train_leg(exact, steps, eps=0.0, unfused=False, seed=None):
     """one training run of tests/golden/train_run_spec.py on the GPU.  exact: precision.exact_f32(); eps: the initial
-    weights multiplied by (1 + eps) -- the sensitivity probe; unfused: the per-layer sparse path instead of the fused stack"""
+    weights multiplied by (1 + eps) -- the sensitivity probe; unfused: the per-layer sparse path instead of the fused stack;
+    seed: another default initialisation (torch.manual_seed(seed) on the CPU generator) instead of the spec's seed 0"""
     import train_run_spec as T
     from det3d_amd import build_detector, sparse_block, sparse_stack, synthetic
 
@@ -138,7 +139,11 @@ def _train_leg(exact, steps, eps=0.0, unfused=False):
             sparse_stack.FUSE_STACK = sparse_block.FUSE_BLOCK = False
         with _mode(exact):
             model = build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg)
-            model.load_state_dict(T.initial_state(cfg))
+            if seed is None:
+                model.load_state_dict(T.initial_state(cfg))
+            else:
+                torch.manual_seed(seed)
+                model.load_state_dict(build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).state_dict())
             if eps:
                 with torch.no_grad():
                     for p in model.parameters():
@@ -222,3 +227,29 @@ def test_300_training_steps_split_vs_exact_f32_vs_cpu_oracle():
     # (d) fused sparse stack == per-layer path, bit for bit, over 60 optimizer steps
     l_unfused, _ = _train_leg(False, 60, unfused=True)
     assert np.array_equal(l_unfused, legs["split"][0][:60])
+
+
+def test_300_training_steps_five_seeds_per_mode():
+    """VERDICT round 5 (weak 1): the 300-step comparison above rests on one seed pair per mode, and the run is chaotic --
+    one pair says little.  Here: FIVE different initialisations (torch.manual_seed(1..5)), each trained for 300 steps in
+    split arithmetic and in exact f32 from the same weights, batches and schedule.  Asserted on the two DISTRIBUTIONS of
+    the final loss (mean of the last 20 steps): every leg trains (loss falls by > 100 x), the medians of the two modes
+    agree within the exact-f32 legs' own max / min spread (at least a factor 1.5), and no split leg ends outside
+    [min / 2, 2 max] of the exact legs.  The per-seed pairs are printed: which mode ends lower flips from seed to seed."""
+    import train_run_spec as T
+
+    seeds = [1, 2, 3, 4, 5]
+    split = [_train_leg(False, T.STEPS, seed=s)[0] for s in seeds]
+    exact = [_train_leg(True, T.STEPS, seed=s)[0] for s in seeds]
+    fs = np.array([l[-20:].mean() for l in split])
+    fe = np.array([l[-20:].mean() for l in exact])
+    print("300 steps x 5 seeds, final loss (mean of the last 20): split %s | exact f32 %s" % (np.round(fs, 4).tolist(), np.round(fe, 4).tolist()))
+    print("medians: split %.4f exact %.4f; exact spread max / min %.2f; split lower than exact on %d of %d seeds" % (
+        np.median(fs), np.median(fe), fe.max() / fe.min(), int((fs < fe).sum()), len(seeds)))
+    for l in split + exact:
+        assert np.isfinite(l).all() and l[-20:].mean() < 0.01 * l[0]
+    spread = max(fe.max() / fe.min(), 1.5)
+    assert 1.0 / spread <= np.median(fs) / np.median(fe) <= spread, (fs, fe)
+    assert fe.min() / 2 <= fs.min() and fs.max() <= 2 * fe.max(), (fs, fe)
+    first = max(abs(a[0] - b[0]) / abs(b[0]) for a, b in zip(split, exact))
+    assert first <= 1e-4, first  # step 0 sees identical weights: the forward agrees to the product format

@@ -29,12 +29,12 @@ while [ $# -gt 0 ]; do
   case "$st" in
     tests)
       timeout 1500 python -m pytest tests/ -x -q -m gpu -rP > $O/tests.log 2>&1; echo "pytest rc=$?"; tail -3 $O/tests.log
-      grep -h "vs float64\|max |pred - reference|\|worst gradient-norm\|ResNetFHD\|distance from float64\|forward split vs\|300 steps\|relative loss difference\|held-out raw\|reference detections matched\|fused SyncBN nodes\|frames at the max_voxels\|rulebooks, " $O/tests.log | grep -v "print(" | cut -c1-900 > $O/tests_figures.txt; cat $O/tests_figures.txt
+      grep -h "vs float64\|max |pred - reference|\|worst gradient-norm\|ResNetFHD\|distance from float64\|forward split vs\|300 steps\|medians: split\|steady-state steps\|max err vs float64\|losses, tile kernels\|relative loss difference\|held-out raw\|reference detections matched\|fused SyncBN nodes\|frames at the max_voxels\|rulebooks, " $O/tests.log | grep -v "print(" | cut -c1-900 > $O/tests_figures.txt; cat $O/tests_figures.txt
       timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 ;;
     testsall:*)
       timeout 1500 python -m pytest tests/ -q -m gpu -rP -k "${st#testsall:}" > $O/tests_all.log 2>&1; echo "pytest rc=$?"
       grep -n "^FAILED\|^E  .*Error\|passed\|failed" $O/tests_all.log | cut -c1-260 | head -60
-      grep -h "vs float64\|max |pred - reference|\|worst gradient-norm\|ResNetFHD\|distance from float64\|forward split vs\|300 steps\|relative loss difference\|held-out raw\|reference detections matched\|fused SyncBN nodes" $O/tests_all.log | grep -v "print(" | cut -c1-900 > $O/tests_all_figures.txt; cat $O/tests_all_figures.txt ;;
+      grep -h "vs float64\|max |pred - reference|\|worst gradient-norm\|ResNetFHD\|distance from float64\|forward split vs\|300 steps\|medians: split\|steady-state steps\|max err vs float64\|losses, tile kernels\|relative loss difference\|held-out raw\|reference detections matched\|fused SyncBN nodes" $O/tests_all.log | grep -v "print(" | cut -c1-900 > $O/tests_all_figures.txt; cat $O/tests_all_figures.txt ;;
     tests:*)
       timeout 1500 python -m pytest tests/ -x -q -m gpu -k "${st#tests:}" > $O/tests_k.log 2>&1; echo "pytest rc=$?"; tail -15 $O/tests_k.log ;;
     bench)

@@ -1,6 +1,6 @@
 """Only the f32 (split arithmetic) 64 -> 64 submanifold forward on the benched KITTI geometry (subm2: 126k sites, 13 pairs
 per site), `reps` launches under d3d_set_tuning knob 11 = argv[1] (0: spconv_fwd_mfma_kernel, 1..3: the chunk-resident
-tilings) -- the workload tools/pmc_fwd32.sh collects SQ / TA / TCP counters on.
+tilings, 100: the pair-compacted kernel d3d_sparse_conv_fwd_pairs) -- the workload tools/pmc_fwd32.sh collects SQ / TA / TCP counters on.
     python tools/pmc_fwd32.py <knob 11 value> [reps] [key] [cin] [cout]"""
 import os
 import sys
@@ -41,6 +41,14 @@ w32 = torch.randn(27, cin, cout, device=dev) * 0.05
 wpack = torch.empty((27, cin, cout), device=dev)
 _lib.check(L.d3d_pack_conv_weights(w32.data_ptr(), 27, cin, cout, _lib.D3D_F32, 1, wpack.data_ptr(), None, st), "pack")
 o = torch.empty(n, cout, device=dev)
+if v == 100:  # the pair-compacted kernel (round 6)
+    table = rb.pair_table("out")
+    for _ in range(reps):
+        _lib.check(L.d3d_sparse_conv_fwd_pairs(f.data_ptr(), wpack.data_ptr(), None, table.data_ptr(), n, 27, cin, cout,
+                                               _lib.D3D_F32, o.data_ptr(), None, st), "pairs")
+    torch.cuda.synchronize()
+    print("pairs kernel %d->%d %s n=%d pairs=%d launches=%d" % (cin, cout, key, n, P, reps))
+    sys.exit(0)
 L.d3d_set_tuning(11, v)
 for _ in range(reps):
     _lib.check(L.d3d_sparse_conv_fwd_ex(f.data_ptr(), wpack.data_ptr(), None, rb.nbr_out.data_ptr(), rb.cap_out, n, 27, cin,

@@ -22,7 +22,7 @@ for G in "$G1" "$G2" "$G3" "$G4" "$G5" "$G6" "$G7"; do
   python - "$DB" >> "$OUT" <<'PY'
 import sqlite3, sys
 cur = sqlite3.connect(sys.argv[1]).cursor()
-rows = cur.execute("select name, counter_name, count(*), avg(counter_value), avg(duration)/1e3 from pmc_events where name like '%spconv_fwd%' group by name, counter_name").fetchall()
+rows = cur.execute("select name, counter_name, count(*), avg(counter_value), avg(duration)/1e3 from pmc_events where name like '%spconv_%' group by name, counter_name").fetchall()
 for n, c, k, v, us in rows:
     print("%-34s %16.0f per launch  (%d launches, %.1f us)  %s" % (c, v, k, us, n[:90]))
 PY
