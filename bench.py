@@ -139,6 +139,11 @@ def parse():
                          "(BASELINE configs[2..4] are 'DDP + SyncBN'): cross-rank BatchNorm statistics, one packed all-reduce "
                          "per layer and direction inside the fused conv nodes; needs a process group (several ranks, or "
                          "D3D_DIST_SINGLE=1 for a 1-rank RCCL communicator)")
+    ap.add_argument("--wgrad-stream", default=None, choices=["all", "sparse", "off"],
+                    help="det3d_amd.runtime wgrad_stream: weight gradients of the fused backward nodes on a second stream "
+                         "(all), only in the sparse stack (sparse), or on the step's stream (off)")
+    ap.add_argument("--pair-kernels", default=None, choices=["off", "measured", "all"],
+                    help="det3d_amd.runtime pair_kernels: which f32 sparse launches take the pair-compacted kernel")
     ap.add_argument("--rank-diagnostics", action="store_true",
                     help="per-rank medians of step / exchange wait / geometry wait / host enqueue over 8 extra untimed steps "
                          "(always on with more than one rank)")
@@ -643,7 +648,7 @@ def attach_pmc_traffic(roof, wl):
     """HBM traffic needs PMC passes (rocprofv3 --pmc cannot run inside this process): take the committed
     measurement (tools/pmc_spconv.sh) only if it was taken on THIS kernel source, THESE host files (tools/stamp.py:
     d3d_spconv.hip, its headers, spconv.py, sparse_stack.py, sparse_block.py) and this workload."""
-    name = "profiles/round5_pmc_spconv.json"
+    name = "profiles/round6_pmc_spconv.json"
     try:
         pmc = json.load(open(os.path.join(ROOT, name)))
         sha = _stamp()
@@ -666,7 +671,7 @@ def attach_pmc_traffic(roof, wl):
 def roofline_sources(roof, wl, extra_groups, key):
     """one kernel, three clocks.  `frac` stays the contract's figure (HIP events on the launch stream
     inside the timed region); `sources` puts the other two next to it -- the extra all-launches step of the `kernels`
-    table and the committed rocprofv3 kernel-trace average (tools/profile_step.sh -> profiles/round5_rocprof_spconv.json,
+    table and the committed rocprofv3 kernel-trace average (tools/profile_step.sh -> profiles/round6_rocprof_spconv.json,
     used only when its source stamp and workload match) -- each with the frac the same algorithmic bytes give."""
     b = roof["alg_bytes_per_launch"]
 
@@ -683,7 +688,7 @@ def roofline_sources(roof, wl, extra_groups, key):
         src["extra_step_events"] = entry(1e3 * g["ms"] / g["launches"], g["launches"],
                                          "one untimed step after the region with EVERY sparse launch event-timed "
                                          "(the `kernels` table); its own bytes: %d per launch" % int(g["bytes"] / g["launches"]))
-    name = "profiles/round5_rocprof_spconv.json"
+    name = "profiles/round6_rocprof_spconv.json"
     try:
         rp = json.load(open(os.path.join(ROOT, name)))
         if rp.get("source_sha16") != _stamp():
@@ -1246,7 +1251,9 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d -- the line's n_gpus would not be the requested one"
                          % (args.gpus, env_world))
     from det3d_amd import dist as D
+    from det3d_amd import runtime as _rt
 
+    _rt.configure(**{k: v for k, v in (("wgrad_stream", args.wgrad_stream), ("pair_kernels", args.pair_kernels)) if v})
     t_start = time.perf_counter()
     rank, local_rank, world = D.init_dist()
     if not torch.cuda.is_available():
@@ -1315,6 +1322,7 @@ def main():
                                "(max over ranks per window)" % (len(wl.windows_ms), args.steps) if len(wl.windows_ms) > 1
                                else "one window of %d steps" % args.steps,
                    "distinct_batches": wl.n_batches,
+                   "runtime": __import__("det3d_amd.runtime", fromlist=["describe"]).describe(),
                    "allocator": wl.alloc,
                    "burn_in_steps": getattr(wl, "burn_in_steps", 0),
                    "graphed_tail": bool(wl.model.__dict__.get("_graph_tails")),

@@ -233,7 +233,8 @@ class _DenseStackFn(torch.autograd.Function):
         # gradient's blocks (572 work items on 256 CUs) and its statistics epilogue
         from . import sparse_stack
         main = torch.cuda.current_stream(dev)
-        side = sparse_stack.wgrad_stream(dev) if sparse_stack.WGRAD_STREAM and len(layers) > 1 else None
+        from . import runtime
+        side = sparse_stack.wgrad_stream(dev) if sparse_stack.WGRAD_STREAM and runtime.wgrad_side("dense") and len(layers) > 1 else None
         keep = []  # the gradient planes the side stream reads stay referenced until it has been joined
         for li in range(len(layers) - 1, -1, -1):
             ly = layers[li]

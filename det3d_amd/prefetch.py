@@ -67,7 +67,9 @@ _RESERVED = {}  # device index -> stream created by reserve_stream
 
 def _new_stream(dev):
     # small kernels: by default they may cut in front of the step's (D3D_PREFETCH_PRIORITY=0: equal priority)
-    return torch.cuda.Stream(dev, priority=int(os.environ.get("D3D_PREFETCH_PRIORITY", "-1")))
+    from . import runtime
+
+    return torch.cuda.Stream(dev, priority=int(runtime.get("prefetch_priority")))
 
 
 def reserve_stream(dev):
@@ -104,11 +106,15 @@ def _stream_for(dev):
 
 
 class GeometryPrefetcher:
-    def __init__(self, make_example, detector=None, device=None, enabled=True, ring=3):
+    def __init__(self, make_example, detector=None, device=None, enabled=True, ring=None):
         """make_example(batch) -> example dict (runs the device voxelizer etc. on the CURRENT stream);
         detector: if its backbone has `plan_geometry`, the rulebooks are built here too and travel in
         example["sparse_plan"].  ring: slots of the geometry arena ring (module docstring); 0 = caching allocator."""
         self.make_example = make_example
+        if ring is None:
+            from . import runtime
+
+            ring = runtime.get("geometry_ring")
         self.ring = int(ring) if (enabled and torch.cuda.is_available()) else 0
         self._slots = {}
         self._seq = 0

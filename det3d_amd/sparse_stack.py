@@ -29,7 +29,9 @@ FUSE_STACK = os.environ.get("D3D_FUSE_STACK", "1") != "0"
 # data-gradient chain produces after it, and every sparse kernel leaves CUs idle in its ramp and tail (its waves are resident
 # 61-63 % of its duration: profiles/round5_fwd_anatomy.txt) -- the weight gradient of layer l fills them while the chain goes
 # on with the BatchNorm sweeps and data gradient of layer l - 1.  Same kernels, same arguments: bit-identical gradients.
-WGRAD_STREAM = os.environ.get("D3D_WGRAD_STREAM", "1") != "0"
+from . import runtime  # noqa: E402  (the authoritative switches; the module variable below is what the loops read)
+
+WGRAD_STREAM = runtime.get("wgrad_stream") != "off"
 _SIDE = {}
 
 
@@ -37,7 +39,7 @@ def wgrad_stream(dev):
     key = (dev.type, dev.index)
     if key not in _SIDE:
         # D3D_WGRAD_PRIORITY: the chain on the main stream is the critical path; a lower priority (1) lets its blocks go first
-        _SIDE[key] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("D3D_WGRAD_PRIORITY", "0")))
+        _SIDE[key] = torch.cuda.Stream(device=dev, priority=int(runtime.get("wgrad_priority")))
     return _SIDE[key]
 
 

@@ -385,7 +385,9 @@ def finalize_conv_rulebook(rb, n_in, n_out):
 #             the gathers it saves: DESIGN.md section 10.
 # Default "off": inside the training step those data gradients share the CUs with the weight-gradient stream, which a
 # 160 KB block locks out.
-PAIR_KERNELS = "off"
+from . import runtime as _runtime  # noqa: E402
+
+PAIR_KERNELS = _runtime.get("pair_kernels")  # (det3d_amd.runtime.configure(pair_kernels=...) sets it)
 _PAIRS_OK = {}
 
 

@@ -51,12 +51,16 @@ class OneCycle:
 
 class TrainStep:
     def __init__(self, model, total_steps, lr_max=3e-3, wd=0.01, moms=(0.95, 0.85), div_factor=10.0,
-                 pct_start=0.4, grad_clip=35.0, autocast_dtype=None, step_arena=True):
+                 pct_start=0.4, grad_clip=35.0, autocast_dtype=None, step_arena=None):
         """step_arena: the data-dependent tensors of the sparse forward / backward (activations, their gradients,
         workspaces) come from the device's step arena, rewound at the start of every call (arena.py) -- a steady-state
         step then allocates nothing from the device.  Needs forward, backward and optimizer inside this call on one
         stream, which is what __call__ does."""
         self.model = model
+        if step_arena is None:
+            from . import runtime
+
+            step_arena = runtime.get("step_arena")
         self.step_arena = bool(step_arena)
         self.sched = OneCycle(total_steps, lr_max, moms, div_factor, pct_start)
         self.wd = wd

@@ -1,7 +1,7 @@
-"""profiles/round5_pmc_spconv.json from the per-counter summaries of tools/pmc_spconv.sh: HBM traffic per launch of
+"""profiles/round6_pmc_spconv.json from the per-counter summaries of tools/pmc_spconv.sh: HBM traffic per launch of
 the roofline kernel (read side doubled per MI355X_MICROARCH.md: gfx950's FETCH_SIZE tallies 128-B requests at 64 B)
 stamped with the sha of the kernel source AND the host files that launch it (tools/stamp.py), so bench.py can refuse a stale file; MFMA-busy fraction of the dense conv
-kernels.  usage: pmc_json.py <dir with round5_pmc_*.txt>"""
+kernels.  usage: pmc_json.py <dir with round6_pmc_*.txt>"""
 import json
 import os
 import re
@@ -35,7 +35,7 @@ def pick(rs, pat):
     return None
 
 
-fetch, write, mfma = rows("round5_pmc_fetch_size.txt"), rows("round5_pmc_write_size.txt"), rows("round5_pmc_sq_valu_mfma_busy_cycles.txt")
+fetch, write, mfma = rows("round6_pmc_fetch_size.txt"), rows("round6_pmc_write_size.txt"), rows("round6_pmc_sq_valu_mfma_busy_cycles.txt")
 # the roofline kernel of the default (f32, split arithmetic) step; D3D_PMC_DTYPE=bf16 for the autocast step
 DT = os.environ.get("D3D_PMC_DTYPE", "fp32")
 # (the trailing `false` of the mfma kernel = not the planned variant of the strided data gradients)
@@ -76,5 +76,5 @@ if mfma:
     wgm = pick(mfma, r"spconv_wgrad_tile_kernel<64, 64, 9")
     if wgm:
         out.setdefault("wgrad_64x64", {})["mfma_busy_frac"] = round(busy_frac(wgm), 4)
-json.dump(out, open(os.path.join(d, "round5_pmc_spconv.json"), "w"), indent=1)
-print("wrote", os.path.join(d, "round5_pmc_spconv.json"))
+json.dump(out, open(os.path.join(d, "round6_pmc_spconv.json"), "w"), indent=1)
+print("wrote", os.path.join(d, "round6_pmc_spconv.json"))

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 rm -rf /tmp/d3d_prof && mkdir -p /tmp/d3d_prof
 cd /tmp
 STEPS=10
-CMD="python $REPO/bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-launch-log --no-extras $*"
+CMD="python $REPO/bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-launch-log --no-extras --windows 1 $*"
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/d3d_prof -- $CMD > /tmp/d3d_prof/bench.out 2> /tmp/d3d_prof/bench.err || { tail -20 /tmp/d3d_prof/bench.err; exit 1; }
 LINE=$(grep '"metric"' /tmp/d3d_prof/bench.out | tail -1)
 DB=$(find /tmp/d3d_prof -name "*.db" | head -1)

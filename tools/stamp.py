@@ -1,11 +1,11 @@
 """sha of everything that decides how the roofline kernel is launched: the kernel source, its internal header, and the
-host files that choose its tile shapes / arguments.  profiles/round5_pmc_spconv.json and round5_rocprof_spconv.json carry
+host files that choose its tile shapes / arguments.  profiles/round6_pmc_spconv.json and round6_rocprof_spconv.json carry
 it; bench.py refuses a committed measurement whose stamp differs from the tree it runs from."""
 import hashlib
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = ("det3d_amd/csrc/d3d_spconv.hip", "det3d_amd/csrc/d3d_spconv_internal.h", "det3d_amd/csrc/d3d_fold.h",
+FILES = ("det3d_amd/csrc/d3d_spconv.hip", "det3d_amd/csrc/d3d_spconv_shared.h", "det3d_amd/csrc/d3d_spconv_internal.h", "det3d_amd/csrc/d3d_fold.h",
          "det3d_amd/spconv.py", "det3d_amd/sparse_stack.py", "det3d_amd/sparse_block.py")
 
 
