@@ -95,3 +95,36 @@ def test_bench_refuses_to_run_without_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0",
                           "--no-cpu-baseline"], capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "no CPU fallback" in (out.stderr + out.stdout)
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """a line whose n_gpus differs from --gpus must not be printed (round 5: `--gpus 8` silently ran one rank): under a
+    launcher's environment with another WORLD_SIZE the run is refused before anything else happens"""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in (out.stderr + out.stdout)
+
+
+def test_rank_core_shares_are_disjoint_and_cover():
+    import bench
+
+    if not hasattr(os, "sched_getaffinity"):
+        pytest.skip("no sched_setaffinity here")
+    before = os.sched_getaffinity(0)
+    try:
+        cores = sorted(before)
+        world = max(1, len(cores) // 4)
+        if world < 2:
+            pytest.skip("needs >= 8 cores for two shares of 4")
+        shares = []
+        for r in range(world):
+            os.sched_setaffinity(0, before)
+            shares.append(bench.pin_rank_cores(r, world))
+        assert all(s is not None and len(s) == len(cores) // world for s in shares)
+        flat = [c for s in shares for c in s]
+        assert len(flat) == len(set(flat)) and set(flat) <= set(cores)
+        os.sched_setaffinity(0, before)
+        assert bench.pin_rank_cores(0, 1) is None and bench.pin_rank_cores(0, len(cores)) is None  # one rank / shares < 4 cores
+    finally:
+        os.sched_setaffinity(0, before)

@@ -28,7 +28,7 @@ while [ $# -gt 0 ]; do
   echo "=== stage $st"
   case "$st" in
     tests)
-      timeout 1500 python -m pytest tests/ -x -q -m gpu -rP > $O/tests.log 2>&1; echo "pytest rc=$?"; tail -3 $O/tests.log
+      timeout 1800 python -m pytest tests/ -x -q -m gpu -rP --durations=25 > $O/tests.log 2>&1; echo "pytest rc=$?"; tail -3 $O/tests.log; grep -A 27 "slowest" $O/tests.log | cut -c1-150
       grep -h "vs float64\|max |pred - reference|\|worst gradient-norm\|ResNetFHD\|distance from float64\|forward split vs\|300 steps\|medians: split\|steady-state steps\|max err vs float64\|losses, tile kernels\|relative loss difference\|held-out raw\|reference detections matched\|fused SyncBN nodes\|frames at the max_voxels\|rulebooks, " $O/tests.log | grep -v "print(" | cut -c1-900 > $O/tests_figures.txt; cat $O/tests_figures.txt
       timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 ;;
     testsall:*)
