@@ -155,7 +155,13 @@ def run_tail(detector, example, bev):
         if len(cache) >= 4:  # shapes keep changing (ragged batches): graphs would be re-captured forever
             return None
         try:
-            gt = GraphedTail.build(detector, example, bev, autocast_dtype)
+            # a captured graph bakes in the addresses of everything allocated during capture: the step arena (arena.py)
+            # hands out addresses that depend on the sparse stack's sizes of THIS batch, so the capture (and the warm-up
+            # runs in front of it) allocates from the caching allocator's graph pool instead
+            from . import arena
+
+            with arena.bound(None):
+                gt = GraphedTail.build(detector, example, bev, autocast_dtype)
         except Exception as e:  # capture is an optimisation: report loudly, continue eagerly
             import warnings
 

@@ -9,7 +9,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from . import _lib
+from . import _lib, arena as mem
 from .nn_utils import build_norm_layer
 from .registry import READERS
 
@@ -30,10 +30,11 @@ class _PFNFn(torch.autograd.Function):
         m, t, c = voxels.shape
         f = weight.shape[0]
         dev = voxels.device
-        out = torch.empty((m, f), dtype=torch.float32, device=dev)
-        argmax = torch.empty((m, f), dtype=torch.int32, device=dev)
+        lease = mem.Lease()  # the pillar count follows the batch: step arena, if the caller runs under one (arena.py)
+        out = mem.empty((m, f), torch.float32, dev, lease.arena)
+        argmax = mem.empty((m, f), torch.int32, dev, lease.arena)
         save = torch.empty((2, f), dtype=torch.float32, device=dev)
-        ws = torch.empty((L.d3d_pfn_ws_floats(m, c, f),), dtype=torch.float32, device=dev)  # slabs of the fixed-order sums
+        ws = mem.empty((L.d3d_pfn_ws_floats(m, c, f),), torch.float32, dev, lease.arena)  # slabs of the fixed-order sums
         w = weight.detach().float().contiguous()
         vx, vy, xo, yo = geom
         rc = L.d3d_pfn_fwd(voxels.data_ptr(), num_points.data_ptr(), coors.data_ptr(), m, t, c, vx, vy, xo, yo,
@@ -45,6 +46,7 @@ class _PFNFn(torch.autograd.Function):
         ctx.save_for_backward(voxels, num_points, coors, w, gamma, save, out, argmax)
         ctx.geom = geom
         ctx.training = training
+        ctx.lease = lease
         return out
 
     @staticmethod
@@ -60,7 +62,7 @@ class _PFNFn(torch.autograd.Function):
         dout = dout.float().contiguous()
         dw = torch.empty_like(w)
         g = torch.empty((2, f), dtype=torch.float32, device=w.device)
-        ws = torch.empty((L.d3d_pfn_ws_floats(m, c, f),), dtype=torch.float32, device=w.device)
+        ws = mem.empty((L.d3d_pfn_ws_floats(m, c, f),), torch.float32, w.device, ctx.lease.check("PillarFeatureNet"))
         rc = L.d3d_pfn_bwd(voxels.data_ptr(), num_points.data_ptr(), coors.data_ptr(), m, t, c, vx, vy, xo, yo,
                            w.data_ptr(), f, _lib.ptr(gamma), save[0].data_ptr(), save[1].data_ptr(),
                            out.data_ptr(), dout.data_ptr(), argmax.data_ptr(), dw.data_ptr(), g[0].data_ptr(),
