@@ -36,38 +36,49 @@
 
 // ---------------------------------------------------------------------------------------------------- table build
 // ctab[k][cap64]: segment [slab * 64, +cnt) of row k = the pairs of (slab, k), entry = input row | (output row % 64) << 26
-// cnt[slab][32] : pairs per offset (u8, <= 64)
+// cnt[slab][32] : pairs per offset (u8, <= 64); cnt_lo[slab][32]: those of the slab's rows 0..31 -- entries are in ascending
+//                 row order, so a segment splits into the pair lists of its two 32-row halves at cnt_lo
 __global__ void __launch_bounds__(256)
     pair_table_build_kernel(const int32_t *__restrict__ nbr, int cap, const int32_t *__restrict__ n_rows_dev, int n_rows_cap,
-                            int kvol, int cap64, uint32_t *__restrict__ ctab, uint8_t *__restrict__ cnt) {
+                            int kvol, int cap64, uint32_t *__restrict__ ctab, uint8_t *__restrict__ cnt,
+                            uint8_t *__restrict__ cnt_lo) {
   const int lane = threadIdx.x & 63;
   const int slab = blockIdx.x * 4 + (threadIdx.x >> 6);
   int n_rows = n_rows_dev ? *n_rows_dev : n_rows_cap;
   n_rows = n_rows < n_rows_cap ? n_rows : n_rows_cap;
   const int row = slab * D3D_PAIR_SLAB + lane;
   if (slab * D3D_PAIR_SLAB >= n_rows_cap) return;
-  int mine = 0;
+  int mine = 0, mine_lo = 0;
   for (int k = 0; k < kvol; ++k) {
     const int v = row < n_rows ? nbr[(int64_t)k * cap + row] : -1;
     const bool ok = v >= 0;
     const unsigned long long m = __ballot(ok);
     const int rank = __popcll(m & ((1ull << lane) - 1ull));
     if (ok) ctab[(int64_t)k * cap64 + slab * D3D_PAIR_SLAB + rank] = (uint32_t)v | ((uint32_t)lane << D3D_PAIR_ROW_BITS);
-    if (lane == k) mine = __popcll(m);
+    if (lane == k) {
+      mine = __popcll(m);
+      mine_lo = __popcll(m & 0xffffffffull);  // pairs of rows 0..31 of the slab: they come first in the segment
+    }
   }
-  if (lane < 32) cnt[(int64_t)slab * 32 + lane] = (uint8_t)mine;
+  if (lane < 32) {
+    cnt[(int64_t)slab * 32 + lane] = (uint8_t)mine;
+    cnt_lo[(int64_t)slab * 32 + lane] = (uint8_t)mine_lo;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------- conv kernel
-template <int CIN, int COUT, int WAVES, int DEPTH>
+// R = rows per wave: 64 (a whole slab; the weight fragments of an offset stay in registers: WREG) or 32 (half a slab, twice
+// the waves: 16 per CU at 64 output channels = four per SIMD, which needs <= 128 registers -- the weight fragments are
+// then read from LDS per tile and k-step)
+template <int CIN, int COUT, int WAVES, int DEPTH, int R = D3D_PAIR_SLAB, bool WREG = true>
 __global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 4 : 2))
     spconv_pairs_kernel(const void *__restrict__ feat_, const void *__restrict__ wpack_, const float *__restrict__ bias,
-                        const uint32_t *__restrict__ ctab, const uint8_t *__restrict__ cnt, int cap64, int n_out, int kvol,
-                        void *__restrict__ out_, ConvEpiDev ep) {
+                        const uint32_t *__restrict__ ctab, const uint8_t *__restrict__ cnt, const uint8_t *__restrict__ cnt_lo,
+                        int cap64, int n_out, int kvol, void *__restrict__ out_, ConvEpiDev ep) {
   static_assert(CIN % 32 == 0 && COUT % 16 == 0 && COUT <= 64, "f32 features, x32 MFMA steps, slab rows of <= 256 B");
+  static_assert(R == 64 || R == 32, "a wave owns a slab or half of one");
   constexpr int NT = COUT / 16;
   constexpr int KS = CIN / 32;
-  constexpr int R = D3D_PAIR_SLAB;
   constexpr bool SWZ = CIN == 64;                  // weight rows: as in spconv_fwd_resident_kernel
   constexpr int ROWB = SWZ ? CIN * 2 : CIN * 2 + 16;
   constexpr int WBYTES = 2 * COUT * ROWB;          // one offset: hi plane rows, then lo plane rows
@@ -83,8 +94,10 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 4 : 2))
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int slab = blockIdx.x * WAVES + wave;
-  const int row0 = slab * R;
+  const int unit = blockIdx.x * WAVES + wave;       // the wave's R rows
+  const int slab = R == 64 ? unit : unit >> 1;      // 64-row segment of the table
+  const int half = R == 64 ? 0 : unit & 1;
+  const int row0 = unit * R;
   float *myslab = (float *)(plds + wave * SLABB);
 
   // ---- zero the slab (16-byte stores, one row segment per lane and step)
@@ -93,8 +106,15 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 4 : 2))
 
   // ---- the wave's tile list: lane k holds the pair count of offset k, tiles(k) = max(1, ceil(cnt / 16))
   const bool slab_live = row0 < n_out;
-  int cntv = 0;
-  if (lane < kvol && slab_live) cntv = (int)cnt[(int64_t)slab * 32 + lane];
+  int cntv = 0, basev = 0;  // pairs of this wave's rows per offset; where they start in the slab's segment
+  if (lane < kvol && slab_live) {
+    cntv = (int)cnt[(int64_t)slab * 32 + lane];
+    if constexpr (R == 32) {
+      const int lo = (int)cnt_lo[(int64_t)slab * 32 + lane];
+      basev = half ? lo : 0;
+      cntv = half ? cntv - lo : lo;
+    }
+  }
   const int tl = lane < kvol ? ((cntv + 15) >> 4 > 0 ? (cntv + 15) >> 4 : 1) : 0;
   int incl = tl;  // inclusive prefix over lanes (kvol <= 32)
 #pragma unroll
@@ -112,6 +132,10 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 4 : 2))
     t = q - __builtin_amdgcn_readlane(excl, kk);
     c = k < kvol ? __builtin_amdgcn_readlane(cntv, kk) : 0;
   };
+  auto seg_base = [&](int k) -> int {  // first entry of this wave's pairs of offset k inside the slab's segment
+    if constexpr (R == 64) return 0;
+    return __builtin_amdgcn_readlane(basev, k < kvol ? k : kvol - 1);
+  };
 
   const __amdgpu_buffer_rsrc_t feat_rs = d3d_make_rsrc(feat_);
   const __amdgpu_buffer_rsrc_t tab_rs = d3d_make_rsrc(ctab);
@@ -121,7 +145,7 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 4 : 2))
     int k, t, c;
     locate(q, k, t, c);
     const bool ok = t * 16 + lr < c;
-    const uint32_t off = ((uint32_t)k * (uint32_t)cap64 + (uint32_t)(slab * R + t * 16 + lr)) * 4u;
+    const uint32_t off = ((uint32_t)k * (uint32_t)cap64 + (uint32_t)(slab * D3D_PAIR_SLAB + seg_base(k) + t * 16 + lr)) * 4u;
     return (uint32_t)d3d_buffer_load4(tab_rs, ok ? off : D3D_OOB_OFFSET);
   };
   struct Frag32 { uint4 a, b; };
@@ -194,15 +218,17 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 4 : 2))
           publish_w(k & 1, wr);
           load_w(k + 1, wr);
           d3d_lds_barrier();
-          if (c > 0) {
-            const unsigned char *wcur = wlds + (k & 1) * WBYTES;
+          if constexpr (WREG) {
+            if (c > 0) {
+              const unsigned char *wcur = wlds + (k & 1) * WBYTES;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-              const int cb = ((ks * 32 + lg * 8) * 2) ^ (SWZ ? ((lr >> 1) & 7) << 4 : 0);
+              for (int ks = 0; ks < KS; ++ks) {
+                const int cb = ((ks * 32 + lg * 8) * 2) ^ (SWZ ? ((lr >> 1) & 7) << 4 : 0);
 #pragma unroll
-              for (int n = 0; n < NT; ++n) {
-                wh[n][ks] = *(const uint4 *)(wcur + (n * 16 + lr) * ROWB + cb);
-                wl[n][ks] = *(const uint4 *)(wcur + (COUT + n * 16 + lr) * ROWB + cb);
+                for (int n = 0; n < NT; ++n) {
+                  wh[n][ks] = *(const uint4 *)(wcur + (n * 16 + lr) * ROWB + cb);
+                  wl[n][ks] = *(const uint4 *)(wcur + (COUT + n * 16 + lr) * ROWB + cb);
+                }
               }
             }
           }
@@ -210,7 +236,7 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 4 : 2))
         if (c > 0) {
           // this lane ends up with couts n * 16 + lg * 4 + (0..3) of pair lr, whose output row is o: fetch the row's
           // running sums now, they arrive behind the MFMAs (lanes past the count read row 0 and write nothing)
-          const uint32_t o = ecur[d] >> D3D_PAIR_ROW_BITS;
+          const uint32_t o = (ecur[d] >> D3D_PAIR_ROW_BITS) & (uint32_t)(R - 1);
           const uint32_t rowb = slab_base + o * (uint32_t)(COUT * 4);
           uint32_t ca[NT];
           f32x4_t run[NT];
@@ -222,10 +248,19 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 4 : 2))
           f32x4_t acc[NT];
 #pragma unroll
           for (int n = 0; n < NT; ++n) acc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          const unsigned char *wtile = wlds + (k & 1) * WBYTES;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
             uint4 xh, xl;
             spconv_split8(fr[d][ks].a, fr[d][ks].b, xh, xl);
+            if constexpr (!WREG) {  // this k-step's weight fragments from the LDS stage (they stay there until the next rendezvous)
+              const int cb = ((ks * 32 + lg * 8) * 2) ^ (SWZ ? ((lr >> 1) & 7) << 4 : 0);
+#pragma unroll
+              for (int n = 0; n < NT; ++n) {
+                wh[n][ks] = *(const uint4 *)(wtile + (n * 16 + lr) * ROWB + cb);
+                wl[n][ks] = *(const uint4 *)(wtile + (COUT + n * 16 + lr) * ROWB + cb);
+              }
+            }
 #pragma unroll
             for (int n = 0; n < NT; ++n)
               acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wh[n][ks]),
@@ -271,18 +306,18 @@ __global__ void __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 4 : 2))
   spconv_fwd_epilogue<COUT, MT, false, NTHREADS>(acc, site, live, bias, out_, ep, (float *)wlds, lr, lg);
 }
 
-template <int CIN, int COUT, int WAVES, int DEPTH>
+template <int CIN, int COUT, int WAVES, int DEPTH, int R = D3D_PAIR_SLAB, bool WREG = true>
 static int launch_pairs(const void *feat, const void *wpack, const float *bias, const uint32_t *ctab, const uint8_t *cnt,
-                        int cap64, int n_out, int kvol, void *out, ConvEpiDev ep, hipStream_t stream) {
-  const int rows_per_block = WAVES * D3D_PAIR_SLAB;
+                        const uint8_t *cnt_lo, int cap64, int n_out, int kvol, void *out, ConvEpiDev ep, hipStream_t stream) {
+  const int rows_per_block = WAVES * R;
   const int nb = (n_out + rows_per_block - 1) / rows_per_block;
   if (int rc = epi_prepare(ep, nb, COUT)) return rc;
-  constexpr size_t lds = (size_t)WAVES * D3D_PAIR_SLAB * COUT * 4 + 2 * (size_t)(2 * COUT * (CIN == 64 ? CIN * 2 : CIN * 2 + 16));
+  constexpr size_t lds = (size_t)WAVES * R * COUT * 4 + 2 * (size_t)(2 * COUT * (CIN == 64 ? CIN * 2 : CIN * 2 + 16));
   static_assert(lds <= 160 * 1024, "LDS of one CU");
-  D3D_HIP_TRY(hipFuncSetAttribute((const void *)spconv_pairs_kernel<CIN, COUT, WAVES, DEPTH>,
+  D3D_HIP_TRY(hipFuncSetAttribute((const void *)spconv_pairs_kernel<CIN, COUT, WAVES, DEPTH, R, WREG>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((spconv_pairs_kernel<CIN, COUT, WAVES, DEPTH>), dim3(nb), dim3(WAVES * 64), lds, stream, feat, wpack,
-                     bias, ctab, cnt, cap64, n_out, kvol, out, ep);
+  hipLaunchKernelGGL((spconv_pairs_kernel<CIN, COUT, WAVES, DEPTH, R, WREG>), dim3(nb), dim3(WAVES * 64), lds, stream, feat,
+                     wpack, bias, ctab, cnt, cnt_lo, cap64, n_out, kvol, out, ep);
   D3D_LAUNCH_TRY("spconv_pairs_kernel");
   return D3D_OK;
 }

@@ -23,7 +23,7 @@ static inline int pair_cap64(int n_rows) { return (n_rows + D3D_PAIR_SLAB - 1) /
 static inline size_t pair_cnt_offset(int n_rows, int kvol) { return d3d_align_up((size_t)kvol * pair_cap64(n_rows) * 4); }
 extern "C" size_t d3d_pair_table_bytes(int n_rows, int kvol) {
   if (n_rows < 1 || kvol < 1 || kvol > 32) return 0;
-  return pair_cnt_offset(n_rows, kvol) + d3d_align_up((size_t)(pair_cap64(n_rows) / D3D_PAIR_SLAB) * 32);
+  return pair_cnt_offset(n_rows, kvol) + 2 * d3d_align_up((size_t)(pair_cap64(n_rows) / D3D_PAIR_SLAB) * 32);  // cnt, cnt_lo
 }
 extern "C" int d3d_pair_table_build(const int32_t *nbr, int cap, int n_rows, int kvol, void *table, size_t table_bytes,
                                     d3d_stream_t stream_) {
@@ -39,7 +39,8 @@ extern "C" int d3d_pair_table_build(const int32_t *nbr, int cap, int n_rows, int
   const int nslab = pair_cap64(n_rows) / D3D_PAIR_SLAB;
   hipLaunchKernelGGL(pair_table_build_kernel, dim3((nslab + 3) / 4), dim3(256), 0, (hipStream_t)stream_, nbr, cap,
                      (const int32_t *)nullptr, n_rows, kvol, pair_cap64(n_rows), (uint32_t *)table,
-                     (uint8_t *)table + pair_cnt_offset(n_rows, kvol));
+                     (uint8_t *)table + pair_cnt_offset(n_rows, kvol),
+                     (uint8_t *)table + pair_cnt_offset(n_rows, kvol) + d3d_align_up((size_t)nslab * 32));
   D3D_LAUNCH_TRY("pair_table_build_kernel");
   return D3D_OK;
 }
@@ -61,26 +62,28 @@ extern "C" int d3d_sparse_conv_fwd_pairs(const void *feat, const void *wpack, co
   const uint32_t *ctab = (const uint32_t *)table;
   const uint8_t *cnt = (const uint8_t *)table + pair_cnt_offset(n_out, kvol);
   const int cap64 = pair_cap64(n_out);
+  const uint8_t *cnt_lo = cnt + d3d_align_up((size_t)(cap64 / D3D_PAIR_SLAB) * 32);
   // 8-wave blocks (512 rows, one block per CU) where they fill the chip, 4-wave blocks on the small levels
   const bool wide = (n_out + 511) / 512 >= 192;
-  static const int depth = getenv("D3D_PAIRS_DEPTH") ? atoi(getenv("D3D_PAIRS_DEPTH")) : 3;
+  // tiling: D3D_PAIRS_TILING (tools/bench_pairs.py): 0 = 64-row slabs, 8-wave blocks where they fill the chip else 4-wave
+  // blocks, weight fragments in registers (round 6, first version); 1 = 32 rows per wave, 16-wave blocks (four waves per
+  // SIMD, <= 128 registers), weight fragments from LDS per k-step; 2 = 32 rows per wave, 8-wave blocks
+  static const int tiling = getenv("D3D_PAIRS_TILING") ? atoi(getenv("D3D_PAIRS_TILING")) : 0;
   static const int force_w = getenv("D3D_PAIRS_WAVES") ? atoi(getenv("D3D_PAIRS_WAVES")) : 0;
   const bool w8 = force_w ? force_w == 8 : wide;
-#define PAIRS_D(CI, CO, WV, DP) \
-  if (depth == DP) return launch_pairs<CI, CO, WV, DP>(feat, wpack, bias, ctab, cnt, cap64, n_out, kvol, out, ep, stream);
-#define PAIRS_CASE(CI, CO)                                                                                          \
-  if (cin == CI && cout == CO) {                                                                                    \
-    if (w8) { PAIRS_D(CI, CO, 8, 2) PAIRS_D(CI, CO, 8, 4) PAIRS_D(CI, CO, 8, 5) PAIRS_D(CI, CO, 8, 6)              \
-      return launch_pairs<CI, CO, 8, 3>(feat, wpack, bias, ctab, cnt, cap64, n_out, kvol, out, ep, stream); }       \
-    PAIRS_D(CI, CO, 4, 2) PAIRS_D(CI, CO, 4, 4) PAIRS_D(CI, CO, 4, 5) PAIRS_D(CI, CO, 4, 6)                        \
-    return launch_pairs<CI, CO, 4, 3>(feat, wpack, bias, ctab, cnt, cap64, n_out, kvol, out, ep, stream);           \
+#define PAIRS_CASE(CI, CO)                                                                                                    \
+  if (cin == CI && cout == CO) {                                                                                              \
+    if (tiling == 1) return launch_pairs<CI, CO, 16, 2, 32, false>(feat, wpack, bias, ctab, cnt, cnt_lo, cap64, n_out, kvol, out, ep, stream); \
+    if (tiling == 2) return launch_pairs<CI, CO, 8, 2, 32, false>(feat, wpack, bias, ctab, cnt, cnt_lo, cap64, n_out, kvol, out, ep, stream);  \
+    if (tiling == 3) return launch_pairs<CI, CO, 16, 1, 32, false>(feat, wpack, bias, ctab, cnt, cnt_lo, cap64, n_out, kvol, out, ep, stream); \
+    if (w8) return launch_pairs<CI, CO, 8, 3>(feat, wpack, bias, ctab, cnt, cnt_lo, cap64, n_out, kvol, out, ep, stream);     \
+    return launch_pairs<CI, CO, 4, 3>(feat, wpack, bias, ctab, cnt, cnt_lo, cap64, n_out, kvol, out, ep, stream);             \
   }
   PAIRS_CASE(32, 32)
   PAIRS_CASE(32, 64)
   PAIRS_CASE(64, 32)
   PAIRS_CASE(64, 64)
 #undef PAIRS_CASE
-#undef PAIRS_D
   return d3d_set_error(D3D_EINVAL, "d3d_sparse_conv_fwd_pairs: channels %d -> %d", cin, cout);
 }
 

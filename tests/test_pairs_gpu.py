@@ -56,8 +56,16 @@ def test_pair_table_is_the_compacted_neighbour_table(gi, n_per):
         ent = raw[: rb.kvol * cap64 * 4].view(np.uint32).reshape(rb.kvol, cap64)
         off = (rb.kvol * cap64 * 4 + 255) // 256 * 256
         cnt = raw[off: off + cap64 // 64 * 32].reshape(cap64 // 64, 32)
+        off_lo = off + (cap64 // 64 * 32 + 255) // 256 * 256
+        cnt_lo = raw[off_lo: off_lo + cap64 // 64 * 32].reshape(cap64 // 64, 32)
         want_ent, used, want_cnt = _table_ref(nbr.view(rb.kvol, cap).cpu().numpy(), n, rb.kvol)
         assert np.array_equal(cnt, want_cnt)
+        # pairs of a slab's rows 0..31: they come first in the segment (ascending rows) -- the split point of its two halves
+        tab = nbr.view(rb.kvol, cap).cpu().numpy()[:, :n]
+        padded = np.full((rb.kvol, cap64), -1, tab.dtype)
+        padded[:, :n] = tab
+        want_lo = (padded.reshape(rb.kvol, cap64 // 64, 64)[:, :, :32] >= 0).sum(2).T
+        assert np.array_equal(cnt_lo[:, :rb.kvol], want_lo)
         assert np.array_equal(ent[used], want_ent[used])  # (entries past a segment's count are never read)
         assert int(want_cnt.sum()) == rb.pairs()
 
