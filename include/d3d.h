@@ -218,7 +218,9 @@ int d3d_sparse_conv_fwd_ex(const void *feat, const void *wpack, const float *bia
  * d3d_sparse_conv_fwd_ex with `table` in place of (nbr, cap); results agree with it to f32 rounding (an offset's
  * products are summed before they are added to the row), not bit for bit.
  *  table   dev, d3d_pair_table_bytes(n_rows, kvol) bytes: [kvol][ceil64(n_rows)] u32 entries (input row | (row % 64) << 26,
- *          the pairs of a slab packed to the front of its 64-entry segment), then [slabs][32] u8 pair counts;
+ *          the pairs of a slab packed to the front of its 64-entry segment in ascending row order), then [slabs][32] u8
+ *          pair counts and [slabs][32] u8 counts of the pairs of a slab's rows 0..31 (where a segment splits into the
+ *          lists of its two 32-row halves: the 16-wave tilings give a wave half a slab);
  *          built once per rulebook (one launch, no host sync), shared by every layer, direction and step using it
  *  d3d_sparse_conv_pairs_supported: f32 features (split arithmetic), channel pairs 32/64 -> 32/64; kvol <= 32 */
 size_t d3d_pair_table_bytes(int n_rows, int kvol);
