@@ -15,11 +15,11 @@ def pytest_configure(config):
 
 
 # GPU run order (`pytest -m gpu -x` stops at the first failure, so what proves the kernels goes first): kernel-level
-# parity files, then the model-level goldens, then the distributed paths, and the optional features (hipGraph tail)
-# last.  Files not listed keep their alphabetical place between the kernel files and the end-to-end ones.
+# parity files, then the model-level goldens, then the distributed paths, the optional features (hipGraph tail) and,
+# last, the long training-run comparisons of test_precision_gpu (8 of the suite's 12.5 minutes).  Files not listed keep their alphabetical place between the kernel files and the end-to-end ones.
 _GPU_ORDER = ["test_voxelize_gpu", "test_spconv_gpu", "test_determinism_gpu", "test_conv2d_gpu", "test_nms_gpu",
               "test_iou3d_gpu", "test_loss_gpu", "test_optim_gpu", "test_pfn_gpu", "test_assign_gpu", "test_pipeline_gpu",
-              "test_e2e_gpu", "test_dist_gpu", "test_graph_tail_gpu"]
+              "test_e2e_gpu", "test_dist_gpu", "test_graph_tail_gpu", "test_precision_gpu"]
 
 
 def _order_key(item):
