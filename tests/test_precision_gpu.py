@@ -123,7 +123,20 @@ def test_split_against_exact_f32_on_the_detector_goldens(name):
     assert l2 <= bl2 and cos <= bcos
 
 
+_LEGS = {}  # (exact, steps, eps, seed) -> (losses, held-out predictions): the two 300-step tests share their common legs
+
+
 def _train_leg(exact, steps, eps=0.0, unfused=False, seed=None):
+    key = (bool(exact), int(steps), float(eps), seed)
+    if not unfused and key in _LEGS:
+        return _LEGS[key]
+    out = _train_leg_run(exact, steps, eps, unfused, seed)
+    if not unfused:
+        _LEGS[key] = out
+    return out
+
+
+def _train_leg_run(exact, steps, eps=0.0, unfused=False, seed=None):
     """one training run of tests/golden/train_run_spec.py on the GPU.  exact: precision.exact_f32(); eps: the initial
     weights multiplied by (1 + eps) -- the sensitivity probe; unfused: the per-layer sparse path instead of the fused stack;
     seed: another default initialisation (torch.manual_seed(seed) on the CPU generator) instead of the spec's seed 0"""
@@ -229,23 +242,24 @@ def test_300_training_steps_split_vs_exact_f32_vs_cpu_oracle():
     assert np.array_equal(l_unfused, legs["split"][0][:60])
 
 
-def test_300_training_steps_five_seeds_per_mode():
-    """VERDICT round 5 (weak 1): the 300-step comparison above rests on one seed pair per mode, and the run is chaotic --
-    one pair says little.  Here: FIVE different initialisations (torch.manual_seed(1..5)), each trained for 300 steps in
-    split arithmetic and in exact f32 from the same weights, batches and schedule.  Asserted on the two DISTRIBUTIONS of
-    the final loss (mean of the last 20 steps): every leg trains (loss falls by > 100 x), the medians of the two modes
-    agree within the exact-f32 legs' own max / min spread (at least a factor 1.5), and no split leg ends outside
-    [min / 2, 2 max] of the exact legs.  The per-seed pairs are printed: which mode ends lower flips from seed to seed."""
+def test_300_training_steps_five_initialisations_per_mode():
+    """VERDICT round 5 (weak 1): the comparison above rests on one seed pair per mode, and the run is chaotic -- one pair
+    says little.  Here: FIVE initialisations per mode -- the spec's seed-0 weights, their (1 + 1e-6) twin (both shared
+    with the test above: the legs are cached) and torch.manual_seed(1..3) -- each trained for 300 steps in split
+    arithmetic and in exact f32 from the same weights, batches and schedule.  Asserted on the two DISTRIBUTIONS of the
+    final loss (mean of the last 20 steps): every leg trains (loss falls by > 100 x), the medians of the two modes agree
+    within the exact-f32 legs' own max / min spread (at least a factor 1.5), and no split leg ends outside [min / 2,
+    2 max] of the exact legs.  Which mode ends lower flips from initialisation to initialisation (printed)."""
     import train_run_spec as T
 
-    seeds = [1, 2, 3, 4, 5]
-    split = [_train_leg(False, T.STEPS, seed=s)[0] for s in seeds]
-    exact = [_train_leg(True, T.STEPS, seed=s)[0] for s in seeds]
+    inits = [dict(), dict(eps=1e-6), dict(seed=1), dict(seed=2), dict(seed=3)]
+    split = [_train_leg(False, T.STEPS, **kw)[0] for kw in inits]
+    exact = [_train_leg(True, T.STEPS, **kw)[0] for kw in inits]
     fs = np.array([l[-20:].mean() for l in split])
     fe = np.array([l[-20:].mean() for l in exact])
-    print("300 steps x 5 seeds, final loss (mean of the last 20): split %s | exact f32 %s" % (np.round(fs, 4).tolist(), np.round(fe, 4).tolist()))
-    print("medians: split %.4f exact %.4f; exact spread max / min %.2f; split lower than exact on %d of %d seeds" % (
-        np.median(fs), np.median(fe), fe.max() / fe.min(), int((fs < fe).sum()), len(seeds)))
+    print("300 steps x 5 initialisations, final loss (mean of the last 20): split %s | exact f32 %s" % (np.round(fs, 4).tolist(), np.round(fe, 4).tolist()))
+    print("medians: split %.4f exact %.4f; exact spread max / min %.2f; split lower than exact on %d of %d" % (
+        np.median(fs), np.median(fe), fe.max() / fe.min(), int((fs < fe).sum()), len(inits)))
     for l in split + exact:
         assert np.isfinite(l).all() and l[-20:].mean() < 0.01 * l[0]
     spread = max(fe.max() / fe.min(), 1.5)
