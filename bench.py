@@ -502,6 +502,10 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
     ms1 = torch.cuda.memory_stats(dev)
     alloc = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
     alloc["reserved_MB"] = int(ms1.get("reserved_bytes.all.current", 0) >> 20)
+    # large pool = every tensor >= 1 MB (nothing data-dependent may grow it); small pool = 2 MB segments of the tensors
+    # PyTorch allocates itself (scalars, count tensors), which may still take a segment when the host runs further ahead
+    alloc["large_pool_growth_MB"] = int((ms1.get("reserved_bytes.large_pool.current", 0) - ms0.get("reserved_bytes.large_pool.current", 0)) >> 20)
+    alloc["small_pool_growth_MB"] = int((ms1.get("reserved_bytes.small_pool.current", 0) - ms0.get("reserved_bytes.small_pool.current", 0)) >> 20)
     alloc["steps"] = steps * len(times)
     from det3d_amd import arena as _arena
     alloc["step_arena"] = _arena.step_arena(dev).stats()

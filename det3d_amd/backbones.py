@@ -107,6 +107,13 @@ class _SparseMiddle(nn.Module):
             voxel_features = voxel_features.to(torch.get_autocast_dtype("cuda"))
         ret = spconv.SparseConvTensor(voxel_features, coors, sparse_shape.tolist(), batch_size)
         if plan is not None and plan["coors"].data_ptr() == coors.data_ptr() and plan["coors"].shape == coors.shape:
+            ticket = plan.get("ring_ticket")
+            if ticket is not None and ticket[0].generation != ticket[1]:
+                from ._lib import D3dError
+
+                raise D3dError("the rulebooks of this example lived in slot '%s' of a GeometryPrefetcher ring that has been "
+                               "rewound since (generation %d -> %d): the example was kept for more than ring - 1 further "
+                               "builds; use GeometryPrefetcher(ring=0) for such a loop" % (ticket[0].name, ticket[1], ticket[0].generation))
             ret.indice_dict = plan["indice_dict"]  # built ahead of time for exactly these coordinates
         else:
             self.middle_conv.plan(ret)  # every rulebook of the stack, one host sync

@@ -9,7 +9,7 @@ meaning and return layout -- on top of the C ABI `d3d_voxelize` (include/d3d.h).
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, arena as mem
 
 
 def grid_size_of(voxel_size, coors_range):
@@ -65,13 +65,15 @@ def voxelize_batch(points, frame_offsets, voxel_size, coors_range, max_points, m
     grid = grid_size_of(voxel_size, coors_range)
     rows = batch * max_voxels
     dev = points.device
-    coors = torch.empty((rows, 4), dtype=torch.int32, device=dev)
-    num_points = torch.empty((rows,), dtype=torch.int32, device=dev)
-    voxels = torch.empty((rows, max_points, c), dtype=torch.float32, device=dev) if want_voxels else None
-    mean = torch.empty((rows, mean_channels), dtype=torch.float32, device=dev) if mean_channels else None
-    num_voxels = torch.empty((batch + 1,), dtype=torch.int32, device=dev)
+    # (from the calling thread's arena when it has one -- the geometry ring slot of a prefetched build, arena.py -- else
+    # torch.empty: the direct API never sees an arena)
+    coors = mem.empty((rows, 4), torch.int32, dev)
+    num_points = mem.empty((rows,), torch.int32, dev)
+    voxels = mem.empty((rows, max_points, c), torch.float32, dev) if want_voxels else None
+    mean = mem.empty((rows, mean_channels), torch.float32, dev) if mean_channels else None
+    num_voxels = mem.empty((batch + 1,), torch.int32, dev)
     ws_bytes = L.d3d_voxelize_workspace_bytes(n, batch, max_points, max_voxels)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    ws = mem.empty((ws_bytes,), torch.uint8, dev)
     rc = L.d3d_voxelize(points.data_ptr(), n, c, frame_offsets.data_ptr(), batch,
                         _lib.f32_array(np.asarray(voxel_size, dtype=np.float32)),
                         _lib.f32_array(np.asarray(coors_range, dtype=np.float32)),

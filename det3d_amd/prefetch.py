@@ -210,6 +210,10 @@ class GeometryPrefetcher:
             ex = self.make_example(batch)
             if self.backbone is not None and "coordinates" in ex and "sparse_plan" not in ex:
                 ex["sparse_plan"] = self.backbone.plan_geometry(ex["coordinates"], len(ex["num_voxels"]), ex["shape"][0])
+        if slot is not None and isinstance(ex.get("sparse_plan"), dict):
+            # the rulebooks live in this ring slot until build q + ring rewinds it: the backbone refuses a plan whose slot
+            # has moved on (an example kept longer than the ring allows) instead of reading recycled tables
+            ex["sparse_plan"]["ring_ticket"] = (slot, slot.generation)
         return ex
 
 

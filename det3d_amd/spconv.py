@@ -275,7 +275,7 @@ def build_conv_rulebook(indices, n_dev, n, cap_in, batch, in_shape, ksize, strid
     cells = batch * out_shape[0] * out_shape[1] * out_shape[2]
     cap_out = int(max(1, min(cap_in * fan, cells)))
     coords_out = mem.empty((cap_out, 4), torch.int32, dev)
-    n_out_dev = torch.empty((1,), dtype=torch.int32, device=dev)
+    n_out_dev = mem.empty((1,), torch.int32, dev)
     nbr_out = mem.empty((kvol * cap_out,), torch.int32, dev)
     nbr_in = mem.empty((kvol * cap_in,), torch.int32, dev)
     pc = torch.empty((kvol,), dtype=torch.int32, device=dev) if count_pairs else None
@@ -325,7 +325,7 @@ def build_conv_rulebook_chain(indices, n_dev, cap0, batch, in_shape, convs):
         cells = batch * out_shape[0] * out_shape[1] * out_shape[2]
         cap_out = int(max(1, min(cap_in * fan, cells)))
         coords_out = mem.empty((cap_out, 4), torch.int32, dev)
-        n_out_dev = torch.empty((1,), dtype=torch.int32, device=dev)
+        n_out_dev = mem.empty((1,), torch.int32, dev)
         nbr_out = mem.empty((kvol * cap_out,), torch.int32, dev)
         nbr_in = mem.empty((kvol * cap_in,), torch.int32, dev)
         plan = None

@@ -212,11 +212,13 @@ def assign_targets_device(anchors, gt, gt_count, matched_threshold=0.6, unmatche
     B, gmax = gt.shape[0], gt.shape[1]
     A = anchors.shape[0]
     dev = anchors.device
-    labels = torch.empty((B, A), dtype=torch.int32, device=dev)
-    targets = torch.empty((B, A, 7), dtype=torch.float32, device=dev)
-    weights = torch.empty((B, A), dtype=torch.float32, device=dev)
+    from . import arena as mem  # (the calling thread's arena if it has one: a prefetched build's ring slot)
+
+    labels = mem.empty((B, A), torch.int32, dev)
+    targets = mem.empty((B, A, 7), torch.float32, dev)
+    weights = mem.empty((B, A), torch.float32, dev)
     wsb = L.d3d_assign_targets_workspace_bytes(A, B, gmax)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    ws = mem.empty((wsb,), torch.uint8, dev)
     cls = gt_classes.int().contiguous() if gt_classes is not None else None
     rc = L.d3d_assign_targets(anchors.data_ptr(), A, gt.data_ptr(), _lib.ptr(cls), gt_count.data_ptr(), B,
                               gmax, float(matched_threshold), float(unmatched_threshold), labels.data_ptr(),
@@ -247,11 +249,13 @@ def assign_targets_task_device(anchors, num_classes, per_class, matched, unmatch
     (A, nd), (B, gmax) = anchors.shape, gt.shape[:2]
     code = nd - 1 + (2 if encode_angle_vector else 1)
     dev = anchors.device
-    labels = torch.empty((B, A), dtype=torch.int32, device=dev)
-    targets = torch.empty((B, A, code), dtype=torch.float32, device=dev)
-    weights = torch.empty((B, A), dtype=torch.float32, device=dev)
+    from . import arena as mem
+
+    labels = mem.empty((B, A), torch.int32, dev)
+    targets = mem.empty((B, A, code), torch.float32, dev)
+    weights = mem.empty((B, A), torch.float32, dev)
     wsb = L.d3d_assign_targets_workspace_bytes(A, B, gmax)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    ws = mem.empty((wsb,), torch.uint8, dev)
     rc = L.d3d_assign_targets_task(anchors.data_ptr(), A, nd, int(num_classes), int(per_class),
                                    _lib.f32_array(matched), _lib.f32_array(unmatched), int(encode_angle_vector),
                                    gt.data_ptr(), _lib.ptr(gt_classes), gt_count.data_ptr(), B, gmax,

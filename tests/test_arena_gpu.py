@@ -54,12 +54,16 @@ def test_steady_state_step_allocates_nothing_from_the_device():
     m1 = torch.cuda.memory_stats(dev)
     state["next"].result()
     pf.close()
-    d = {k: m1[k] - m0[k] for k in ("num_device_alloc", "num_device_free", "reserved_bytes.all.current")}
+    d = {k: m1[k] - m0[k] for k in ("num_device_alloc", "num_device_free", "reserved_bytes.all.current",
+                                    "reserved_bytes.large_pool.current", "reserved_bytes.small_pool.current")}
     sa = arena.step_arena(dev).stats()
     print("50 steady-state steps: %s; step arena %s; geometry ring %s" % (d, sa, pf.arena_stats()))
-    # (one 2 MB small-pool segment has been seen on one box in ten: sub-megabyte tensors whose release waits for another
-    # stream's event; the data-dependent tensors -- everything that used to grow the pools -- are in the arenas)
-    assert d["num_device_alloc"] <= 1 and d["reserved_bytes.all.current"] <= (2 << 20), d
+    # The claim: nothing data-dependent reaches hipMalloc -- the LARGE pool (every tensor >= 1 MB) does not move at all.
+    # The small pool (2 MB segments of sub-megabyte tensors PyTorch itself allocates: scalars, count tensors, H2D staging)
+    # may still take a few segments on a box where the host runs further ahead than during the warm-up -- their release
+    # waits for another stream's event -- : 0 on three boxes, 1 and 5 segments on two others.  Bounded, not asserted to zero.
+    assert d["reserved_bytes.large_pool.current"] == 0, d
+    assert d["reserved_bytes.small_pool.current"] <= (32 << 20) and d["num_device_alloc"] <= 16, d
     assert sa["spills"] == 0 or sa["grows"] >= 1
     assert all(torch.isfinite(l) for l in losses)
 
@@ -146,3 +150,21 @@ def test_backward_runs_under_the_forwards_library_context():
     assert _lib.current_ctx() is None
     for a, b in zip(want, got):
         assert torch.equal(a, b)
+
+
+def test_an_example_that_outlives_its_ring_slot_is_refused():
+    """the geometry ring's contract (prefetch.py): an example is dead by the time `ring - 1` further builds were requested.
+    The backbone checks the slot's generation and raises instead of convolving over recycled neighbour tables."""
+    from det3d_amd import _lib
+    from det3d_amd.prefetch import GeometryPrefetcher
+
+    model, step, make, dev = _setup()
+    pf = GeometryPrefetcher(make, model, dev, ring=3)
+    old = pf.prepare(0)
+    keep = [pf.prepare(i) for i in (1, 2)]
+    step(old)                       # two further builds: still its slot's tenant
+    keep.append(pf.prepare(3))      # the third rewinds slot 0
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.D3dError, match="rewound"):
+        step(old)
+    pf.close()
