@@ -52,7 +52,14 @@ def rulebook_of(sp, block, x):
         return None
     c1, c2 = block.conv1, block.conv2
     feats = x.features
-    if not (feats.is_cuda and feats.dtype in sp._DT and feats.dim() == 2 and feats.shape[0] > 1):
+    sync = syncbn.fused_sync(block.bn1) or syncbn.fused_sync(block.bn2)
+    if not (feats.is_cuda and feats.dtype in sp._DT and feats.dim() == 2):
+        return None
+    if sync and feats.shape[0] < 1:
+        # (as in sparse_stack._eligible: with a cross-rank BatchNorm the decision must not depend on this rank's row count)
+        raise _lib.D3dError("SparseBasicBlock: this rank has no active sites at a SyncBN layer; its statistics are undefined "
+                            "and the other ranks are waiting in the exchange")
+    if not sync and feats.shape[0] <= 1:
         return None
     c = c1.in_channels
     if not (c1.subm and c2.subm and c1.out_channels == c and c2.in_channels == c and c2.out_channels == c):
