@@ -115,6 +115,10 @@ class GeometryPrefetcher:
             from . import runtime
 
             ring = runtime.get("geometry_ring")
+        if int(ring) in (1, 2):
+            # build q waits for the event of request q - 1, which covers the step that consumed build q - 3 (two builds are
+            # outstanding in the threaded loop): a slot may only come round again after three builds
+            raise ValueError("GeometryPrefetcher: ring must be 0 (caching allocator) or >= 3, got %r" % (ring,))
         self.ring = int(ring) if (enabled and torch.cuda.is_available()) else 0
         self._slots = {}
         self._seq = 0
