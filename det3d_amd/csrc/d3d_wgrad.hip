@@ -367,11 +367,16 @@ static int wg_waves(int kvol, int cin, int cout, int dtype) {
 // and 128x128) get two rounds -- 24 splits x 9 = 216 blocks left 40 CUs idle, 56 x 9 = 504 fills two rounds (measured on the
 // CBGS rulebooks: 1049 -> 850 us and 514 -> 472 us per launch; the nine-offset layers are flat or slower with more splits)
 // (tuning knob 1 carries two numbers: value % 100000 = blocks, value / 100000 = kernel variant, see wg_variant)
-static int wg_target_blocks(int kg, int dtype) {
+static int wg_target_blocks(int kg, int dtype, int n_out) {
   static const int v = getenv("D3D_WGRAD_BLOCKS") ? atoi(getenv("D3D_WGRAD_BLOCKS")) : 0;
   if (g_d3d_wgrad_blocks > 0 && g_d3d_wgrad_blocks % 100000 > 0) return g_d3d_wgrad_blocks % 100000;
   if (v >= 1) return v;
-  return (dtype == D3D_F32 && kg == 3) ? 512 : 256;
+  // 208, not one block per CU (round 6): the weight gradient runs on a second stream NEXT TO the data-gradient chain, and
+  // with ~50 CUs left to that chain the step is 1.3-1.9 % faster than with 256 (same box, 540 timed steps each: 192 blocks
+  // 646.4 / 645.5 / 648.2 frames/s, 224: 645.1, 256: 634.0 / 638.5 / 642.3, 160: 632.9, 128: 641.0, 384: 630.1); alone on
+  // the device 256 is the faster launch
+  // (on the 800 k-row layers of nuScenes CBGS the two counts measure the same: 237.5 vs 238.5 frames/s -- 256 stays there)
+  return (dtype == D3D_F32 && kg == 3) ? 512 : (n_out < 300000 ? 208 : 256);
 }
 
 // offsets per block: the accumulators of a wave are 4 * KG * TPW registers
@@ -398,7 +403,7 @@ static WgPlan wg_plan(int n_out, int kvol, int cin, int cout, int dtype) {
   p.csplit = wg_csplit(cin, cout, dtype, p.waves);
   const int kgroups = kvol / p.kg;
   const int tiles = (n_out + p.step - 1) / p.step;
-  int splits = (wg_target_blocks(p.kg, dtype) * (WG_WAVES / p.waves) + kgroups - 1) / kgroups;
+  int splits = (wg_target_blocks(p.kg, dtype, n_out) * (WG_WAVES / p.waves) + kgroups - 1) / kgroups;
   int max_splits = (tiles + 1) / 2;  // >= 2 tiles per block
   if (max_splits < 1) max_splits = 1;
   if (splits > max_splits) splits = max_splits;
