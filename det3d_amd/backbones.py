@@ -120,6 +120,10 @@ class _SparseMiddle(nn.Module):
         spconv.ARENA.reset(voxel_features.device)  # rewind the fold workspaces of this pass's conv epilogues (no launch)
         ret = self.middle_conv(ret)
         self.last_indice_dict = ret.indice_dict
+        if voxel_features.is_cuda and self.training:
+            from . import prefetch
+
+            prefetch.mark_sparse_forward(voxel_features.device)  # (runtime "geometry_gate": where the next build may start)
         # [B, C, D, H, W] -> [B, C*D, H, W]; on the GPU as a channels-last tensor written directly by the scatter
         # kernel: the layout the dense conv kernels (dense_stack.py) and the BatchNorm sweeps work on
         return ret.dense_2d(channels_last=getattr(self, "dense_channels_last", voxel_features.is_cuda))

@@ -236,6 +236,7 @@ class _DenseStackFn(torch.autograd.Function):
         from . import runtime
         side = sparse_stack.wgrad_stream(dev) if sparse_stack.WGRAD_STREAM and runtime.wgrad_side("dense") and len(layers) > 1 else None
         keep = []  # the gradient planes the side stream reads stay referenced until it has been joined
+        defer = side is not None and runtime.wgrad_after_dgrad("dense")
         for li in range(len(layers) - 1, -1, -1):
             ly = layers[li]
             bn = ly.bn
@@ -266,14 +267,19 @@ class _DenseStackFn(torch.autograd.Function):
                                      save[0].data_ptr(), save[1].data_ptr(), int(ly.relu), partial.data_ptr(), 1,
                                      g_hi.data_ptr(), gbn[0].data_ptr(), gbn[1].data_ptr(), st)
                 _lib.check(rc, "d3d_bn_bwd_dx")
-            if side is not None:
+            def side_wgrad():
                 side.wait_event(main.record_event())
                 keep.append((g_hi, g_lo))
                 with torch.cuda.stream(side):  # (its workspace comes from, and returns to, the side stream's pool)
-                    gw = dc.wgrad_raw(g_hi, g_lo, a_hi, a_lo, ly.ksz, ly.stride, ly.pad, mode)
-                gw.record_stream(main)
-            else:
+                    w = dc.wgrad_raw(g_hi, g_lo, a_hi, a_lo, ly.ksz, ly.stride, ly.pad, mode)
+                w.record_stream(main)
+                return w
+
+            gw = None
+            if side is None:
                 gw = dc.wgrad_raw(g_hi, g_lo, a_hi, a_lo, ly.ksz, ly.stride, ly.pad, mode)
+            elif not defer:
+                gw = side_wgrad()
             partial = None
             if li > 0 or ctx.need_in_grad:
                 wd_hi, wd_lo = dc._packed(ly.conv.weight, "dgrad", mode)
@@ -290,6 +296,11 @@ class _DenseStackFn(torch.autograd.Function):
                                                 bn_backward=bnb)
             else:
                 dy = None
+            if gw is None:
+                # wgrad_after_dgrad: the weight gradient starts when this layer's data gradient has FINISHED, i.e. next to
+                # the BatchNorm sweeps of the layer below (HBM-bound) instead of next to its own data gradient (MFMA-bound
+                # like itself: the two only time-share the CUs, and the sweeps then run with the second stream idle)
+                gw = side_wgrad()
             if sync is not None:
                 gbn = sync  # grad_gamma / grad_beta summed over ranks (syncbn.py:99-103)
             grads.append([gw, gbn[0], gbn[1]])

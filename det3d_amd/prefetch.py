@@ -100,6 +100,22 @@ def reserve_stream(dev):
     return _RESERVED[idx]
 
 
+_GATE = {}  # device index -> event recorded on the training stream behind the most recent sparse forward
+
+
+def mark_sparse_forward(dev):
+    """Called by the sparse backbones at the end of their training forward.  With runtime `geometry_gate` = "sparse_fwd"
+    a build requested afterwards starts on the device only when that forward has FINISHED: the geometry kernels (hash
+    probes, atomics, scans -- latency-bound) then run next to the dense RPN's MFMA-bound kernels instead of next to the
+    gather-bound sparse forward of the same step, which they slow down (profiles/round6_geometry_gate.txt)."""
+    from . import runtime
+
+    if runtime.get("geometry_gate") != "sparse_fwd":
+        return
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    _GATE[idx] = torch.cuda.current_stream(dev).record_event()
+
+
 def _stream_for(dev):
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     return _RESERVED.get(idx) or _new_stream(dev)
@@ -141,10 +157,13 @@ class GeometryPrefetcher:
             self.stream = _stream_for(dev)
         main = torch.cuda.current_stream(dev)
         slot, mark = self._next_slot(dev, main)
+        gate = _GATE.get(dev.index)
         if ready_event is not None:
             self.stream.wait_event(ready_event)
         if mark is not None:
             self.stream.wait_event(mark)
+        if gate is not None:
+            self.stream.wait_event(gate)
         with torch.cuda.stream(self.stream):
             ex = self._build(batch, slot)
             done = torch.cuda.Event()
@@ -169,6 +188,7 @@ class GeometryPrefetcher:
             self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="d3d-geometry")
 
         slot, mark = self._next_slot(dev, torch.cuda.current_stream(dev))
+        gate = _GATE.get(dev.index)  # as of this request: the sparse forward of the step enqueued last
 
         def work():
             torch.cuda.set_device(dev)  # current device and current stream are per thread
@@ -176,6 +196,8 @@ class GeometryPrefetcher:
                 self.stream.wait_event(ready_event)
             if mark is not None:
                 self.stream.wait_event(mark)
+            if gate is not None:
+                self.stream.wait_event(gate)
             with torch.cuda.stream(self.stream):
                 ex = self._build(batch, slot)
                 done = torch.cuda.Event()

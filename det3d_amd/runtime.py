@@ -24,15 +24,19 @@ import os
 
 _VALID = {
     "wgrad_stream": ("all", "sparse", "off"),
+    "wgrad_after_dgrad": ("off", "dense", "sparse", "all"),
     "pair_kernels": ("off", "measured", "all"),
+    "geometry_gate": ("off", "sparse_fwd"),
 }
 _state = {
     "wgrad_stream": "off" if os.environ.get("D3D_WGRAD_STREAM", "1") == "0" else os.environ.get("D3D_WGRAD_STREAM_MODE", "all"),
+    "wgrad_after_dgrad": os.environ.get("D3D_WGRAD_AFTER_DGRAD", "off"),
     "wgrad_priority": int(os.environ.get("D3D_WGRAD_PRIORITY", "0")),
     "prefetch_priority": int(os.environ.get("D3D_PREFETCH_PRIORITY", "-1")),
     "pair_kernels": os.environ.get("D3D_PAIR_KERNELS", "off"),
     "step_arena": os.environ.get("D3D_STEP_ARENA", "1") != "0",
     "geometry_ring": int(os.environ.get("D3D_GEOMETRY_RING", "3")),
+    "geometry_gate": os.environ.get("D3D_GEOMETRY_GATE", "off"),
 }
 
 
@@ -48,6 +52,12 @@ def wgrad_side(kind):
     """does the backward node of `kind` ("sparse" | "dense") run its weight gradients on the second stream?"""
     m = _state["wgrad_stream"]
     return m == "all" or (m == "sparse" and kind == "sparse")
+
+
+def wgrad_after_dgrad(kind):
+    """does a layer's weight gradient wait for that layer's data gradient to FINISH (instead of starting next to it)?"""
+    m = _state["wgrad_after_dgrad"]
+    return m == "all" or m == kind
 
 
 def configure(**kw):

@@ -175,6 +175,7 @@ class _StackFn(torch.autograd.Function):
         main = torch.cuda.current_stream(dev)
         side = wgrad_stream(dev) if WGRAD_STREAM and len(layers) > 1 else None
         keep = []  # what the side stream reads / writes stays referenced until it has been joined
+        defer = side is not None and runtime.wgrad_after_dgrad("sparse")
         for li in range(len(layers) - 1, -1, -1):
             ly = layers[li]
             rb, conv, bn = ly.rb, ly.conv, ly.bn
@@ -224,6 +225,8 @@ class _StackFn(torch.autograd.Function):
                 if pad_cin != cin:
                     gin = gin[:, :cin].contiguous()
             if side is not None:  # (buffers from the main stream's pool; `gout` was finished on the main stream)
+                if defer:  # runtime.wgrad_after_dgrad: start when this layer's data gradient has finished
+                    gout_ready = main.record_event()
                 side.wait_event(gout_ready)
                 keep.append((gout, ws, gw, x))
                 with torch.cuda.stream(side):
