@@ -67,16 +67,22 @@ class _HeadLossFn(torch.autograd.Function):
         _lib.check(rc, "d3d_head_loss")
         ctx.save_for_backward(g_box, g_cls, *([g_dir] if g_dir is not None else []))
         ctx.has_dir = g_dir is not None
-        return scalars
+        # the loss also as an output of its own (a 0-dim view of element 0): a caller that differentiates THAT instead of
+        # `scalars[0]` spares autograd the select-backward pair (zero fill + copy of an 18-float vector) every step
+        ctx.set_materialize_grads(False)
+        return scalars, scalars[0]
 
     @staticmethod
     @_lib.ctx_backward
-    def backward(ctx, gs):
+    def backward(ctx, gs, gl):
         saved = ctx.saved_tensors
-        g = gs[0]  # only element 0 (the loss) is differentiable; the rest are logging sums
-        g_box, g_cls = saved[0] * g.to(saved[0].dtype), saved[1] * g.to(saved[1].dtype)
-        g_dir = saved[2] * g.to(saved[2].dtype) if ctx.has_dir else None
-        return g_box, g_cls, g_dir, None, None, None, None
+        # only the loss is differentiable (element 0 of the vector / the second output); the rest are logging sums
+        g = gl if gs is None else (gs[0] if gl is None else gs[0] + gl)
+        if g is None:
+            return (None,) * 7
+        # one multi-tensor launch for the two or three prediction gradients (they share a dtype: see forward)
+        scaled = torch._foreach_mul(list(saved), g.to(saved[0].dtype))
+        return scaled[0], scaled[1], (scaled[2] if ctx.has_dir else None), None, None, None, None
 
 
 def _eager_task_loss(head, preds, labels, reg_targets, anchors, num_class, batch):
@@ -350,9 +356,9 @@ class MultiGroupHead(nn.Module):
             return False
         return self.box_n_dim <= 10
 
-    def loss_vector(self, example, preds_dict, task_id, batch_size):
+    def loss_vector(self, example, preds_dict, task_id, batch_size, want=0):
         """the [D3D_LOSS_SCALARS] result of d3d_head_loss for one task group (element 0 = the loss); tensor in,
-        tensor out, so that graph_tail.py can capture it"""
+        tensor out, so that graph_tail.py can capture it.  want=slice(None): (vector, loss as a 0-dim tensor of its own)"""
         num_class = self.num_classes[task_id]
         labels = example["labels"][task_id].contiguous()
         reg_targets = example["reg_targets"][task_id].float().contiguous()
@@ -368,18 +374,19 @@ class MultiGroupHead(nn.Module):
                    alpha=self.loss_cls._alpha, gamma=self.loss_cls._gamma or 0.0, sigma=self.loss_reg._sigma,
                    w_loc=self.loss_reg._loss_weight, w_cls=self.loss_cls._loss_weight,
                    w_dir=self.loss_aux._loss_weight if self.use_direction_classifier else 0.0)
-        return _HeadLossFn.apply(box_preds, cls_preds, dir_preds, labels, reg_targets, anchors, cfg)
+        return _HeadLossFn.apply(box_preds, cls_preds, dir_preds, labels, reg_targets, anchors, cfg)[want]
 
-    def _loss_dict(self, s):
+    def _loss_dict(self, s, loss=None):
         d = s.detach()
-        return {"loss": s[0], "cls_pos_loss": d[4], "cls_neg_loss": d[5],
+        counts = d[6:8].long()  # (one conversion launch for the two anchor counts)
+        return {"loss": s[0] if loss is None else loss, "cls_pos_loss": d[4], "cls_neg_loss": d[5],
                 "dir_loss_reduced": d[3] if self.use_direction_classifier else torch.tensor(0),
                 "cls_loss_reduced": d[2], "loc_loss_reduced": d[1],
                 "loc_loss_elem": list(d[8: 8 + self.box_n_dim].unbind(0)),
-                "num_pos": d[6].long(), "num_neg": d[7].long()}
+                "num_pos": counts[0], "num_neg": counts[1]}
 
     def _loss_fused(self, example, preds_dict, task_id, batch_size):
-        return self._loss_dict(self.loss_vector(example, preds_dict, task_id, batch_size))
+        return self._loss_dict(*self.loss_vector(example, preds_dict, task_id, batch_size, want=slice(None)))
 
     def loss_vector_ok(self, feature_map, labels):
         """every task group of this head goes through the fused loss for inputs like these"""

@@ -625,18 +625,20 @@ __global__ void __launch_bounds__(128 * WCI, 2)
 
 #include "d3d_conv2d_wgrad3.h"
 
-// dw = sum over splits of part[s], in a fixed order (8 slab groups walked in parallel, folded through LDS in group
-// order), written in nn.Conv2d's parameter layout [cout][cin][kh][kw]; part is [split][tap][cout][cin]
+// dw = sum over splits of part[s], in a fixed order (block = 8 float4 elements x 32 slab groups: a thread adds slabs g,
+// g + 32, ... in that order, the groups are folded through LDS in group order), written in nn.Conv2d's parameter layout
+// [cout][cin][kh][kw]; part is [split][tap][cout][cin]
 __global__ void __launch_bounds__(256)
     conv2d_wgrad_reduce_kernel(const float4 *__restrict__ part, int splits, int taps, int cout, int cin,
                                float *__restrict__ dw) {
-  __shared__ float4 red[8][32];
+  __shared__ float4 red[32][8];
   const int64_t n4 = (int64_t)taps * cout * cin / 4;
-  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int64_t e = (int64_t)blockIdx.x * 32 + el;
+  const int el = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const int64_t e = (int64_t)blockIdx.x * 8 + el;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < n4) {
-    for (int s0 = g; s0 < splits; s0 += 8) {
+#pragma unroll 4
+    for (int s0 = g; s0 < splits; s0 += 32) {
       const float4 u = part[(int64_t)s0 * n4 + e];
       a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
     }
@@ -646,7 +648,7 @@ __global__ void __launch_bounds__(256)
   if (g == 0 && e < n4) {
     float4 r = red[0][el];
 #pragma unroll
-    for (int j = 1; j < 8; ++j) {
+    for (int j = 1; j < 32; ++j) {
       r.x += red[j][el].x; r.y += red[j][el].y; r.z += red[j][el].z; r.w += red[j][el].w;
     }
     const int64_t e1 = e * 4;  // (tap, co, ci .. ci + 3)
@@ -1079,7 +1081,7 @@ extern "C" int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const v
                        (float *)workspace, G, sps, ns);
     D3D_LAUNCH_TRY("conv2d_wgrad3n_kernel");
     const int64_t n4 = (int64_t)9 * 64 * 64 / 4;
-    hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((n4 + 7) / 8)), dim3(256), 0, stream,
                        (const float4 *)workspace, ns, 9, 64, 64, dw);
     D3D_LAUNCH_TRY("conv2d_wgrad_reduce_kernel");
     return D3D_OK;
@@ -1108,7 +1110,7 @@ extern "C" int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const v
 #undef C2_WG3
     D3D_LAUNCH_TRY("conv2d_wgrad3_kernel");
     const int64_t n4 = (int64_t)9 * cout * cin / 4;
-    hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((n4 + 7) / 8)), dim3(256), 0, stream,
                        (const float4 *)workspace, ns, 9, cout, cin, dw);
     D3D_LAUNCH_TRY("conv2d_wgrad_reduce_kernel");
     return D3D_OK;
@@ -1134,7 +1136,7 @@ extern "C" int d3d_conv2d_nhwc_wgrad(const void *g_hi, const void *g_lo, const v
 #undef C2_WG
   D3D_LAUNCH_TRY("conv2d_wgrad_kernel");
   const int64_t n4 = (int64_t)ksz * ksz * cout * cin / 4;
-  hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((n4 + 7) / 8)), dim3(256), 0, stream,
                      (const float4 *)workspace, nsplit, ksz * ksz, cout, cin, dw);
   D3D_LAUNCH_TRY("conv2d_wgrad_reduce_kernel");
   return D3D_OK;

@@ -302,38 +302,29 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 16 ? 1 : 4)
   }
 }
 
-// dw[e] = sum over slabs of part[s][e] in a fixed order.  Block = 32 float4 elements x 8 slab groups: every
-// thread walks slabs g, g+8, ... with FOUR independent chains (round 6: two before -- with ~85 slabs of 442 KB the sweep
-// is a latency chain of ~5 dependent loads per thread, 31 us for 38 MB; four loads in flight: see profiles/round6_*),
-// the 8 groups are folded through LDS in order.  The order of the sum is fixed by (slab index, chain, group): bit-reproducible.
+// dw[e] = sum over slabs of part[s][e] in a fixed order.  Block = 8 float4 elements x 32 slab groups: thread (element, g)
+// adds slabs g, g + 32, ... in that order (their loads are independent: the unrolled loop keeps four in flight), the 32
+// groups are folded through LDS in group order -- bit-reproducible.  (Rounds 2-6 ran 32 elements x 8 groups with up to 17
+// slabs per thread: 864 blocks for the 64 x 64 layers, 25-28 us for 60 MB; this shape has 3456 blocks of short chains.)
 __global__ void __launch_bounds__(256)
     wgrad_reduce_kernel(const float4 *__restrict__ part, int slabs, int64_t total4, float4 *__restrict__ dw) {
-  __shared__ float4 red[8][32];
-  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int64_t e = (int64_t)blockIdx.x * 32 + el;
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a, d = a;
+  __shared__ float4 red[32][8];
+  const int el = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const int64_t e = (int64_t)blockIdx.x * 8 + el;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < total4) {
-    int s = g;
-    for (; s + 24 < slabs; s += 32) {
-      const float4 u = part[(int64_t)s * total4 + e], v = part[(int64_t)(s + 8) * total4 + e];
-      const float4 w = part[(int64_t)(s + 16) * total4 + e], x = part[(int64_t)(s + 24) * total4 + e];
-      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
-      b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
-      c.x += w.x; c.y += w.y; c.z += w.z; c.w += w.w;
-      d.x += x.x; d.y += x.y; d.z += x.z; d.w += x.w;
-    }
-    for (int j = 0; s < slabs; s += 8, ++j) {  // up to three left: chains a, b, c in turn
+#pragma unroll 4
+    for (int s = g; s < slabs; s += 32) {
       const float4 u = part[(int64_t)s * total4 + e];
-      float4 &t = j == 0 ? a : (j == 1 ? b : c);
-      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
     }
   }
-  red[g][el] = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+  red[g][el] = a;
   __syncthreads();
   if (g == 0 && e < total4) {
     float4 r = red[0][el];
 #pragma unroll
-    for (int j = 1; j < 8; ++j) {
+    for (int j = 1; j < 32; ++j) {
       r.x += red[j][el].x; r.y += red[j][el].y; r.z += red[j][el].z; r.w += red[j][el].w;
     }
     dw[e] = r;
@@ -504,7 +495,7 @@ extern "C" int d3d_sparse_conv_wgrad(const void *feat, const void *dout, const i
   int rc = wg_dispatch(feat, dout, nbr, cap, n_out, kvol, cin, cout, dtype == D3D_BF16, p, part, stream);
   if (rc) return rc;
   const int64_t total4 = (int64_t)kvol * cin * cout / 4;
-  const int nb = (int)((total4 + 31) / 32);
+  const int nb = (int)((total4 + 7) / 8);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, stream, (const float4 *)part,
                      p.splits * p.csplit, total4, (float4 *)dw);
   D3D_LAUNCH_TRY("wgrad_reduce_kernel");

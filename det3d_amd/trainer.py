@@ -140,7 +140,7 @@ class TrainStep:
         self.bucket.zero()
         with self._ctx():
             losses = self.model(example, return_loss=True)
-        loss = sum(losses["loss"])
+        loss = losses["loss"][0] if len(losses["loss"]) == 1 else sum(losses["loss"])  # (sum() starts from 0: one launch)
         if after_forward is not None:
             after_forward()
         loss.backward()

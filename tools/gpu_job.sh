@@ -189,6 +189,15 @@ PY
         else PYTORCH_HIP_ALLOC_CONF=$v PYTORCH_CUDA_ALLOC_CONF=$v timeout 300 python bench.py --gpus 1 $B > $O/a_$n.json 2> $O/a_$n.err; fi
         echo "$v: $(grep -h 'timed region done' $O/a_$n.err | cut -c1-220)"; show $O/a_$n.json 1
       done ;;
+    abtree|abtree:*)
+      # this tree against another checkout of the repository that travelled with the snapshot (default ab_base/: `git worktree
+      # add ab_base <commit>` + its own build), alternating, same box:  abtree[:<dir>]
+      d=${st#abtree}; d=${d#:}; d=${d:-ab_base}
+      for rep in 1 2 3; do for t in base new; do
+        if [ $t = base ]; then b=$d/bench.py; else b=bench.py; fi
+        timeout 300 python $b --gpus 1 --steps 60 --warmup 3 --no-cpu-baseline --no-extras > $O/abtree_${t}_$rep.json 2> $O/abtree_${t}_$rep.err
+        echo "$t: $(show $O/abtree_${t}_$rep.json 2 | tr '\n' ' ' | cut -c1-120)"
+      done; done | tee $O/abtree.txt ;;
     ab:*)
       # bench.py with an environment switch off and on, twice each, same box:  ab:D3D_PACK_ALL
       v=${st#ab:}
