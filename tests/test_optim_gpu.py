@@ -152,7 +152,13 @@ def test_training_steps_with_the_fused_optimizer_follow_the_torch_sequence(monke
     (la, na, pa), (lb, nb, pb) = runs["1"], runs["0"]
     assert la[0] == lb[0] and lb[2] < 0.9 * lb[0]           # same start, and the steps do move the loss
     assert np.allclose(la, lb, rtol=2e-3), (la, lb)
-    assert np.allclose(na, nb, rtol=5e-3), (na, nb)
+    # gradient norms: equal at the first step (same weights, same kernels: only the norm's own summation differs), then the
+    # two optimizers drift apart the way ANY reordering of a sum does -- an element whose gradient is rounding noise takes
+    # Adam's +-lr with the sign of that noise, and the next steps amplify it (tools/optim_follow.py: the fold order of the
+    # weight-gradient slabs alone moves the second step's norm by 1 %, in both optimizers alike).  An update the layers do
+    # not see leaves the loss where it was and the norms a factor apart, not a few per cent.
+    assert np.allclose(na[:1], nb[:1], rtol=1e-6) and np.allclose(na[1:2], nb[1:2], rtol=2e-3), (na, nb)
+    assert np.allclose(na, nb, rtol=3e-2), (na, nb)
     # the first update, tensor by tensor (same gradients on both sides): f32 rounding of two operation orders.  Later
     # updates are not compared element-wise: an element whose gradient is ~0 takes Adam's +-0.75 lr on rounding noise,
     # in either implementation
