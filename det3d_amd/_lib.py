@@ -167,6 +167,10 @@ def lib():
             raise D3dError(
                 "%s not found: build it with `python -m det3d_amd.csrc.build` "
                 "(__graft_entry__.build()); det3d_amd has no CPU fallback" % LIB_PATH)
+        # CDLL, not PyDLL: the calls release the GIL.  Every entry point is a short non-blocking enqueue, but the training
+        # thread and the geometry thread issue ~250 of them per step between them and their HIP launches overlap only with
+        # the GIL released: bf16 step (host-bound) 970 / 966 / 898 frames/s against 840 / 836 / 878 with the GIL kept
+        # (round 6, same box, alternating)
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
