@@ -202,8 +202,7 @@ class _BlockFn(torch.autograd.Function):
             if side is not None:  # `gout` was finished on the main stream just before this call
                 side.wait_event(main.record_event())
                 keep.append((src, gout, ws, gw))
-                with torch.cuda.stream(side):
-                    rc = sp._timed("wgrad", c, c, n, rb, dev, lambda: launch(_lib.stream_ptr(dev)))
+                rc = sp._timed("wgrad", c, c, n, rb, dev, lambda: launch(side.cuda_stream), stream=side)  # (no stream context: sparse_stack.py)
             else:
                 rc = sp._timed("wgrad", c, c, n, rb, dev, lambda: launch(st))
             _lib.check(rc, "d3d_sparse_conv_wgrad")

@@ -229,10 +229,11 @@ class _StackFn(torch.autograd.Function):
                     gout_ready = main.record_event()
                 side.wait_event(gout_ready)
                 keep.append((gout, ws, gw, x))
-                with torch.cuda.stream(side):
-                    rc = sp._timed("wgrad", pad_cin, cout, rb.n_out, rb, dev, lambda: L.d3d_sparse_conv_wgrad(
-                        x.data_ptr(), gout.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, rb.n_out, rb.kvol, pad_cin, cout,
-                        dt, gw.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr(dev)))
+                # (the launch takes the side stream's handle; no `with torch.cuda.stream(side)`: nothing is allocated in here,
+                # and entering / leaving that context costs the host ~12 us per layer)
+                rc = sp._timed("wgrad", pad_cin, cout, rb.n_out, rb, dev, lambda: L.d3d_sparse_conv_wgrad(
+                    x.data_ptr(), gout.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, rb.n_out, rb.kvol, pad_cin, cout,
+                    dt, gw.data_ptr(), ws.data_ptr(), wsb, side.cuda_stream), stream=side)
             else:
                 rc = sp._timed("wgrad", pad_cin, cout, rb.n_out, rb, dev, lambda: L.d3d_sparse_conv_wgrad(
                     x.data_ptr(), gout.data_ptr(), rb.nbr_out.data_ptr(), rb.cap_out, rb.n_out, rb.kvol, pad_cin, cout,

@@ -39,13 +39,14 @@ LAUNCH_FILTER = None  # optional predicate (kind, cin, cout) -> bool: a timing e
 #                       ~0.4 ms of stream time on ROCm, so bench.py times only a sample
 
 
-def _timed(kind, cin, cout, n_out, rb, dev, fn):
+def _timed(kind, cin, cout, n_out, rb, dev, fn, stream=None):
+    """fn() = one launch; `stream`: the torch stream it goes to when that is not the current one"""
     if LAUNCH_LOG is None or len(LAUNCH_LOG) >= LAUNCH_LOG_LIMIT or \
             (LAUNCH_FILTER is not None and not LAUNCH_FILTER(kind, cin, cout)):
         return fn()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
-    st = torch.cuda.current_stream(dev)
+    st = stream if stream is not None else torch.cuda.current_stream(dev)
     e0.record(st)
     rc = fn()
     e1.record(st)
