@@ -426,18 +426,13 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
         submitted a step ago and is built while step i is enqueued; example i+2 is submitted here)"""
         drain()
         t_a = time.perf_counter()
-        if threaded and SUBMIT_MID:
-            # the build of example i + 2 starts on the worker thread once step i's forward is enqueued: the two threads
-            # then share the interpreter during the backward enqueue (GPU-bound) instead of the forward enqueue (host-bound)
-            out = wl.step_fn(state["ex"], after_forward=lambda: state.__setitem__("later", pf.submit(i + 2)))
-        else:
-            out = wl.step_fn(state["ex"])
+        out = wl.step_fn(state["ex"])
         if "first" not in state:
             state["first"] = out  # the loss of the very first optimizer step (device scalar; read after the region)
         t_b = time.perf_counter()
         if threaded:
             state["ex"] = state["next"].result()
-            state["next"] = state.pop("later") if SUBMIT_MID else pf.submit(i + 2)
+            state["next"] = pf.submit(i + 2)
         else:
             state["ex"] = pf.prepare(i + 1)
         t_c = time.perf_counter()
@@ -596,7 +591,6 @@ def _pairs_of(rb):
     return P[1]
 
 
-SUBMIT_MID = os.environ.get("D3D_SUBMIT_MID", "0") == "1"  # geometry builds start mid-step (measured neutral: 579.6 vs 579.0 frames/s)
 FWD64_BF16 = "spconv_fwd_group_kernel<64,64>"
 FIND_MODE = [0]  # D3D_MIOPEN_FIND, set in main()
 
