@@ -407,7 +407,7 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
     # i trains; --no-prefetch builds it inline at the start of each step
     pf = GeometryPrefetcher(wl.example, wl.model, dev, enabled=prefetch)
     threaded = prefetch and prefetch_thread  # the builds (and their two host syncs) on a worker thread
-    host = {"enqueue": 0.0, "geometry": 0.0}
+    host = {"enqueue": 0.0, "geometry": 0.0, "cpu": 0.0}  # wall, wall, CPU time of ALL threads of the process
 
     def drain():
         if spconv.LAUNCH_LOG:
@@ -438,6 +438,7 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
         t_c = time.perf_counter()
         host["enqueue"] += t_b - t_a
         host["geometry"] += t_c - t_b
+        host["cpu"] = time.process_time()
         return out
 
     burn = 0
@@ -477,6 +478,7 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
     torch.cuda.synchronize()
     ms0 = torch.cuda.memory_stats(dev)
     host["enqueue"] = host["geometry"] = 0.0
+    cpu0 = time.process_time()
     loss = None
     done = burn + warmup
     times = []
@@ -510,6 +512,7 @@ def timed_region(wl, steps, warmup, rank, world, dev, note, launch_filter=None, 
     pf.close()
     spconv.LAUNCH_LOG = None
     spconv.LAUNCH_FILTER = None
+    host["cpu"] = max(host["cpu"] - cpu0, 0.0)  # what the step costs the host's cores (enqueue, autograd and geometry threads)
     wl.host_ms = {k: round(1e3 * v / max(steps * len(times), 1), 3) for k, v in host.items()}
     wl.first_loss = float(state["first"]) if "first" in state else None
     wl.steps_run = done

@@ -71,6 +71,8 @@ SIGNATURES = {
     "d3d_bn_bwd_dx_residual": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
     "d3d_bn_bwd_dx": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]),
     "d3d_pack_all": (i32, [vp, i32, vp]),
+    "d3d_sparse_stack_forward": (i32, [vp, i32, i32, vp]),
+    "d3d_sparse_stack_backward": (i32, [vp, i32, i32, vp, vp, vp]),
     "d3d_conv2d_supported": (i32, [i32, i32, i32, i32]),
     "d3d_conv2d_supported_split3x3": (i32, [i32, i32]),
     "d3d_conv2d_stats_ws_floats": (sz, [i32, i32, i32, i32]),
@@ -115,7 +117,7 @@ SIGNATURES = {
     "d3d_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
 }
 
-ABI_VERSION = 11  # include/d3d.h D3D_ABI_VERSION
+ABI_VERSION = 12  # include/d3d.h D3D_ABI_VERSION
 D3D_F32 = 0
 D3D_BF16 = 1
 D3D_CONV_BF16, D3D_CONV_SPLIT = 0, 1
@@ -132,6 +134,19 @@ class ConvEpilogue(ctypes.Structure):
     """D3dConvEpilogue of include/d3d.h (device pointers as integers)"""
     _fields_ = [("stats", vp), ("bn_x", vp), ("bn_mean", vp), ("bn_invstd", vp), ("bn_gamma", vp),
                 ("bn_beta", vp), ("bn_relu", i32), ("bn_partial", vp), ("ws_floats", i32), ("addend", vp)]
+
+
+class StackLayer(ctypes.Structure):
+    """D3dStackLayer of include/d3d.h"""
+    _fields_ = [("nbr_out", vp), ("nbr_in", vp), ("dgrad_plan", vp),
+                ("cap_out", i32), ("cap_in", i32), ("n_in", i32), ("n_out", i32), ("kvol", i32), ("subm", i32),
+                ("cin", i32), ("cout", i32), ("relu", i32), ("partial_by_epilogue", i32),
+                ("momentum", ctypes.c_float), ("eps", ctypes.c_float),
+                ("x", vp), ("out", vp), ("y", vp), ("wpack", vp), ("wd", vp), ("stats", vp),
+                ("stats_floats", i32), ("partial_floats", i32),
+                ("gamma", vp), ("beta", vp), ("running_mean", vp), ("running_var", vp), ("save_mean", vp), ("save_invstd", vp),
+                ("gout", vp), ("gin", vp), ("partial", vp), ("gbn", vp), ("gw", vp), ("wgrad_ws", vp),
+                ("wgrad_ws_bytes", ctypes.c_size_t)]
 
 
 class PackDesc(ctypes.Structure):

@@ -23,6 +23,7 @@ SOURCES = [
     "d3d_spconv.hip",
     "d3d_spconv_pairs.hip",
     "d3d_wgrad.hip",
+    "d3d_stack.hip",
     "d3d_bn.hip",
     "d3d_conv2d.hip",
     "d3d_head.hip",

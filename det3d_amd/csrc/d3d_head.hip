@@ -567,7 +567,7 @@ extern "C" int d3d_head_conv_wgrad(const void *x, void *const *g, const int *n, 
   const size_t lds = (size_t)(HC_TP * HC_XROW + HC_TP * HC_MAXC) * sizeof(float);
   float *part = ws + HC_WG_NVAL;
   if (dtype == D3D_F32 && !g_hc_valu) {
-    // one 8-wave block per CU at most (never more slabs than the VALU path's workspace holds: nb2 <= nb whenever m >= 64 K)
+    // one 8-wave block per CU at most; nb2 <= nb, so the slabs fit the workspace d3d_head_conv_wgrad_ws_floats() sized
     int nb2 = nb < 256 ? nb : 256;
     int64_t ppb2 = (m + nb2 - 1) / nb2;
     ppb2 = (ppb2 + 2 * HC_WG2_WAVES - 1) / (2 * HC_WG2_WAVES) * (2 * HC_WG2_WAVES);  // whole rounds of pixel pairs

@@ -14,6 +14,11 @@ runs keep working), but the authoritative state is here and is settable from cod
   wgrad_priority   stream priority of that second stream (0; 1 = lower than the chain)        [D3D_WGRAD_PRIORITY]
   prefetch_priority stream priority of the geometry stream (-1 = its small kernels cut in front) [D3D_PREFETCH_PRIORITY]
   pair_kernels     "off" | "measured" | "all": which f32 sparse launches take the pair-compacted kernel (spconv.PAIR_KERNELS)
+  stack_executor   "python" | "c": the fused sparse stack's launches call by call from sparse_stack.py, or from one foreign call
+                   per direction (csrc/d3d_stack.hip: same entry points, same order, bit-identical).  Default "python": the
+                   executor changes neither the step time nor the process's CPU time per step (15.1 vs 15.3 ms, bf16 and
+                   f32 alike, profiles/round6_stack_executor.txt) -- it is not the interpreter that bounds the host
+                   [D3D_STACK_EXECUTOR]
   step_arena       TrainStep's default for its step arena (arena.py)
   geometry_ring    slots of GeometryPrefetcher's arena ring (0 = caching allocator)
 
@@ -27,6 +32,7 @@ _VALID = {
     "wgrad_after_dgrad": ("off", "dense", "sparse", "all"),
     "pair_kernels": ("off", "measured", "all"),
     "geometry_gate": ("off", "sparse_fwd"),
+    "stack_executor": ("c", "python"),
 }
 _state = {
     "wgrad_stream": "off" if os.environ.get("D3D_WGRAD_STREAM", "1") == "0" else os.environ.get("D3D_WGRAD_STREAM_MODE", "all"),
@@ -37,6 +43,7 @@ _state = {
     "step_arena": os.environ.get("D3D_STEP_ARENA", "1") != "0",
     "geometry_ring": int(os.environ.get("D3D_GEOMETRY_RING", "3")),
     "geometry_gate": os.environ.get("D3D_GEOMETRY_GATE", "off"),
+    "stack_executor": os.environ.get("D3D_STACK_EXECUTOR", "python"),
 }
 
 

@@ -118,7 +118,48 @@ class _StackFn(torch.autograd.Function):
         need_in_grad = ctx.needs_input_grad[0]
         rec = []
         x = feats
-        for li, ly in enumerate(layers):
+        ctx.desc = None
+        if _c_executor_ok(sp, layers):
+            # one foreign call for the whole run (csrc/d3d_stack.hip): this loop only allocates and fills descriptors
+            desc = (_lib.StackLayer * len(layers))()
+            for li, ly in enumerate(layers):
+                rb, conv, bn = ly.rb, ly.conv, ly.bn
+                cin, cout, pad_cin = ly.cin, ly.cout, ly.pad_cin
+                if x.shape[0] != rb.n_in or x.shape[1] != cin:
+                    raise _lib.D3dError("sparse stack: features %s do not match the rulebook (%d rows) / the conv "
+                                        "(%d channels)" % (tuple(x.shape), rb.n_in, cin))
+                if pad_cin != cin:
+                    x = torch.nn.functional.pad(x, (0, pad_cin - cin))
+                sp.check_gather_source(x, "the feature matrix")
+                wpack, wd = sp._packed_weights(conv.weight, rb.kvol, cin, cout, dtype, rb.subm,
+                                               li > 0 or need_in_grad, pad_cin)
+                out = mem.empty((rb.n_out, cout), dtype, dev, A)
+                stats = sp.epilogue_ws(dev, rb.n_out, cout)
+                y = mem.empty((rb.n_out, cout), dtype, dev, A)
+                save = torch.empty((2, cout), dtype=torch.float32, device=dev)
+                partial = sp.epilogue_ws(dev, rb.n_out, cout) if li + 1 < len(layers) else None
+                d = desc[li]
+                d.nbr_out, d.cap_out = rb.nbr_out.data_ptr(), rb.cap_out
+                if not rb.subm:
+                    d.nbr_in, d.cap_in = rb.nbr_in.data_ptr(), rb.cap_in
+                    if rb.dgrad_plan is not None:
+                        d.dgrad_plan = rb.dgrad_plan.data_ptr()
+                d.n_in, d.n_out, d.kvol, d.subm = rb.n_in, rb.n_out, rb.kvol, int(rb.subm)
+                d.cin, d.cout, d.relu = pad_cin, cout, int(ly.relu)
+                d.momentum, d.eps = float(bn.momentum), float(bn.eps)
+                d.x, d.out, d.y = x.data_ptr(), out.data_ptr(), y.data_ptr()
+                d.wpack = wpack.data_ptr()
+                d.wd = wd.data_ptr() if wd is not None else None
+                d.stats, d.stats_floats = stats.data_ptr(), stats.numel()
+                d.gamma, d.beta = bn.weight.data_ptr(), _lib.ptr(bn.bias)
+                d.running_mean, d.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                sm = save.data_ptr()
+                d.save_mean, d.save_invstd = sm, sm + 4 * cout
+                rec.append((x, out, save, wd, partial, None))
+                x = y
+            _lib.check(L.d3d_sparse_stack_forward(desc, len(layers), dt, st), "d3d_sparse_stack_forward")
+            ctx.desc = desc
+        for li, ly in enumerate(layers if ctx.desc is None else ()):  # call by call (what the executor cannot take)
             rb, conv, bn = ly.rb, ly.conv, ly.bn
             cin, cout, pad_cin = ly.cin, ly.cout, ly.pad_cin
             if x.shape[0] != rb.n_in or x.shape[1] != cin:
@@ -176,6 +217,8 @@ class _StackFn(torch.autograd.Function):
         side = wgrad_stream(dev) if WGRAD_STREAM and len(layers) > 1 else None
         keep = []  # what the side stream reads / writes stays referenced until it has been joined
         defer = side is not None and runtime.wgrad_after_dgrad("sparse")
+        if ctx.desc is not None and fused and not defer and _c_executor_ok(sp, layers):
+            return _StackFn._backward_c(ctx, g, L, sp, layers, rec, dtype, dt, dev, st, A, side)
         for li in range(len(layers) - 1, -1, -1):
             ly = layers[li]
             rb, conv, bn = ly.rb, ly.conv, ly.bn
@@ -256,6 +299,74 @@ class _StackFn(torch.autograd.Function):
             keep.clear()
         flat = [t for lg in reversed(grads) for t in lg]
         return (g, None, None) + tuple(flat)
+
+
+def _c_executor_ok(sp, layers):
+    """may this run go through d3d_sparse_stack_forward / _backward?  Not with a collective between the launches
+    (DistributedSyncBN), convolution biases, pair-compacted kernels or per-launch timing events (bench.py's sampled step)."""
+    if runtime.get("stack_executor") != "c" or sp.LAUNCH_LOG is not None or sp.PAIR_KERNELS != "off":
+        return False
+    return all(type(ly.bn) is nn.BatchNorm1d and ly.conv.bias is None for ly in layers)
+
+
+def _backward_c(ctx, g, L, sp, layers, rec, dtype, dt, dev, st, A, side):
+    """the backward of _StackFn as one call: allocate every buffer, complete the forward's descriptors, d3d_sparse_stack_backward"""
+    desc = ctx.desc
+    n = len(layers)
+    dy = g.contiguous()
+    if dy.dtype != dtype:
+        dy = dy.to(dtype)
+    bufs = []
+    for li in range(n - 1, -1, -1):
+        ly = layers[li]
+        rb, cin, cout, pad_cin = ly.rb, ly.cin, ly.cout, ly.pad_cin
+        d = desc[li]
+        gout = mem.empty((rb.n_out, cout), dtype, dev, A)
+        sp.check_gather_source(gout, "the output gradient")
+        gbn = torch.empty((2, cout), dtype=torch.float32, device=dev)
+        gw = torch.empty((rb.kvol, pad_cin, cout), dtype=torch.float32, device=dev)
+        wsb = L.d3d_sparse_conv_wgrad_workspace_bytes(rb.n_out, rb.kvol, pad_cin, cout, dt)
+        ws = mem.empty((wsb,), torch.uint8, dev, A)
+        gin = None
+        if li > 0 or ctx.needs_input_grad[0]:
+            gin = mem.empty((rb.n_in, pad_cin), dtype, dev, A)
+            if li > 0 and pad_cin == cin and sp.has_epilogue(cout, pad_cin, dtype):
+                p = desc[li - 1]  # this layer's data gradient reduces the BatchNorm sums of the layer below
+                ppartial = rec[li - 1][4]
+                p.partial_by_epilogue, p.partial, p.partial_floats = 1, ppartial.data_ptr(), ppartial.numel()
+        if not d.partial_by_epilogue:
+            partial = sp.reduce_ws(dev, rb.n_out, cout, dtype, A)
+            d.partial, d.partial_floats = partial.data_ptr(), partial.numel()
+            bufs.append(partial)
+        d.gout, d.gbn, d.gw = gout.data_ptr(), gbn.data_ptr(), gw.data_ptr()
+        d.gin = gin.data_ptr() if gin is not None else None
+        d.wgrad_ws, d.wgrad_ws_bytes = ws.data_ptr(), wsb
+        bufs.append((gout, gbn, gw, ws, gin))
+    # (every buffer the second stream touches exists before the call records its first event, see backward())
+    rc = L.d3d_sparse_stack_backward(desc, n, dt, dy.data_ptr(), st, side.cuda_stream if side is not None else None)
+    _lib.check(rc, "d3d_sparse_stack_backward")
+    grads, gfirst = [], None
+    for item in bufs:
+        if not isinstance(item, tuple):
+            continue
+        li = n - 1 - len(grads)
+        ly = layers[li]
+        gout, gbn, gw, ws, gin = item
+        if ly.pad_cin != ly.cin:
+            gw = gw[:, :ly.cin]
+            if gin is not None:
+                gin = gin[:, :ly.cin].contiguous()
+        lg = [gw.reshape(ly.conv.weight.shape), gbn[0]]
+        if ly.bn.bias is not None:
+            lg.append(gbn[1])
+        grads.append(lg)
+        if li == 0:
+            gfirst = gin
+    flat = [t for lg in reversed(grads) for t in lg]
+    return (gfirst, None, None) + tuple(flat)
+
+
+_StackFn._backward_c = staticmethod(_backward_c)
 
 
 def params_of(layers):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 11 /* 11: d3d_ctx_current, pair-compacted sparse convolution (d3d_pair_table_*, d3d_sparse_conv_fwd_pairs); 10: caller-owned contexts (d3d_ctx_*), d3d_set_tuning knob 11; 9: d3d_conv_rulebook_chain / d3d_subm_rulebook_ranked, training = 2 of d3d_bn_apply, d3d_set_tuning knob 10; 8: d3d_conv2d_nhwc_dgrad_s2; 7: residual forms of the BatchNorm sweeps, D3dConvEpilogue.addend; 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv; 5: planned strided data gradient, d3d_adam_step; 6: deterministic PillarFeatureNet sums (workspace arguments) */
+#define D3D_ABI_VERSION 12 /* 12: d3d_sparse_stack_forward / _backward; 11: d3d_ctx_current, pair-compacted sparse convolution (d3d_pair_table_*, d3d_sparse_conv_fwd_pairs); 10: caller-owned contexts (d3d_ctx_*), d3d_set_tuning knob 11; 9: d3d_conv_rulebook_chain / d3d_subm_rulebook_ranked, training = 2 of d3d_bn_apply, d3d_set_tuning knob 10; 8: d3d_conv2d_nhwc_dgrad_s2; 7: residual forms of the BatchNorm sweeps, D3dConvEpilogue.addend; 4: deterministic BatchNorm reductions (fold workspaces instead of zeroed atomic accumulators), dense NHWC conv; 5: planned strided data gradient, d3d_adam_step; 6: deterministic PillarFeatureNet sums (workspace arguments) */
 
 #define D3D_OK 0
 #define D3D_EINVAL -1    /* bad argument / unsupported shape           */
@@ -339,6 +339,53 @@ typedef struct D3dPackDesc {
   int flip, dtype;
 } D3dPackDesc;
 int d3d_pack_all(const D3dPackDesc *descs, int n, d3d_stream_t stream);
+
+/* A run of (sparse conv -> BatchNorm1d -> ReLU) layers as ONE call per direction (ABI 12; csrc/d3d_stack.hip).  Replaces
+ * the launch sequence of spconv.SparseSequential over det3d/models/backbones/scn.py:106-157 (SubMConv3d / SparseConv3d +
+ * build_norm_layer + nn.ReLU triples; training-mode BatchNorm, no convolution bias) that det3d_amd/sparse_stack.py issues
+ * call by call: the entry points named below, in the same order, on the same streams -- bit-identical results, one
+ * foreign call instead of three to five per layer and direction.  `layers` is a HOST array, first layer first; every
+ * buffer is the caller's (sizes as for the per-layer entry points).
+ *  forward, per layer:  d3d_sparse_conv_fwd_ex(x, wpack, nbr_out .. -> out, epilogue.stats = stats) then
+ *                       d3d_bn_apply(out -> y, training = 1, stats_ws = stats, save_mean / save_invstd written).
+ *  backward, last layer first; dy of the last layer = dy_last, of layer i = layers[i + 1].gin:
+ *    d3d_bn_bwd_reduce(out, dy -> partial) unless layers[i].partial_by_epilogue and layer i + 1 has a data gradient;
+ *    d3d_bn_bwd_dx(out, dy, partial -> gout, gbn[0 .. cout) = dgamma, gbn[cout .. 2 cout) = dbeta);
+ *    if gin: the data gradient gout -> gin (d3d_sparse_conv_dgrad_planned when the layer is strided, carries a plan and
+ *      the channel pair supports it, else d3d_sparse_conv_fwd_ex over nbr_out (submanifold) / nbr_in with wd), with the
+ *      BatchNorm-backward sums of layer i - 1 reduced in its epilogue when layers[i - 1].partial_by_epilogue;
+ *    d3d_sparse_conv_wgrad(x, gout -> gw) on `side` behind an event recorded on `main` after d3d_bn_bwd_dx
+ *      (side == NULL: on `main`);
+ *    at the end `main` waits for `side`. */
+typedef struct D3dStackLayer {
+  const int32_t *nbr_out; /* output-stationary table, kvol * cap_out */
+  const int32_t *nbr_in;  /* input-stationary twin of a strided layer, kvol * cap_in (NULL for submanifold) */
+  const int32_t *dgrad_plan; /* row plan of the strided data gradient or NULL */
+  int cap_out, cap_in, n_in, n_out, kvol, subm;
+  int cin, cout; /* channels as the kernels see them (a stem's input channels already padded) */
+  int relu;
+  int partial_by_epilogue; /* the data gradient of layer i + 1 reduces this layer's BatchNorm-backward sums */
+  float momentum, eps;
+  const void *x; /* [n_in, cin] input rows */
+  void *out;     /* [n_out, cout] conv output (kept for the backward) */
+  void *y;       /* [n_out, cout] after BatchNorm (+ ReLU) */
+  const void *wpack; /* d3d_pack_conv_weights' wpack_fwd */
+  const void *wd;    /* its wpack_dgrad; NULL when gin is NULL */
+  float *stats; /* d3d_conv_epilogue_ws_floats(n_out, cout) floats */
+  int stats_floats, partial_floats;
+  const float *gamma, *beta;
+  float *running_mean, *running_var, *save_mean, *save_invstd;
+  void *gout;     /* backward: [n_out, cout] gradient at the conv output */
+  void *gin;      /* backward: [n_in, cin] gradient at the layer input, or NULL (first layer without input gradient) */
+  float *partial; /* backward: fold workspace of the BatchNorm-backward sums (d3d_bn_reduce_ws_floats / epilogue size) */
+  float *gbn;     /* backward: [2, cout] dgamma | dbeta */
+  float *gw;      /* backward: [kvol, cin, cout] weight gradient */
+  void *wgrad_ws; /* backward: d3d_sparse_conv_wgrad_workspace_bytes(n_out, kvol, cin, cout, dtype) bytes */
+  size_t wgrad_ws_bytes;
+} D3dStackLayer;
+int d3d_sparse_stack_forward(const D3dStackLayer *layers, int n, int dtype, d3d_stream_t stream);
+int d3d_sparse_stack_backward(const D3dStackLayer *layers, int n, int dtype, const void *dy_last, d3d_stream_t main,
+                              d3d_stream_t side);
 
 /* ------------------------------------------------------------------------
  * BatchNorm1d (+ReLU) over the active sites: replaces the nn.BatchNorm1d / nn.ReLU module

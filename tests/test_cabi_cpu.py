@@ -28,7 +28,7 @@ def test_binding_table_matches_header(hip_lib):
     from det3d_amd import _lib
 
     assert sorted(_lib.SIGNATURES) == _declared()
-    assert hip_lib.d3d_abi_version() == _lib.ABI_VERSION == 11
+    assert hip_lib.d3d_abi_version() == _lib.ABI_VERSION == 12
 
 
 def test_rulebook_chain_planning_and_argument_checks_without_gpu(hip_lib):
