@@ -25,6 +25,19 @@ def _prod(xs):
     return reduce(mul, xs, 1)
 
 
+def _run_joined(stage, deblock, x):
+    """stage and deblock as one run of det3d_amd.dense_stack, or None when the library's kernels do not cover both"""
+    if not (torch.is_tensor(x) and x.is_cuda) or not isinstance(stage, Sequential) or not isinstance(deblock, Sequential):
+        return None
+    from . import dense_stack
+
+    mods = list(stage._modules.values()) + list(deblock._modules.values())
+    layers, nxt = dense_stack.collect(mods, 0, x)
+    if not layers or nxt != len(mods):
+        return None
+    return dense_stack.run(layers, x)
+
+
 @NECKS.register_module
 class RPN(nn.Module):
     def __init__(self, layer_nums, ds_layer_strides, ds_num_filters, us_layer_strides, us_num_filters,
@@ -90,8 +103,17 @@ class RPN(nn.Module):
     def forward(self, x):
         outs = []
         for i, stage in enumerate(self.blocks):
-            x = stage(x)
             j = i - self._upsample_start_idx
+            if j >= 0 and i + 1 == len(self.blocks):
+                # the last stage's map has one reader, its deblock: where that is a plain 1x1 conv -> BN -> ReLU (stride-1
+                # "upsampling", rpn.py:85-93) the two Sequentials run as ONE conv stack -- the stage's last BatchNorm
+                # writes the operand planes the deblock's conv reads (no f32 copy of the map, no split sweep over it:
+                # 25 us of the KITTI step) and the deblock's weight gradient joins the second stream
+                y = _run_joined(stage, self.deblocks[j], x)
+                if y is not None:
+                    outs.append(y)
+                    break
+            x = stage(x)
             if j >= 0:
                 outs.append(self.deblocks[j](x))
         if len(outs) == 1:
