@@ -18,7 +18,7 @@ stream).  Rank 0 prints ONE JSON line and refuses to if the loss or the gradient
 
 ROUND 6.  `--gpus N` started without a launcher becomes one (spawn_ranks: torch.distributed.run, one rank per device over
 RCCL, each rank pinned to its share of the host cores) and a line whose n_gpus is not N is refused.  The timed region is
-`--windows` back-to-back windows of `--steps` steps (default 9 when --steps <= 60), each bracketed by barrier +
+`--windows` back-to-back windows of `--steps` steps (default 15 when --steps <= 30, 9 up to 60), each bracketed by barrier +
 synchronize; `value` is the MEDIAN window (`config.windows_ms` has all of them) -- 20 steps are 0.13 s, and one window is
 at the mercy of a single host hiccup.  The data-dependent tensors of the step come from bump arenas (det3d_amd/arena.py:
 step arena + geometry ring), `config.allocator` reports what the caching allocator still had to do during the windows
@@ -101,8 +101,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--windows", type=int, default=None,
                     help="back-to-back timed windows of --steps steps each, every one bracketed by barrier + synchronize; "
-                         "`value` is the MEDIAN window (all of them in `windows_ms`).  Default: 9 when a window is short "
-                         "(--steps <= 60: the driver's 20 steps are 0.13 s, one hiccup of the host moves them by 10 %%), else 1")
+                         "`value` is the MEDIAN window (all of them in `windows_ms`).  Default: 15 when a window is short "
+                         "(--steps <= 30: the driver's 20 steps are 0.12 s, one hiccup of the host moves them by 10 %%), 9 up to "
+                         "60 steps, else 1")
     ap.add_argument("--batch", type=int, default=None,
                     help="frames per GPU (default: the workload's configured samples_per_gpu; 4 for the headline)")
     ap.add_argument("--points", type=int, default=None, help="points per synthetic frame (default: the workload's)")
@@ -1292,7 +1293,9 @@ def main():
     roof_key = FWD64_BF16 if (args.dtype == "bf16" and dom_c == 64) else "spconv_fwd_mfma_kernel<%d,%d>" % (dom_c, dom_c)
     if head in ("c3", "c1"):
         dominant = None  # PointPillars has no sparse convolutions
-    windows = args.windows if args.windows else (9 if args.steps <= 60 else 1)
+    # 15 windows for the driver's 20-step region (1.8 s in all: a host busy for half a second spoils four of them and the
+    # median stands; round 6 saw 60-step windows between 360 and 407 ms on a box whose host was busy), 9 up to 60 steps
+    windows = args.windows if args.windows else (15 if args.steps <= 30 else (9 if args.steps <= 60 else 1))
     elapsed, records, loss = timed_region(wl, args.steps, args.warmup, rank, world, dev, note, dominant,
                                           freeze=not args.no_gc_freeze, burn_in_s=args.burn_in,
                                           prefetch=not args.no_prefetch, prefetch_thread=not args.no_prefetch_thread,
