@@ -4,9 +4,9 @@ Stage i:  ZeroPad2d(1) + Conv3x3(stride s_i) + BN + ReLU, then n_i x (Conv3x3(pa
 all bias-free.  The last len(us_layer_strides) stages each feed a "deblock": ConvTranspose2d
 (kernel = stride = u) when u > 1, otherwise a Conv2d with kernel = stride = round(1/u); + BN + ReLU.
 Deblock outputs are concatenated along C.  Child modules are numbered exactly like the reference
-(`blocks.<i>.<j>`, `deblocks.<i>.<j>`) so checkpoints load.  The dense convolutions run on
-MIOpen / rocBLAS through PyTorch-ROCm (bf16 under autocast, NHWC when the backbone hands over a
-channels-last tensor).
+(`blocks.<i>.<j>`, `deblocks.<i>.<j>`) so checkpoints load.  On the GPU the conv -> BN -> ReLU runs of the
+Sequentials execute on the library's own kernels (det3d_amd/dense_stack.py: csrc/d3d_conv2d.hip); what those do not
+cover (kernel == stride deblocks of other shapes, CPU tensors) goes through PyTorch-ROCm / MIOpen.
 """
 import logging
 from functools import reduce
