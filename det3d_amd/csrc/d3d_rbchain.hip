@@ -100,9 +100,28 @@ __device__ __forceinline__ int rc_wave_rank(int cls, int (*wc)[D3D_PLAN_MAX_CLAS
   return rank;
 }
 
+#define RC_NO_WORD 0xffffffffu
+// One atomicOr per RUN of lanes that hold the same bitmap word instead of one per lane.  From the second level on the
+// rows of a layer arrive in ascending cell order, so the 64 rows of a wave reach a handful of words of a few output
+// lines, and 64 same-address atomics serialise at the L2 (rc_mark: 33 us per launch alone on the device, 15 G atomics/s).
+// Segmented inclusive OR-scan over the lanes (Hillis-Steele; the segment test compares the ORIGINAL words, so inside a
+// run of equal words lane j ends with the OR of the run's lanes <= j); the last lane of every run issues the atomic.
+// Equal words that are not adjacent only OR bits in twice -- the bitmap is the same for any row order.
+// Every lane of the wave must call this (wa = RC_NO_WORD, ba = 0 for lanes without a candidate).
+__device__ __forceinline__ void rc_wave_or(uint32_t *__restrict__ bitmap, uint32_t wa, uint32_t ba) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t wu = (uint32_t)__shfl_up((int)wa, d, 64), bu = (uint32_t)__shfl_up((int)ba, d, 64);
+    if (lane >= d && wu == wa) ba |= bu;
+  }
+  const uint32_t wn = (uint32_t)__shfl_down((int)wa, 1, 64);
+  if (wa != RC_NO_WORD && ba != 0u && (lane == 63 || wn != wa)) atomicOr(&bitmap[wa], ba);
+}
+
 __global__ void __launch_bounds__(RC_ROWS)
     rc_mark_kernel(const int4 *__restrict__ coords, const int32_t *__restrict__ n_dev, int cap, RcGeom G,
-                   uint32_t *__restrict__ bitmap, int32_t *__restrict__ blockhist) {
+                   uint32_t *__restrict__ bitmap, int32_t *__restrict__ blockhist, int wave_or) {
   // grid = (row blocks, kernel (z, y) pairs): blockIdx.y = kz * kH + ky walks the kW offsets of that pair, so a level of
   // 65k rows is 64 x 9 blocks instead of 64 (the first version: 64 of 256 CUs busy, 27 serial candidates per thread)
   // The row blocks are walked with a grid-stride loop: the row COUNT lives on the device, the capacity is 8x per level
@@ -116,6 +135,9 @@ __global__ void __launch_bounds__(RC_ROWS)
     const int r = blk * RC_ROWS + threadIdx.x;
     const bool live = r < n;
     int4 c = make_int4(0, 0, 0, 0);
+    // This thread's <= kW candidates share the output line (b, oz, oy) and sit next to each other on it: they are
+    // collected as bits of ONE bitmap word (wa | ba); a candidate that falls into another word goes out on its own.
+    uint32_t wa = RC_NO_WORD, ba = 0u;
     if (live) {
       c = coords[r];
       const int oz = rc_axis(c.y, G.p[0], kz, G.s[0], G.out_shape[0]);
@@ -126,11 +148,15 @@ __global__ void __launch_bounds__(RC_ROWS)
           const int ox = rc_axis(c.w, G.p[2], kx, G.s[2], G.out_shape[2]);
           if (ox >= 0) {
             const uint32_t key = base + (uint32_t)ox;
-            atomicOr(&bitmap[key >> 5], 1u << (key & 31));
+            const uint32_t w = key >> 5, bit = 1u << (key & 31);
+            if (wave_or && wa == RC_NO_WORD) wa = w;
+            if (w == wa) ba |= bit;
+            else atomicOr(&bitmap[w], bit);
           }
         }
       }
     }
+    if (wave_or) rc_wave_or(bitmap, wa, ba);  // (launch-uniform; D3D_RC_WAVE_OR=0: one atomic per candidate, round 5)
     if (blockhist && blockIdx.y == 0) {
       rc_wave_rank(live ? rc_class(G, c) : -1, wc);
       __syncthreads();
@@ -481,7 +507,9 @@ extern "C" int d3d_conv_rulebook_chain(int n_layers, D3dChainLayer *layers, int 
     if (nb > 256) nb = 256;  // x kzy blocks of 1024 threads; the kernels stride over the row blocks that exist
     int32_t *blockhist = Y.plan ? Y.plan + D3D_PLAN_PERM + cap_in : nullptr;
     const int kzy = G[l].k[0] * G[l].k[1];  // grid.y: one (kz, ky) pair of the kernel per block row
-    hipLaunchKernelGGL(rc_mark_kernel, dim3(nb, kzy), dim3(RC_ROWS), 0, stream, cin, nin, cap_in, G[l], bitmap[l], blockhist);
+    static const int wave_or = getenv("D3D_RC_WAVE_OR") ? atoi(getenv("D3D_RC_WAVE_OR")) : 1;
+    hipLaunchKernelGGL(rc_mark_kernel, dim3(nb, kzy), dim3(RC_ROWS), 0, stream, cin, nin, cap_in, G[l], bitmap[l], blockhist,
+                       wave_or);
     D3D_LAUNCH_TRY("rc_mark_kernel");
     const int ntiles = d3d_scan_num_tiles((int64_t)words[l]);
     hipLaunchKernelGGL(rc_reduce_kernel, dim3(ntiles), dim3(D3D_SCAN_THREADS), 0, stream, bitmap[l], (int64_t)words[l],
