@@ -50,6 +50,7 @@ struct Conv2dEpi {
   const void *bn_x;
   const float *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;
   int bn_relu;
+  int bn_stage;  // conv2d_halo_kernel: the bn_x tile through LDS (whole pixel rows by LDS-DMA) instead of 16-byte loads at pixel stride
 };
 
 // TR launches (the data gradient of a stride-2 layer, round 4): the rows of a block are the pixels of ONE parity class
@@ -829,6 +830,8 @@ extern "C" int d3d_conv2d_nhwc_fwd(const void *x_hi, const void *x_lo, const voi
     if (bn) {
       eh.bn_x = bn->x; eh.bn_mean = bn->mean; eh.bn_invstd = bn->invstd; eh.bn_gamma = bn->gamma; eh.bn_beta = bn->beta;
       eh.bn_relu = bn->relu;
+      static const int stage = getenv("D3D_DENSE_BN_STAGE") ? atoi(getenv("D3D_DENSE_BN_STAGE")) : 1;
+      eh.bn_stage = stage;
     }
     if (stats_ws) {
       D3D_REQUIRE(hp.fold_nb <= D3D_FOLD_MAX_BLOCKS, "d3d_conv2d_nhwc_fwd: %d blocks > %d for the statistics fold",

@@ -281,6 +281,77 @@ __device__ __forceinline__ void c2h_body(const void *__restrict__ x_hi, const vo
     live[j] = oy < G.ho && ox < G.wo;
     pix[j] = ((int64_t)(img * G.ho + oy) * G.wo + ox) * G.cout;
   }
+  if (want_bnb && ep.bn_stage) {
+    // ---- BatchNorm-backward sums with the previous layer's pre-BN tile staged through LDS (round 6, last session).
+    // A lane owns four channels of ONE pixel, so reading x from memory next to the stores below costs 16 loads of 16 bytes at
+    // pixel stride per lane (two 32-byte pieces of every 128-byte line per instruction): +35 us on a 115 us launch, more than
+    // the streaming d3d_bn_bwd_reduce it replaces (29 us).  The main loop is over and LDS is free: the block's
+    // [256 pixels][CT channels] f32 tile arrives by LDS-DMA in whole pixel rows (CT * 4 contiguous bytes), chunk c of pixel
+    // q at physical chunk c ^ (q mod chunks) -- the swizzle on the SOURCE address, as everywhere -- so that the 32 pixels
+    // of a ds_read_b128 hit 32 different 16-byte slots.
+    constexpr int CH = CT / 4;          // 16-byte chunks per pixel row
+    constexpr int PPI = 64 / CH;        // pixels per LDS-DMA instruction (1 KiB)
+    constexpr int IPW = 256 / PPI / 8;  // instructions per wave
+    static_assert(CH >= 8 && CH <= 32 && IPW >= 1 && 256 * CT * 4 <= 2 * XBUF + 3 * WSLOT, "x tile fits the block's LDS");
+    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)ep.bn_x, 0, (int)((uint32_t)G.m * (uint32_t)G.cout * 4u), 0x00020000);
+#pragma unroll
+    for (int u = 0; u < IPW; ++u) {
+      const int t = wave * IPW + u;
+      const int q = t * PPI + lane / CH, pc = lane % CH;
+      const int oy = oy0 + q / PW, ox = ox0 + q % PW;
+      const bool ok = oy < G.ho && ox < G.wo;
+      const uint32_t el = (uint32_t)((img * G.ho + oy) * G.wo + ox) * (uint32_t)G.cout + (uint32_t)(n0 + ((pc ^ (q & (CH - 1))) << 2));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (c2_lds_void *)(smem + t * 1024), 16, (int)(ok ? el * 4u : D3D_OOB_OFFSET),
+                                               0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cl = wco * (NI * 32) + i * 32 + 4 * (lane >> 5) + 8 * g;  // channel inside the block's tile
+        const int co = n0 + cl;
+        float is[4], mi[4], zs[4], zb[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // the arithmetic of bn_bwd_reduce_kernel (d3d_bn.hip), as in the direct path below
+          const float gm = ep.bn_gamma ? ep.bn_gamma[co + e] : 1.f, bt = ep.bn_beta ? ep.bn_beta[co + e] : 0.f;
+          is[e] = ep.bn_invstd[co + e];
+          mi[e] = -ep.bn_mean[co + e] * is[e];
+          zs[e] = gm * is[e];
+          zb[e] = fmaf(mi[e], gm, bt);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (!live[j]) continue;
+          const int q = wpx * (NJ * 32) + j * 32 + frow;
+          const float4 xr = *(const float4 *)(smem + q * (CT * 4) + ((((cl >> 2) ^ q) & (CH - 1)) << 4));
+          const float x[4] = {xr.x, xr.y, xr.z, xr.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = acc[i][j][4 * g + e];
+            const float dz = (ep.bn_relu && fmaf(x[e], zs[e], zb[e]) <= 0.f) ? 0.f : v;
+            s1[i][4 * g + e] = fmaf(dz, fmaf(x[e], is[e], mi[e]), s1[i][4 * g + e]);
+            s2[i][4 * g + e] += dz;
+          }
+        }
+      }
+    }
+    // the output tile after the sums: waited for in front of them (vmcnt(0) covers loads and stores alike), its stores
+    // would cost the block their whole drain
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = n0 + wco * (NI * 32) + i * 32 + 4 * (lane >> 5) + 8 * g;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          if (live[j])
+            *(float4 *)(y + pix[j] + co) =
+                make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+      }
+  } else
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int co_base = n0 + wco * (NI * 32) + i * 32 + 4 * (lane >> 5);

@@ -27,11 +27,15 @@ from . import dense_conv as dc
 
 ENABLED = os.environ.get("D3D_DENSE_CONV", "1") != "0"
 FP32_MODE = os.environ.get("D3D_RPN_FP32", "split")  # "split" | "exact" (MIOpen f32)
-# BN-backward sums in the dgrad epilogue.  OFF: measured on the [4, 200, 176, 128] maps the epilogue (x re-read with
-# 16-byte accesses at pixel stride + the 62-shuffle butterfly) adds ~35 us to a split-mode data-gradient launch while the
-# streaming d3d_bn_bwd_reduce it replaces takes 29 us (gpurun_out r3j11 vs r3j5); the forward statistics epilogue
-# (+11-19 us against 11-20 us for d3d_bn_stats) is break-even and stays on because it saves the launches.
-FUSE_BN_BACKWARD = os.environ.get("D3D_DENSE_FUSE_BN_BWD", "0") == "1"
+# BN-backward sums in the dgrad epilogue (split 3x3 layers = conv2d_halo_kernel).  Round 3 measured the epilogue at +35 us
+# per launch on the [4, 200, 176, 128] maps against 29 us for the streaming d3d_bn_bwd_reduce it replaces: a lane owns four
+# channels of one pixel and re-read x with 16-byte accesses at pixel stride.  Round 6 (last session) stages the block's x tile
+# through LDS in whole pixel rows (d3d_conv2d_halo.h): with the weight-gradient stream beside it the step is 1.0-1.3 %
+# faster with the sums in the epilogue (670.6 / 671.0 -> 679.5 / 679.4 frames/s, same box, alternating;
+# profiles/round6_session4_ab.txt), so it is ON for those layers.  The bf16 and the 1x1 layers (conv2d_nhwc_kernel, whose
+# epilogue still reads x at pixel stride: 37 -> 89 us on the 1x1 deblock) keep the sweep.  The forward statistics epilogue
+# (+6 us against 11-20 us for d3d_bn_stats) stays on as before.
+FUSE_BN_BACKWARD = os.environ.get("D3D_DENSE_FUSE_BN_BWD", "1") == "1"
 STATS_EPILOGUE_BF16 = os.environ.get("D3D_DENSE_STATS_EPILOGUE_BF16", "1") == "1"
 
 
@@ -287,7 +291,7 @@ class _DenseStackFn(torch.autograd.Function):
                     dy = dc.conv2d_dgrad_s2(g_hi, g_lo, wd_hi, wd_lo, a_hi.shape[1], a_hi.shape[2], ly.ksz, ly.pad, mode)
                 else:
                     bnb = None
-                    if li > 0 and FUSE_BN_BACKWARD:
+                    if li > 0 and FUSE_BN_BACKWARD and split and ly.ksz == 3:
                         # the rows this launch produces are dL/dz of layer li - 1's BatchNorm + ReLU: reduce its sums here
                         pl = layers[li - 1]
                         _, _, py, psave, _ = rec[li - 1]
