@@ -494,7 +494,10 @@ int d3d_channel_affine_bwd(const void *x, const void *dy, int n, int c, int dtyp
  * that made the convolution's input (rpn.py:124-142): instead of the statistics of the produced rows, the epilogue
  * leaves sum dz * xhat | sum dz in stats_ws[0 .. 2*cout) -- what d3d_bn_bwd_reduce computes -- with x = that layer's
  * pre-BN activations [batch, ho, wo, cout] in this launch's OUTPUT element type, its saved mean / invstd and its
- * gamma / beta (NULL = 1 / 0), dz = dy masked by the ReLU when relu != 0. */
+ * gamma / beta (NULL = 1 / 0), dz = dy masked by the ReLU when relu != 0.
+ * Cost: the 3x3 / stride-1 D3D_CONV_SPLIT layers (conv2d_halo_kernel) stage the block's tile of x through LDS in whole pixel
+ * rows and replace the separate d3d_bn_bwd_reduce sweep at a gain (det3d_amd/dense_stack.py does this for every such layer but
+ * the last of a run); the other layer shapes read x at pixel stride and are faster with the sweep. */
 typedef struct D3dDenseBnBackward {
   const void *x;
   const float *mean, *invstd, *gamma, *beta;
