@@ -1025,9 +1025,18 @@ static int c2_wgrad_splits(int m, int blocks_per_split) {
   if (s > max_s) s = max_s;
   return s < 1 ? 1 : s;
 }
-// conv2d_wgrad3_kernel (3x3 stride 1, split mode): one block per CU over (splits x 3 kernel rows x weight tiles)
+// conv2d_wgrad3_kernel (3x3 stride 1, split mode): blocks over (splits x 3 kernel rows x weight tiles).  One block per CU
+// (256) is the faster launch alone on the device, but the kernel runs on the second stream NEXT TO the data gradient of its
+// layer, and neither its blocks (104 KB of LDS) nor conv2d_halo_kernel's (132 KB) share a CU with the other: with a block on
+// every CU the data-gradient chain -- the critical path, 188 us per layer against 115 us here -- waits for whole
+// weight-gradient blocks.  Round 6 (last session), 128 -> 128 layers of the KITTI RPN, same box, two runs each: 256 blocks
+// 675.7 frames/s, 224: 673.9, 192: 674.0, 160: 679.5, 144: 674.7, 128: 683.8 / 684.5, 112: 681.2, 96: 675.9, 80: 659, 64:
+// 626 -> 128 for one weight tile.  The 256 -> 256 layers of the CBGS necks measure the same either way (242.1 / 242.1,
+// 113.7-114.4) and keep 256.  D3D_C2_WGRAD3_BLOCKS overrides.
 static int c2_wgrad3_splits(int total_segs, int wtiles) {
-  int s = 256 / (3 * wtiles);
+  static const int env_blocks = getenv("D3D_C2_WGRAD3_BLOCKS") ? atoi(getenv("D3D_C2_WGRAD3_BLOCKS")) : 0;
+  const int blocks = env_blocks > 0 ? env_blocks : (wtiles == 1 ? 128 : 256);
+  int s = blocks / (3 * wtiles);
   if (s > total_segs) s = total_segs;
   return s < 1 ? 1 : s;
 }
