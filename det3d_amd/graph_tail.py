@@ -114,11 +114,22 @@ class GraphedTail:
         # packed conv weights: a capture packs into its own buffers with its own launch (dense_conv._packed), so that a
         # replay convolves with the weights of ITS step; entries of an earlier capture must not satisfy this one
         dense_conv._CAPTURE_PACK.clear()
+        # No cyclic garbage collection while the stream is capturing: a collection that starts inside the capture can
+        # finalise objects of EARLIER work that own device resources (streams, events, library contexts), and releasing
+        # those is not a capturable operation -- seen once as an abort of the test process with "Garbage-collecting" on top
+        # of the capture's stack (round 6, in a full-suite run; the test passes on its own).  Collect first, then hold.
+        import gc
+
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
         try:
             with ctx, torch.backends.cudnn.flags(enabled=True, benchmark=False,
                                                  deterministic=torch.backends.cudnn.deterministic):
                 graphed = torch.cuda.make_graphed_callables(tail, sample, num_warmup_iters=3, allow_unused_input=True)
         finally:
+            if gc_was_on:
+                gc.enable()
             dense_conv._CAPTURE_PACK.clear()  # the graphs' private pool owns the buffers from here on
         with torch.no_grad():
             sd = tail.state_dict()
