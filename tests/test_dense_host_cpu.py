@@ -67,3 +67,25 @@ def test_which_convolutions_the_dense_stack_takes():
     assert ok(nn.Conv2d(128, 128, 3, padding=1, bias=True), 0) is None
     assert ok(c(128, 128, 3, padding=1, dilation=2), 0) is None
     assert dc.dgrad_s2_supported(128, 256, 3) and not dc.dgrad_s2_supported(64, 64, 3) and not dc.dgrad_s2_supported(128, 256, 1)
+
+
+def test_default_switches_of_the_dense_backward():
+    """Round 6: the BatchNorm-backward sums of the split 3x3 layers ride in the data gradient's epilogue by default
+    (dense_stack.FUSE_BN_BACKWARD; the reference has no such choice -- cuDNN's batch-norm backward, det3d/models/necks/rpn.py
+    through autograd); D3D_DENSE_FUSE_BN_BWD=0 is the switch back to the stand-alone d3d_bn_bwd_reduce sweep."""
+    import importlib
+    import os
+
+    saved = os.environ.pop("D3D_DENSE_FUSE_BN_BWD", None)
+    try:
+        importlib.reload(dense_stack)
+        assert dense_stack.FUSE_BN_BACKWARD is True
+        os.environ["D3D_DENSE_FUSE_BN_BWD"] = "0"
+        importlib.reload(dense_stack)
+        assert dense_stack.FUSE_BN_BACKWARD is False
+    finally:
+        if saved is None:
+            os.environ.pop("D3D_DENSE_FUSE_BN_BWD", None)
+        else:
+            os.environ["D3D_DENSE_FUSE_BN_BWD"] = saved
+        importlib.reload(dense_stack)
